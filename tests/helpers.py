@@ -1,0 +1,63 @@
+"""Shared test helpers: golden-case loading and conversions between the three views of a case.
+
+* ``raw``   -- user-level constraint data (A1,b1,A2,b2, lists P,q,r / M,s,c,d / F, y0)
+* ``csd``   -- the preprocessed fields the oracle's ``precompute`` reads
+* ``cs``    -- this package's ``ConvexConstraints`` built from ``raw``
+"""
+import glob
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    raw = dict(A1=None, b1=None, A2=None, b2=None, do_preprocessing_linear=False)
+    for key in ("A1", "b1", "A2", "b2"):
+        if "raw_" + key in z:
+            raw[key] = z["raw_" + key]
+    for key in ("P", "q", "r", "M", "s", "c", "d", "F"):
+        raw[key] = list(z["raw_" + key]) if "raw_" + key in z else []
+    raw["y0"] = z["raw_y0"]
+    csd = {key: z["cs_" + key] for key in ("A_p", "b_p", "NA_E", "yp", "z0")}
+    csd["y0"] = raw["y0"]
+    for key in ("P", "q", "r", "M", "s", "c", "d", "F"):
+        csd[key] = raw[key]
+    return raw, csd, z
+
+
+def csd_from_cs(cs):
+    """Oracle input dict from a (this package's) ConvexConstraints object."""
+    csd = {key: getattr(cs, key) for key in ("A_p", "b_p", "NA_E", "yp", "z0", "y0")}
+    csd["P"] = [qc.P for qc in cs.qcs]
+    csd["q"] = [qc.q for qc in cs.qcs]
+    csd["r"] = [qc.r for qc in cs.qcs]
+    csd["M"] = [s.M for s in cs.socs]
+    csd["s"] = [s.s for s in cs.socs]
+    csd["c"] = [s.c for s in cs.socs]
+    csd["d"] = [s.d for s in cs.socs]
+    csd["F"] = list(cs.lmic.all_F) if cs.lmic is not None else []
+    return csd
+
+
+def raw_from_cs(cs):
+    raw = dict(A1=None, b1=None, A2=None, b2=None)
+    if cs.lc is not None:
+        raw.update(A1=cs.lc.A1, b1=cs.lc.b1, A2=cs.lc.A2, b2=cs.lc.b2)
+    raw.update({k: v for k, v in csd_from_cs(cs).items() if k in "PqrMscdF"})
+    return raw
+
+
+def rel_err_rows(y, y_ref):
+    """Per-sample inf-norm relative error (the 1e-5 parity metric of BASELINE.json)."""
+    y = np.asarray(y, dtype=np.float64)
+    y_ref = np.asarray(y_ref, dtype=np.float64)
+    num = np.max(np.abs(y - y_ref), axis=1)
+    den = np.maximum(np.max(np.abs(y_ref), axis=1), 1e-30)
+    return num / den
