@@ -1,0 +1,192 @@
+#!/usr/bin/env python
+"""Throughput of the RAYEN projection on MI355X -- the driver's bench contract.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (``ConstraintModule.forward`` with the identity
+mapper = one launch of the fused projection) over one batch of synthetic directions
+that is already resident in HBM.  Default workload: BASELINE.json ``configs[2]``, the
+headline -- k=64, 128 linear + 4 quadratic + 2 SOC constraints, batch 262144 per GPU,
+fp32.  N>1 runs one process per GPU (torchrun, backend nccl = RCCL); the batch
+dimension is sharded with fixed per-GPU work (weak scaling) and no data-path
+collective (samples are independent; ``--gather`` adds the all-gather of ``y`` the
+north_star describes for a caller that wants every output on every rank).
+
+One JSON line on rank 0: metric / value (whole-job projections/s) plus
+``roofline`` (dominant kernel, live HIP-event timing) and ``cpu_baseline`` (the
+PyTorch-CPU oracle, same workload, timed on this box's host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector = FP32 MFMA peak (spec)
+PEAK_HBM_GBS = 8000.0      # HBM3E spec (≈6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="c3", choices=["c1", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0 = the BASELINE.json size)")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp64"])
+    ap.add_argument("--gather", action="store_true", help="all-gather y across ranks inside the step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(raw, cs, B, dtype, budget_s):
+    """Reference op sequence (oracle/rayen_oracle.py) on the host cores, same workload."""
+    from oracle import rayen_oracle as oracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    csd = {key: getattr(cs, key) for key in ("A_p", "b_p", "NA_E", "yp", "z0", "y0")}
+    csd.update(P=raw["P"], q=raw["q"], r=raw["r"], M=raw["M"], s=raw["s"], c=raw["c"], d=raw["d"],
+               F=raw["F"])
+    buf = oracle.precompute(csd, dtype)
+    gen = torch.Generator().manual_seed(1234)
+    x = torch.empty(B, cs.n, 1, dtype=dtype).uniform_(-1.0, 1.0, generator=gen)
+    best, reps, t_start = float("inf"), 0, time.perf_counter()
+    with torch.no_grad():
+        oracle.forward(buf, x)  # warm-up
+        while reps < 3 or (time.perf_counter() - t_start < budget_s and reps < 20):
+            t0 = time.perf_counter()
+            oracle.forward(buf, x)
+            best = min(best, time.perf_counter() - t0)
+            reps += 1
+    return {"value": B / best, "unit": "projections/s", "cores": cores, "kind": "port",
+            "sample": f"full batch B={B} of the same workload, best of {reps} calls after 1 warm-up, "
+                      f"{str(dtype).split('.')[-1]}, torch {torch.__version__} CPU, {cores} threads"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    from rayen_amd import workloads
+    from rayen_amd.constraint_module import ConstraintModule
+    from rayen_amd import ops
+
+    dtype = torch.float32 if args.dtype == "fp32" else torch.float64
+    torch.set_default_dtype(dtype)
+    raw = workloads.make_raw(args.config, seed=0)
+    cs = workloads.build_constraints(raw)
+    layer = ConstraintModule(cs, method="RAYEN", create_map=False).to(device)
+    layer.check_nan = False                      # no host sync inside the timed region
+    B = args.batch or workloads.CONFIGS[args.config][2]
+    if args.config == "c5" and not args.batch:
+        B = B // 8                               # 2M over 8 GPUs -> 262144 per GPU
+    rng = workloads.CONFIGS[args.config][3]
+    gen = torch.Generator(device=device).manual_seed(1000 + rank)
+    x = torch.empty(B, cs.n, 1, device=device, dtype=dtype).uniform_(-rng, rng, generator=gen)
+    gathered = torch.empty(world * B, cs.k, 1, device=device, dtype=dtype) if (args.gather and world > 1) else None
+
+    def step():
+        y = layer(x)
+        if gathered is not None:
+            dist.all_gather_into_tensor(gathered, y)
+        return y
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            y = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(args.steps):
+            y = step()
+        ev1.record()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1) / args.steps    # HIP events on the launch stream
+
+    t = torch.tensor([elapsed, dev_ms], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, dev_ms = float(t[0]), float(t[1])
+
+    # feasibility of what was just computed (fp64 residuals on a slice, outside the timed region)
+    from rayen_amd.constraints import ConvexConstraints  # noqa: F401
+    sl = y[: min(B, 65536), :, 0].double().cpu().numpy()
+    max_violation = cs.getMaxViolation(sl)
+
+    if rank == 0:
+        bytes_pp, flops_pp = workloads.algorithmic_work(cs)
+        if dtype == torch.float64:
+            bytes_pp *= 2
+        kern_s = dev_ms * 1e-3
+        tflops = flops_pp * B / kern_s / 1e12
+        gbs = bytes_pp * B / kern_s / 1e9
+        ai = flops_pp / bytes_pp
+        ridge = PEAK_FP32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+        if ai > ridge and dtype == torch.float32:
+            roof = {"bound": "mfma", "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tflops / PEAK_FP32_TFLOPS, "traffic": None}
+        else:
+            roof = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": gbs / PEAK_HBM_GBS, "traffic": None}
+        roof.update({"kernel_ms": dev_ms, "algorithmic_flops_per_projection": flops_pp,
+                     "algorithmic_bytes_per_projection": bytes_pp, "hbm_GBps": gbs,
+                     "hbm_frac": gbs / PEAK_HBM_GBS, "fp32_TFLOPs": tflops})
+        info = layer.device_pack(device)[0].info()
+        out = {
+            "metric": "feasible projections/sec at k=64, 128 lin+4 quad+2 SOC; max violation"
+                      if args.config == "c3" else f"feasible projections/sec ({args.config})",
+            "value": world * B * args.steps / elapsed,
+            "unit": "projections/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if dtype == torch.float32 else "f64", "data": "synthetic",
+            "config": {"workload": f"{args.config}: k={cs.k} n={cs.n}, {cs.A_p.shape[0]} linear + "
+                                   f"{len(cs.qcs)} quadratic + {len(cs.socs)} SOC"
+                                   f"{' + 1 LMI' if cs.has_lmi_constraints else ''}, "
+                                   f"batch {B} per GPU, v~U(-{rng:g},{rng:g})",
+                       "batch_per_gpu": B, "global_batch": world * B,
+                       "parallelism": f"batch-sharded x{world}" + (" + all-gather(y)" if gathered is not None else ""),
+                       "kernel": "mfma_f32" if info.mfma_f32 and dtype == torch.float32 else "generic"},
+            "max_violation": max_violation,
+            "violations_gt_1e-6": int(max_violation > 1e-6),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(raw, cs, B, dtype, args.cpu_seconds)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

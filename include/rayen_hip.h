@@ -1,0 +1,150 @@
+/*
+ * rayen_hip.h -- C ABI of the MI355X (gfx950) ray-shooting projection.
+ *
+ * The reference (leggedrobotics/rayen, pure Python/PyTorch) has no FFI layer; its
+ * boundary for this path is the Python method ConstraintModule.forward
+ * (rayen/constraint_module.py:520-533) -> forwardForRAYEN (:468-474) ->
+ * computeKappa (:351-458) -> getyFromz (:512-514).  This header is the C-ABI a
+ * binding for that path attaches to: plain pointers and sizes, no torch types.
+ * INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Mathematical contract (homogeneity identity):
+ *
+ *     y = y0 + NA_E v / max(1, kappa(v)),     kappa(v) = max_c kappa_c(v) >= 0
+ *
+ * which equals constraint_module.py:468-474 (normalise, kappa(v_bar), clip the
+ * step at 1/kappa, lift with NA_E, add yp) for every v, including v = 0.
+ *
+ * All constants are handed over ONCE, in fp64 and on the HOST, as a matrix W
+ * [n_rows x n] whose rows are the linear functionals of v that computeKappa
+ * needs, plus a segment table that says how each group of rows is reduced:
+ *
+ *   LIN       rows D_i = A_p,i / (b_p,i - A_p,i z0)           kappa = relu(max_i D_i v)      (:38, :353)
+ *   QUAD_SYM  aux row phi NA_E ; rows G = NA_E' delta NA_E    kappa = phi.v + sqrt(v'Gv)     (:99-122, :374)
+ *   QUAD_FAC  aux row phi NA_E ; rows U with U'U = G          kappa = phi.v + ||U v||        (same, low-rank form)
+ *   SOC       aux rows c'NA_E, (M'beta)'NA_E ; rows M NA_E    larger root of a'x^2+b'x+c'=0  (:383-399, :339-348)
+ *   LMI       rows = packed lower triangle of -L'F_a L . NA_E  kappa = relu(lambda_max)      (:43-52, :401-449)
+ *
+ * The library uploads W to the current HIP device and builds whatever device
+ * images its kernels want (fragment-ordered for MFMA, row-blocked for the
+ * generic path); those layouts are private.
+ *
+ * Conventions: every entry point returns 0 on success or a negative RAYEN_E_*
+ * code; nothing throws across the ABI; no per-call allocation; launches are
+ * asynchronous on the caller's stream (no host sync); tensor memory is owned by
+ * the caller and must live on the pack's device; a pack is immutable after
+ * creation, so it may be shared by threads and streams.
+ */
+#ifndef RAYEN_HIP_H
+#define RAYEN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAYEN_ABI_VERSION 1
+
+enum {
+  RAYEN_OK = 0,
+  RAYEN_E_BAD_ARG = -1,       /* null pointer, negative size, inconsistent table */
+  RAYEN_E_ABI = -2,           /* desc->abi_version != RAYEN_ABI_VERSION */
+  RAYEN_E_NO_DEVICE = -3,     /* no HIP device / wrong architecture (needs gfx950) */
+  RAYEN_E_ALLOC = -4,         /* device allocation or upload failed in pack_create */
+  RAYEN_E_LAUNCH = -5,        /* hipGetLastError() after a launch */
+  RAYEN_E_UNSUPPORTED = -6,   /* shape outside what the kernels handle (see rayen_pack_info) */
+  RAYEN_E_DEVICE_MISMATCH = -7 /* pack lives on another device than the current one */
+};
+
+enum {
+  RAYEN_SEG_LIN = 0,
+  RAYEN_SEG_QUAD_SYM = 1,
+  RAYEN_SEG_QUAD_FAC = 2,
+  RAYEN_SEG_SOC = 3,
+  RAYEN_SEG_LMI = 4
+};
+
+typedef struct RayenSegment {
+  int32_t type;     /* RAYEN_SEG_* */
+  int32_t row0;     /* first row of the group in W */
+  int32_t nrows;    /* LIN m | QUAD_SYM n | QUAD_FAC rank | SOC r_M | LMI r(r+1)/2 */
+  int32_t aux_row;  /* QUAD_*: row of phi NA_E | SOC: row of c'NA_E, next row is (M'beta)'NA_E | else -1 */
+  int32_t dim;      /* LMI: r | else 0 */
+  int32_t reserved;
+  double f0;        /* SOC: tau = c'y0 + d */
+  double f1;        /* SOC: a' = ||M y0 + s||^2 - tau^2  (< 0 for an interior y0) */
+} RayenSegment;
+
+typedef struct RayenPackDesc {
+  int32_t abi_version;          /* RAYEN_ABI_VERSION */
+  int32_t k;                    /* ambient dimension (rows of NA_E, length of y) */
+  int32_t n;                    /* subspace dimension (columns of W, used columns of v) */
+  int32_t n_rows;               /* rows of W */
+  int32_t n_segments;
+  int32_t out_identity;         /* 1: NA_E is the k x k identity (no equality constraints) */
+  const double* W;              /* HOST [n_rows, n] row-major */
+  const RayenSegment* segments; /* HOST [n_segments] */
+  const double* NA_E;           /* HOST [k, n] row-major; may be NULL when out_identity */
+  const double* y0;             /* HOST [k] */
+} RayenPackDesc;
+
+typedef struct RayenPackInfo {
+  int32_t k, n, n_rows, n_segments;
+  int32_t device;               /* HIP device ordinal the pack lives on */
+  int32_t mfma_f32;             /* 1: the fp32 MFMA path serves this pack */
+  int32_t generic_block;        /* workgroup size the generic path uses for fp32 (0 = unsupported) */
+  int32_t reserved;
+  int64_t device_bytes;         /* bytes of device memory the pack holds so far */
+} RayenPackInfo;
+
+typedef struct RayenPack RayenPack;
+
+int rayen_abi_version(void);
+const char* rayen_strerror(int code);
+
+/* Upload the constants to the CURRENT HIP device.  Host arrays are copied; they
+ * may be freed after the call returns. */
+int rayen_pack_create(const RayenPackDesc* desc, RayenPack** out);
+void rayen_pack_destroy(RayenPack* pack);
+int rayen_pack_info(const RayenPack* pack, RayenPackInfo* info);
+
+/* Forward: v [B, ldv] row-major (first n columns read) -> y [B, ldy] (first k
+ * columns written).  Optional outputs (NULL to skip):
+ *   kappa  [B]    kappa(v) of the UN-normalised direction
+ *   active [B,2]  (segment index or -1 when kappa == 0, W row of the active
+ *                 linear constraint or 0)  -- what the backward needs
+ *   nan_flag [1]  set to 1 (never cleared) when any written y is NaN; the
+ *                 fused replacement of constraint_module.py:531's full-tensor check
+ * y may be NULL to compute kappa only (the computeKappa helper, :351).
+ * `stream` is a hipStream_t (NULL = the null stream). */
+int rayen_ray_project_f32(const RayenPack* pack, const float* v, int64_t B, int64_t ldv,
+                          float* y, int64_t ldy, float* kappa, int32_t* active,
+                          int32_t* nan_flag, void* stream);
+int rayen_ray_project_f64(const RayenPack* pack, const double* v, int64_t B, int64_t ldv,
+                          double* y, int64_t ldy, double* kappa, int32_t* active,
+                          int32_t* nan_flag, void* stream);
+
+/* Same contract, forced through the generic (non-MFMA) kernels; used by the
+ * parity tests to cover both implementations on every shape. */
+int rayen_ray_project_generic_f32(const RayenPack* pack, const float* v, int64_t B, int64_t ldv,
+                                  float* y, int64_t ldy, float* kappa, int32_t* active,
+                                  int32_t* nan_flag, void* stream);
+
+/* Backward of y w.r.t. v (vector-Jacobian product):
+ *   grad_v = s N'g - [kappa > 1] s^2 (g . N v) grad kappa(v),   s = 1/max(1,kappa)
+ * with grad kappa taken on the active constraint only, which is what autograd
+ * produces for constraint_module.py:351-474 (max -> argmax, relu, eigvalsh). */
+int rayen_ray_project_bwd_f32(const RayenPack* pack, const float* v, int64_t B, int64_t ldv,
+                              const float* kappa, const int32_t* active,
+                              const float* grad_y, int64_t ldg,
+                              float* grad_v, int64_t ldgv, void* stream);
+int rayen_ray_project_bwd_f64(const RayenPack* pack, const double* v, int64_t B, int64_t ldv,
+                              const double* kappa, const int32_t* active,
+                              const double* grad_y, int64_t ldg,
+                              double* grad_v, int64_t ldgv, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAYEN_HIP_H */

@@ -1,0 +1,102 @@
+"""ctypes binding of the C ABI in ``include/rayen_hip.h`` (``librayen_hip.so``).
+
+There is deliberately no fallback: if the shared library is missing or an entry
+point fails, the error is raised to the caller.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+from ._build import LIBRARY
+
+ABI_VERSION = 1
+
+SEG_LIN, SEG_QUAD_SYM, SEG_QUAD_FAC, SEG_SOC, SEG_LMI = range(5)
+
+# every symbol include/rayen_hip.h declares
+EXPORTS = (
+    "rayen_abi_version", "rayen_strerror", "rayen_pack_create", "rayen_pack_destroy",
+    "rayen_pack_info", "rayen_ray_project_f32", "rayen_ray_project_f64",
+    "rayen_ray_project_generic_f32", "rayen_ray_project_bwd_f32", "rayen_ray_project_bwd_f64",
+)
+
+
+class RayenSegment(ctypes.Structure):
+    _fields_ = [("type", ctypes.c_int32), ("row0", ctypes.c_int32), ("nrows", ctypes.c_int32),
+                ("aux_row", ctypes.c_int32), ("dim", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("f0", ctypes.c_double), ("f1", ctypes.c_double)]
+
+
+class RayenPackDesc(ctypes.Structure):
+    _fields_ = [("abi_version", ctypes.c_int32), ("k", ctypes.c_int32), ("n", ctypes.c_int32),
+                ("n_rows", ctypes.c_int32), ("n_segments", ctypes.c_int32),
+                ("out_identity", ctypes.c_int32),
+                ("W", ctypes.POINTER(ctypes.c_double)),
+                ("segments", ctypes.POINTER(RayenSegment)),
+                ("NA_E", ctypes.POINTER(ctypes.c_double)),
+                ("y0", ctypes.POINTER(ctypes.c_double))]
+
+
+class RayenPackInfo(ctypes.Structure):
+    _fields_ = [("k", ctypes.c_int32), ("n", ctypes.c_int32), ("n_rows", ctypes.c_int32),
+                ("n_segments", ctypes.c_int32), ("device", ctypes.c_int32),
+                ("mfma_f32", ctypes.c_int32), ("generic_block", ctypes.c_int32),
+                ("reserved", ctypes.c_int32), ("device_bytes", ctypes.c_int64)]
+
+
+class RayenError(RuntimeError):
+    def __init__(self, code, what):
+        super().__init__(f"{what} failed with code {code}: {strerror(code)}")
+        self.code = code
+
+
+_lib = None
+
+
+def library_path():
+    return LIBRARY
+
+
+def load():
+    """Load ``librayen_hip.so`` (once) and declare the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIBRARY):
+        raise RuntimeError(
+            f"{LIBRARY} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). rayen_amd has no CPU or eager fallback.")
+    lib = ctypes.CDLL(LIBRARY)
+    p, i64, i32p = ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p
+    lib.rayen_abi_version.restype = ctypes.c_int
+    lib.rayen_abi_version.argtypes = []
+    lib.rayen_strerror.restype = ctypes.c_char_p
+    lib.rayen_strerror.argtypes = [ctypes.c_int]
+    lib.rayen_pack_create.restype = ctypes.c_int
+    lib.rayen_pack_create.argtypes = [ctypes.POINTER(RayenPackDesc), ctypes.POINTER(ctypes.c_void_p)]
+    lib.rayen_pack_destroy.restype = None
+    lib.rayen_pack_destroy.argtypes = [p]
+    lib.rayen_pack_info.restype = ctypes.c_int
+    lib.rayen_pack_info.argtypes = [p, ctypes.POINTER(RayenPackInfo)]
+    fwd = [p, p, i64, i64, p, i64, p, i32p, i32p, p]
+    for name in ("rayen_ray_project_f32", "rayen_ray_project_f64", "rayen_ray_project_generic_f32"):
+        getattr(lib, name).restype = ctypes.c_int
+        getattr(lib, name).argtypes = fwd
+    bwd = [p, p, i64, i64, p, i32p, p, i64, p, i64, p]
+    for name in ("rayen_ray_project_bwd_f32", "rayen_ray_project_bwd_f64"):
+        getattr(lib, name).restype = ctypes.c_int
+        getattr(lib, name).argtypes = bwd
+    if lib.rayen_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"librayen_hip.so ABI {lib.rayen_abi_version()} != binding ABI {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def strerror(code):
+    return load().rayen_strerror(int(code)).decode()
+
+
+def check(code, what):
+    if code != 0:
+        raise RayenError(code, what)

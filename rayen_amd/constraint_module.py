@@ -1,0 +1,215 @@
+"""``ConstraintModule``: the RAYEN layer, drop-in for ``rayen.constraint_module.ConstraintModule``.
+
+Same constructor, same ``forward`` contract (any ``[B, ...]`` tensor in, ``[B, k, 1]`` out,
+rayen/constraint_module.py:520-533), same buffer names (so ``state_dict``s and
+pickles written with the reference load here) and the same helper methods
+(``getDimAfterMap, gety0, getyFromz, getzFromy, computeKappa``; :351, :506-518).
+
+What differs is how ``forwardForRAYEN`` (:468-474) is executed: instead of ~165
+PyTorch ops and 10 host syncs per call, one hand-written gfx950 kernel computes
+``kappa`` for every constraint family and writes ``y = y0 + NA_E v / max(1, kappa(v))``
+(the homogeneity identity of SURVEY.md §0, equal to :468-474 for every ``v``).
+The layer only runs on an MI355X: CPU tensors raise (no fallback path exists).
+
+Only ``method='RAYEN'`` (the default) is the hot path this package accelerates;
+``'UU'`` is the identity and kept because it is free; the paper baselines
+(``RAYEN_old, UP, PP, DC3, Bar``) are out of scope and raise
+``NotImplementedError``.
+
+Documented deviation: for an SOC whose ray never meets the cone (negative
+discriminant with ``c' < 0``) the reference's assert at :342 fires (or NaN under
+``python -O``); here that constraint contributes ``kappa_j = 0``, its mathematical value.
+"""
+from __future__ import annotations
+
+import copy
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops, pack as _pack, utils
+
+
+class ConstraintModule(torch.nn.Module):
+    def __init__(self, cs, input_dim=None, method='RAYEN', create_map=True, args_DC3=None):
+        super().__init__()
+
+        self.method = method
+        if method not in ('RAYEN', 'UU'):
+            if method in ('RAYEN_old', 'UP', 'PP', 'DC3', 'Bar'):
+                raise NotImplementedError(
+                    f"method '{method}' is one of the reference's comparison baselines; rayen_amd "
+                    "implements the RAYEN projection only")
+            raise NotImplementedError
+        self.args_DC3 = args_DC3
+
+        self.cs = cs
+        self.k = cs.k  # dimension of the ambient space
+        self.n = cs.n  # dimension of the embedded space
+
+        # every row of A_p divided by its slack at z0 (rayen/constraint_module.py:38)
+        D = cs.A_p / ((cs.b_p - cs.A_p @ cs.z0) @ np.ones((1, cs.n)))
+
+        all_P, all_q, all_r = utils.getAllPqrFromQcs(cs.qcs)
+        all_M, all_s, all_c, all_d = utils.getAllMscdFromSocs(cs.socs)
+
+        if cs.has_lmi_constraints:
+            # H = F_k + sum_i y0_i F_i,  H^-1 = L L'  (:43-52); like the reference, the
+            # last slot of the all_F buffer ends up holding H
+            all_F = copy.deepcopy(cs.lmic.all_F)
+            H = np.array(all_F[-1], dtype=np.float64)
+            for i in range(cs.lmic.dim()):
+                H = H + cs.y0[i, 0] * cs.lmic.all_F[i]
+            all_F[-1] = H
+            Hinv = np.linalg.inv(H)
+            self.register_buffer("mHinv", torch.Tensor(-Hinv))
+            self.register_buffer("L", torch.Tensor(np.linalg.cholesky(Hinv)))
+        else:
+            all_F = []
+
+        # buffers follow .to(device) and appear in state_dict under the reference's names (:59-74)
+        self.register_buffer("D", torch.Tensor(D))
+        self.register_buffer("all_P", torch.Tensor(np.array(all_P)))
+        self.register_buffer("all_q", torch.Tensor(np.array(all_q)))
+        self.register_buffer("all_r", torch.Tensor(np.array(all_r)))
+        self.register_buffer("all_M", torch.Tensor(np.array(all_M)))
+        self.register_buffer("all_s", torch.Tensor(np.array(all_s)))
+        self.register_buffer("all_c", torch.Tensor(np.array(all_c)))
+        self.register_buffer("all_d", torch.Tensor(np.array(all_d)))
+        self.register_buffer("all_F", torch.Tensor(np.array(all_F)))
+        self.register_buffer("A_p", torch.Tensor(cs.A_p))
+        self.register_buffer("b_p", torch.Tensor(cs.b_p))
+        self.register_buffer("yp", torch.Tensor(cs.yp))
+        self.register_buffer("NA_E", torch.Tensor(cs.NA_E))
+        self.register_buffer("z0", torch.Tensor(cs.z0))
+        self.register_buffer("y0", torch.Tensor(cs.y0))
+
+        if cs.has_quadratic_constraints:
+            # sigma, phi, delta per quadratic, evaluated at the default dtype like the reference (:99-122)
+            all_delta, all_phi = [], []
+            y0 = self.y0
+            for i in range(self.all_P.shape[0]):
+                P, q, r = self.all_P[i, :, :], self.all_q[i, :, :], self.all_r[i, :, :]
+                g_y0 = 0.5 * y0.T @ P @ y0 + q.T @ y0 + r
+                sigma = 2 * g_y0
+                grad_row = y0.T @ P + q.T
+                all_phi.append(-grad_row / sigma)
+                all_delta.append((grad_row.T @ grad_row - 4 * g_y0 * 0.5 * P) / torch.square(sigma))
+            self.register_buffer("all_delta", torch.stack(all_delta))
+            self.register_buffer("all_phi", torch.stack(all_phi))
+
+        if self.method == 'RAYEN':
+            self.forwardForMethod = self.forwardForRAYEN
+            self.dim_after_map = self.n
+        else:  # 'UU'
+            self.forwardForMethod = self.forwardForUU
+            self.dim_after_map = self.k
+
+        if create_map:
+            utils.verify(input_dim is not None, "input_dim needs to be provided")
+            self.mapper = nn.Linear(input_dim, self.dim_after_map)
+        else:
+            self.mapper = nn.Sequential()  # mapper does nothing
+
+        # fused NaN check: the kernel raises a device flag instead of re-reading y (:531)
+        self.check_nan = True
+        self._device_packs = {}
+        self._consts = None
+
+    # ------------------------------------------------------------------ constant packs
+    def _invalidate_packs(self):
+        self._device_packs = {}
+        self._consts = None
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._invalidate_packs()  # buffers moved or changed dtype
+        return out
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self._invalidate_packs()
+        return out
+
+    def packed_constants(self):
+        """Host-side (fp64) row matrix + segment table derived from the buffers."""
+        if self._consts is None:
+            names = ("D", "NA_E", "z0", "yp", "y0", "all_phi", "all_delta", "all_M", "all_s",
+                     "all_c", "all_d", "all_F", "L")
+            self._consts = _pack.pack_constants({n: getattr(self, n) for n in names if hasattr(self, n)})
+        return self._consts
+
+    def device_pack(self, device):
+        """(pack, pack_id) with the constants resident on ``device`` (built on first use)."""
+        index = device.index if device.index is not None else torch.cuda.current_device()
+        entry = self._device_packs.get(index)
+        if entry is None:
+            dp = _pack.DevicePack(self.packed_constants(), index)
+            entry = (dp, ops.register_pack(dp))
+            self._device_packs[index] = entry
+        return entry
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_device_packs"] = {}   # device handles are not picklable; rebuilt lazily
+        state["_consts"] = None
+        state.pop("forwardForMethod", None)
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self.forwardForMethod = self.forwardForRAYEN if self.method == 'RAYEN' else self.forwardForUU
+
+    # ------------------------------------------------------------------ the projection
+    def _project(self, q):
+        """``q [B, >=n, 1]`` (or ``[B, >=n]``) -> ``(y [B,k], kappa [B])`` through the fused HIP op."""
+        v = q.reshape(q.shape[0], -1)
+        if not v.is_cuda:
+            raise RuntimeError(
+                "rayen_amd.ConstraintModule runs on an MI355X (HIP) device only; got a "
+                f"{v.device} tensor. Call .to('cuda') on the model and the input.")
+        _, pack_id = self.device_pack(v.device)
+        y, kappa, _ = torch.ops.rayen_amd.ray_project(v, pack_id)
+        return y, kappa
+
+    def computeKappa(self, v_bar):
+        """``kappa [B,1,1]`` of directions ``v_bar [B,n,1]`` (rayen/constraint_module.py:351-458)."""
+        v = v_bar.reshape(v_bar.shape[0], -1)
+        dp, _ = self.device_pack(v.device)
+        _, kappa, _ = ops.project_raw(v, dp, want_y=False)
+        return kappa.reshape(-1, 1, 1)
+
+    def forwardForRAYEN(self, q):
+        y, _ = self._project(q)
+        return y.unsqueeze(2)
+
+    def forwardForUU(self, q):
+        return q
+
+    # ------------------------------------------------------------------ reference helper surface
+    def getDimAfterMap(self):
+        return self.dim_after_map
+
+    def gety0(self):
+        return self.getyFromz(self.z0)
+
+    def getyFromz(self, z):
+        return self.NA_E @ z + self.yp
+
+    def getzFromy(self, y):
+        return self.NA_E.T @ (y - self.yp)
+
+    def forward(self, x):
+        # x: [nsib, numel_input_mapper, 1]; after the mapper q is [nsib, numel_output_mapper, 1]
+        q = self.mapper(x.view(x.size(0), -1))
+        q = torch.unsqueeze(q, dim=2)
+
+        y = self.forwardForMethod(q)
+
+        if __debug__ and self.check_nan and self.method == 'RAYEN':
+            dp, _ = self.device_pack(y.device)
+            if int(dp.nan_flag.item()) != 0:
+                dp.nan_flag.zero_()
+                raise AssertionError("the projection produced NaN (NaN in the input?)")
+        return y

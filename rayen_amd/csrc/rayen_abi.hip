@@ -1,0 +1,215 @@
+// C-ABI entry points of librayen_hip.so (declared in include/rayen_hip.h).
+#include "rayen_internal.h"
+
+#include <cstring>
+#include <new>
+
+using namespace rayen;
+
+namespace {
+
+bool device_is_gfx950(int dev) {
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+  return std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+}
+
+int check_table(const RayenPackDesc* d) {
+  if (d->k <= 0 || d->n <= 0 || d->n > d->k || d->n_rows < 0 || d->n_segments < 0) return RAYEN_E_BAD_ARG;
+  if (d->n_rows > 0 && d->W == nullptr) return RAYEN_E_BAD_ARG;
+  if (d->n_segments > 0 && d->segments == nullptr) return RAYEN_E_BAD_ARG;
+  if (d->y0 == nullptr) return RAYEN_E_BAD_ARG;
+  if (!d->out_identity && d->NA_E == nullptr) return RAYEN_E_BAD_ARG;
+  if (d->out_identity && d->k != d->n) return RAYEN_E_BAD_ARG;
+  for (int s = 0; s < d->n_segments; ++s) {
+    const RayenSegment& g = d->segments[s];
+    if (g.type < RAYEN_SEG_LIN || g.type > RAYEN_SEG_LMI) return RAYEN_E_BAD_ARG;
+    if (g.row0 < 0 || g.nrows < 0 || g.row0 + g.nrows > d->n_rows) return RAYEN_E_BAD_ARG;
+    const int aux = (g.type == RAYEN_SEG_QUAD_SYM || g.type == RAYEN_SEG_QUAD_FAC) ? 1
+                    : (g.type == RAYEN_SEG_SOC) ? 2 : 0;
+    if (aux && (g.aux_row < 0 || g.aux_row + aux > d->n_rows)) return RAYEN_E_BAD_ARG;
+    if (g.type == RAYEN_SEG_QUAD_SYM && g.nrows != d->n) return RAYEN_E_BAD_ARG;
+    if (g.type == RAYEN_SEG_LMI && (g.dim <= 0 || g.nrows != g.dim * (g.dim + 1) / 2)) return RAYEN_E_BAD_ARG;
+  }
+  return RAYEN_OK;
+}
+
+template <typename T> GenericImage<T>& image_of(const RayenPack* p);
+template <> GenericImage<float>& image_of<float>(const RayenPack* p) { return p->g32; }
+template <> GenericImage<double>& image_of<double>(const RayenPack* p) { return p->g64; }
+
+int check_device(const RayenPack* p) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return RAYEN_E_NO_DEVICE;
+  return dev == p->device ? RAYEN_OK : RAYEN_E_DEVICE_MISMATCH;
+}
+
+template <typename T>
+int ensure_generic(const RayenPack* p) {
+  std::lock_guard<std::mutex> lock(p->mu);
+  GenericImage<T>& img = image_of<T>(p);
+  if (img.built) return RAYEN_OK;
+  const int rc = generic_build<T>(p, &img);
+  if (rc != RAYEN_OK) { generic_free<T>(&img); return rc; }
+  p->device_bytes += img.bytes;
+  return RAYEN_OK;
+}
+
+int ensure_mfma(const RayenPack* p) {
+  std::lock_guard<std::mutex> lock(p->mu);
+  if (p->m32_tried) return RAYEN_OK;
+  p->m32_tried = true;
+  if (!mfma_eligible(p)) return RAYEN_OK;
+  int64_t bytes = 0;
+  MfmaImage* img = nullptr;
+  const int rc = mfma_build(p, &img, &bytes);
+  if (rc != RAYEN_OK) return rc;
+  p->m32 = img;
+  p->device_bytes += bytes;
+  return RAYEN_OK;
+}
+
+template <typename T>
+int project_generic(const RayenPack* p, const T* v, int64_t B, int64_t ldv, T* y, int64_t ldy, T* kappa,
+                    int32_t* active, int32_t* nan_flag, void* stream) {
+  if (p == nullptr || B < 0 || (B > 0 && v == nullptr) || ldv < p->n || (y != nullptr && ldy < p->k))
+    return RAYEN_E_BAD_ARG;
+  int rc = check_device(p);
+  if (rc) return rc;
+  rc = ensure_generic<T>(p);
+  if (rc) return rc;
+  return generic_forward<T>(p, image_of<T>(p), v, B, ldv, y, ldy, kappa, active, nan_flag,
+                            static_cast<hipStream_t>(stream));
+}
+
+template <typename T>
+int project_bwd(const RayenPack* p, const T* v, int64_t B, int64_t ldv, const T* kappa,
+                const int32_t* active, const T* grad_y, int64_t ldg, T* grad_v, int64_t ldgv, void* stream) {
+  if (p == nullptr || B < 0 || ldv < p->n || ldg < p->k || ldgv < p->n) return RAYEN_E_BAD_ARG;
+  if (B > 0 && (!v || !kappa || !active || !grad_y || !grad_v)) return RAYEN_E_BAD_ARG;
+  int rc = check_device(p);
+  if (rc) return rc;
+  rc = ensure_generic<T>(p);
+  if (rc) return rc;
+  return generic_backward<T>(p, image_of<T>(p), v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv,
+                             static_cast<hipStream_t>(stream));
+}
+
+}  // namespace
+
+extern "C" {
+
+int rayen_abi_version(void) { return RAYEN_ABI_VERSION; }
+
+const char* rayen_strerror(int code) {
+  switch (code) {
+    case RAYEN_OK: return "ok";
+    case RAYEN_E_BAD_ARG: return "bad argument (null pointer, negative size or inconsistent segment table)";
+    case RAYEN_E_ABI: return "ABI version mismatch";
+    case RAYEN_E_NO_DEVICE: return "no usable HIP device (this library targets gfx950 / MI355X)";
+    case RAYEN_E_ALLOC: return "device allocation or upload failed";
+    case RAYEN_E_LAUNCH: return "kernel launch failed";
+    case RAYEN_E_UNSUPPORTED: return "shape or operation not supported by the kernels";
+    case RAYEN_E_DEVICE_MISMATCH: return "the pack lives on another device than the current one";
+    default: return "unknown error code";
+  }
+}
+
+int rayen_pack_create(const RayenPackDesc* desc, RayenPack** out) {
+  if (desc == nullptr || out == nullptr) return RAYEN_E_BAD_ARG;
+  *out = nullptr;
+  if (desc->abi_version != RAYEN_ABI_VERSION) return RAYEN_E_ABI;
+  int rc = check_table(desc);
+  if (rc) return rc;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return RAYEN_E_NO_DEVICE;
+  if (!device_is_gfx950(dev)) return RAYEN_E_NO_DEVICE;
+  RayenPack* p = new (std::nothrow) RayenPack();
+  if (p == nullptr) return RAYEN_E_ALLOC;
+  p->device = dev;
+  p->k = desc->k;
+  p->n = desc->n;
+  p->n_rows = desc->n_rows;
+  p->out_identity = desc->out_identity ? 1 : 0;
+  p->W.assign(desc->W, desc->W + (size_t)desc->n_rows * desc->n);
+  p->y0.assign(desc->y0, desc->y0 + desc->k);
+  p->NA_E.assign((size_t)desc->k * desc->n, 0.0);
+  if (p->out_identity) {
+    for (int i = 0; i < desc->k; ++i) p->NA_E[(size_t)i * desc->n + i] = 1.0;
+  } else {
+    p->NA_E.assign(desc->NA_E, desc->NA_E + (size_t)desc->k * desc->n);
+  }
+  p->segs.assign(desc->segments, desc->segments + desc->n_segments);
+  *out = p;
+  return RAYEN_OK;
+}
+
+void rayen_pack_destroy(RayenPack* p) {
+  if (p == nullptr) return;
+  int prev = -1;
+  const bool switched = hipGetDevice(&prev) == hipSuccess && prev != p->device &&
+                        hipSetDevice(p->device) == hipSuccess;
+  generic_free<float>(&p->g32);
+  generic_free<double>(&p->g64);
+  if (p->m32) mfma_free(p->m32);
+  if (switched) (void)hipSetDevice(prev);
+  delete p;
+}
+
+int rayen_pack_info(const RayenPack* p, RayenPackInfo* info) {
+  if (p == nullptr || info == nullptr) return RAYEN_E_BAD_ARG;
+  std::memset(info, 0, sizeof(*info));
+  info->k = p->k;
+  info->n = p->n;
+  info->n_rows = p->n_rows;
+  info->n_segments = (int32_t)p->segs.size();
+  info->device = p->device;
+  info->mfma_f32 = mfma_eligible(p) ? 1 : 0;
+  int lmi_words = 0;
+  for (const RayenSegment& g : p->segs)
+    if (g.type == RAYEN_SEG_LMI && g.nrows + 4 * g.dim > lmi_words) lmi_words = g.nrows + 4 * g.dim;
+  GenericImage<float> probe;
+  probe.lmi_words = lmi_words;
+  info->generic_block = generic_block_for<float>(p, probe);
+  info->device_bytes = p->device_bytes;
+  return RAYEN_OK;
+}
+
+int rayen_ray_project_generic_f32(const RayenPack* p, const float* v, int64_t B, int64_t ldv, float* y,
+                                  int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
+                                  void* stream) {
+  return project_generic<float>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+}
+
+int rayen_ray_project_f32(const RayenPack* p, const float* v, int64_t B, int64_t ldv, float* y,
+                          int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag, void* stream) {
+  if (p == nullptr || B < 0 || (B > 0 && v == nullptr) || ldv < p->n || (y != nullptr && ldy < p->k))
+    return RAYEN_E_BAD_ARG;
+  int rc = check_device(p);
+  if (rc) return rc;
+  rc = ensure_mfma(p);
+  if (rc) return rc;
+  if (p->m32 != nullptr && y != nullptr)
+    return mfma_forward(p, p->m32, v, B, ldv, y, ldy, kappa, active, nan_flag,
+                        static_cast<hipStream_t>(stream));
+  return project_generic<float>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+}
+
+int rayen_ray_project_f64(const RayenPack* p, const double* v, int64_t B, int64_t ldv, double* y,
+                          int64_t ldy, double* kappa, int32_t* active, int32_t* nan_flag, void* stream) {
+  return project_generic<double>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+}
+
+int rayen_ray_project_bwd_f32(const RayenPack* p, const float* v, int64_t B, int64_t ldv,
+                              const float* kappa, const int32_t* active, const float* grad_y,
+                              int64_t ldg, float* grad_v, int64_t ldgv, void* stream) {
+  return project_bwd<float>(p, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, stream);
+}
+
+int rayen_ray_project_bwd_f64(const RayenPack* p, const double* v, int64_t B, int64_t ldv,
+                              const double* kappa, const int32_t* active, const double* grad_y,
+                              int64_t ldg, double* grad_v, int64_t ldgv, void* stream) {
+  return project_bwd<double>(p, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,449 @@
+// Generic path: one lane = one sample, any shape that fits LDS, fp32 and fp64.
+//
+// Replaces the op chain of rayen/constraint_module.py:351-474 (computeKappa +
+// forwardForRAYEN + getyFromz) with one kernel.  A workgroup of BLOCK lanes owns
+// BLOCK samples.  The block's directions are staged once in LDS, transposed
+// ([n][BLOCK+1], conflict-free both for the coalesced fill and for the
+// lane-per-sample reads).  Every constant is wave-uniform: the rows of W are
+// walked in blocks of eight, stored as Wg[rb][j][8], so the eight multipliers of
+// column j arrive with ONE scalar load (s_load_dwordx8) and feed eight v_fmac
+// whose other operand is the single ds_read of v_j.  All reductions of
+// computeKappa (row max, v'Gv, ||Uv||^2, the SOC quadratic, lambda_max) are
+// lane-local: no cross-lane traffic, no atomics, no second pass over HBM.
+//
+// HBM traffic per sample: n loads + k stores (the algorithmic minimum); the
+// constants stream through the scalar cache / L2.
+#include "rayen_internal.h"
+
+#include <cmath>
+#include <cstring>
+#include <type_traits>
+
+namespace rayen {
+
+template <typename T> struct Num;
+template <> struct Num<float> {
+  static constexpr int bisect_iters = 32;
+  __device__ static float tiny() { return 1.0e-30f; }
+};
+template <> struct Num<double> {
+  static constexpr int bisect_iters = 60;
+  __device__ static double tiny() { return 1.0e-290; }
+};
+
+template <typename T> __device__ __forceinline__ T fma_(T a, T b, T c);
+template <> __device__ __forceinline__ float fma_(float a, float b, float c) { return fmaf(a, b, c); }
+template <> __device__ __forceinline__ double fma_(double a, double b, double c) { return fma(a, b, c); }
+
+// acc[r] = sum_j Wg[rb][j][r] * vT[j][lane]
+template <typename T, int LD>
+__device__ __forceinline__ void dot8(const T* __restrict__ Wg, int rb, int ncols,
+                                     const T* vcol, T (&acc)[kRowBlock]) {
+#pragma unroll
+  for (int r = 0; r < kRowBlock; ++r) acc[r] = T(0);
+  const T* __restrict__ w = Wg + (size_t)rb * (size_t)ncols * kRowBlock;
+  int j = 0;
+  for (; j + 4 <= ncols; j += 4) {
+    const T x0 = vcol[(j + 0) * LD];
+    const T x1 = vcol[(j + 1) * LD];
+    const T x2 = vcol[(j + 2) * LD];
+    const T x3 = vcol[(j + 3) * LD];
+#pragma unroll
+    for (int r = 0; r < kRowBlock; ++r) acc[r] = fma_(w[(j + 0) * kRowBlock + r], x0, acc[r]);
+#pragma unroll
+    for (int r = 0; r < kRowBlock; ++r) acc[r] = fma_(w[(j + 1) * kRowBlock + r], x1, acc[r]);
+#pragma unroll
+    for (int r = 0; r < kRowBlock; ++r) acc[r] = fma_(w[(j + 2) * kRowBlock + r], x2, acc[r]);
+#pragma unroll
+    for (int r = 0; r < kRowBlock; ++r) acc[r] = fma_(w[(j + 3) * kRowBlock + r], x3, acc[r]);
+  }
+  for (; j < ncols; ++j) {
+    const T x0 = vcol[j * LD];
+#pragma unroll
+    for (int r = 0; r < kRowBlock; ++r) acc[r] = fma_(w[j * kRowBlock + r], x0, acc[r]);
+  }
+}
+
+// Largest eigenvalue of the symmetric r x r matrix whose packed lower triangle
+// sits in this lane's LDS column (entry idx at lm[idx * BLOCK]).  Householder
+// tridiagonalisation followed by Sturm-count bisection: backward stable, no
+// convergence test, identical control flow on every lane.  This is the
+// per-sample replacement of torch.linalg.eigvalsh + max (constraint_module.py:424-425).
+template <typename T, int BLOCK>
+__device__ T lambda_max_packed(T* lm, int r) {
+  const int npk = r * (r + 1) / 2;
+  auto A = [&](int i, int j) -> T& { return lm[(size_t)((i * (i + 1)) / 2 + j) * BLOCK]; };  // i >= j
+  if (r == 1) return A(0, 0);
+  T* hv = lm + (size_t)npk * BLOCK;  // Householder vector
+  T* hp = hv + (size_t)r * BLOCK;    // p, then w
+  T* dd = hp + (size_t)r * BLOCK;    // diagonal of T
+  T* e2 = dd + (size_t)r * BLOCK;    // squared off-diagonal of T
+
+  for (int c = 0; c + 2 < r; ++c) {
+    const T x0 = A(c + 1, c);
+    T sigma = T(0);
+    for (int i = c + 2; i < r; ++i) { const T a = A(i, c); sigma = fma_(a, a, sigma); }
+    const T mu = sqrt(fma_(x0, x0, sigma));
+    const bool act = sigma > T(0);
+    const T v0 = (x0 <= T(0)) ? (x0 - mu) : (-sigma / (x0 + mu));
+    const T beta = act ? (T(2) * v0 * v0 / (sigma + v0 * v0)) : T(0);
+    const T inv_v0 = act ? (T(1) / v0) : T(0);
+    hv[(size_t)(c + 1) * BLOCK] = T(1);
+    for (int i = c + 2; i < r; ++i) hv[(size_t)i * BLOCK] = A(i, c) * inv_v0;
+    dd[(size_t)c * BLOCK] = A(c, c);
+    e2[(size_t)c * BLOCK] = act ? (mu * mu) : (x0 * x0);
+
+    T pv = T(0);
+    for (int i = c + 1; i < r; ++i) {
+      T acc = T(0);
+      for (int j = c + 1; j < r; ++j) {
+        const T a = (i >= j) ? A(i, j) : A(j, i);
+        acc = fma_(a, hv[(size_t)j * BLOCK], acc);
+      }
+      acc *= beta;
+      hp[(size_t)i * BLOCK] = acc;
+      pv = fma_(acc, hv[(size_t)i * BLOCK], pv);
+    }
+    const T K = T(0.5) * beta * pv;
+    for (int i = c + 1; i < r; ++i) hp[(size_t)i * BLOCK] -= K * hv[(size_t)i * BLOCK];
+    for (int i = c + 1; i < r; ++i) {
+      const T vi = hv[(size_t)i * BLOCK], wi = hp[(size_t)i * BLOCK];
+      for (int j = c + 1; j <= i; ++j)
+        A(i, j) -= vi * hp[(size_t)j * BLOCK] + wi * hv[(size_t)j * BLOCK];
+    }
+  }
+  dd[(size_t)(r - 2) * BLOCK] = A(r - 2, r - 2);
+  dd[(size_t)(r - 1) * BLOCK] = A(r - 1, r - 1);
+  { const T e = A(r - 1, r - 2); e2[(size_t)(r - 2) * BLOCK] = e * e; }
+
+  // Gershgorin bracket of lambda_max: max diag <= lambda_max <= max(d_i + |e_{i-1}| + |e_i|)
+  T lo = dd[0], hi = dd[0], emax = T(0);
+  {
+    T eprev = T(0);
+    for (int i = 0; i < r; ++i) {
+      const T d = dd[(size_t)i * BLOCK];
+      const T enext = (i + 1 < r) ? sqrt(e2[(size_t)i * BLOCK]) : T(0);
+      lo = (i == 0) ? d : fmax(lo, d);
+      hi = (i == 0) ? (d + enext) : fmax(hi, d + eprev + enext);
+      emax = fmax(emax, enext);
+      eprev = enext;
+    }
+  }
+  const T pivmin = Num<T>::tiny() * fmax(T(1), emax * emax);
+  for (int it = 0; it < Num<T>::bisect_iters; ++it) {
+    const T mid = T(0.5) * (lo + hi);
+    T q = dd[0] - mid;
+    int below = q < T(0);
+    for (int i = 1; i < r; ++i) {
+      if (fabs(q) < pivmin) q = -pivmin;
+      q = dd[(size_t)i * BLOCK] - mid - e2[(size_t)(i - 1) * BLOCK] / q;
+      below += q < T(0);
+    }
+    if (below == r) hi = mid; else lo = mid;  // all eigenvalues < mid  ->  lambda_max < mid
+  }
+  return T(0.5) * (lo + hi);
+}
+
+template <typename T, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void generic_fwd_kernel(
+    const T* __restrict__ Wg, const T* __restrict__ Ng, const T* __restrict__ y0,
+    const GSeg* __restrict__ segs, int n_gseg, int out_nrb, int k, int n, int lmi_words,
+    const T* __restrict__ v, int64_t B, int64_t ldv, T* __restrict__ y, int64_t ldy,
+    T* __restrict__ kappa_out, int32_t* __restrict__ active_out, int32_t* __restrict__ nan_flag) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int LD = BLOCK + 1;
+  const int n_pad = (n + kRowBlock - 1) / kRowBlock * kRowBlock;
+  T* vT = reinterpret_cast<T*>(smem_raw);  // [n_pad][LD]
+  T* sc = vT + (size_t)n_pad * LD;         // [BLOCK] clip factor
+  T* lmi = sc + BLOCK;                     // [lmi_words][BLOCK]
+
+  const int tid = threadIdx.x;
+  const int64_t b0 = (int64_t)blockIdx.x * BLOCK;
+  const int nb = (int)((B - b0) < (int64_t)BLOCK ? (B - b0) : (int64_t)BLOCK);
+
+  // coalesced fill of the transposed tile (zero for the tail samples and the pad rows)
+  for (int idx = tid; idx < BLOCK * n_pad; idx += BLOCK) {
+    const int bl = idx / n_pad;
+    const int j = idx - bl * n_pad;
+    T x = T(0);
+    if (bl < nb && j < n) x = v[(b0 + bl) * ldv + j];
+    vT[j * LD + bl] = x;
+  }
+  __syncthreads();
+
+  const T* vcol = vT + tid;
+  T kap = T(0);
+  int aseg = -1, arow = 0;
+  T acc[kRowBlock];
+
+  for (int s = 0; s < n_gseg; ++s) {
+    const GSeg sg = segs[s];
+    if (sg.type == RAYEN_SEG_LIN) {
+      for (int b = 0; b < sg.nrb; ++b) {
+        dot8<T, LD>(Wg, sg.rb0 + b, n, vcol, acc);
+#pragma unroll
+        for (int r = 0; r < kRowBlock; ++r) {
+          if (acc[r] > kap) { kap = acc[r]; aseg = sg.seg; arow = sg.row0 + b * kRowBlock + r; }
+        }
+      }
+    } else if (sg.type == RAYEN_SEG_QUAD_SYM || sg.type == RAYEN_SEG_QUAD_FAC) {
+      dot8<T, LD>(Wg, sg.aux_rb, n, vcol, acc);
+      const T lin = acc[0];
+      T qf = T(0);
+      for (int b = 0; b < sg.nrb; ++b) {
+        dot8<T, LD>(Wg, sg.rb0 + b, n, vcol, acc);
+        if (sg.type == RAYEN_SEG_QUAD_SYM) {
+#pragma unroll
+          for (int r = 0; r < kRowBlock; ++r) qf = fma_(acc[r], vcol[(b * kRowBlock + r) * LD], qf);
+        } else {
+#pragma unroll
+          for (int r = 0; r < kRowBlock; ++r) qf = fma_(acc[r], acc[r], qf);
+        }
+      }
+      const T kq = lin + sqrt(fmax(qf, T(0)));
+      if (kq > kap) { kap = kq; aseg = sg.seg; arow = 0; }
+    } else if (sg.type == RAYEN_SEG_SOC) {
+      dot8<T, LD>(Wg, sg.aux_rb, n, vcol, acc);
+      const T cr = acc[0], br = acc[1];
+      T mm = T(0);
+      for (int b = 0; b < sg.nrb; ++b) {
+        dot8<T, LD>(Wg, sg.rb0 + b, n, vcol, acc);
+#pragma unroll
+        for (int r = 0; r < kRowBlock; ++r) mm = fma_(acc[r], acc[r], mm);
+      }
+      // a' x^2 + b' x + c' = 0  (constraint_module.py:392-396), a' < 0
+      const T tau = (T)sg.f0, ap = (T)sg.f1;
+      const T cp = mm - cr * cr;
+      const T bp = T(2) * br - T(2) * cr * tau;
+      const T disc = bp * bp - T(4) * ap * cp;
+      T ks = T(0);
+      if (disc >= T(0)) {
+        const T root = sqrt(disc);
+        const T inv2a = T(0.5) / ap;
+        ks = fmax((-bp - root) * inv2a, (-bp + root) * inv2a);
+      }
+      if (ks > kap) { kap = ks; aseg = sg.seg; arow = 0; }
+    } else if (sg.type == RAYEN_SEG_LMI) {
+      T* lm = lmi + tid;
+      for (int b = 0; b < sg.nrb; ++b) {
+        dot8<T, LD>(Wg, sg.rb0 + b, n, vcol, acc);
+#pragma unroll
+        for (int r = 0; r < kRowBlock; ++r) {
+          const int idx = b * kRowBlock + r;
+          if (idx < sg.nrows) lm[(size_t)idx * BLOCK] = acc[r];
+        }
+      }
+      const T lam = lambda_max_packed<T, BLOCK>(lm, sg.dim);
+      if (lam > kap) { kap = lam; aseg = sg.seg; arow = 0; }
+    }
+  }
+
+  const T scale = T(1) / fmax(T(1), kap);
+  const bool live = tid < nb;
+  if (live) {
+    if (kappa_out) kappa_out[b0 + tid] = kap;
+    if (active_out) { active_out[2 * (b0 + tid)] = aseg; active_out[2 * (b0 + tid) + 1] = arow; }
+  }
+  if (y == nullptr) return;
+
+  bool bad = false;
+  if (Ng == nullptr) {
+    // NA_E = I: y = y0 + v * scale, written coalesced from the staged tile
+    sc[tid] = scale;
+    __syncthreads();
+    for (int idx = tid; idx < nb * n; idx += BLOCK) {
+      const int bl = idx / n;
+      const int j = idx - bl * n;
+      const T val = fma_(vT[j * LD + bl], sc[bl], y0[j]);
+      bad |= (val != val);
+      y[(b0 + bl) * ldy + j] = val;
+    }
+  } else {
+    for (int b = 0; b < out_nrb; ++b) {
+      dot8<T, LD>(Ng, b, n, vcol, acc);
+      if (live) {
+#pragma unroll
+        for (int r = 0; r < kRowBlock; ++r) {
+          const int i = b * kRowBlock + r;
+          if (i < k) {
+            const T val = fma_(acc[r], scale, y0[i]);
+            bad |= (val != val);
+            y[(b0 + tid) * ldy + i] = val;
+          }
+        }
+      }
+    }
+  }
+  if (nan_flag && bad) atomicOr(nan_flag, 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side: image construction and launch
+// ---------------------------------------------------------------------------------------------
+
+template <typename T>
+static int upload(const std::vector<T>& host, T** dev, int64_t* bytes) {
+  *dev = nullptr;
+  if (host.empty()) return RAYEN_OK;
+  if (hipMalloc(dev, host.size() * sizeof(T)) != hipSuccess) return RAYEN_E_ALLOC;
+  if (hipMemcpy(*dev, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess)
+    return RAYEN_E_ALLOC;
+  *bytes += (int64_t)(host.size() * sizeof(T));
+  return RAYEN_OK;
+}
+
+// append rows [row0, row0+nrows) of a row-major [*, ncols] matrix as row blocks
+template <typename T>
+static int append_rowblocks(std::vector<T>& out, const double* M, int row0, int nrows, int ncols) {
+  const int nrb = (nrows + kRowBlock - 1) / kRowBlock;
+  const size_t base = out.size();
+  out.resize(base + (size_t)nrb * ncols * kRowBlock, T(0));
+  for (int r = 0; r < nrows; ++r) {
+    const int rb = r / kRowBlock, rr = r % kRowBlock;
+    for (int j = 0; j < ncols; ++j)
+      out[base + ((size_t)rb * ncols + j) * kRowBlock + rr] = (T)M[(size_t)(row0 + r) * ncols + j];
+  }
+  return nrb;
+}
+
+template <typename T>
+int generic_build(const RayenPack* p, GenericImage<T>* img) {
+  std::vector<T> Wg;
+  std::vector<GSeg> gs;
+  int rb = 0, lmi_words = 0;
+  for (size_t s = 0; s < p->segs.size(); ++s) {
+    const RayenSegment& sg = p->segs[s];
+    GSeg g;
+    std::memset(&g, 0, sizeof(g));
+    g.type = sg.type;
+    g.seg = (int32_t)s;
+    g.row0 = sg.row0;
+    g.nrows = sg.nrows;
+    g.dim = sg.dim;
+    g.f0 = sg.f0;
+    g.f1 = sg.f1;
+    g.aux_rb = -1;
+    if (sg.type == RAYEN_SEG_QUAD_SYM || sg.type == RAYEN_SEG_QUAD_FAC) {
+      g.aux_rb = rb;
+      rb += append_rowblocks(Wg, p->W.data(), sg.aux_row, 1, p->n);
+    } else if (sg.type == RAYEN_SEG_SOC) {
+      g.aux_rb = rb;
+      rb += append_rowblocks(Wg, p->W.data(), sg.aux_row, 2, p->n);
+    } else if (sg.type == RAYEN_SEG_LMI) {
+      const int words = sg.nrows + 4 * sg.dim;
+      if (words > lmi_words) lmi_words = words;
+    }
+    g.rb0 = rb;
+    g.nrb = append_rowblocks(Wg, p->W.data(), sg.row0, sg.nrows, p->n);
+    rb += g.nrb;
+    gs.push_back(g);
+  }
+  img->n_rb = rb;
+  img->n_gseg = (int)gs.size();
+  img->lmi_words = lmi_words;
+  int rc = upload(Wg, &img->Wg, &img->bytes);
+  if (rc) return rc;
+  if (!gs.empty()) {
+    if (hipMalloc(&img->segs, gs.size() * sizeof(GSeg)) != hipSuccess) return RAYEN_E_ALLOC;
+    if (hipMemcpy(img->segs, gs.data(), gs.size() * sizeof(GSeg), hipMemcpyHostToDevice) != hipSuccess)
+      return RAYEN_E_ALLOC;
+    img->bytes += (int64_t)(gs.size() * sizeof(GSeg));
+  }
+  std::vector<T> y0(p->y0.begin(), p->y0.end());
+  rc = upload(y0, &img->y0, &img->bytes);
+  if (rc) return rc;
+  if (!p->out_identity) {
+    std::vector<T> Ng;
+    img->out_nrb = append_rowblocks(Ng, p->NA_E.data(), 0, p->k, p->n);
+    rc = upload(Ng, &img->Ng, &img->bytes);
+    if (rc) return rc;
+    // NA_E' for the backward: rows = n, columns = k
+    std::vector<double> NT((size_t)p->n * p->k);
+    for (int i = 0; i < p->k; ++i)
+      for (int j = 0; j < p->n; ++j) NT[(size_t)j * p->k + i] = p->NA_E[(size_t)i * p->n + j];
+    std::vector<T> NTg;
+    append_rowblocks(NTg, NT.data(), 0, p->n, p->k);
+    rc = upload(NTg, &img->NTg, &img->bytes);
+    if (rc) return rc;
+  }
+  img->built = true;
+  return RAYEN_OK;
+}
+
+template <typename T>
+void generic_free(GenericImage<T>* img) {
+  if (img->Wg) (void)hipFree(img->Wg);
+  if (img->Ng) (void)hipFree(img->Ng);
+  if (img->NTg) (void)hipFree(img->NTg);
+  if (img->y0) (void)hipFree(img->y0);
+  if (img->segs) (void)hipFree(img->segs);
+  *img = GenericImage<T>();
+}
+
+template <typename T>
+static size_t generic_lds_bytes(int n, int lmi_words, int block) {
+  const int n_pad = (n + kRowBlock - 1) / kRowBlock * kRowBlock;
+  return sizeof(T) * ((size_t)n_pad * (block + 1) + block + (size_t)lmi_words * block);
+}
+
+constexpr size_t kLdsSoft = 64 * 1024;    // keep >= 2 workgroups per CU when possible
+constexpr size_t kLdsHard = 160 * 1024;   // gfx950 LDS per CU
+
+template <typename T>
+int generic_block_for(const RayenPack* p, const GenericImage<T>& img) {
+  for (int block : {256, 128, 64})
+    if (generic_lds_bytes<T>(p->n, img.lmi_words, block) <= kLdsSoft) return block;
+  if (generic_lds_bytes<T>(p->n, img.lmi_words, 64) <= kLdsHard) return 64;
+  return 0;
+}
+
+template <typename T, int BLOCK>
+static int launch_fwd(const RayenPack* p, const GenericImage<T>& img, const T* v, int64_t B,
+                      int64_t ldv, T* y, int64_t ldy, T* kappa, int32_t* active, int32_t* nan_flag,
+                      hipStream_t stream) {
+  const size_t lds = generic_lds_bytes<T>(p->n, img.lmi_words, BLOCK);
+  auto kern = generic_fwd_kernel<T, BLOCK>;
+  if (lds > 48 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return RAYEN_E_LAUNCH;
+  }
+  const int64_t grid = (B + BLOCK - 1) / BLOCK;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), lds, stream, img.Wg, img.Ng, img.y0,
+                     img.segs, img.n_gseg, img.out_nrb, p->k, p->n, img.lmi_words, v, B, ldv, y, ldy,
+                     kappa, active, nan_flag);
+  return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
+}
+
+template <typename T>
+int generic_forward(const RayenPack* p, const GenericImage<T>& img, const T* v, int64_t B,
+                    int64_t ldv, T* y, int64_t ldy, T* kappa, int32_t* active, int32_t* nan_flag,
+                    hipStream_t stream) {
+  if (B == 0) return RAYEN_OK;
+  switch (generic_block_for<T>(p, img)) {
+    case 256: return launch_fwd<T, 256>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+    case 128: return launch_fwd<T, 128>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+    case 64: return launch_fwd<T, 64>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+    default: return RAYEN_E_UNSUPPORTED;
+  }
+}
+
+template <typename T>
+int generic_backward(const RayenPack*, const GenericImage<T>&, const T*, int64_t, int64_t, const T*,
+                     const int32_t*, const T*, int64_t, T*, int64_t, hipStream_t) {
+  return RAYEN_E_UNSUPPORTED;
+}
+
+#define RAYEN_INSTANTIATE(T)                                                                        \
+  template int generic_build<T>(const RayenPack*, GenericImage<T>*);                               \
+  template void generic_free<T>(GenericImage<T>*);                                                  \
+  template int generic_block_for<T>(const RayenPack*, const GenericImage<T>&);                      \
+  template int generic_forward<T>(const RayenPack*, const GenericImage<T>&, const T*, int64_t,      \
+                                  int64_t, T*, int64_t, T*, int32_t*, int32_t*, hipStream_t);       \
+  template int generic_backward<T>(const RayenPack*, const GenericImage<T>&, const T*, int64_t,     \
+                                   int64_t, const T*, const int32_t*, const T*, int64_t, T*,        \
+                                   int64_t, hipStream_t);
+RAYEN_INSTANTIATE(float)
+RAYEN_INSTANTIATE(double)
+
+}  // namespace rayen

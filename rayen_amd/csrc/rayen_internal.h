@@ -1,0 +1,93 @@
+// Private definitions shared by the translation units of librayen_hip.so.
+// Nothing here is part of the C ABI (include/rayen_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <mutex>
+#include <vector>
+
+#include "rayen_hip.h"
+
+namespace rayen {
+
+constexpr int kRowBlock = 8;  // rows handled together by the generic (lane = sample) path
+
+// Device-side segment record of the generic path.  Row blocks are groups of
+// kRowBlock rows stored as Wg[(rb * n + j) * kRowBlock + r] so that the eight
+// multipliers of column j are one aligned, wave-uniform (scalar) load.
+struct GSeg {
+  int32_t type;
+  int32_t aux_rb;  // row block holding the aux rows (phi | c, b) or -1
+  int32_t rb0;     // first main row block
+  int32_t nrb;     // number of main row blocks
+  int32_t nrows;   // true number of main rows
+  int32_t dim;     // LMI: r
+  int32_t seg;     // index into the caller's segment table (reported in `active`)
+  int32_t row0;    // first logical W row (reported for LIN)
+  double f0, f1;
+};
+
+template <typename T>
+struct GenericImage {
+  bool built = false;
+  T* Wg = nullptr;        // [n_rb, n, 8]
+  T* Ng = nullptr;        // output map NA_E, row-blocked the same way: [out_nrb, n, 8] (null if identity)
+  T* NTg = nullptr;       // NA_E' (rows = n, columns = k) for the backward: [ceil(n/8), k, 8] (null if identity)
+  T* y0 = nullptr;        // [k]
+  GSeg* segs = nullptr;   // [n_gseg]
+  int n_gseg = 0;
+  int n_rb = 0;
+  int out_nrb = 0;
+  int lmi_words = 0;      // per-sample LDS words the largest LMI needs
+  int64_t bytes = 0;
+};
+
+struct MfmaImage;  // rayen_mfma.hip
+
+}  // namespace rayen
+
+struct RayenPack {
+  int device = -1;
+  int k = 0, n = 0, n_rows = 0;
+  int out_identity = 0;
+  std::vector<double> W;         // host copy [n_rows, n]
+  std::vector<double> NA_E;      // host copy [k, n] (identity materialised)
+  std::vector<double> y0;        // host copy [k]
+  std::vector<RayenSegment> segs;
+  mutable std::mutex mu;         // guards the lazily built images
+  mutable rayen::GenericImage<float> g32;
+  mutable rayen::GenericImage<double> g64;
+  mutable rayen::MfmaImage* m32 = nullptr;
+  mutable bool m32_tried = false;
+  mutable int64_t device_bytes = 0;
+};
+
+namespace rayen {
+
+// generic path (rayen_generic.hip)
+template <typename T>
+int generic_build(const RayenPack* p, GenericImage<T>* img);
+template <typename T>
+void generic_free(GenericImage<T>* img);
+template <typename T>
+int generic_block_for(const RayenPack* p, const GenericImage<T>& img);
+template <typename T>
+int generic_forward(const RayenPack* p, const GenericImage<T>& img, const T* v, int64_t B,
+                    int64_t ldv, T* y, int64_t ldy, T* kappa, int32_t* active, int32_t* nan_flag,
+                    hipStream_t stream);
+template <typename T>
+int generic_backward(const RayenPack* p, const GenericImage<T>& img, const T* v, int64_t B,
+                     int64_t ldv, const T* kappa, const int32_t* active, const T* grad_y,
+                     int64_t ldg, T* grad_v, int64_t ldgv, hipStream_t stream);
+
+// fp32 MFMA path (rayen_mfma.hip)
+bool mfma_eligible(const RayenPack* p);
+int mfma_build(const RayenPack* p, MfmaImage** out, int64_t* bytes);
+void mfma_free(MfmaImage* img);
+int mfma_forward(const RayenPack* p, const MfmaImage* img, const float* v, int64_t B, int64_t ldv,
+                 float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
+                 hipStream_t stream);
+
+}  // namespace rayen

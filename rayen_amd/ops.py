@@ -1,0 +1,135 @@
+"""``torch.library`` custom ops in front of the C ABI (``include/rayen_hip.h``).
+
+``rayen_amd::ray_project(v, pack_id) -> (y, kappa, active)`` is the fused
+replacement of ``forwardForRAYEN`` (rayen/constraint_module.py:468-474); it is
+asynchronous on torch's current HIP stream and differentiable (the backward is
+``rayen_amd::ray_project_bwd``, another HIP kernel).  PyTorch is used here for
+device memory and the stream only.
+
+There is no CPU or eager fallback: a tensor that does not live on a HIP device,
+or a dtype other than float32/float64, raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import weakref
+
+import torch
+
+from . import _lib
+
+_packs = weakref.WeakValueDictionary()
+_next_id = [1]
+
+
+def register_pack(pack) -> int:
+    pack_id = _next_id[0]
+    _next_id[0] += 1
+    _packs[pack_id] = pack
+    return pack_id
+
+
+def _pack(pack_id):
+    pack = _packs.get(pack_id)
+    if pack is None or pack.handle is None:
+        raise RuntimeError(f"rayen_amd: constant pack {pack_id} no longer exists")
+    return pack
+
+
+def _check_input(v, pack):
+    if not v.is_cuda:
+        raise RuntimeError("rayen_amd: the projection runs on an MI355X (HIP) device only; got a "
+                           f"{v.device} tensor. Move the module and its input to 'cuda'.")
+    if v.dtype not in (torch.float32, torch.float64):
+        raise RuntimeError(f"rayen_amd: unsupported dtype {v.dtype} (float32 and float64 only)")
+    if v.dim() != 2 or v.shape[1] < pack.consts.n:
+        raise RuntimeError(f"rayen_amd: expected v of shape [B, >= {pack.consts.n}], got {tuple(v.shape)}")
+    if v.device.index != pack.device_index:
+        raise RuntimeError("rayen_amd: input and constant pack live on different devices")
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_FWD = {(torch.float32, False): "rayen_ray_project_f32", (torch.float64, False): "rayen_ray_project_f64",
+        (torch.float32, True): "rayen_ray_project_generic_f32",
+        (torch.float64, True): "rayen_ray_project_f64"}
+
+
+def project_raw(v, pack, want_y=True, force_generic=False):
+    """Direct call of the C ABI on an existing ``DevicePack``; returns (y|None, kappa, active)."""
+    _check_input(v, pack)
+    if v.stride(1) != 1:
+        v = v.contiguous()
+    B = v.shape[0]
+    k = pack.consts.k
+    y = torch.empty((B, k), dtype=v.dtype, device=v.device) if want_y else None
+    kappa = torch.empty((B,), dtype=v.dtype, device=v.device)
+    active = torch.empty((B, 2), dtype=torch.int32, device=v.device)
+    fn = getattr(_lib.load(), _FWD[(v.dtype, bool(force_generic))])
+    with torch.cuda.device(v.device):
+        code = fn(pack.handle, _ptr(v), B, v.stride(0) if B else pack.consts.n, _ptr(y), k,
+                  _ptr(kappa), _ptr(active), _ptr(pack.nan_flag), _stream())
+    _lib.check(code, "rayen_ray_project")
+    return y, kappa, active
+
+
+@torch.library.custom_op("rayen_amd::ray_project", mutates_args=())
+def ray_project(v: torch.Tensor, pack_id: int) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    y, kappa, active = project_raw(v, _pack(pack_id))
+    return y, kappa, active
+
+
+@ray_project.register_fake
+def _(v, pack_id):
+    pack = _pack(pack_id)
+    B = v.shape[0]
+    return (v.new_empty((B, pack.consts.k)), v.new_empty((B,)),
+            v.new_empty((B, 2), dtype=torch.int32))
+
+
+@torch.library.custom_op("rayen_amd::ray_project_bwd", mutates_args=())
+def ray_project_bwd(v: torch.Tensor, kappa: torch.Tensor, active: torch.Tensor,
+                    grad_y: torch.Tensor, pack_id: int) -> torch.Tensor:
+    pack = _pack(pack_id)
+    _check_input(v, pack)
+    if v.stride(1) != 1:
+        v = v.contiguous()
+    grad_y = grad_y.contiguous()
+    B = v.shape[0]
+    grad_v = torch.zeros_like(v)
+    name = "rayen_ray_project_bwd_f32" if v.dtype == torch.float32 else "rayen_ray_project_bwd_f64"
+    with torch.cuda.device(v.device):
+        code = getattr(_lib.load(), name)(pack.handle, _ptr(v), B, v.stride(0) if B else pack.consts.n,
+                                          _ptr(kappa), _ptr(active), _ptr(grad_y), grad_y.shape[1],
+                                          _ptr(grad_v), grad_v.stride(0) if B else pack.consts.n,
+                                          _stream())
+    _lib.check(code, "rayen_ray_project_bwd")
+    return grad_v
+
+
+@ray_project_bwd.register_fake
+def _(v, kappa, active, grad_y, pack_id):
+    return torch.empty_like(v)
+
+
+def _setup_context(ctx, inputs, output):
+    v, pack_id = inputs
+    _, kappa, active = output
+    ctx.pack_id = pack_id
+    ctx.save_for_backward(v, kappa, active)
+
+
+def _backward(ctx, grad_y, grad_kappa, grad_active):
+    v, kappa, active = ctx.saved_tensors
+    if grad_y is None:
+        return torch.zeros_like(v), None
+    return torch.ops.rayen_amd.ray_project_bwd(v, kappa, active, grad_y, ctx.pack_id), None
+
+
+ray_project.register_autograd(_backward, setup_context=_setup_context)

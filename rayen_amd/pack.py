@@ -1,0 +1,199 @@
+"""Fold the layer's constant buffers into one row matrix ``W`` + a segment table.
+
+Everything ``computeKappa`` (rayen/constraint_module.py:351-458) does before its
+per-sample reductions is linear in the direction ``v``:
+
+=========  ============================================  =================================
+family     rows of ``W`` (all have ``n`` columns)          reduction (kernel epilogue)
+=========  ============================================  =================================
+LIN        ``D``                                          ``relu(max_i D_i v)``         CM:353
+QUAD_SYM   ``phi NA_E`` ; ``G = NA_E' delta NA_E``        ``phi.v + sqrt(v'Gv)``        CM:374
+QUAD_FAC   ``phi NA_E`` ; ``U`` with ``U'U = G``          ``phi.v + ||Uv||``  (low rank)
+SOC        ``c'NA_E``, ``(M'beta)'NA_E`` ; ``M NA_E``     root of ``a'x^2+b'x+c'``      CM:383-399
+LMI        packed lower triangle of ``-L'F_a L`` . NA_E   ``relu(lambda_max)``          CM:401-449
+=========  ============================================  =================================
+
+and the output is ``y = (NA_E z0 + yp) + NA_E v / max(1, kappa)`` (CM:468-474, 512-514).
+The products with ``NA_E`` are folded in here, once, in fp64, so the kernels never
+form ``rho = NA_E v``.  The constants are taken from the module's *buffers* (the
+same tensors the reference reads in its forward), upcast to fp64.
+
+Row-count reductions that keep the value of every reduction unchanged:
+all-zero ``D`` rows are dropped (``relu`` makes them no-ops); an SOC block ``M NA_E``
+with more rows than columns is replaced by its triangular QR factor (same
+``||M NA_E v||``); a quadratic whose ``G`` has numerical rank ``<= n/2`` is stored as
+the factor ``U`` (rank rows instead of n), which also makes its radicand a sum of
+squares.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+
+
+@dataclass
+class Segment:
+    type: int
+    row0: int
+    nrows: int
+    aux_row: int = -1
+    dim: int = 0
+    f0: float = 0.0
+    f1: float = 0.0
+
+
+@dataclass
+class PackedConstants:
+    """Host-side (fp64) description handed to ``rayen_pack_create``."""
+    k: int
+    n: int
+    W: np.ndarray                      # [n_rows, n]
+    segments: list = field(default_factory=list)
+    NA_E: np.ndarray = None            # [k, n]
+    y0: np.ndarray = None              # [k]  (= NA_E z0 + yp)
+    out_identity: bool = False
+
+    @property
+    def n_rows(self):
+        return self.W.shape[0]
+
+
+def _f64(t):
+    if t is None:
+        return None
+    if hasattr(t, "detach"):
+        t = t.detach().cpu().numpy()
+    return np.asarray(t, dtype=np.float64)
+
+
+def _buffer_eps(t):
+    if hasattr(t, "dtype") and str(t.dtype).endswith("float64"):
+        return np.finfo(np.float64).eps
+    return np.finfo(np.float32).eps
+
+
+def pack_constants(buffers: dict, low_rank: bool = True) -> PackedConstants:
+    """``buffers``: the module's ``D, NA_E, z0, yp, y0, all_phi, all_delta, all_M, all_s, all_c,
+    all_d, all_F, L`` (torch tensors or arrays; absent/empty families may be missing)."""
+    eps = _buffer_eps(buffers["D"])
+    D = _f64(buffers["D"])
+    N = _f64(buffers["NA_E"])
+    k, n = N.shape
+    y0 = _f64(buffers["y0"]).reshape(k)
+    z0 = _f64(buffers["z0"]).reshape(n)
+    yp = _f64(buffers["yp"]).reshape(k)
+
+    rows, segments = [], []
+
+    def add_rows(block):
+        start = sum(r.shape[0] for r in rows)
+        rows.append(np.asarray(block, dtype=np.float64).reshape(-1, n))
+        return start
+
+    # ---- linear (CM:38, CM:353)
+    keep = np.any(D != 0.0, axis=1)
+    if np.any(keep):
+        row0 = add_rows(D[keep])
+        segments.append(Segment(_lib.SEG_LIN, row0, int(np.count_nonzero(keep))))
+
+    # ---- convex quadratic (CM:99-122, CM:374)
+    phi = _f64(buffers.get("all_phi"))
+    delta = _f64(buffers.get("all_delta"))
+    if phi is not None and phi.ndim == 3:
+        for i in range(phi.shape[0]):
+            aux = add_rows(phi[i].reshape(1, k) @ N)
+            G = N.T @ delta[i] @ N
+            G = 0.5 * (G + G.T)
+            lam, vec = np.linalg.eigh(G)
+            lam_max = max(float(lam[-1]), 0.0)
+            big = lam > 16.0 * eps * lam_max
+            rank = int(np.count_nonzero(big))
+            if low_rank and lam_max > 0.0 and rank <= n // 2:
+                U = (np.sqrt(lam[big])[:, None]) * vec[:, big].T
+                row0 = add_rows(U)
+                segments.append(Segment(_lib.SEG_QUAD_FAC, row0, rank, aux_row=aux))
+            else:
+                row0 = add_rows(G)
+                segments.append(Segment(_lib.SEG_QUAD_SYM, row0, n, aux_row=aux))
+
+    # ---- second-order cone (CM:383-399)
+    M_all = _f64(buffers.get("all_M"))
+    if M_all is not None and M_all.ndim == 3:
+        s_all, c_all, d_all = _f64(buffers["all_s"]), _f64(buffers["all_c"]), _f64(buffers["all_d"])
+        y0c = y0.reshape(k, 1)
+        for j in range(M_all.shape[0]):
+            M, s, c, d = M_all[j], s_all[j], c_all[j], d_all[j]
+            beta = M @ y0c + s
+            tau = float((c.T @ y0c + d).item())
+            MN = M @ N
+            aux = add_rows(np.concatenate((c.T @ N, beta.T @ MN), axis=0))
+            if MN.shape[0] > n:
+                MN = np.linalg.qr(MN, mode="r")
+            row0 = add_rows(MN)
+            segments.append(Segment(_lib.SEG_SOC, row0, MN.shape[0], aux_row=aux,
+                                    f0=tau, f1=float((beta.T @ beta).item()) - tau * tau))
+
+    # ---- LMI (CM:43-52, CM:401-449)
+    F = _f64(buffers.get("all_F"))
+    if F is not None and F.ndim == 3:
+        L = _f64(buffers["L"])
+        r = L.shape[0]
+        G_a = -np.einsum("pi,aij,jq->apq", L.T, F[:-1], L)      # [k, r, r], symmetric
+        G_b = np.einsum("ab,apq->bpq", N, G_a)                   # fold NA_E: [n, r, r]
+        G_b = 0.5 * (G_b + np.transpose(G_b, (0, 2, 1)))
+        il, jl = np.tril_indices(r)                              # packed index p(p+1)/2 + q, p >= q
+        row0 = add_rows(G_b[:, il, jl].T)
+        segments.append(Segment(_lib.SEG_LMI, row0, len(il), dim=r))
+
+    W = np.concatenate(rows, axis=0) if rows else np.zeros((0, n))
+    identity = (k == n) and np.array_equal(N, np.eye(k))
+    return PackedConstants(k=k, n=n, W=np.ascontiguousarray(W), segments=segments,
+                           NA_E=np.ascontiguousarray(N), y0=N @ z0 + yp, out_identity=identity)
+
+
+def _as_double_ptr(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+class DevicePack:
+    """Owner of one ``RayenPack*`` (constants resident on one HIP device)."""
+
+    def __init__(self, consts: PackedConstants, device_index: int):
+        import torch
+        self.consts = consts
+        self.device_index = int(device_index)
+        lib = _lib.load()
+        segs = (_lib.RayenSegment * max(1, len(consts.segments)))()
+        for i, s in enumerate(consts.segments):
+            segs[i] = _lib.RayenSegment(s.type, s.row0, s.nrows, s.aux_row, s.dim, 0, s.f0, s.f1)
+        W = np.ascontiguousarray(consts.W, dtype=np.float64)
+        N = np.ascontiguousarray(consts.NA_E, dtype=np.float64)
+        y0 = np.ascontiguousarray(consts.y0, dtype=np.float64)
+        desc = _lib.RayenPackDesc(_lib.ABI_VERSION, consts.k, consts.n, W.shape[0],
+                                  len(consts.segments), int(consts.out_identity),
+                                  _as_double_ptr(W), segs, _as_double_ptr(N), _as_double_ptr(y0))
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device_index):
+            _lib.check(lib.rayen_pack_create(ctypes.byref(desc), ctypes.byref(handle)), "rayen_pack_create")
+            self.nan_flag = torch.zeros(1, dtype=torch.int32, device=f"cuda:{self.device_index}")
+        self.handle = handle
+
+    def info(self):
+        out = _lib.RayenPackInfo()
+        _lib.check(_lib.load().rayen_pack_info(self.handle, ctypes.byref(out)), "rayen_pack_info")
+        return out
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _lib.load().rayen_pack_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover - interpreter shutdown order
+        try:
+            self.close()
+        except Exception:
+            pass

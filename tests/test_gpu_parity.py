@@ -1,0 +1,242 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the reference's golden vectors,
+the CPU oracle, closed-form answers and size-independent properties.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden_names, load_golden, rel_err_rows, csd_from_cs, raw_from_cs
+from oracle import rayen_oracle as oracle
+from rayen_amd import constraints, ops, workloads
+from rayen_amd.constraint_module import ConstraintModule
+
+pytestmark = pytest.mark.gpu
+
+FP32_TOL = 1e-5     # BASELINE.json: "within 1e-5 relative fp32" (per-sample inf-norm relative error)
+FP64_TOL = 1e-9
+VIOLATION_TOL = 1e-6
+
+
+def _layer(raw_or_cs, dtype=torch.float32, **kw):
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        cs = raw_or_cs if isinstance(raw_or_cs, constraints.ConvexConstraints) \
+            else workloads.build_constraints(raw_or_cs)
+        return cs, ConstraintModule(cs, method="RAYEN", create_map=False, **kw).to("cuda")
+    finally:
+        torch.set_default_dtype(prev)
+
+
+def _to_my_basis(cs, csd_ref, x, dtype):
+    R = cs.NA_E.T @ csd_ref["NA_E"]
+    v = x[:, :, 0].astype(np.float64) @ R.T
+    return torch.tensor(v, dtype=dtype).unsqueeze(2)
+
+
+def _oracle_forward(cs, x_cpu, dtype):
+    return oracle.forward(oracle.precompute(csd_from_cs(cs), dtype), x_cpu.to(dtype)).numpy()[:, :, 0]
+
+
+# --------------------------------------------------------------------------- golden vectors
+@pytest.mark.parametrize("name", golden_names())
+@pytest.mark.parametrize("tag,dtype,tol", [("32", torch.float32, FP32_TOL), ("64", torch.float64, FP64_TOL)])
+def test_golden(name, tag, dtype, tol):
+    raw, csd, z = load_golden(name)
+    cs, layer = _layer(raw, dtype)
+    x = _to_my_basis(cs, csd, z["x"], dtype)
+    y = layer(x.cuda()).cpu().numpy()[:, :, 0]
+    assert y.shape == z["y" + tag].shape
+    assert np.max(rel_err_rows(y, z["y" + tag])) <= tol
+    assert oracle.max_violation(raw, y) <= (VIOLATION_TOL if tag == "32" else 1e-11)
+    # the computeKappa helper on normalised directions
+    v_bar = torch.nn.functional.normalize(x[:, 0:cs.n, 0:1], dim=1)
+    kb = layer.computeKappa(v_bar.cuda()).cpu().numpy()[:, 0, 0]
+    ref = z["kappa_bar" + tag]
+    assert kb.shape == ref.shape
+    assert np.max(np.abs(kb - ref) / np.maximum(1.0, np.abs(ref))) <= 20 * tol
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_generic_fp32_kernel(name):
+    """Same vectors through the generic (lane = sample) fp32 kernel, whatever the dispatcher prefers."""
+    raw, csd, z = load_golden(name)
+    cs, layer = _layer(raw, torch.float32)
+    x = _to_my_basis(cs, csd, z["x"], torch.float32).cuda()
+    dp, _ = layer.device_pack(x.device)
+    y, kappa, active = ops.project_raw(x.reshape(x.shape[0], -1), dp, force_generic=True)
+    assert np.max(rel_err_rows(y.cpu().numpy(), z["y32"])) <= FP32_TOL
+    assert bool((kappa >= 0).all())
+    a = active.cpu().numpy()
+    assert np.all((a[:, 0] >= -1) & (a[:, 0] < len(dp.consts.segments)))
+    assert np.all((a[:, 0] == -1) == (kappa.cpu().numpy() == 0))
+
+
+# --------------------------------------------------------------------------- oracle on fresh seeds
+@pytest.mark.parametrize("name,B", [("c1", 500), ("c2", 4096), ("c3", 4096), ("c4", 2048), ("c5", 4096)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, FP32_TOL), (torch.float64, FP64_TOL)])
+def test_against_oracle(name, B, dtype, tol):
+    raw = workloads.make_raw(name, seed=21)
+    cs, layer = _layer(raw, dtype)
+    gen = torch.Generator().manual_seed(5)
+    rng = workloads.CONFIGS[name][3]
+    x = torch.empty(B, cs.n, 1, dtype=torch.float32).uniform_(-rng, rng, generator=gen).to(dtype)
+    y = layer(x.cuda()).cpu().numpy()[:, :, 0]
+    y_ref = _oracle_forward(cs, x, dtype)
+    assert np.max(rel_err_rows(y, y_ref)) <= tol
+    assert oracle.max_violation(raw, y) <= (VIOLATION_TOL if dtype == torch.float32 else 1e-11)
+
+
+# --------------------------------------------------------------------------- closed-form answers
+def _run(layer, v):
+    return layer(torch.tensor(v, dtype=torch.float32).unsqueeze(2).cuda()).cpu().numpy()[:, :, 0].astype(np.float64)
+
+
+def test_known_answer_sphere():
+    rho = 2.0
+    E = np.eye(3) / rho ** 2
+    qc = constraints.ConvexQuadraticConstraint(2 * E, np.zeros((3, 1)), np.array([[-1.0]]))
+    cs = constraints.ConvexConstraints(qcs=[qc], y0=np.zeros((3, 1)))
+    _, layer = _layer(cs)
+    v = np.random.default_rng(0).uniform(-5, 5, size=(777, 3))
+    want = v * np.minimum(1.0, rho / np.linalg.norm(v, axis=1))[:, None]
+    assert np.max(np.abs(_run(layer, v) - want)) < 1e-5
+
+
+def test_known_answer_cube_and_halfspace():
+    cs = workloads.build_constraints(workloads.cube())
+    _, layer = _layer(cs)
+    v = np.random.default_rng(1).uniform(-5, 5, size=(500, 3))
+    want = 0.5 + v / np.maximum(1.0, 2 * np.max(np.abs(v), axis=1))[:, None]
+    assert np.max(np.abs(_run(layer, v) - want)) < 1e-5
+
+    a = np.array([[1.0, -2.0, 0.5]])
+    y0 = np.array([[0.1], [0.2], [0.3]])
+    lc = constraints.LinearConstraint(a, np.array([[2.0]]), None, None)
+    cs = constraints.ConvexConstraints(lc=lc, y0=y0, do_preprocessing_linear=False)
+    _, layer = _layer(cs)
+    kappa = np.maximum(0.0, (v @ a.T)[:, 0] / (2.0 - float(a @ y0)))
+    want = y0.T + v / np.maximum(1.0, kappa)[:, None]
+    assert np.max(np.abs(_run(layer, v) - want)) < 1e-5
+
+
+def test_known_answer_soc_cone():
+    """||(y1,y2)|| <= y3 from y0 = (0,0,1): first positive root of ||v12|| t = 1 + v3 t."""
+    M = np.array([[1.0, 0, 0], [0, 1.0, 0], [0, 0, 0]])
+    soc = constraints.SOCConstraint(M, np.zeros((3, 1)), np.array([[0.0], [0.0], [1.0]]), np.array([[0.0]]))
+    y0 = np.array([[0.0], [0.0], [1.0]])
+    cs = constraints.ConvexConstraints(socs=[soc], y0=y0)
+    _, layer = _layer(cs)
+    v = np.random.default_rng(2).uniform(-5, 5, size=(600, 3))
+    kappa = np.maximum(0.0, np.linalg.norm(v[:, :2], axis=1) - v[:, 2])   # 1/t*
+    want = y0.T + v / np.maximum(1.0, kappa)[:, None]
+    assert np.max(np.abs(_run(layer, v) - want)) < 1e-5
+
+
+def test_known_answer_psd_cone():
+    """[[y1,y2],[y2,y3]] >= 0 from y0 = (1,0,1) = I: kappa = -lambda_min([[v1,v2],[v2,v3]])."""
+    F = [np.array([[1.0, 0], [0, 0]]), np.array([[0, 1.0], [1.0, 0]]), np.array([[0, 0], [0, 1.0]]),
+         np.zeros((2, 2))]
+    y0 = np.array([[1.0], [0.0], [1.0]])
+    cs = constraints.ConvexConstraints(lmic=constraints.LMIConstraint(F), y0=y0)
+    _, layer = _layer(cs)
+    v = np.random.default_rng(3).uniform(-5, 5, size=(600, 3))
+    lam_min = 0.5 * (v[:, 0] + v[:, 2]) - np.sqrt(0.25 * (v[:, 0] - v[:, 2]) ** 2 + v[:, 1] ** 2)
+    kappa = np.maximum(0.0, -lam_min)
+    want = y0.T + v / np.maximum(1.0, kappa)[:, None]
+    assert np.max(np.abs(_run(layer, v) - want)) < 2e-5
+
+
+# --------------------------------------------------------------------------- edge cases
+def test_edge_shapes_and_strides():
+    raw = workloads.make_raw("c2", seed=4)
+    cs, layer = _layer(raw)
+    # empty batch
+    y = layer(torch.zeros(0, cs.n, 1, device="cuda"))
+    assert y.shape == (0, cs.k, 1)
+    gen = torch.Generator().manual_seed(9)
+    for B in (1, 63, 64, 65, 257, 1000):                # ragged tails around the wave / block sizes
+        x = torch.empty(B, cs.n, 1).uniform_(-1, 1, generator=gen)
+        y = layer(x.cuda()).cpu().numpy()[:, :, 0]
+        assert np.max(rel_err_rows(y, _oracle_forward(cs, x, torch.float32))) <= FP32_TOL
+    # wider input than n: only the first n columns are read (constraint_module.py:469)
+    x = torch.empty(300, cs.n + 5, 1).uniform_(-1, 1, generator=gen)
+    y = layer(x.cuda()).cpu().numpy()[:, :, 0]
+    assert np.max(rel_err_rows(y, _oracle_forward(cs, x[:, :cs.n], torch.float32))) <= FP32_TOL
+    # image-like input is flattened (constraint_module.py:525)
+    x4 = x[:, :cs.n].reshape(300, 4, cs.n // 4, 1)
+    y4 = layer(x4.cuda()).cpu().numpy()[:, :, 0]
+    assert np.array_equal(y4, layer(x[:, :cs.n].cuda()).cpu().numpy()[:, :, 0])
+
+
+def test_zero_tiny_and_huge_directions():
+    raw = workloads.make_raw("c3", seed=6)
+    cs, layer = _layer(raw)
+    y0 = cs.y0[:, 0]
+    x = torch.zeros(4, cs.n, 1)
+    x[1] = 1e-6
+    x[2] = 1e6
+    x[3, 0] = -1e30
+    y = layer(x.cuda()).cpu().numpy()[:, :, 0].astype(np.float64)
+    assert np.array_equal(y[0], y0.astype(np.float32).astype(np.float64))   # v = 0 -> exactly y0
+    assert np.allclose(y[1], y0 + 1e-6, atol=1e-9)                           # interior: unclipped
+    assert np.all(np.isfinite(y))
+    assert oracle.max_violation(raw, y) <= VIOLATION_TOL
+
+
+def test_nan_input_raises_like_the_reference():
+    raw = workloads.make_raw("c2", seed=4)
+    cs, layer = _layer(raw)
+    x = torch.zeros(8, cs.n, 1)
+    x[3, 2] = float("nan")
+    with pytest.raises(AssertionError):
+        layer(x.cuda())
+    layer(torch.zeros(8, cs.n, 1).cuda())          # the flag is cleared after it fired
+
+
+def test_module_with_mapper_in_a_sequential():
+    """readme.md:76-78 usage: the layer owns an nn.Linear mapper and sits at the end of a model."""
+    raw = workloads.make_raw("c2", seed=8)
+    cs = workloads.build_constraints(raw)
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(3, 64), torch.nn.ReLU(),
+                                ConstraintModule(cs, input_dim=64, create_map=True)).cuda()
+    x = torch.empty(500, 3, 1).uniform_(-1, 1)
+    y = model(x.cuda())
+    assert y.shape == (500, cs.k, 1)
+    q = model[:3](x.cuda()) @ model[3].mapper.weight.T + model[3].mapper.bias
+    y_ref = _oracle_forward(cs, q.detach().cpu().unsqueeze(2), torch.float32)
+    assert np.max(rel_err_rows(y.detach().cpu().numpy()[:, :, 0], y_ref)) <= FP32_TOL
+
+
+# --------------------------------------------------------------------------- full-size properties
+@pytest.mark.parametrize("name", ["c3", "c4", "c5"])
+def test_full_size_properties(name):
+    """BASELINE.json batch sizes: feasibility, scale invariance once clipped, linearity inside."""
+    B = min(workloads.CONFIGS[name][2], 262144)
+    raw = workloads.make_raw(name, seed=0)
+    cs, layer = _layer(raw)
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.empty(B, cs.n, 1, device="cuda").uniform_(-1, 1, generator=gen)
+    y = layer(x)
+    assert y.shape == (B, cs.k, 1)
+    assert bool(torch.isfinite(y).all())
+    yc = y[:, :, 0].cpu().numpy()
+    res = oracle.residuals(raw, yc)
+    worst = max(float(np.max(r)) for r in res.values())
+    count = sum(int(np.count_nonzero(r > VIOLATION_TOL)) for r in res.values())
+    assert worst <= VIOLATION_TOL
+    assert count == 0
+    # clipped samples: y(t v) == y(v) for t > 1 (same ray, same boundary point)
+    kappa = layer.computeKappa(x)[:, 0, 0]
+    clipped = kappa > 1.5
+    assert int(clipped.sum()) > B // 2
+    y3 = layer(3.0 * x)[:, :, 0]
+    d = (y3 - y[:, :, 0])[clipped].abs().max().item()
+    assert d <= 2e-5 * max(1.0, float(np.max(np.abs(yc))))
+    # interior samples: the map is the affine lift y0 + NA_E v
+    small = 1e-3 * x
+    lift = layer.gety0()[:, 0][None, :] + small[:, :, 0] @ layer.NA_E.T
+    assert (layer(small)[:, :, 0] - lift).abs().max().item() <= 1e-6
+    # order independence: a permuted batch gives the permuted result bit-for-bit
+    perm = torch.randperm(B, device="cuda", generator=gen)
+    assert torch.equal(layer(x[perm]), y[perm])

@@ -1,0 +1,136 @@
+"""Host logic without a GPU: constraint preprocessing, module buffers, constant packing."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden_names, load_golden, rel_err_rows, csd_from_cs
+from oracle import rayen_oracle as oracle
+from packed_eval import evaluate
+from rayen_amd import _lib, workloads
+from rayen_amd.constraint_module import ConstraintModule
+from rayen_amd.pack import pack_constants
+
+
+def _module_from_raw(raw, dtype):
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        cs = workloads.build_constraints(raw)
+        return cs, ConstraintModule(cs, method="RAYEN", create_map=False)
+    finally:
+        torch.set_default_dtype(prev)
+
+
+def _to_my_basis(cs, csd_ref, x):
+    """Golden inputs are coordinates in the reference's null-space basis; re-express them in ours."""
+    R = cs.NA_E.T @ csd_ref["NA_E"]                       # orthogonal n x n
+    return (x[:, :, 0].astype(np.float64) @ R.T)
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_preprocessing_matches_reference(name):
+    """ConvexConstraints with explicit y0: same subspace, same A_p/b_p/yp/z0 up to the basis choice."""
+    raw, csd, z = load_golden(name)
+    cs = workloads.build_constraints(raw)
+    assert (cs.k, cs.n) == (csd["NA_E"].shape[0], csd["NA_E"].shape[1])
+    # same subspace: projectors agree
+    assert np.allclose(cs.NA_E @ cs.NA_E.T, csd["NA_E"] @ csd["NA_E"].T, atol=1e-12)
+    assert np.allclose(cs.yp, csd["yp"], atol=1e-12)
+    assert np.allclose(cs.NA_E @ cs.z0, csd["NA_E"] @ csd["z0"], atol=1e-12)
+    assert np.allclose(cs.b_p, csd["b_p"], atol=1e-12)
+    R = cs.NA_E.T @ csd["NA_E"]
+    assert np.allclose(cs.A_p @ R, csd["A_p"], atol=1e-12)
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_module_buffers_match_reference(name):
+    """Buffers the reference registers (D, all_phi, all_delta, L) come out the same at fp32 and fp64."""
+    raw, csd, z = load_golden(name)
+    for tag, dtype, tol in (("64", torch.float64, 1e-12), ("32", torch.float32, 2e-6)):
+        cs, layer = _module_from_raw(raw, dtype)
+        if np.allclose(cs.NA_E, csd["NA_E"]):
+            ref = z["buf_D" + tag]
+            assert np.max(np.abs(layer.D.numpy() - ref)) <= tol * max(1.0, np.max(np.abs(ref)))
+        for bname in ("all_phi", "all_delta", "L"):
+            key = f"buf_{bname}{tag}"
+            if key in z:
+                ref = z[key]
+                got = getattr(layer, bname).numpy()
+                assert got.shape == ref.shape
+                assert np.max(np.abs(got - ref)) <= tol * max(1.0, np.max(np.abs(ref))), bname
+        assert layer.getDimAfterMap() == cs.n
+        sd = layer.state_dict()
+        for key in ("D", "all_P", "all_q", "all_r", "all_M", "all_s", "all_c", "all_d", "all_F",
+                    "A_p", "b_p", "yp", "NA_E", "z0", "y0"):
+            assert key in sd
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_packed_form_reproduces_reference_fp64(name):
+    """numpy evaluation of (W, segments) == the reference's fp64 forward on the golden inputs."""
+    raw, csd, z = load_golden(name)
+    cs, layer = _module_from_raw(raw, torch.float64)
+    consts = layer.packed_constants()
+    v = _to_my_basis(cs, csd, z["x"])
+    y, kappa, _ = evaluate(consts, v)
+    assert np.max(rel_err_rows(y, z["y64"])) < 1e-9
+    # kappa of the normalised direction (what computeKappa returns in the reference)
+    norm = np.linalg.norm(v, axis=1)
+    ok = norm > 0
+    kb = kappa[ok] / norm[ok]
+    ref = z["kappa_bar64"][ok]
+    assert np.max(np.abs(kb - ref) / np.maximum(1.0, np.abs(ref))) < 1e-8
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_packed_form_fp32_buffers_within_parity_bar(name):
+    """Constants folded from fp32 buffers still reproduce the reference's fp32 output to 1e-5."""
+    raw, csd, z = load_golden(name)
+    cs, layer = _module_from_raw(raw, torch.float32)
+    v = _to_my_basis(cs, csd, z["x"])
+    y, _, _ = evaluate(layer.packed_constants(), v)
+    assert np.max(rel_err_rows(y, z["y32"])) < 1e-5
+
+
+def test_row_reductions():
+    """Zero D rows dropped, tall SOC blocks QR-reduced, low-rank quadratics factored."""
+    raw = workloads.corridor_like(k=20, n_eq=5, m=30, n_quad=3, rank=2, seed=1)
+    cs, layer = _module_from_raw(raw, torch.float64)
+    consts = layer.packed_constants()
+    kinds = [s.type for s in consts.segments]
+    assert kinds.count(_lib.SEG_QUAD_FAC) == 3
+    for s in consts.segments:
+        if s.type == _lib.SEG_QUAD_FAC:
+            assert s.nrows == 3            # rank(P) + 1
+    raw = workloads.random_lin_quad_soc(k=6, m=0, n_quad=0, n_soc=1, r_M=15, seed=3)
+    cs, layer = _module_from_raw(raw, torch.float64)
+    consts = layer.packed_constants()
+    assert [s.type for s in consts.segments] == [_lib.SEG_SOC]       # the 0 z <= 1 filler row is gone
+    assert consts.segments[0].nrows == 6                             # 15 x 6 block -> 6 x 6 factor
+    assert consts.out_identity
+
+
+def test_unsupported_methods_and_cpu_input_fail_loudly():
+    cs = workloads.build_constraints(workloads.cube())
+    with pytest.raises(NotImplementedError):
+        ConstraintModule(cs, method="DC3", create_map=False)
+    with pytest.raises(RuntimeError):
+        ConstraintModule(cs, create_map=True)              # input_dim missing (utils.verify)
+    layer = ConstraintModule(cs, create_map=False)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        layer(torch.zeros(4, 3, 1))                        # CPU tensor: no fallback path
+
+
+def test_state_dict_and_pickle_roundtrip():
+    import io
+    cs = workloads.build_constraints(workloads.make_raw("c2"))
+    layer = ConstraintModule(cs, input_dim=8, create_map=True)
+    other = ConstraintModule(cs, input_dim=8, create_map=True)
+    other.load_state_dict(layer.state_dict())
+    assert torch.equal(other.mapper.weight, layer.mapper.weight)
+    blob = io.BytesIO()
+    torch.save(layer, blob)
+    blob.seek(0)
+    again = torch.load(blob, weights_only=False)
+    assert torch.equal(again.all_delta, layer.all_delta)
+    assert again.getDimAfterMap() == layer.getDimAfterMap()
