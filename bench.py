@@ -50,27 +50,42 @@ def parse():
 
 
 def cpu_baseline(raw, cs, B, dtype, budget_s):
-    """Reference op sequence (oracle/rayen_oracle.py) on the host cores, same workload."""
+    """Reference op sequence (oracle/rayen_oracle.py) on the host cores, bounded sample of the workload."""
     from oracle import rayen_oracle as oracle
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     csd = {key: getattr(cs, key) for key in ("A_p", "b_p", "NA_E", "yp", "z0", "y0")}
     csd.update(P=raw["P"], q=raw["q"], r=raw["r"], M=raw["M"], s=raw["s"], c=raw["c"], d=raw["d"],
                F=raw["F"])
     buf = oracle.precompute(csd, dtype)
     gen = torch.Generator().manual_seed(1234)
-    x = torch.empty(B, cs.n, 1, dtype=dtype).uniform_(-1.0, 1.0, generator=gen)
-    best, reps, t_start = float("inf"), 0, time.perf_counter()
+    Bs = min(B, 32768)
+    x = torch.empty(Bs, cs.n, 1, dtype=dtype).uniform_(-1.0, 1.0, generator=gen)
+
+    def timed(xx):
+        t0 = time.perf_counter()
+        oracle.forward(buf, xx)
+        return time.perf_counter() - t0
+
     with torch.no_grad():
-        oracle.forward(buf, x)  # warm-up
-        while reps < 3 or (time.perf_counter() - t_start < budget_s and reps < 20):
-            t0 = time.perf_counter()
-            oracle.forward(buf, x)
-            best = min(best, time.perf_counter() - t0)
+        # PyTorch-CPU does not scale to every core on this op mix: probe a few thread counts, keep the best
+        probe = x[:4096]
+        rates = {}
+        for threads in sorted({t for t in (4, 8, 16, 32, 64, cores) if t <= cores}):
+            torch.set_num_threads(threads)
+            timed(probe)
+            rates[threads] = probe.shape[0] / min(timed(probe), timed(probe))
+        threads = max(rates, key=rates.get)
+        torch.set_num_threads(threads)
+        timed(x)
+        best, reps, t_start = float("inf"), 0, time.perf_counter()
+        while reps < 3 or (time.perf_counter() - t_start < budget_s and reps < 30):
+            best = min(best, timed(x))
             reps += 1
-    return {"value": B / best, "unit": "projections/s", "cores": cores, "kind": "port",
-            "sample": f"full batch B={B} of the same workload, best of {reps} calls after 1 warm-up, "
-                      f"{str(dtype).split('.')[-1]}, torch {torch.__version__} CPU, {cores} threads"}
+    return {"value": Bs / best, "unit": "projections/s", "cores": threads, "kind": "port",
+            "host_cores": cores,
+            "sample": f"B={Bs} slice of the same workload, best of {reps} calls after warm-up, "
+                      f"{str(dtype).split('.')[-1]}, torch {torch.__version__} CPU, {threads} threads "
+                      f"(best of thread counts {sorted(rates)})"}
 
 
 def main():

@@ -202,7 +202,7 @@ class ConstraintModule(torch.nn.Module):
 
     def forward(self, x):
         # x: [nsib, numel_input_mapper, 1]; after the mapper q is [nsib, numel_output_mapper, 1]
-        q = self.mapper(x.view(x.size(0), -1))
+        q = self.mapper(torch.flatten(x, 1))  # == x.view(B, -1), and defined for B = 0
         q = torch.unsqueeze(q, dim=2)
 
         y = self.forwardForMethod(q)
