@@ -13,7 +13,7 @@ import subprocess
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 INCLUDE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
 SOURCES = ["rayen_abi.hip", "rayen_generic.hip", "rayen_mfma.hip"]
-LIBRARY = os.path.join(CSRC, "librayen_hip.so")
+LIBRARY = os.environ.get("RAYEN_HIP_LIBRARY") or os.path.join(CSRC, "librayen_hip.so")
 
 
 def hipcc_path():

@@ -164,18 +164,19 @@ class ConstraintModule(torch.nn.Module):
     # ------------------------------------------------------------------ the projection
     def _project(self, q):
         """``q [B, >=n, 1]`` (or ``[B, >=n]``) -> ``(y [B,k], kappa [B])`` through the fused HIP op."""
-        v = q.reshape(q.shape[0], -1)
+        v = torch.flatten(q, 1)
         if not v.is_cuda:
             raise RuntimeError(
                 "rayen_amd.ConstraintModule runs on an MI355X (HIP) device only; got a "
                 f"{v.device} tensor. Call .to('cuda') on the model and the input.")
         _, pack_id = self.device_pack(v.device)
-        y, kappa, _ = torch.ops.rayen_amd.ray_project(v, pack_id)
+        need_active = torch.is_grad_enabled() and v.requires_grad
+        y, kappa, _ = torch.ops.rayen_amd.ray_project(v, pack_id, need_active)
         return y, kappa
 
     def computeKappa(self, v_bar):
         """``kappa [B,1,1]`` of directions ``v_bar [B,n,1]`` (rayen/constraint_module.py:351-458)."""
-        v = v_bar.reshape(v_bar.shape[0], -1)
+        v = torch.flatten(v_bar, 1)
         dp, _ = self.device_pack(v.device)
         _, kappa, _ = ops.project_raw(v, dp, want_y=False)
         return kappa.reshape(-1, 1, 1)

@@ -1,17 +1,585 @@
-// fp32 MFMA path (placeholder until the fragment-ordered kernel lands; the
-// dispatcher in rayen_abi.hip falls through to the generic kernels).
+// fp32 MFMA path: T = W . V' on v_mfma_f32_32x32x2_f32 with the whole epilogue in registers.
+//
+// One wave owns NT tiles of 32 samples and walks every 32-row tile of W.  Per
+// tile it issues n_pad/2 MFMAs per sample tile (A = 32 rows of W, B = 32
+// samples of V) and reduces the 32x32 result at once:
+//
+//   D[row][sample]: lane l holds sample l&31 and rows (g&3) + 8(g>>2) + 4(l>>5), g = 0..15
+//
+// so every reduction of computeKappa (rayen/constraint_module.py:351-458) runs
+// along the lane's own 16 registers plus ONE exchange between the two half-waves.
+// The K order of the MFMA chain is free, and is chosen so that the B operand of
+// K-step kk IS the direction element that matches result register kk&15 of row
+// tile kk>>4:  element(kk, half) = 8*(kk>>2) + 4*half + (kk&3).  Consequences:
+//   * a lane loads its half of v as float4s and keeps it in registers for the
+//     whole kernel (B operands of every tile, n/2 VGPRs);
+//   * the quadratic form v'Gv needs no second pass: acc[g] * v[16t+g] summed;
+//   * with NA_E = I the output y = y0 + v/max(1,kappa) is written straight from
+//     those registers, again as float4s.
+// W is stored in fragment order ([tile][k-group][lane] float4): each A fetch is
+// one contiguous 1 KiB global_load_dwordx4 per wave, served by L2 (the image is
+// <= a few hundred KiB and shared by every wave), software-prefetched one
+// k-group (4 MFMAs x NT) ahead.  No LDS staging, no workgroup barriers.
+//
+// HBM traffic per sample: n loads + k stores, the algorithmic minimum.
 #include "rayen_internal.h"
+
+#include <cstring>
+#include <vector>
 
 namespace rayen {
 
-struct MfmaImage {};
+using f32x16 = float __attribute__((ext_vector_type(16)));
+using f32x4 = float __attribute__((ext_vector_type(4)));
 
-bool mfma_eligible(const RayenPack*) { return false; }
-int mfma_build(const RayenPack*, MfmaImage**, int64_t*) { return RAYEN_E_UNSUPPORTED; }
-void mfma_free(MfmaImage* img) { delete img; }
-int mfma_forward(const RayenPack*, const MfmaImage*, const float*, int64_t, int64_t, float*, int64_t,
-                 float*, int32_t*, int32_t*, hipStream_t) {
-  return RAYEN_E_UNSUPPORTED;
+enum : int32_t { MI_AUX = 0, MI_LIN = 1, MI_QSYM = 2, MI_QFAC = 3, MI_SOC = 4, MI_OUT = 5, MI_NOP = 6 };
+enum : int32_t { MF_FIRST = 1, MF_LAST = 2 };
+
+// One work item of the tile walk = one 32-row tile of W.
+struct MItem {
+  int32_t type;
+  int32_t flags;
+  int32_t seg;     // caller's segment index (reported in `active`)
+  int32_t row0;    // LIN: logical W row of the tile's first row | QSYM: tile index | OUT: first output row
+  int32_t aux;     // row of phi | c (b is aux+1) inside the aux tile
+  int32_t pad;
+  float f0, f1;    // SOC: tau, a'
+};
+
+#ifndef RAYEN_MFMA_NT
+#define RAYEN_MFMA_NT 2
+#endif
+#ifndef RAYEN_MFMA_WPS
+#define RAYEN_MFMA_WPS 2
+#endif
+constexpr int kMfmaWavesPerSimd = RAYEN_MFMA_WPS;
+
+struct MfmaImage {
+  f32x4* W = nullptr;      // [n_tiles + 1][NQ][64] float4, fragment order (one spare tile for the prefetch)
+  MItem* items = nullptr;
+  float* y0 = nullptr;     // [k_pad]
+  int n_items = 0;
+  int nkk = 0;             // n_pad / 32
+  int identity = 0;
+  int n_simd = 1024;       // SIMDs on the device (CUs x 4)
+  int waves_per_simd = kMfmaWavesPerSimd;  // resident waves per SIMD the kernel is built for
+  int64_t bytes = 0;
+};
+
+template <int NKK>
+struct MfmaCfg {
+  static constexpr int NT = (NKK <= 2) ? RAYEN_MFMA_NT : 1;  // sample tiles per wave
+  static constexpr int NQ = NKK * 4;             // k-groups (4 MFMA steps each) per row tile
+  static constexpr int KK = NKK * 16;            // MFMA steps per row tile = registers of v per sample tile
+};
+
+#ifndef RAYEN_MFMA_WAVES
+#define RAYEN_MFMA_WAVES 8
+#endif
+constexpr int kMfmaWaves = RAYEN_MFMA_WAVES;  // waves per workgroup (independent; the workgroup is only a launch unit)
+
+__device__ __forceinline__ float xhalf(float x) { return __shfl_xor(x, 32); }
+
+template <int NKK, bool TRACK>
+__global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_fwd_kernel(
+    const f32x4* __restrict__ Wimg, const MItem* __restrict__ items, int n_items,
+    const float* __restrict__ y0, int identity, int k, int n, const float* __restrict__ v, int64_t B,
+    int64_t ldv, int vec_in, float* __restrict__ y, int64_t ldy, int vec_out,
+    float* __restrict__ kappa_out, int32_t* __restrict__ active_out, int32_t* __restrict__ nan_flag) {
+  using C = MfmaCfg<NKK>;
+  constexpr int NT = C::NT, NQ = C::NQ, KK = C::KK;
+  __shared__ float aux_lds[kMfmaWaves][NT][32][32];  // [wave][sample tile][aux row][sample]
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int col = lane & 31;  // sample within the tile
+  const int hi = lane >> 5;   // which half of the rows / k pairs this lane holds
+  const int64_t n_groups = (B + NT * 32 - 1) / (NT * 32);
+  const int64_t wave_id = (int64_t)blockIdx.x * kMfmaWaves + wave;
+  const int64_t wave_stride = (int64_t)gridDim.x * kMfmaWaves;
+  bool bad = false;
+#ifdef RAYEN_MFMA_PRIO
+  // waves w and w+4 of a workgroup share a SIMD: give one of each pair static priority so the two
+  // do not drift into lockstep (MFMA phases on top of each other, epilogues on top of each other)
+  if (__builtin_amdgcn_readfirstlane(wave) >= kMfmaWaves / 2) __builtin_amdgcn_s_setprio(RAYEN_MFMA_PRIO);
+#endif
+
+#ifdef RAYEN_TIMING
+  // developer instrumentation: lane 0 of one wave logs s_memtime stamps into LDS, dumped at the end
+  __shared__ unsigned ts_lds[256];
+  int ts_n = 0;
+  const bool ts_on = (blockIdx.x == RAYEN_TIMING) && (threadIdx.x == 0);
+#define TS() do { __builtin_amdgcn_sched_barrier(0); if (ts_on && ts_n < 256) { ts_lds[ts_n++] = (unsigned)__builtin_amdgcn_s_memtime(); } __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define TS() do {} while (0)
+#endif
+  // persistent walk over groups of NT*32 samples (no workgroup barriers anywhere)
+  for (int64_t grp = wave_id; grp < n_groups; grp += wave_stride) {
+  TS();
+  const int64_t s_base = grp * (NT * 32);
+
+  // ---- this lane's half of v for each of its samples, as B operands
+  float vr[NT][KK];
+  bool live[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int64_t s = s_base + t * 32 + col;
+    live[t] = s < B;
+    const float* row = v + (live[t] ? s : 0) * ldv;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int c0 = 8 * q + 4 * hi;
+      f32x4 x = {0.f, 0.f, 0.f, 0.f};
+#if defined(RAYEN_ABL) && (RAYEN_ABL & 8)
+      x = f32x4{0.001f * (float)(lane + q), -0.002f * (float)(col + t), 0.25f, -0.125f};
+      if (false) {
+#else
+      if (live[t]) {
+#endif
+        if (vec_in && c0 + 3 < n) {
+          x = *reinterpret_cast<const f32x4*>(row + c0);
+        } else {
+          if (c0 + 0 < n) x[0] = row[c0 + 0];
+          if (c0 + 1 < n) x[1] = row[c0 + 1];
+          if (c0 + 2 < n) x[2] = row[c0 + 2];
+          if (c0 + 3 < n) x[3] = row[c0 + 3];
+        }
+      }
+      vr[t][4 * q + 0] = x[0];
+      vr[t][4 * q + 1] = x[1];
+      vr[t][4 * q + 2] = x[2];
+      vr[t][4 * q + 3] = x[3];
+    }
+  }
+
+#if defined(RAYEN_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for (int t = 0; t < NT; ++t) asm volatile("" ::"v"(vr[t][0]), "v"(vr[t][KK - 1]));
+#endif
+  TS();
+  float kap[NT], part[NT], scale[NT];
+  int aseg[NT], arow[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { kap[t] = 0.f; part[t] = 0.f; scale[t] = 1.f; aseg[t] = -1; arow[t] = 0; }
+
+  // A fragments: two whole-tile register buffers.  While the MFMAs of tile t run out of one
+  // buffer, the NQ loads of tile t+1 (issued at the top of tile t, a full tile = NQ*4*NT MFMAs
+  // ahead) land in the other, so an L2 or Infinity-Cache round trip never reaches the MFMA
+  // stream.  The item walk is unrolled by two to keep the buffer choice static; the
+  // sched_barrier keeps hipcc from sinking the loads next to their uses.
+  const f32x4* wp = Wimg + lane;
+  f32x4 buf_a[NQ], buf_b[NQ];
+  auto fetch_tile = [&](f32x4 (&buf)[NQ]) {
+#if defined(RAYEN_ABL) && (RAYEN_ABL & 4)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) buf[q] = f32x4{0.5f, -0.25f, 0.125f, 1.f};
+#else
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) buf[q] = wp[q * 64];
+#endif
+    wp += NQ * 64;
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  fetch_tile(buf_a);
+
+  // one 32-row tile: NQ k-groups of 4 MFMA steps on every sample tile
+  auto run_tile = [&](f32x16 (&acc)[NT], const f32x4 (&a)[NQ]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
+#if defined(RAYEN_ABL) && (RAYEN_ABL & 2)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t][q & 15] += a[q][0] * vr[t][4 * q];
+#else
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][c], vr[t][4 * q + c], acc[t], 0, 0, 0);
+#endif
+  };
+
+  auto finish_kappa = [&]() {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float other = xhalf(kap[t]);
+      if (TRACK) {
+        const int oseg = __shfl_xor(aseg[t], 32), orow = __shfl_xor(arow[t], 32);
+        // deterministic tie-break so both halves agree
+        if (other > kap[t] || (other == kap[t] && hi == 1)) { aseg[t] = oseg; arow[t] = orow; }
+      }
+      kap[t] = fmaxf(kap[t], other);
+      scale[t] = 1.0f / fmaxf(1.0f, kap[t]);
+    }
+  };
+
+  f32x16 acc[NT];
+  auto process = [&](const MItem item, const f32x4 (&a)[NQ]) {
+    if (item.type == MI_NOP) return;  // pairing filler: no MFMAs, no epilogue
+    // rows of NA_E come last: kappa is final once the first of those tiles is reached
+    if (item.type == MI_OUT && (item.flags & MF_FIRST)) finish_kappa();
+    run_tile(acc, a);
+    TS();
+#if defined(RAYEN_ABL) && (RAYEN_ABL & 1) && defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) asm volatile("" ::"v"(acc[t]));
+    if (item.type != MI_OUT) return;
+#endif
+    if (item.type == MI_LIN) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (TRACK) {
+#pragma unroll
+          for (int g = 0; g < 16; ++g)
+            if (acc[t][g] > kap[t]) {
+              kap[t] = acc[t][g];
+              aseg[t] = item.seg;
+              arow[t] = item.row0 + (g & 3) + 8 * (g >> 2) + 4 * hi;
+            }
+        } else {
+#pragma unroll
+          for (int g = 0; g < 16; ++g) kap[t] = fmaxf(kap[t], acc[t][g]);
+        }
+      }
+    } else if (item.type == MI_AUX) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; ++g)
+          aux_lds[wave][t][(g & 3) + 8 * (g >> 2) + 4 * hi][col] = acc[t][g];
+      __builtin_amdgcn_wave_barrier();
+    } else if (item.type == MI_OUT) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (!live[t]) continue;
+        float* yrow = y + (s_base + t * 32 + col) * ldy;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int r0 = item.row0 + 8 * a + 4 * hi;
+          if (r0 >= k) continue;
+          f32x4 o;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            o[c] = fmaf(acc[t][4 * a + c], scale[t], y0[r0 + c]);  // y0 is padded to a tile multiple
+            bad |= (o[c] != o[c]) && (r0 + c < k);
+          }
+          if (vec_out && r0 + 3 < k) {
+            *reinterpret_cast<f32x4*>(yrow + r0) = o;
+          } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (r0 + c < k) yrow[r0 + c] = o[c];
+          }
+        }
+      }
+    } else {
+      // QSYM / QFAC / SOC: a running sum over the segment's tiles, closed on its last tile
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        float sum = (item.flags & MF_FIRST) ? 0.f : part[t];
+        if (item.type == MI_QSYM) {
+          // radicand v'Gv = sum_j (G v)_j v_j ; v_j of row tile tp is register 16*tp+g of vr
+#pragma unroll
+          for (int tp = 0; tp < NKK; ++tp)
+            if (item.row0 == tp) {
+#pragma unroll
+              for (int g = 0; g < 16; ++g) sum = fmaf(acc[t][g], vr[t][16 * tp + g], sum);
+            }
+        } else {
+#pragma unroll
+          for (int g = 0; g < 16; ++g) sum = fmaf(acc[t][g], acc[t][g], sum);
+        }
+        part[t] = sum;
+      }
+      if (item.flags & MF_LAST) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float total = part[t] + xhalf(part[t]);
+          const float a0 = aux_lds[wave][t][item.aux][col];
+          float kc;
+          if (item.type != MI_SOC) {
+            kc = a0 + sqrtf(fmaxf(total, 0.f));
+          } else {
+            // a' x^2 + b' x + c' = 0  (rayen/constraint_module.py:392-396, 339-348), a' < 0
+            const float br = aux_lds[wave][t][item.aux + 1][col];
+            const float cp = total - a0 * a0;
+            const float bp = 2.f * br - 2.f * a0 * item.f0;
+            const float disc = bp * bp - 4.f * item.f1 * cp;
+            kc = 0.f;
+            if (disc >= 0.f) {
+              const float root = sqrtf(disc);
+              const float inv2a = 0.5f / item.f1;
+              kc = fmaxf((-bp - root) * inv2a, (-bp + root) * inv2a);
+            }
+          }
+          if (kc > kap[t]) { kap[t] = kc; aseg[t] = item.seg; arow[t] = 0; }
+        }
+      }
+    }
+  };
+  for (int it = 0; it < n_items; it += 2) {  // n_items is even (padded with a no-op tile)
+    fetch_tile(buf_b);
+    process(items[it], buf_a);
+    TS();
+    fetch_tile(buf_a);
+    process(items[it + 1], buf_b);
+    TS();
+  }
+
+#if defined(RAYEN_ABL) && (RAYEN_ABL & 16)
+  if (identity && kap[0] == 12345.678f) {
+#else
+  if (identity) {
+#endif
+    finish_kappa();
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (!live[t]) continue;
+      float* yrow = y + (s_base + t * 32 + col) * ldy;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int c0 = 8 * q + 4 * hi;
+        if (c0 >= k) continue;
+        f32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          o[c] = fmaf(vr[t][4 * q + c], scale[t], y0[c0 + c]);
+          bad |= (o[c] != o[c]) && (c0 + c < k);
+        }
+        if (vec_out && c0 + 3 < k) {
+          *reinterpret_cast<f32x4*>(yrow + c0) = o;
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (c0 + c < k) yrow[c0 + c] = o[c];
+        }
+      }
+    }
+  }
+
+  if (hi == 0) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (!live[t]) continue;
+      const int64_t s = s_base + t * 32 + col;
+      if (kappa_out) kappa_out[s] = kap[t];
+      if (TRACK) { active_out[2 * s] = aseg[t]; active_out[2 * s + 1] = arow[t]; }
+    }
+  }
+  TS();
+  }  // persistent loop over sample groups
+#ifdef RAYEN_TIMING
+  if (ts_on) for (int i = 0; i < ts_n; ++i) nan_flag[16 + i] = (int32_t)ts_lds[i];
+#endif
+  if (nan_flag && bad) atomicOr(nan_flag, 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host: eligibility, image construction, launch
+// ---------------------------------------------------------------------------------------------
+
+static int n_pad_of(int n) { return (n + 31) / 32 * 32; }
+
+bool mfma_eligible(const RayenPack* p) {
+  if (p->n > 128) return false;  // v lives in registers: n_pad/2 VGPRs per sample tile
+  int aux_rows = 0;
+  int64_t useful = 0, padded = 0;
+  const int n_pad = n_pad_of(p->n);
+  for (const RayenSegment& g : p->segs) {
+    if (g.type == RAYEN_SEG_LMI) return false;  // eigen-solve epilogue lives on the generic path
+    if (g.type == RAYEN_SEG_QUAD_SYM || g.type == RAYEN_SEG_QUAD_FAC) aux_rows += 1;
+    if (g.type == RAYEN_SEG_SOC) aux_rows += 2;
+    const int rows = (g.type == RAYEN_SEG_QUAD_SYM) ? n_pad : (g.nrows + 31) / 32 * 32;
+    useful += g.nrows;
+    padded += rows;
+  }
+  if (aux_rows > 32) return false;  // one aux tile
+  if (aux_rows) { useful += aux_rows; padded += 32; }
+  if (!p->out_identity) { useful += p->k; padded += (p->k + 31) / 32 * 32; }
+  if (padded == 0) return false;
+  // 32-row tiles must be reasonably full, and columns not mostly padding; otherwise the
+  // 8-row generic path wastes less
+  return useful * 2 >= padded && p->n * 2 >= n_pad;
+}
+
+namespace {
+
+struct ImageBuilder {
+  int n, n_pad, nq;
+  std::vector<float> frag;  // fragment-ordered image
+  std::vector<MItem> items;
+
+  // rows: pointers to up to 32 source rows (nullptr = zero row), each with `ncols` valid columns
+  void add_tile(const std::vector<const double*>& rows, int ncols) {
+    const size_t base = frag.size();
+    frag.resize(base + (size_t)nq * 64 * 4, 0.f);
+    for (int q = 0; q < nq; ++q)
+      for (int l = 0; l < 64; ++l) {
+        const int r = l & 31, h = l >> 5;
+        if (r >= (int)rows.size() || rows[r] == nullptr) continue;
+        for (int c = 0; c < 4; ++c) {
+          const int colx = 8 * q + 4 * h + c;
+          if (colx < ncols) frag[base + ((size_t)q * 64 + l) * 4 + c] = (float)rows[r][colx];
+        }
+      }
+  }
+};
+
+}  // namespace
+
+int mfma_build(const RayenPack* p, MfmaImage** out, int64_t* bytes) {
+  ImageBuilder b;
+  b.n = p->n;
+  b.n_pad = n_pad_of(p->n);
+  b.nq = b.n_pad / 8;
+  const double* W = p->W.data();
+  auto wrow = [&](int r) { return W + (size_t)r * p->n; };
+
+  // aux tile: phi rows and (c, b) row pairs, in segment order
+  std::vector<int> aux_slot(p->segs.size(), -1);
+  {
+    std::vector<const double*> rows;
+    for (size_t s = 0; s < p->segs.size(); ++s) {
+      const RayenSegment& g = p->segs[s];
+      if (g.type == RAYEN_SEG_QUAD_SYM || g.type == RAYEN_SEG_QUAD_FAC) {
+        aux_slot[s] = (int)rows.size();
+        rows.push_back(wrow(g.aux_row));
+      } else if (g.type == RAYEN_SEG_SOC) {
+        aux_slot[s] = (int)rows.size();
+        rows.push_back(wrow(g.aux_row));
+        rows.push_back(wrow(g.aux_row + 1));
+      }
+    }
+    if (!rows.empty()) {
+      MItem it;
+      std::memset(&it, 0, sizeof(it));
+      it.type = MI_AUX;
+      b.items.push_back(it);
+      b.add_tile(rows, p->n);
+    }
+  }
+  for (size_t s = 0; s < p->segs.size(); ++s) {
+    const RayenSegment& g = p->segs[s];
+    const int total = (g.type == RAYEN_SEG_QUAD_SYM) ? b.n_pad : g.nrows;
+    const int ntiles = (total + 31) / 32;
+    for (int t = 0; t < ntiles; ++t) {
+      std::vector<const double*> rows;
+      for (int r = 32 * t; r < 32 * t + 32 && r < g.nrows; ++r) rows.push_back(wrow(g.row0 + r));
+      b.add_tile(rows, p->n);
+      MItem it;
+      std::memset(&it, 0, sizeof(it));
+      it.seg = (int32_t)s;
+      it.aux = aux_slot[s];
+      it.f0 = (float)g.f0;
+      it.f1 = (float)g.f1;
+      it.flags = (t == 0 ? MF_FIRST : 0) | (t == ntiles - 1 ? MF_LAST : 0);
+      switch (g.type) {
+        case RAYEN_SEG_LIN: it.type = MI_LIN; it.row0 = g.row0 + 32 * t; break;
+        case RAYEN_SEG_QUAD_SYM: it.type = MI_QSYM; it.row0 = t; break;
+        case RAYEN_SEG_QUAD_FAC: it.type = MI_QFAC; break;
+        case RAYEN_SEG_SOC: it.type = MI_SOC; break;
+        default: return RAYEN_E_UNSUPPORTED;
+      }
+      b.items.push_back(it);
+    }
+  }
+  const int k_tiles = (p->k + 31) / 32;
+  if (!p->out_identity) {
+    for (int t = 0; t < k_tiles; ++t) {
+      std::vector<const double*> rows;
+      for (int r = 32 * t; r < 32 * t + 32 && r < p->k; ++r) rows.push_back(p->NA_E.data() + (size_t)r * p->n);
+      b.add_tile(rows, p->n);
+      MItem it;
+      std::memset(&it, 0, sizeof(it));
+      it.type = MI_OUT;
+      it.row0 = 32 * t;
+      it.flags = (t == 0 ? MF_FIRST : 0) | (t == k_tiles - 1 ? MF_LAST : 0);
+      b.items.push_back(it);
+    }
+  }
+  if (b.items.size() % 2) {  // the kernel walks tiles in pairs
+    MItem it;
+    std::memset(&it, 0, sizeof(it));
+    it.type = MI_NOP;
+    b.items.push_back(it);
+    b.add_tile({}, p->n);
+  }
+  b.frag.resize(b.frag.size() + (size_t)b.nq * 64 * 4, 0.f);  // spare tile: the prefetch runs one tile past the end
+
+  MfmaImage* img = new MfmaImage();
+  img->nkk = b.n_pad / 32;
+  img->identity = p->out_identity;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0)
+      img->n_simd = prop.multiProcessorCount * 4;
+  }
+  img->n_items = (int)b.items.size();
+  std::vector<float> y0((size_t)k_tiles * 32 + 32, 0.f);
+  for (int i = 0; i < p->k; ++i) y0[i] = (float)p->y0[i];
+  bool ok = hipMalloc(&img->W, b.frag.size() * sizeof(float)) == hipSuccess &&
+            hipMemcpy(img->W, b.frag.data(), b.frag.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMalloc(&img->y0, y0.size() * sizeof(float)) == hipSuccess &&
+            hipMemcpy(img->y0, y0.data(), y0.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+  if (ok && !b.items.empty())
+    ok = hipMalloc(&img->items, b.items.size() * sizeof(MItem)) == hipSuccess &&
+         hipMemcpy(img->items, b.items.data(), b.items.size() * sizeof(MItem), hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) { mfma_free(img); return RAYEN_E_ALLOC; }
+  img->bytes = (int64_t)(b.frag.size() * sizeof(float) + y0.size() * sizeof(float) + b.items.size() * sizeof(MItem));
+  *bytes = img->bytes;
+  *out = img;
+  return RAYEN_OK;
+}
+
+void mfma_free(MfmaImage* img) {
+  if (img == nullptr) return;
+  if (img->W) (void)hipFree(img->W);
+  if (img->items) (void)hipFree(img->items);
+  if (img->y0) (void)hipFree(img->y0);
+  delete img;
+}
+
+template <int NKK>
+static int launch_mfma(const RayenPack* p, const MfmaImage* img, const float* v, int64_t B, int64_t ldv,
+                       float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
+                       hipStream_t stream) {
+  // persistent waves: at most `slots` waves are resident (VGPR-limited waves per SIMD x SIMDs);
+  // give every wave the same number of sample groups so that no SIMD idles in a ragged last round
+  constexpr int per_wave = MfmaCfg<NKK>::NT * 32;
+  const int64_t n_groups = (B + per_wave - 1) / per_wave;
+  const int64_t slots = (int64_t)img->n_simd * img->waves_per_simd;
+  const int64_t rounds = (n_groups + slots - 1) / slots;
+  const int64_t waves = (n_groups + rounds - 1) / rounds;
+  const int64_t grid = (waves + kMfmaWaves - 1) / kMfmaWaves;
+  const int vec_in = (ldv % 4 == 0) && ((reinterpret_cast<uintptr_t>(v) & 15) == 0);
+  const int vec_out = (ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+  if (active != nullptr) {
+    hipLaunchKernelGGL((mfma_fwd_kernel<NKK, true>), dim3((unsigned)grid), dim3(kMfmaWaves * 64), 0, stream,
+                       img->W, img->items, img->n_items, img->y0, img->identity, p->k, p->n, v, B, ldv,
+                       vec_in, y, ldy, vec_out, kappa, active, nan_flag);
+  } else {
+    hipLaunchKernelGGL((mfma_fwd_kernel<NKK, false>), dim3((unsigned)grid), dim3(kMfmaWaves * 64), 0, stream,
+                       img->W, img->items, img->n_items, img->y0, img->identity, p->k, p->n, v, B, ldv,
+                       vec_in, y, ldy, vec_out, kappa, active, nan_flag);
+  }
+  return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
+}
+
+int mfma_forward(const RayenPack* p, const MfmaImage* img, const float* v, int64_t B, int64_t ldv, float* y,
+                 int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream) {
+  if (B == 0) return RAYEN_OK;
+  switch (img->nkk) {
+    case 1: return launch_mfma<1>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+    case 2: return launch_mfma<2>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+    case 3: return launch_mfma<3>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+    case 4: return launch_mfma<4>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+    default: return RAYEN_E_UNSUPPORTED;
+  }
 }
 
 }  // namespace rayen

@@ -61,8 +61,8 @@ _FWD = {(torch.float32, False): "rayen_ray_project_f32", (torch.float64, False):
         (torch.float64, True): "rayen_ray_project_f64"}
 
 
-def project_raw(v, pack, want_y=True, force_generic=False):
-    """Direct call of the C ABI on an existing ``DevicePack``; returns (y|None, kappa, active)."""
+def project_raw(v, pack, want_y=True, force_generic=False, want_active=True):
+    """Direct call of the C ABI on an existing ``DevicePack``; returns (y|None, kappa, active|None)."""
     _check_input(v, pack)
     if v.stride(1) != 1:
         v = v.contiguous()
@@ -70,7 +70,7 @@ def project_raw(v, pack, want_y=True, force_generic=False):
     k = pack.consts.k
     y = torch.empty((B, k), dtype=v.dtype, device=v.device) if want_y else None
     kappa = torch.empty((B,), dtype=v.dtype, device=v.device)
-    active = torch.empty((B, 2), dtype=torch.int32, device=v.device)
+    active = torch.empty((B, 2), dtype=torch.int32, device=v.device) if want_active else None
     fn = getattr(_lib.load(), _FWD[(v.dtype, bool(force_generic))])
     with torch.cuda.device(v.device):
         code = fn(pack.handle, _ptr(v), B, v.stride(0) if B else pack.consts.n, _ptr(y), k,
@@ -80,17 +80,21 @@ def project_raw(v, pack, want_y=True, force_generic=False):
 
 
 @torch.library.custom_op("rayen_amd::ray_project", mutates_args=())
-def ray_project(v: torch.Tensor, pack_id: int) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    y, kappa, active = project_raw(v, _pack(pack_id))
+def ray_project(v: torch.Tensor, pack_id: int, need_active: bool) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """``need_active``: also record which constraint set kappa (only the backward reads it; without
+    it the kernels skip the arg-max bookkeeping and ``active`` comes back empty)."""
+    y, kappa, active = project_raw(v, _pack(pack_id), want_active=need_active)
+    if active is None:
+        active = torch.empty((0, 2), dtype=torch.int32, device=v.device)
     return y, kappa, active
 
 
 @ray_project.register_fake
-def _(v, pack_id):
+def _(v, pack_id, need_active):
     pack = _pack(pack_id)
     B = v.shape[0]
     return (v.new_empty((B, pack.consts.k)), v.new_empty((B,)),
-            v.new_empty((B, 2), dtype=torch.int32))
+            v.new_empty((B if need_active else 0, 2), dtype=torch.int32))
 
 
 @torch.library.custom_op("rayen_amd::ray_project_bwd", mutates_args=())
@@ -119,7 +123,10 @@ def _(v, kappa, active, grad_y, pack_id):
 
 
 def _setup_context(ctx, inputs, output):
-    v, pack_id = inputs
+    v, pack_id, need_active = inputs
+    if not need_active:
+        raise RuntimeError("rayen_amd::ray_project was called with need_active=False on an input that "
+                           "requires grad")
     _, kappa, active = output
     ctx.pack_id = pack_id
     ctx.save_for_backward(v, kappa, active)
@@ -128,8 +135,8 @@ def _setup_context(ctx, inputs, output):
 def _backward(ctx, grad_y, grad_kappa, grad_active):
     v, kappa, active = ctx.saved_tensors
     if grad_y is None:
-        return torch.zeros_like(v), None
-    return torch.ops.rayen_amd.ray_project_bwd(v, kappa, active, grad_y, ctx.pack_id), None
+        return torch.zeros_like(v), None, None
+    return torch.ops.rayen_amd.ray_project_bwd(v, kappa, active, grad_y, ctx.pack_id), None, None
 
 
 ray_project.register_autograd(_backward, setup_context=_setup_context)
