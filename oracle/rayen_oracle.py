@@ -143,7 +143,7 @@ def forward_rayen(buf: dict, q: torch.Tensor) -> torch.Tensor:
 
 def forward(buf: dict, x: torch.Tensor) -> torch.Tensor:
     """Layer forward with the identity mapper (CM:520-533, ``create_map=False``)."""
-    q = x.reshape(x.shape[0], -1).unsqueeze(2)
+    q = torch.flatten(x, 1).unsqueeze(2)  # == x.view(B, -1), and defined for B = 0
     y = forward_rayen(buf, q)
     assert not torch.isnan(y).any()
     return y

@@ -1,0 +1,83 @@
+"""World-size-2 test of the batch sharding + all-gather logic on CPU (gloo backend).
+
+The HIP kernels cannot run here, so the per-rank compute is the CPU oracle; what is
+under test is `rayen_amd.dist` (shard bounds, uneven shards, chunked gather, row order).
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, B, chunks, result_dir):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from helpers import csd_from_cs
+        from oracle import rayen_oracle as oracle
+        from rayen_amd import workloads
+        from rayen_amd.dist import ShardedProjection, shard_bounds
+
+        torch.set_num_threads(1)
+        cs = workloads.build_constraints(workloads.make_raw("c2", seed=3))
+        buf = oracle.precompute(csd_from_cs(cs), torch.float32)
+
+        def project(x):
+            return oracle.forward(buf, x)
+
+        gen = torch.Generator().manual_seed(17)           # same stream on every rank
+        x_full = torch.empty(B, cs.n, 1).uniform_(-1, 1, generator=gen)
+        sharded = ShardedProjection(project)
+        y_rep = sharded.forward_replicated(x_full, chunks=chunks)
+        lo, hi = shard_bounds(B, world, rank)
+        y_gat = sharded.forward_gather(x_full[lo:hi], chunks=chunks)
+        y_loc = sharded.forward_local(x_full[lo:hi])
+        want = project(x_full)
+        assert y_rep.shape == want.shape
+        assert torch.equal(y_rep, want), "replicated-input path"
+        assert torch.equal(y_gat, want), "local-input path"
+        assert torch.equal(y_loc, want[lo:hi])
+        # deliberately unequal shards on the local-input path
+        cut = B // 3
+        mine = x_full[:cut] if rank == 0 else x_full[cut:]
+        assert torch.equal(sharded.forward_gather(mine, chunks=chunks), want)
+        np.save(os.path.join(result_dir, f"ok_{rank}.npy"), np.array([1]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B,chunks", [(64, 1), (101, 1), (101, 4), (7, 3)])
+def test_sharded_projection_world2(tmp_path, B, chunks):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, B, chunks, str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        assert os.path.exists(tmp_path / f"ok_{rank}.npy")
+
+
+def test_shard_bounds_cover_and_order():
+    from rayen_amd.dist import shard_bounds, shard_sizes
+    for total in (0, 1, 7, 64, 1000003):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = shard_sizes(total, world)
+            assert sum(sizes) == total and max(sizes) - min(sizes) <= 1
