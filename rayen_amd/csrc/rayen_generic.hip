@@ -428,10 +428,298 @@ int generic_forward(const RayenPack* p, const GenericImage<T>& img, const T* v, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// backward: grad_v = s N'g - [kappa > 1] s^2 (N'g . v) grad kappa(v),  s = 1/max(1, kappa)
+//
+// Same lane = sample layout.  grad kappa is evaluated on the active constraint only (the one the
+// forward recorded), which is what autograd gives for rayen/constraint_module.py:351-474: max ->
+// its arg-max, relu, sqrt, the SOC root (implicit differentiation of a'x^2+b'x+c'=0) and
+// eigvalsh -> x x' for the top eigenvector.  The segment loop stays wave-uniform; a wave skips a
+// segment none of its lanes is active in.
+// ---------------------------------------------------------------------------------------------
+
+// u_j += sum_r Wg[rb][j][r] * w[r]   (W' w for one row block), masked per lane
+template <typename T, int LD>
+__device__ __forceinline__ void axpy8_t(const T* __restrict__ Wg, int rb, int ncols, T* ucol,
+                                        const T (&w)[kRowBlock], bool on) {
+  const T* __restrict__ wp = Wg + (size_t)rb * (size_t)ncols * kRowBlock;
+  for (int j = 0; j < ncols; ++j) {
+    T a = T(0);
+#pragma unroll
+    for (int r = 0; r < kRowBlock; ++r) a = fma_(wp[j * kRowBlock + r], w[r], a);
+    if (on) ucol[j * LD] += a;
+  }
+}
+
+// Unit eigenvector of lambda_max for the packed symmetric matrix in lm (destroyed): Cholesky of
+// C = (lambda + shift) I - A (positive definite by construction) + 3 steps of inverse iteration.
+template <typename T, int BLOCK>
+__device__ void top_eigenvector_packed(T* lm, int r, T lam, T* x) {
+  auto A = [&](int i, int j) -> T& { return lm[(size_t)((i * (i + 1)) / 2 + j) * BLOCK]; };  // i >= j
+  T scale = fabs(lam);
+  for (int i = 0; i < r; ++i) scale = fmax(scale, fabs(A(i, i)));
+  const T shift = (sizeof(T) == 4 ? T(2e-4) : T(1e-9)) * fmax(scale, Num<T>::tiny());
+  for (int i = 0; i < r; ++i) {
+    for (int j = 0; j <= i; ++j) A(i, j) = -A(i, j);
+    A(i, i) += lam + shift;
+  }
+  // in-place Cholesky C = L L'
+  for (int j = 0; j < r; ++j) {
+    T d = A(j, j);
+    for (int p = 0; p < j; ++p) { const T l = A(j, p); d = fma_(-l, l, d); }
+    d = sqrt(fmax(d, shift * T(1e-3)));
+    A(j, j) = d;
+    const T inv = T(1) / d;
+    for (int i = j + 1; i < r; ++i) {
+      T a = A(i, j);
+      for (int p = 0; p < j; ++p) a = fma_(-A(i, p), A(j, p), a);
+      A(i, j) = a * inv;
+    }
+  }
+  for (int i = 0; i < r; ++i) x[(size_t)i * BLOCK] = T(1) + T(0.01) * T(i);  // not orthogonal to anything special
+  for (int it = 0; it < 3; ++it) {
+    for (int i = 0; i < r; ++i) {  // L z = x
+      T a = x[(size_t)i * BLOCK];
+      for (int p = 0; p < i; ++p) a = fma_(-A(i, p), x[(size_t)p * BLOCK], a);
+      x[(size_t)i * BLOCK] = a / A(i, i);
+    }
+    T nrm = T(0);
+    for (int i = r - 1; i >= 0; --i) {  // L' y = z
+      T a = x[(size_t)i * BLOCK];
+      for (int p = i + 1; p < r; ++p) a = fma_(-A(p, i), x[(size_t)p * BLOCK], a);
+      a /= A(i, i);
+      x[(size_t)i * BLOCK] = a;
+      nrm = fma_(a, a, nrm);
+    }
+    const T inv = T(1) / sqrt(fmax(nrm, Num<T>::tiny()));
+    for (int i = 0; i < r; ++i) x[(size_t)i * BLOCK] *= inv;
+  }
+}
+
+template <typename T, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void generic_bwd_kernel(
+    const T* __restrict__ Wg, const T* __restrict__ NTg, const GSeg* __restrict__ segs, int n_gseg,
+    int k, int n, int w_rows, int lmi_words, const T* __restrict__ v, int64_t B, int64_t ldv,
+    const T* __restrict__ kappa, const int32_t* __restrict__ active, const T* __restrict__ grad_y,
+    int64_t ldg, T* __restrict__ grad_v, int64_t ldgv) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int LD = BLOCK + 1;
+  const int n_pad = (n + kRowBlock - 1) / kRowBlock * kRowBlock;
+  const int k_pad = (k + kRowBlock - 1) / kRowBlock * kRowBlock;
+  T* vT = reinterpret_cast<T*>(smem_raw);  // [n_pad][LD]
+  T* tT = vT + (size_t)n_pad * LD;         // [n_pad][LD]  N'g, finally the result
+  T* uT = tT + (size_t)n_pad * LD;         // [n_pad][LD]  grad kappa
+  T* gT = uT + (size_t)n_pad * LD;         // [k_pad][LD]  grad_y (unused when NA_E = I)
+  T* wT = gT + (size_t)(NTg ? k_pad : 0) * LD;  // [w_rows][LD]  U v / M v of the active segment
+  T* lmi = wT + (size_t)w_rows * LD;       // [lmi_words][BLOCK]
+
+  const int tid = threadIdx.x;
+  const int64_t b0 = (int64_t)blockIdx.x * BLOCK;
+  const int nb = (int)((B - b0) < (int64_t)BLOCK ? (B - b0) : (int64_t)BLOCK);
+
+  for (int idx = tid; idx < BLOCK * n_pad; idx += BLOCK) {
+    const int bl = idx / n_pad, j = idx - bl * n_pad;
+    T x = T(0), g = T(0);
+    if (bl < nb && j < n) {
+      x = v[(b0 + bl) * ldv + j];
+      if (NTg == nullptr) g = grad_y[(b0 + bl) * ldg + j];
+    }
+    vT[j * LD + bl] = x;
+    tT[j * LD + bl] = g;
+    uT[j * LD + bl] = T(0);
+  }
+  if (NTg != nullptr) {
+    for (int idx = tid; idx < BLOCK * k_pad; idx += BLOCK) {
+      const int bl = idx / k_pad, i = idx - bl * k_pad;
+      gT[i * LD + bl] = (bl < nb && i < k) ? grad_y[(b0 + bl) * ldg + i] : T(0);
+    }
+  }
+  __syncthreads();
+
+  const T* vcol = vT + tid;
+  T* tcol = tT + tid;
+  T* ucol = uT + tid;
+  T acc[kRowBlock];
+  const bool live = tid < nb;
+
+  if (NTg != nullptr) {  // t = NA_E' g
+    const int nrb = n_pad / kRowBlock;
+    for (int b = 0; b < nrb; ++b) {
+      dot8<T, LD>(NTg, b, k, gT + tid, acc);
+#pragma unroll
+      for (int r = 0; r < kRowBlock; ++r) tcol[(b * kRowBlock + r) * LD] = acc[r];
+    }
+  }
+  T tv = T(0);
+  for (int j = 0; j < n; ++j) tv = fma_(tcol[j * LD], vcol[j * LD], tv);
+
+  const T kap = live ? kappa[b0 + tid] : T(0);
+  const int aseg = live ? active[2 * (b0 + tid)] : -1;
+  const int arow = live ? active[2 * (b0 + tid) + 1] : 0;
+  const bool clipped = live && kap > T(1) && aseg >= 0;
+  const T sc = T(1) / fmax(T(1), kap);
+
+  for (int s = 0; s < n_gseg; ++s) {
+    const GSeg sg = segs[s];
+    const bool on = clipped && aseg == sg.seg;
+    if (!__any(on)) continue;  // wave-uniform skip
+    if (sg.type == RAYEN_SEG_LIN) {
+      if (on) {
+        const int r = arow - sg.row0;
+        const T* __restrict__ wp = Wg + ((size_t)(sg.rb0 + r / kRowBlock) * n) * kRowBlock + (r % kRowBlock);
+        for (int j = 0; j < n; ++j) ucol[j * LD] = wp[(size_t)j * kRowBlock];
+      }
+    } else if (sg.type == RAYEN_SEG_QUAD_SYM) {
+      T qf = T(0);
+      for (int b = 0; b < sg.nrb; ++b) {
+        dot8<T, LD>(Wg, sg.rb0 + b, n, vcol, acc);
+#pragma unroll
+        for (int r = 0; r < kRowBlock; ++r) {
+          const int j = b * kRowBlock + r;
+          qf = fma_(acc[r], vcol[j * LD], qf);
+          if (on && j < n) ucol[j * LD] = acc[r];
+        }
+      }
+      const T rinv = qf > T(0) ? T(1) / sqrt(qf) : T(0);
+      const T* __restrict__ ph = Wg + (size_t)sg.aux_rb * n * kRowBlock;
+      if (on)
+        for (int j = 0; j < n; ++j) ucol[j * LD] = fma_(ucol[j * LD], rinv, ph[(size_t)j * kRowBlock]);
+    } else if (sg.type == RAYEN_SEG_QUAD_FAC || sg.type == RAYEN_SEG_SOC) {
+      T ssq = T(0);
+      T* wcol = wT + tid;
+      for (int b = 0; b < sg.nrb; ++b) {
+        dot8<T, LD>(Wg, sg.rb0 + b, n, vcol, acc);
+#pragma unroll
+        for (int r = 0; r < kRowBlock; ++r) {
+          ssq = fma_(acc[r], acc[r], ssq);
+          wcol[(b * kRowBlock + r) * LD] = acc[r];
+        }
+      }
+      // u = coef_w * W'w + coef_0 * aux0 + coef_1 * aux1
+      T cw, c0, c1 = T(0);
+      if (sg.type == RAYEN_SEG_QUAD_FAC) {
+        cw = ssq > T(0) ? T(1) / sqrt(ssq) : T(0);
+        c0 = T(1);
+      } else {
+        dot8<T, LD>(Wg, sg.aux_rb, n, vcol, acc);
+        const T cr = acc[0], br = acc[1];
+        const T tau = (T)sg.f0, ap = (T)sg.f1;
+        const T bp = T(2) * br - T(2) * cr * tau;
+        const T den = T(2) * ap * kap + bp;  // dF/dkappa at the root
+        const T inv = den != T(0) ? T(-1) / den : T(0);
+        cw = T(2) * inv;                        // d c'/dv = 2 M'Mv - 2 (c.v) c
+        c0 = inv * (T(-2) * cr - T(2) * tau * kap);
+        c1 = inv * T(2) * kap;                  // kappa * d b'/dv = kappa (2 b - 2 tau c)
+      }
+      for (int b = 0; b < sg.nrb; ++b) {
+        T w8[kRowBlock];
+#pragma unroll
+        for (int r = 0; r < kRowBlock; ++r) w8[r] = wcol[(b * kRowBlock + r) * LD] * cw;
+        axpy8_t<T, LD>(Wg, sg.rb0 + b, n, ucol, w8, on);
+      }
+      const T* __restrict__ ax = Wg + (size_t)sg.aux_rb * n * kRowBlock;
+      if (on)
+        for (int j = 0; j < n; ++j)
+          ucol[j * LD] += c0 * ax[(size_t)j * kRowBlock] + c1 * ax[(size_t)j * kRowBlock + 1];
+    } else if (sg.type == RAYEN_SEG_LMI) {
+      T* lm = lmi + tid;
+      const int r = sg.dim;
+      for (int b = 0; b < sg.nrb; ++b) {
+        dot8<T, LD>(Wg, sg.rb0 + b, n, vcol, acc);
+#pragma unroll
+        for (int q = 0; q < kRowBlock; ++q) {
+          const int idx = b * kRowBlock + q;
+          if (idx < sg.nrows) lm[(size_t)idx * BLOCK] = acc[q];
+        }
+      }
+      T* x = lm + (size_t)sg.nrows * BLOCK;
+      top_eigenvector_packed<T, BLOCK>(lm, r, kap, x);
+      // u_b = sum_{p>=q} (2 - [p==q]) x_p x_q GL[(p,q)][b]: reuse the row-block walk with w = x x'
+      for (int b = 0; b < sg.nrb; ++b) {
+        T w8[kRowBlock];
+#pragma unroll
+        for (int q = 0; q < kRowBlock; ++q) {
+          const int idx = b * kRowBlock + q;
+          T wv = T(0);
+          if (idx < sg.nrows) {
+            int p = (int)((sqrt((double)(8 * idx + 1)) - 1.0) * 0.5);
+            while ((p + 1) * (p + 2) / 2 <= idx) ++p;
+            while (p * (p + 1) / 2 > idx) --p;
+            const int qq = idx - p * (p + 1) / 2;
+            wv = x[(size_t)p * BLOCK] * x[(size_t)qq * BLOCK] * (p == qq ? T(1) : T(2));
+          }
+          w8[q] = wv;
+        }
+        axpy8_t<T, LD>(Wg, sg.rb0 + b, n, ucol, w8, on);
+      }
+    }
+  }
+
+  // grad_v = s t - [clipped] s^2 (t.v) u
+  const T coef = clipped ? sc * sc * tv : T(0);
+  for (int j = 0; j < n; ++j) tcol[j * LD] = sc * tcol[j * LD] - coef * ucol[j * LD];
+  __syncthreads();
+  for (int idx = tid; idx < nb * n; idx += BLOCK) {
+    const int bl = idx / n, j = idx - bl * n;
+    grad_v[(b0 + bl) * ldgv + j] = tT[j * LD + bl];
+  }
+}
+
 template <typename T>
-int generic_backward(const RayenPack*, const GenericImage<T>&, const T*, int64_t, int64_t, const T*,
-                     const int32_t*, const T*, int64_t, T*, int64_t, hipStream_t) {
-  return RAYEN_E_UNSUPPORTED;
+static void bwd_shape(const RayenPack* p, const GenericImage<T>& img, int* w_rows, int* lmi_words) {
+  *w_rows = 0;
+  *lmi_words = 0;
+  for (const RayenSegment& g : p->segs) {
+    if (g.type == RAYEN_SEG_QUAD_FAC || g.type == RAYEN_SEG_SOC) {
+      const int rows = (g.nrows + kRowBlock - 1) / kRowBlock * kRowBlock;
+      if (rows > *w_rows) *w_rows = rows;
+    }
+    if (g.type == RAYEN_SEG_LMI && g.nrows + 2 * g.dim > *lmi_words) *lmi_words = g.nrows + 2 * g.dim;
+  }
+  (void)img;
+}
+
+template <typename T>
+static size_t bwd_lds_bytes(const RayenPack* p, int w_rows, int lmi_words, int block) {
+  const int n_pad = (p->n + kRowBlock - 1) / kRowBlock * kRowBlock;
+  const int k_pad = p->out_identity ? 0 : (p->k + kRowBlock - 1) / kRowBlock * kRowBlock;
+  return sizeof(T) * ((size_t)(3 * n_pad + k_pad + w_rows) * (block + 1) + (size_t)lmi_words * block);
+}
+
+template <typename T, int BLOCK>
+static int launch_bwd(const RayenPack* p, const GenericImage<T>& img, int w_rows, int lmi_words, const T* v,
+                      int64_t B, int64_t ldv, const T* kappa, const int32_t* active, const T* grad_y,
+                      int64_t ldg, T* grad_v, int64_t ldgv, hipStream_t stream) {
+  const size_t lds = bwd_lds_bytes<T>(p, w_rows, lmi_words, BLOCK);
+  auto kern = generic_bwd_kernel<T, BLOCK>;
+  if (lds > 48 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lds) != hipSuccess)
+    return RAYEN_E_LAUNCH;
+  const int64_t grid = (B + BLOCK - 1) / BLOCK;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), lds, stream, img.Wg, img.NTg, img.segs,
+                     img.n_gseg, p->k, p->n, w_rows, lmi_words, v, B, ldv, kappa, active, grad_y, ldg, grad_v,
+                     ldgv);
+  return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
+}
+
+template <typename T>
+int generic_backward(const RayenPack* p, const GenericImage<T>& img, const T* v, int64_t B, int64_t ldv,
+                     const T* kappa, const int32_t* active, const T* grad_y, int64_t ldg, T* grad_v,
+                     int64_t ldgv, hipStream_t stream) {
+  if (B == 0) return RAYEN_OK;
+  int w_rows, lmi_words;
+  bwd_shape<T>(p, img, &w_rows, &lmi_words);
+  int block = 0;
+  for (int cand : {256, 128, 64})
+    if (bwd_lds_bytes<T>(p, w_rows, lmi_words, cand) <= kLdsSoft) { block = cand; break; }
+  if (block == 0 && bwd_lds_bytes<T>(p, w_rows, lmi_words, 64) <= kLdsHard) block = 64;
+  switch (block) {
+    case 256: return launch_bwd<T, 256>(p, img, w_rows, lmi_words, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, stream);
+    case 128: return launch_bwd<T, 128>(p, img, w_rows, lmi_words, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, stream);
+    case 64: return launch_bwd<T, 64>(p, img, w_rows, lmi_words, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, stream);
+    default: return RAYEN_E_UNSUPPORTED;
+  }
 }
 
 #define RAYEN_INSTANTIATE(T)                                                                        \

@@ -1,0 +1,90 @@
+"""Backward of the fused op (HIP kernel) against autograd through the CPU oracle (fp64)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import csd_from_cs, load_golden
+from oracle import rayen_oracle as oracle
+from rayen_amd import workloads
+from rayen_amd.constraint_module import ConstraintModule
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases():
+    mixed_raw, _, _ = load_golden("config_mixed")          # lin + eq + quad + SOC + LMI, n < k
+    return {
+        "c1": workloads.make_raw("c1"),
+        "c2": workloads.make_raw("c2", seed=31),
+        "c3": workloads.make_raw("c3", seed=32),
+        "c4": workloads.make_raw("c4", seed=33),
+        "c5": workloads.corridor_like(k=20, n_eq=6, m=24, n_quad=5, rank=2, seed=34),
+        "mixed": mixed_raw,
+    }
+
+
+def _oracle_grad(cs, x, G):
+    buf = oracle.precompute(csd_from_cs(cs), torch.float64)
+    xr = x.double().clone().requires_grad_(True)
+    y = oracle.forward(buf, xr)
+    (y[:, :, 0] * G.double()).sum().backward()
+    return xr.grad[:, :, 0].numpy(), y.detach()[:, :, 0].numpy()
+
+
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4", "c5", "mixed"])
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-6), (torch.float32, 5e-3)])
+def test_backward_matches_oracle_autograd(name, dtype, tol):
+    raw = _cases()[name]
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        cs = workloads.build_constraints(raw)
+        layer = ConstraintModule(cs, create_map=False).cuda()
+    finally:
+        torch.set_default_dtype(prev)
+    B = 512
+    gen = torch.Generator().manual_seed(77)
+    scale = 3.0 if name == "c1" else 1.0
+    x = (torch.empty(B, cs.n, 1).uniform_(-scale, scale, generator=gen)).to(dtype)
+    x[:8] *= 1e-3                                            # a few interior (unclipped) samples
+    G = torch.empty(B, cs.k).uniform_(-1, 1, generator=gen).to(dtype)
+
+    xg = x.cuda().requires_grad_(True)
+    y = layer(xg)
+    (y[:, :, 0] * G.cuda()).sum().backward()
+    got = xg.grad[:, :, 0].cpu().double().numpy()
+    want, y_ref = _oracle_grad(cs, x, G)
+
+    assert np.all(np.isfinite(got))
+    scale_g = np.maximum(np.max(np.abs(want), axis=1), 1e-12)
+    err = np.max(np.abs(got - want), axis=1) / scale_g
+    # a sample sitting on a kink of kappa (two constraints tie, or kappa == 1) may legitimately
+    # pick the other one-sided derivative in a different precision: allow a handful
+    frac_ok = np.mean(err <= tol)
+    assert frac_ok >= (0.999 if dtype == torch.float64 else 0.99), (frac_ok, np.sort(err)[-5:])
+    assert np.median(err) <= tol / 10
+    # interior samples: y = y0 + NA_E v exactly, so grad = NA_E' G
+    lift = G[:8].double().numpy() @ cs.NA_E
+    assert np.max(np.abs(got[:8] - lift)) <= 1e-5 * max(1.0, np.max(np.abs(lift)))
+
+
+def test_training_step_through_a_model():
+    """loss.backward() + optimiser step through mapper -> projection (examples/main.py:166-171 usage)."""
+    cs = workloads.build_constraints(workloads.make_raw("c2", seed=5))
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 32), torch.nn.ReLU(),
+                                ConstraintModule(cs, input_dim=32, create_map=True)).cuda()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    x = torch.randn(256, 6, device="cuda")
+    target = torch.zeros(256, cs.k, 1, device="cuda")
+    losses = []
+    for _ in range(30):
+        opt.zero_grad()
+        loss = ((model(x) - target) ** 2).mean()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses))
+    assert losses[-1] < losses[0]
+    for p in model.parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all()
