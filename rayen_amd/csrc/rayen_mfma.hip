@@ -42,7 +42,7 @@ struct MItem {
   int32_t seg;     // caller's segment index (reported in `active`)
   int32_t row0;    // LIN: logical W row of the tile's first row | QSYM: tile index | OUT: first output row
   int32_t aux;     // row of phi | c (b is aux+1) inside the aux tile
-  int32_t pad;
+  int32_t qbegin;  // first k-group this tile needs (QSYM: the block-lower-triangular part is folded away)
   float f0, f1;    // SOC: tau, a'
 };
 
@@ -98,6 +98,12 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_fwd_kern
   const int64_t wave_id = (int64_t)blockIdx.x * kMfmaWaves + wave;
   const int64_t wave_stride = (int64_t)gridDim.x * kMfmaWaves;
   bool bad = false;
+#if defined(RAYEN_MFMA_STAGGER) && RAYEN_MFMA_STAGGER > 0
+  // waves w and w+4 of a workgroup share a SIMD: start the second one a fraction of a group later,
+  // so that the pair never sits at a group boundary (HBM burst, no MFMA work) at the same time
+  if (__builtin_amdgcn_readfirstlane(wave) >= kMfmaWaves / 2)
+    for (int i = 0; i < RAYEN_MFMA_STAGGER; ++i) __builtin_amdgcn_s_sleep(16);  // 16 x 64 cycles each
+#endif
 #ifdef RAYEN_MFMA_PRIO
   // waves w and w+4 of a workgroup share a SIMD: give one of each pair static priority so the two
   // do not drift into lockstep (MFMA phases on top of each other, epilogues on top of each other)
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_fwd_kern
   fetch_tile(buf_a);
 
   // one 32-row tile: NQ k-groups of 4 MFMA steps on every sample tile
-  auto run_tile = [&](f32x16 (&acc)[NT], const f32x4 (&a)[NQ]) {
+  auto run_tile = [&](f32x16 (&acc)[NT], const f32x4 (&a)[NQ], const int qbegin) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -195,12 +201,16 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_fwd_kern
       for (int t = 0; t < NT; ++t) acc[t][q & 15] += a[q][0] * vr[t][4 * q];
 #else
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
+    for (int qb = 0; qb < NKK; ++qb) {  // one 32-column block = 4 k-groups
+      if (4 * qb < qbegin) continue;    // wave-uniform: the block was folded into its transpose
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
+      for (int q = 4 * qb; q < 4 * qb + 4; ++q)
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][c], vr[t][4 * q + c], acc[t], 0, 0, 0);
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][c], vr[t][4 * q + c], acc[t], 0, 0, 0);
+    }
 #endif
   };
 
@@ -223,7 +233,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_fwd_kern
     if (item.type == MI_NOP) return;  // pairing filler: no MFMAs, no epilogue
     // rows of NA_E come last: kappa is final once the first of those tiles is reached
     if (item.type == MI_OUT && (item.flags & MF_FIRST)) finish_kappa();
-    run_tile(acc, a);
+    run_tile(acc, a, item.qbegin);
     TS();
 #if defined(RAYEN_ABL) && (RAYEN_ABL & 1) && defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -469,7 +479,17 @@ int mfma_build(const RayenPack* p, MfmaImage** out, int64_t* bytes) {
     const int ntiles = (total + 31) / 32;
     for (int t = 0; t < ntiles; ++t) {
       std::vector<const double*> rows;
-      for (int r = 32 * t; r < 32 * t + 32 && r < g.nrows; ++r) rows.push_back(wrow(g.row0 + r));
+      std::vector<std::vector<double>> folded;  // QSYM: row tile t keeps column blocks >= t, off-diagonal ones doubled
+      if (g.type == RAYEN_SEG_QUAD_SYM) {
+        for (int r = 32 * t; r < 32 * t + 32 && r < g.nrows; ++r) {
+          std::vector<double> row(p->n, 0.0);
+          for (int c = 32 * t; c < p->n; ++c) row[c] = wrow(g.row0 + r)[c] * (c >= 32 * (t + 1) ? 2.0 : 1.0);
+          folded.push_back(row);
+        }
+        for (auto& row : folded) rows.push_back(row.data());
+      } else {
+        for (int r = 32 * t; r < 32 * t + 32 && r < g.nrows; ++r) rows.push_back(wrow(g.row0 + r));
+      }
       b.add_tile(rows, p->n);
       MItem it;
       std::memset(&it, 0, sizeof(it));
@@ -480,7 +500,7 @@ int mfma_build(const RayenPack* p, MfmaImage** out, int64_t* bytes) {
       it.flags = (t == 0 ? MF_FIRST : 0) | (t == ntiles - 1 ? MF_LAST : 0);
       switch (g.type) {
         case RAYEN_SEG_LIN: it.type = MI_LIN; it.row0 = g.row0 + 32 * t; break;
-        case RAYEN_SEG_QUAD_SYM: it.type = MI_QSYM; it.row0 = t; break;
+        case RAYEN_SEG_QUAD_SYM: it.type = MI_QSYM; it.row0 = t; it.qbegin = 4 * t; break;
         case RAYEN_SEG_QUAD_FAC: it.type = MI_QFAC; break;
         case RAYEN_SEG_SOC: it.type = MI_SOC; break;
         default: return RAYEN_E_UNSUPPORTED;
