@@ -32,7 +32,7 @@ namespace rayen {
 using f32x16 = float __attribute__((ext_vector_type(16)));
 using f32x4 = float __attribute__((ext_vector_type(4)));
 
-enum : int32_t { MI_AUX = 0, MI_LIN = 1, MI_QSYM = 2, MI_QFAC = 3, MI_SOC = 4, MI_OUT = 5, MI_NOP = 6 };
+enum : int32_t { MI_AUX = 0, MI_LIN = 1, MI_QSYM = 2, MI_QFAC = 3, MI_SOC = 4, MI_OUT = 5, MI_NOP = 6, MI_PACK = 7 };
 enum : int32_t { MF_FIRST = 1, MF_LAST = 2 };
 
 // One work item of the tile walk = one 32-row tile of W.
@@ -54,7 +54,16 @@ struct MItem {
 #endif
 constexpr int kMfmaWavesPerSimd = RAYEN_MFMA_WPS;
 
+// A packed tile holds up to eight small factor segments (rank <= 4: one quad of rows = the four
+// registers 4a..4a+3 of one half-wave; rank 5..8: the same quad in both halves).  One record per
+// tile, indexed by MItem::aux; row0 of the item carries the "pair" bits.
+struct MPack {
+  int32_t aux[4][2];  // [quad a][half]: aux row of phi for the segment sitting there
+  int32_t seg[4][2];  // caller's segment index, -1 = empty
+};
+
 struct MfmaImage {
+  MPack* packs = nullptr;
   f32x4* W = nullptr;      // [n_tiles + 1][NQ][64] float4, fragment order (one spare tile for the prefetch)
   MItem* items = nullptr;
   float* y0 = nullptr;     // [k_pad]
@@ -83,7 +92,7 @@ __device__ __forceinline__ float xhalf(float x) { return __shfl_xor(x, 32); }
 template <int NKK, bool TRACK>
 __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_fwd_kernel(
     const f32x4* __restrict__ Wimg, const MItem* __restrict__ items, int n_items,
-    const float* __restrict__ y0, int identity, int k, int n, const float* __restrict__ v, int64_t B,
+    const MPack* __restrict__ packs, const float* __restrict__ y0, int identity, int k, int n, const float* __restrict__ v, int64_t B,
     int64_t ldv, int vec_in, float* __restrict__ y, int64_t ldy, int vec_out,
     float* __restrict__ kappa_out, int32_t* __restrict__ active_out, int32_t* __restrict__ nan_flag) {
   using C = MfmaCfg<NKK>;
@@ -287,6 +296,24 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_fwd_kern
           }
         }
       }
+    } else if (item.type == MI_PACK) {
+      // eight small factor segments in one tile: ||U v||^2 of each is a 4-register sum
+      const MPack pk = packs[item.aux];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int slot = hi ? pk.aux[a][1] : pk.aux[a][0];
+        const int sid = hi ? pk.seg[a][1] : pk.seg[a][0];
+        const bool pair = (item.row0 >> a) & 1;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          float qs = acc[t][4 * a] * acc[t][4 * a];
+#pragma unroll
+          for (int c = 1; c < 4; ++c) qs = fmaf(acc[t][4 * a + c], acc[t][4 * a + c], qs);
+          if (pair) qs += xhalf(qs);
+          const float kc = aux_lds[wave][t][slot & 31][col] + sqrtf(qs);
+          if (sid >= 0 && kc > kap[t]) { kap[t] = kc; aseg[t] = sid; arow[t] = 0; }
+        }
+      }
     } else {
       // QSYM / QFAC / SOC: a running sum over the segment's tiles, closed on its last tile
 #pragma unroll
@@ -395,34 +422,14 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_fwd_kern
 
 static int n_pad_of(int n) { return (n + 31) / 32 * 32; }
 
-bool mfma_eligible(const RayenPack* p) {
-  if (p->n > 128) return false;  // v lives in registers: n_pad/2 VGPRs per sample tile
-  int aux_rows = 0;
-  int64_t useful = 0, padded = 0;
-  const int n_pad = n_pad_of(p->n);
-  for (const RayenSegment& g : p->segs) {
-    if (g.type == RAYEN_SEG_LMI) return false;  // eigen-solve epilogue lives on the generic path
-    if (g.type == RAYEN_SEG_QUAD_SYM || g.type == RAYEN_SEG_QUAD_FAC) aux_rows += 1;
-    if (g.type == RAYEN_SEG_SOC) aux_rows += 2;
-    const int rows = (g.type == RAYEN_SEG_QUAD_SYM) ? n_pad : (g.nrows + 31) / 32 * 32;
-    useful += g.nrows;
-    padded += rows;
-  }
-  if (aux_rows > 32) return false;  // one aux tile
-  if (aux_rows) { useful += aux_rows; padded += 32; }
-  if (!p->out_identity) { useful += p->k; padded += (p->k + 31) / 32 * 32; }
-  if (padded == 0) return false;
-  // 32-row tiles must be reasonably full, and columns not mostly padding; otherwise the
-  // 8-row generic path wastes less
-  return useful * 2 >= padded && p->n * 2 >= n_pad;
-}
-
 namespace {
 
 struct ImageBuilder {
   int n, n_pad, nq;
   std::vector<float> frag;  // fragment-ordered image
   std::vector<MItem> items;
+  std::vector<MPack> packs;
+  int64_t useful_rows = 0;
 
   // rows: pointers to up to 32 source rows (nullptr = zero row), each with `ncols` valid columns
   void add_tile(const std::vector<const double*>& rows, int ncols) {
@@ -437,91 +444,160 @@ struct ImageBuilder {
           if (colx < ncols) frag[base + ((size_t)q * 64 + l) * 4 + c] = (float)rows[r][colx];
         }
       }
+    for (const double* r : rows) useful_rows += (r != nullptr);
   }
 };
 
+int aux_rows_of(const RayenSegment& g) {
+  if (g.type == RAYEN_SEG_QUAD_SYM || g.type == RAYEN_SEG_QUAD_FAC) return 1;
+  if (g.type == RAYEN_SEG_SOC) return 2;
+  return 0;
+}
+
+bool is_small_factor(const RayenSegment& g) { return g.type == RAYEN_SEG_QUAD_FAC && g.nrows <= 8; }
+
+// Lay the whole constant set out as a sequence of 32-row tiles:
+//   segments are taken in order, in batches whose aux rows (phi | c, b) fit one aux tile; each
+//   batch = [AUX tile] [own tiles of the large segments] [packed tiles of the small factor ones];
+//   the rows of NA_E (if it is not the identity) come last.
+int layout(const RayenPack* p, ImageBuilder& b) {
+  const double* W = p->W.data();
+  auto wrow = [&](int r) { return W + (size_t)r * p->n; };
+  auto blank = [](int type) { MItem it; std::memset(&it, 0, sizeof(it)); it.type = type; return it; };
+  const size_t nseg = p->segs.size();
+  size_t s0 = 0;
+  while (s0 < nseg) {
+    // ---- batch [s0, s1): as many segments as one aux tile can serve
+    size_t s1 = s0;
+    int aux_used = 0;
+    while (s1 < nseg && aux_used + aux_rows_of(p->segs[s1]) <= 32) aux_used += aux_rows_of(p->segs[s1++]);
+    if (s1 == s0) return RAYEN_E_UNSUPPORTED;
+    std::vector<int> aux_slot(nseg, -1);
+    if (aux_used > 0) {
+      std::vector<const double*> rows;
+      for (size_t s = s0; s < s1; ++s) {
+        const RayenSegment& g = p->segs[s];
+        if (aux_rows_of(g) == 0) continue;
+        aux_slot[s] = (int)rows.size();
+        for (int r = 0; r < aux_rows_of(g); ++r) rows.push_back(wrow(g.aux_row + r));
+      }
+      b.items.push_back(blank(MI_AUX));
+      b.add_tile(rows, p->n);
+    }
+    // ---- large segments: their own tiles
+    for (size_t s = s0; s < s1; ++s) {
+      const RayenSegment& g = p->segs[s];
+      if (is_small_factor(g)) continue;
+      const int total = (g.type == RAYEN_SEG_QUAD_SYM) ? b.n_pad : g.nrows;
+      const int ntiles = (total + 31) / 32;
+      for (int t = 0; t < ntiles; ++t) {
+        std::vector<const double*> rows;
+        std::vector<std::vector<double>> folded;  // QSYM: row tile t keeps column blocks >= t, off-diagonal ones doubled
+        if (g.type == RAYEN_SEG_QUAD_SYM) {
+          for (int r = 32 * t; r < 32 * t + 32 && r < g.nrows; ++r) {
+            std::vector<double> row(p->n, 0.0);
+            for (int c = 32 * t; c < p->n; ++c) row[c] = wrow(g.row0 + r)[c] * (c >= 32 * (t + 1) ? 2.0 : 1.0);
+            folded.push_back(row);
+          }
+          for (auto& row : folded) rows.push_back(row.data());
+        } else {
+          for (int r = 32 * t; r < 32 * t + 32 && r < g.nrows; ++r) rows.push_back(wrow(g.row0 + r));
+        }
+        b.add_tile(rows, p->n);
+        MItem it = blank(0);
+        it.seg = (int32_t)s;
+        it.aux = aux_slot[s];
+        it.f0 = (float)g.f0;
+        it.f1 = (float)g.f1;
+        it.flags = (t == 0 ? MF_FIRST : 0) | (t == ntiles - 1 ? MF_LAST : 0);
+        switch (g.type) {
+          case RAYEN_SEG_LIN: it.type = MI_LIN; it.row0 = g.row0 + 32 * t; break;
+          case RAYEN_SEG_QUAD_SYM: it.type = MI_QSYM; it.row0 = t; it.qbegin = 4 * t; break;
+          case RAYEN_SEG_QUAD_FAC: it.type = MI_QFAC; break;
+          case RAYEN_SEG_SOC: it.type = MI_SOC; break;
+          default: return RAYEN_E_UNSUPPORTED;
+        }
+        b.items.push_back(it);
+      }
+    }
+    // ---- small factor segments: eight quads of rows per packed tile
+    {
+      std::vector<const double*> rows(32, nullptr);
+      MPack pk;
+      int pair_bits = 0, used = 0;  // `used` counts half-quads handed out: slot = a * 2 + half
+      auto reset = [&]() {
+        std::fill(rows.begin(), rows.end(), nullptr);
+        for (int a = 0; a < 4; ++a) for (int h = 0; h < 2; ++h) { pk.aux[a][h] = 0; pk.seg[a][h] = -1; }
+        pair_bits = 0;
+        used = 0;
+      };
+      auto flush = [&]() {
+        if (used == 0) return;
+        MItem it = blank(MI_PACK);
+        it.aux = (int32_t)b.packs.size();
+        it.row0 = pair_bits;
+        b.packs.push_back(pk);
+        b.items.push_back(it);
+        b.add_tile(rows, p->n);
+        reset();
+      };
+      reset();
+      for (size_t s = s0; s < s1; ++s) {
+        const RayenSegment& g = p->segs[s];
+        if (!is_small_factor(g)) continue;
+        const bool pair = g.nrows > 4;
+        if (pair && (used & 1)) ++used;          // a pair starts on an even half-quad
+        if (used + (pair ? 2 : 1) > 8) flush();
+        const int a = used / 2, h = used & 1;
+        for (int r = 0; r < g.nrows; ++r) rows[8 * a + 4 * h + r] = wrow(g.row0 + r);  // rows 8a+4h.. are contiguous
+        pk.aux[a][h] = aux_slot[s];
+        pk.seg[a][h] = (int32_t)s;
+        if (pair) { pk.aux[a][1] = aux_slot[s]; pk.seg[a][1] = (int32_t)s; pair_bits |= 1 << a; }
+        used += pair ? 2 : 1;
+      }
+      flush();
+    }
+    s0 = s1;
+  }
+  if (!p->out_identity) {
+    const int k_tiles = (p->k + 31) / 32;
+    for (int t = 0; t < k_tiles; ++t) {
+      std::vector<const double*> rows;
+      for (int r = 32 * t; r < 32 * t + 32 && r < p->k; ++r) rows.push_back(p->NA_E.data() + (size_t)r * p->n);
+      b.add_tile(rows, p->n);
+      MItem it = blank(MI_OUT);
+      it.row0 = 32 * t;
+      it.flags = (t == 0 ? MF_FIRST : 0) | (t == k_tiles - 1 ? MF_LAST : 0);
+      b.items.push_back(it);
+    }
+  }
+  return RAYEN_OK;
+}
+
 }  // namespace
+
+bool mfma_eligible(const RayenPack* p) {
+  if (p->n > 128) return false;  // v lives in registers: n_pad/2 VGPRs per sample tile
+  for (const RayenSegment& g : p->segs)
+    if (g.type == RAYEN_SEG_LMI) return false;  // eigen-solve epilogue lives on the generic path
+  ImageBuilder b;
+  b.n = p->n;
+  b.n_pad = n_pad_of(p->n);
+  b.nq = b.n_pad / 8;
+  if (layout(p, b) != RAYEN_OK || b.items.empty()) return false;
+  // 32-row tiles must be reasonably full, and columns not mostly padding; otherwise the
+  // 8-row generic path wastes less
+  const int64_t padded = (int64_t)b.items.size() * 32;
+  return b.useful_rows * 2 >= padded && p->n * 2 >= b.n_pad;
+}
 
 int mfma_build(const RayenPack* p, MfmaImage** out, int64_t* bytes) {
   ImageBuilder b;
   b.n = p->n;
   b.n_pad = n_pad_of(p->n);
   b.nq = b.n_pad / 8;
-  const double* W = p->W.data();
-  auto wrow = [&](int r) { return W + (size_t)r * p->n; };
-
-  // aux tile: phi rows and (c, b) row pairs, in segment order
-  std::vector<int> aux_slot(p->segs.size(), -1);
-  {
-    std::vector<const double*> rows;
-    for (size_t s = 0; s < p->segs.size(); ++s) {
-      const RayenSegment& g = p->segs[s];
-      if (g.type == RAYEN_SEG_QUAD_SYM || g.type == RAYEN_SEG_QUAD_FAC) {
-        aux_slot[s] = (int)rows.size();
-        rows.push_back(wrow(g.aux_row));
-      } else if (g.type == RAYEN_SEG_SOC) {
-        aux_slot[s] = (int)rows.size();
-        rows.push_back(wrow(g.aux_row));
-        rows.push_back(wrow(g.aux_row + 1));
-      }
-    }
-    if (!rows.empty()) {
-      MItem it;
-      std::memset(&it, 0, sizeof(it));
-      it.type = MI_AUX;
-      b.items.push_back(it);
-      b.add_tile(rows, p->n);
-    }
-  }
-  for (size_t s = 0; s < p->segs.size(); ++s) {
-    const RayenSegment& g = p->segs[s];
-    const int total = (g.type == RAYEN_SEG_QUAD_SYM) ? b.n_pad : g.nrows;
-    const int ntiles = (total + 31) / 32;
-    for (int t = 0; t < ntiles; ++t) {
-      std::vector<const double*> rows;
-      std::vector<std::vector<double>> folded;  // QSYM: row tile t keeps column blocks >= t, off-diagonal ones doubled
-      if (g.type == RAYEN_SEG_QUAD_SYM) {
-        for (int r = 32 * t; r < 32 * t + 32 && r < g.nrows; ++r) {
-          std::vector<double> row(p->n, 0.0);
-          for (int c = 32 * t; c < p->n; ++c) row[c] = wrow(g.row0 + r)[c] * (c >= 32 * (t + 1) ? 2.0 : 1.0);
-          folded.push_back(row);
-        }
-        for (auto& row : folded) rows.push_back(row.data());
-      } else {
-        for (int r = 32 * t; r < 32 * t + 32 && r < g.nrows; ++r) rows.push_back(wrow(g.row0 + r));
-      }
-      b.add_tile(rows, p->n);
-      MItem it;
-      std::memset(&it, 0, sizeof(it));
-      it.seg = (int32_t)s;
-      it.aux = aux_slot[s];
-      it.f0 = (float)g.f0;
-      it.f1 = (float)g.f1;
-      it.flags = (t == 0 ? MF_FIRST : 0) | (t == ntiles - 1 ? MF_LAST : 0);
-      switch (g.type) {
-        case RAYEN_SEG_LIN: it.type = MI_LIN; it.row0 = g.row0 + 32 * t; break;
-        case RAYEN_SEG_QUAD_SYM: it.type = MI_QSYM; it.row0 = t; it.qbegin = 4 * t; break;
-        case RAYEN_SEG_QUAD_FAC: it.type = MI_QFAC; break;
-        case RAYEN_SEG_SOC: it.type = MI_SOC; break;
-        default: return RAYEN_E_UNSUPPORTED;
-      }
-      b.items.push_back(it);
-    }
-  }
-  const int k_tiles = (p->k + 31) / 32;
-  if (!p->out_identity) {
-    for (int t = 0; t < k_tiles; ++t) {
-      std::vector<const double*> rows;
-      for (int r = 32 * t; r < 32 * t + 32 && r < p->k; ++r) rows.push_back(p->NA_E.data() + (size_t)r * p->n);
-      b.add_tile(rows, p->n);
-      MItem it;
-      std::memset(&it, 0, sizeof(it));
-      it.type = MI_OUT;
-      it.row0 = 32 * t;
-      it.flags = (t == 0 ? MF_FIRST : 0) | (t == k_tiles - 1 ? MF_LAST : 0);
-      b.items.push_back(it);
-    }
-  }
+  const int rc = layout(p, b);
+  if (rc != RAYEN_OK) return rc;
   if (b.items.size() % 2) {  // the kernel walks tiles in pairs
     MItem it;
     std::memset(&it, 0, sizeof(it));
@@ -530,6 +606,7 @@ int mfma_build(const RayenPack* p, MfmaImage** out, int64_t* bytes) {
     b.add_tile({}, p->n);
   }
   b.frag.resize(b.frag.size() + (size_t)b.nq * 64 * 4, 0.f);  // spare tile: the prefetch runs one tile past the end
+  if (b.packs.empty()) b.packs.push_back(MPack());
 
   MfmaImage* img = new MfmaImage();
   img->nkk = b.n_pad / 32;
@@ -540,17 +617,20 @@ int mfma_build(const RayenPack* p, MfmaImage** out, int64_t* bytes) {
       img->n_simd = prop.multiProcessorCount * 4;
   }
   img->n_items = (int)b.items.size();
+  const int k_tiles = (p->k + 31) / 32;
   std::vector<float> y0((size_t)k_tiles * 32 + 32, 0.f);
   for (int i = 0; i < p->k; ++i) y0[i] = (float)p->y0[i];
   bool ok = hipMalloc(&img->W, b.frag.size() * sizeof(float)) == hipSuccess &&
             hipMemcpy(img->W, b.frag.data(), b.frag.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
             hipMalloc(&img->y0, y0.size() * sizeof(float)) == hipSuccess &&
-            hipMemcpy(img->y0, y0.data(), y0.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
-  if (ok && !b.items.empty())
-    ok = hipMalloc(&img->items, b.items.size() * sizeof(MItem)) == hipSuccess &&
-         hipMemcpy(img->items, b.items.data(), b.items.size() * sizeof(MItem), hipMemcpyHostToDevice) == hipSuccess;
+            hipMemcpy(img->y0, y0.data(), y0.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMalloc(&img->items, b.items.size() * sizeof(MItem)) == hipSuccess &&
+            hipMemcpy(img->items, b.items.data(), b.items.size() * sizeof(MItem), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMalloc(&img->packs, b.packs.size() * sizeof(MPack)) == hipSuccess &&
+            hipMemcpy(img->packs, b.packs.data(), b.packs.size() * sizeof(MPack), hipMemcpyHostToDevice) == hipSuccess;
   if (!ok) { mfma_free(img); return RAYEN_E_ALLOC; }
-  img->bytes = (int64_t)(b.frag.size() * sizeof(float) + y0.size() * sizeof(float) + b.items.size() * sizeof(MItem));
+  img->bytes = (int64_t)(b.frag.size() * sizeof(float) + y0.size() * sizeof(float) +
+                         b.items.size() * sizeof(MItem) + b.packs.size() * sizeof(MPack));
   *bytes = img->bytes;
   *out = img;
   return RAYEN_OK;
@@ -560,6 +640,7 @@ void mfma_free(MfmaImage* img) {
   if (img == nullptr) return;
   if (img->W) (void)hipFree(img->W);
   if (img->items) (void)hipFree(img->items);
+  if (img->packs) (void)hipFree(img->packs);
   if (img->y0) (void)hipFree(img->y0);
   delete img;
 }
@@ -580,11 +661,11 @@ static int launch_mfma(const RayenPack* p, const MfmaImage* img, const float* v,
   const int vec_out = (ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
   if (active != nullptr) {
     hipLaunchKernelGGL((mfma_fwd_kernel<NKK, true>), dim3((unsigned)grid), dim3(kMfmaWaves * 64), 0, stream,
-                       img->W, img->items, img->n_items, img->y0, img->identity, p->k, p->n, v, B, ldv,
+                       img->W, img->items, img->n_items, img->packs, img->y0, img->identity, p->k, p->n, v, B, ldv,
                        vec_in, y, ldy, vec_out, kappa, active, nan_flag);
   } else {
     hipLaunchKernelGGL((mfma_fwd_kernel<NKK, false>), dim3((unsigned)grid), dim3(kMfmaWaves * 64), 0, stream,
-                       img->W, img->items, img->n_items, img->y0, img->identity, p->k, p->n, v, B, ldv,
+                       img->W, img->items, img->n_items, img->packs, img->y0, img->identity, p->k, p->n, v, B, ldv,
                        vec_in, y, ldy, vec_out, kappa, active, nan_flag);
   }
   return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
