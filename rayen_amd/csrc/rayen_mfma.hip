@@ -33,7 +33,7 @@ using f32x16 = float __attribute__((ext_vector_type(16)));
 using f32x4 = float __attribute__((ext_vector_type(4)));
 
 enum : int32_t { MI_AUX = 0, MI_LIN = 1, MI_QSYM = 2, MI_QFAC = 3, MI_SOC = 4, MI_OUT = 5, MI_NOP = 6, MI_PACK = 7 };
-enum : int32_t { MF_FIRST = 1, MF_LAST = 2 };
+enum : int32_t { MF_FIRST = 1, MF_LAST = 2, MF_SYM = 4 };  // SYM: rows of a symmetric form, summed as acc . v
 
 // One work item of the tile walk = one 32-row tile of W.
 struct MItem {
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_fwd_kern
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         float sum = (item.flags & MF_FIRST) ? 0.f : part[t];
-        if (item.type == MI_QSYM) {
+        if (item.flags & MF_SYM) {
           // radicand v'Gv = sum_j (G v)_j v_j ; v_j of row tile tp is register 16*tp+g of vr
 #pragma unroll
           for (int tp = 0; tp < NKK; ++tp)
@@ -488,15 +488,32 @@ int layout(const RayenPack* p, ImageBuilder& b) {
     for (size_t s = s0; s < s1; ++s) {
       const RayenSegment& g = p->segs[s];
       if (is_small_factor(g)) continue;
-      const int total = (g.type == RAYEN_SEG_QUAD_SYM) ? b.n_pad : g.nrows;
+      // a symmetric form v'Gv costs (NKK+1)/2 tiles per 32 rows thanks to the block-triangular fold;
+      // an SOC block M (rows x n) is turned into G = M'M when that is cheaper than its own rows
+      const int sym_cost = (b.n_pad / 32) * (b.n_pad / 32 + 1) / 2;        // both in 32 x 32 blocks of MFMA work
+      const int fac_cost = ((g.nrows + 31) / 32) * (b.n_pad / 32);
+      const bool sym = g.type == RAYEN_SEG_QUAD_SYM || (g.type == RAYEN_SEG_SOC && sym_cost < fac_cost);
+      std::vector<double> gram;  // [n][n] for an SOC in symmetric form
+      if (sym && g.type == RAYEN_SEG_SOC) {
+        gram.assign((size_t)p->n * p->n, 0.0);
+        for (int r = 0; r < g.nrows; ++r)
+          for (int i = 0; i < p->n; ++i) {
+            const double mi = wrow(g.row0 + r)[i];
+            if (mi == 0.0) continue;
+            for (int j = 0; j < p->n; ++j) gram[(size_t)i * p->n + j] += mi * wrow(g.row0 + r)[j];
+          }
+      }
+      auto srow = [&](int r) { return gram.empty() ? wrow(g.row0 + r) : gram.data() + (size_t)r * p->n; };
+      const int srows = sym ? p->n : g.nrows;
+      const int total = sym ? b.n_pad : g.nrows;
       const int ntiles = (total + 31) / 32;
       for (int t = 0; t < ntiles; ++t) {
         std::vector<const double*> rows;
-        std::vector<std::vector<double>> folded;  // QSYM: row tile t keeps column blocks >= t, off-diagonal ones doubled
-        if (g.type == RAYEN_SEG_QUAD_SYM) {
-          for (int r = 32 * t; r < 32 * t + 32 && r < g.nrows; ++r) {
+        std::vector<std::vector<double>> folded;  // symmetric form: row tile t keeps column blocks >= t, off-diagonal ones doubled
+        if (sym) {
+          for (int r = 32 * t; r < 32 * t + 32 && r < srows; ++r) {
             std::vector<double> row(p->n, 0.0);
-            for (int c = 32 * t; c < p->n; ++c) row[c] = wrow(g.row0 + r)[c] * (c >= 32 * (t + 1) ? 2.0 : 1.0);
+            for (int c = 32 * t; c < p->n; ++c) row[c] = srow(r)[c] * (c >= 32 * (t + 1) ? 2.0 : 1.0);
             folded.push_back(row);
           }
           for (auto& row : folded) rows.push_back(row.data());
@@ -509,10 +526,11 @@ int layout(const RayenPack* p, ImageBuilder& b) {
         it.aux = aux_slot[s];
         it.f0 = (float)g.f0;
         it.f1 = (float)g.f1;
-        it.flags = (t == 0 ? MF_FIRST : 0) | (t == ntiles - 1 ? MF_LAST : 0);
+        it.flags = (t == 0 ? MF_FIRST : 0) | (t == ntiles - 1 ? MF_LAST : 0) | (sym ? MF_SYM : 0);
+        if (sym) { it.row0 = t; it.qbegin = 4 * t; }
         switch (g.type) {
           case RAYEN_SEG_LIN: it.type = MI_LIN; it.row0 = g.row0 + 32 * t; break;
-          case RAYEN_SEG_QUAD_SYM: it.type = MI_QSYM; it.row0 = t; it.qbegin = 4 * t; break;
+          case RAYEN_SEG_QUAD_SYM: it.type = MI_QSYM; break;
           case RAYEN_SEG_QUAD_FAC: it.type = MI_QFAC; break;
           case RAYEN_SEG_SOC: it.type = MI_SOC; break;
           default: return RAYEN_E_UNSUPPORTED;
