@@ -171,6 +171,17 @@ def main():
         else:
             roof = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": gbs / PEAK_HBM_GBS, "traffic": None}
+        # HBM bytes per launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE x2 per the
+        # gfx950 correction + WRITE_SIZE), committed under profiles/ by scripts/summarize_profile.py;
+        # bench.py itself cannot collect PMC counters, so this is null for workloads never profiled
+        if args.config == "c3" and dtype == torch.float32 and B == 262144:
+            import glob
+            found = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_c3_mfma_final_rocprofv3.json")))
+            if found:
+                prof = json.load(open(found[-1]))
+                roof["traffic"] = prof.get("derived", {}).get("hbm_bytes_per_launch")
+                roof["traffic_unit"] = "bytes/launch (algorithmic: %d)" % (bytes_pp * B)
+                roof["traffic_source"] = os.path.relpath(found[-1], REPO)
         roof.update({"kernel_ms": dev_ms, "algorithmic_flops_per_projection": flops_pp,
                      "algorithmic_bytes_per_projection": bytes_pp, "hbm_GBps": gbs,
                      "hbm_frac": gbs / PEAK_HBM_GBS, "fp32_TFLOPs": tflops})

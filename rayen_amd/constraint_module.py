@@ -208,7 +208,8 @@ class ConstraintModule(torch.nn.Module):
 
         y = self.forwardForMethod(q)
 
-        if __debug__ and self.check_nan and self.method == 'RAYEN':
+        if (__debug__ and self.check_nan and self.method == 'RAYEN'
+                and not torch.cuda.is_current_stream_capturing()):  # the flag read is a host sync
             dp, _ = self.device_pack(y.device)
             if int(dp.nan_flag.item()) != 0:
                 dp.nan_flag.zero_()

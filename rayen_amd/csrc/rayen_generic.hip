@@ -82,6 +82,7 @@ __device__ T lambda_max_packed(T* lm, int r) {
   for (int c = 0; c + 2 < r; ++c) {
     const T x0 = A(c + 1, c);
     T sigma = T(0);
+#pragma unroll 4
     for (int i = c + 2; i < r; ++i) { const T a = A(i, c); sigma = fma_(a, a, sigma); }
     const T mu = sqrt(fma_(x0, x0, sigma));
     const bool act = sigma > T(0);
@@ -89,25 +90,30 @@ __device__ T lambda_max_packed(T* lm, int r) {
     const T beta = act ? (T(2) * v0 * v0 / (sigma + v0 * v0)) : T(0);
     const T inv_v0 = act ? (T(1) / v0) : T(0);
     hv[(size_t)(c + 1) * BLOCK] = T(1);
+#pragma unroll 4
     for (int i = c + 2; i < r; ++i) hv[(size_t)i * BLOCK] = A(i, c) * inv_v0;
     dd[(size_t)c * BLOCK] = A(c, c);
     e2[(size_t)c * BLOCK] = act ? (mu * mu) : (x0 * x0);
 
     T pv = T(0);
     for (int i = c + 1; i < r; ++i) {
-      T acc = T(0);
-      for (int j = c + 1; j < r; ++j) {
-        const T a = (i >= j) ? A(i, j) : A(j, i);
-        acc = fma_(a, hv[(size_t)j * BLOCK], acc);
-      }
+      // row i of the symmetric matrix: A(i, c+1..i) then A(i+1..r-1, i); independent loads, 4 in flight
+      T acc0 = T(0), acc1 = T(0);
+#pragma unroll 4
+      for (int j = c + 1; j <= i; ++j) acc0 = fma_(A(i, j), hv[(size_t)j * BLOCK], acc0);
+#pragma unroll 4
+      for (int j = i + 1; j < r; ++j) acc1 = fma_(A(j, i), hv[(size_t)j * BLOCK], acc1);
+      T acc = acc0 + acc1;
       acc *= beta;
       hp[(size_t)i * BLOCK] = acc;
       pv = fma_(acc, hv[(size_t)i * BLOCK], pv);
     }
     const T K = T(0.5) * beta * pv;
+#pragma unroll 4
     for (int i = c + 1; i < r; ++i) hp[(size_t)i * BLOCK] -= K * hv[(size_t)i * BLOCK];
     for (int i = c + 1; i < r; ++i) {
       const T vi = hv[(size_t)i * BLOCK], wi = hp[(size_t)i * BLOCK];
+#pragma unroll 4
       for (int j = c + 1; j <= i; ++j)
         A(i, j) -= vi * hp[(size_t)j * BLOCK] + wi * hv[(size_t)j * BLOCK];
     }

@@ -246,3 +246,29 @@ def test_full_size_properties(name):
     # order independence: a permuted batch gives the permuted result bit-for-bit
     perm = torch.randperm(B, device="cuda", generator=gen)
     assert torch.equal(layer(x[perm]), y[perm])
+
+
+def test_hip_graph_capture_replays_the_projection():
+    """The op allocates nothing inside the C call and launches on the current stream, so a whole
+    forward can be captured in a HIP graph (launch-bound small batches: configs 1-2)."""
+    raw = workloads.make_raw("c2", seed=12)
+    cs, layer = _layer(raw)
+    layer.check_nan = False
+    static_x = torch.zeros(4096, cs.n, 1, device="cuda")
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(stream), torch.no_grad():
+        for _ in range(3):
+            layer(static_x)
+    torch.cuda.current_stream().wait_stream(stream)
+    graph = torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.graph(graph):
+        static_y = layer(static_x)
+    gen = torch.Generator().manual_seed(4)
+    for _ in range(3):
+        x = torch.empty(4096, cs.n, 1).uniform_(-1, 1, generator=gen)
+        static_x.copy_(x.cuda())
+        graph.replay()
+        torch.cuda.synchronize()
+        y_ref = _oracle_forward(cs, x, torch.float32)
+        assert np.max(rel_err_rows(static_y.cpu().numpy()[:, :, 0], y_ref)) <= FP32_TOL
