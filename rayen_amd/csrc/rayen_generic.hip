@@ -150,7 +150,83 @@ __device__ T lambda_max_packed(T* lm, int r) {
   return T(0.5) * (lo + hi);
 }
 
-template <typename T, int BLOCK>
+// Register-resident variant of lambda_max_packed for a compile-time size R: the packed matrix, the
+// Householder vectors and the tridiagonal all live in VGPRs (every index is a constant after full
+// unrolling), so the (4/3) R^3 flops run at VALU rate instead of one LDS round trip per operand.
+// `a` holds the packed lower triangle, entry (i,j) at i(i+1)/2 + j; it is destroyed.
+template <typename T, int R>
+__device__ __forceinline__ T lambda_max_regs(T (&a)[R * (R + 1) / 2]) {
+  auto IDX = [](int i, int j) { return i * (i + 1) / 2 + j; };  // i >= j
+  T dd[R], e2[R];
+  if (R == 1) return a[0];
+#pragma unroll
+  for (int c = 0; c + 2 < R; ++c) {
+    const T x0 = a[IDX(c + 1, c)];
+    T sigma = T(0);
+#pragma unroll
+    for (int i = c + 2; i < R; ++i) sigma = fma_(a[IDX(i, c)], a[IDX(i, c)], sigma);
+    const T mu = sqrt(fma_(x0, x0, sigma));
+    const bool act = sigma > T(0);
+    const T v0 = (x0 <= T(0)) ? (x0 - mu) : (-sigma / (x0 + mu));
+    const T beta = act ? (T(2) * v0 * v0 / (sigma + v0 * v0)) : T(0);
+    const T inv_v0 = act ? (T(1) / v0) : T(0);
+    T hv[R], hp[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) hv[i] = T(0);
+    hv[c + 1] = T(1);
+#pragma unroll
+    for (int i = c + 2; i < R; ++i) hv[i] = a[IDX(i, c)] * inv_v0;
+    dd[c] = a[IDX(c, c)];
+    e2[c] = act ? (mu * mu) : (x0 * x0);
+    T pv = T(0);
+#pragma unroll
+    for (int i = c + 1; i < R; ++i) {
+      T acc = T(0);
+#pragma unroll
+      for (int j = c + 1; j < R; ++j) acc = fma_((i >= j) ? a[IDX(i, j)] : a[IDX(j, i)], hv[j], acc);
+      acc *= beta;
+      hp[i] = acc;
+      pv = fma_(acc, hv[i], pv);
+    }
+    const T K = T(0.5) * beta * pv;
+#pragma unroll
+    for (int i = c + 1; i < R; ++i) hp[i] -= K * hv[i];
+#pragma unroll
+    for (int i = c + 1; i < R; ++i)
+#pragma unroll
+      for (int j = c + 1; j <= i; ++j) a[IDX(i, j)] -= hv[i] * hp[j] + hp[i] * hv[j];
+  }
+  dd[R - 2] = a[IDX(R - 2, R - 2)];
+  dd[R - 1] = a[IDX(R - 1, R - 1)];
+  e2[R - 2] = a[IDX(R - 1, R - 2)] * a[IDX(R - 1, R - 2)];
+  e2[R - 1] = T(0);
+
+  T lo = dd[0], hi = dd[0] + sqrt(e2[0]), emax = T(0), eprev = T(0);
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const T enext = (i + 1 < R) ? sqrt(e2[i]) : T(0);
+    lo = (i == 0) ? dd[i] : fmax(lo, dd[i]);
+    hi = (i == 0) ? hi : fmax(hi, dd[i] + eprev + enext);
+    emax = fmax(emax, enext);
+    eprev = enext;
+  }
+  const T pivmin = Num<T>::tiny() * fmax(T(1), emax * emax);
+  for (int it = 0; it < Num<T>::bisect_iters; ++it) {
+    const T mid = T(0.5) * (lo + hi);
+    T q = dd[0] - mid;
+    int below = q < T(0);
+#pragma unroll
+    for (int i = 1; i < R; ++i) {
+      if (fabs(q) < pivmin) q = -pivmin;
+      q = dd[i] - mid - e2[i - 1] / q;
+      below += q < T(0);
+    }
+    if (below == R) hi = mid; else lo = mid;
+  }
+  return T(0.5) * (lo + hi);
+}
+
+template <typename T, int BLOCK, int RREG>
 __global__ __launch_bounds__(BLOCK) void generic_fwd_kernel(
     const T* __restrict__ Wg, const T* __restrict__ Ng, const T* __restrict__ y0,
     const GSeg* __restrict__ segs, int n_gseg, int out_nrb, int k, int n, int lmi_words,
@@ -230,16 +306,40 @@ __global__ __launch_bounds__(BLOCK) void generic_fwd_kernel(
       }
       if (ks > kap) { kap = ks; aseg = sg.seg; arow = 0; }
     } else if (sg.type == RAYEN_SEG_LMI) {
-      T* lm = lmi + tid;
-      for (int b = 0; b < sg.nrb; ++b) {
-        dot8<T, LD>(Wg, sg.rb0 + b, n, vcol, acc);
+      T lam;
+      if constexpr (RREG > 0) {
+        // matrix of size dim <= RREG assembled straight into registers; rows/columns beyond dim are
+        // decoupled and far below every real eigenvalue
+        constexpr int NPK = RREG * (RREG + 1) / 2;
+        T a[NPK];
 #pragma unroll
-        for (int r = 0; r < kRowBlock; ++r) {
-          const int idx = b * kRowBlock + r;
-          if (idx < sg.nrows) lm[(size_t)idx * BLOCK] = acc[r];
+        for (int i = 0; i < RREG; ++i)
+#pragma unroll
+          for (int j = 0; j <= i; ++j) a[i * (i + 1) / 2 + j] = (i == j && i >= sg.dim) ? T(-1e18) : T(0);
+#pragma unroll
+        for (int b = 0; b < (NPK + kRowBlock - 1) / kRowBlock; ++b) {
+          if (b < sg.nrb) {
+            dot8<T, LD>(Wg, sg.rb0 + b, n, vcol, acc);
+#pragma unroll
+            for (int r = 0; r < kRowBlock; ++r) {
+              const int idx = b * kRowBlock + r;  // packed index in a dim x dim matrix == the same index here
+              if (idx < NPK && idx < sg.nrows) a[idx] = acc[r];
+            }
+          }
         }
+        lam = lambda_max_regs<T, RREG>(a);
+      } else {
+        T* lm = lmi + tid;
+        for (int b = 0; b < sg.nrb; ++b) {
+          dot8<T, LD>(Wg, sg.rb0 + b, n, vcol, acc);
+#pragma unroll
+          for (int r = 0; r < kRowBlock; ++r) {
+            const int idx = b * kRowBlock + r;
+            if (idx < sg.nrows) lm[(size_t)idx * BLOCK] = acc[r];
+          }
+        }
+        lam = lambda_max_packed<T, BLOCK>(lm, sg.dim);
       }
-      const T lam = lambda_max_packed<T, BLOCK>(lm, sg.dim);
       if (lam > kap) { kap = lam; aseg = sg.seg; arow = 0; }
     }
   }
@@ -403,12 +503,13 @@ int generic_block_for(const RayenPack* p, const GenericImage<T>& img) {
   return 0;
 }
 
-template <typename T, int BLOCK>
+template <typename T, int BLOCK, int RREG>
 static int launch_fwd(const RayenPack* p, const GenericImage<T>& img, const T* v, int64_t B,
                       int64_t ldv, T* y, int64_t ldy, T* kappa, int32_t* active, int32_t* nan_flag,
                       hipStream_t stream) {
-  const size_t lds = generic_lds_bytes<T>(p->n, img.lmi_words, BLOCK);
-  auto kern = generic_fwd_kernel<T, BLOCK>;
+  const int lmi_words = RREG > 0 ? 0 : img.lmi_words;  // the register path needs no LDS scratch
+  const size_t lds = generic_lds_bytes<T>(p->n, lmi_words, BLOCK);
+  auto kern = generic_fwd_kernel<T, BLOCK, RREG>;
   if (lds > 48 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -416,9 +517,20 @@ static int launch_fwd(const RayenPack* p, const GenericImage<T>& img, const T* v
   }
   const int64_t grid = (B + BLOCK - 1) / BLOCK;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), lds, stream, img.Wg, img.Ng, img.y0,
-                     img.segs, img.n_gseg, img.out_nrb, p->k, p->n, img.lmi_words, v, B, ldv, y, ldy,
+                     img.segs, img.n_gseg, img.out_nrb, p->k, p->n, lmi_words, v, B, ldv, y, ldy,
                      kappa, active, nan_flag);
   return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
+}
+
+// size class of the register-resident eigen-solve (fp32, one LMI of size <= 24), 0 = use LDS
+template <typename T>
+static int lmi_reg_class(const RayenPack* p) {
+  if (!std::is_same<T, float>::value) return 0;
+  int n_lmi = 0, dim = 0;
+  for (const RayenSegment& g : p->segs)
+    if (g.type == RAYEN_SEG_LMI) { ++n_lmi; dim = g.dim; }
+  if (n_lmi != 1 || dim > 24 || dim < 2) return 0;
+  return (dim + 3) / 4 * 4;
 }
 
 template <typename T>
@@ -426,10 +538,23 @@ int generic_forward(const RayenPack* p, const GenericImage<T>& img, const T* v, 
                     int64_t ldv, T* y, int64_t ldy, T* kappa, int32_t* active, int32_t* nan_flag,
                     hipStream_t stream) {
   if (B == 0) return RAYEN_OK;
+  if constexpr (std::is_same<T, float>::value) {
+    if (generic_lds_bytes<T>(p->n, 0, 64) <= kLdsHard) {
+      switch (lmi_reg_class<T>(p)) {
+        case 4: return launch_fwd<T, 64, 4>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+        case 8: return launch_fwd<T, 64, 8>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+        case 12: return launch_fwd<T, 64, 12>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+        case 16: return launch_fwd<T, 64, 16>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+        case 20: return launch_fwd<T, 64, 20>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+        case 24: return launch_fwd<T, 64, 24>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+        default: break;
+      }
+    }
+  }
   switch (generic_block_for<T>(p, img)) {
-    case 256: return launch_fwd<T, 256>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
-    case 128: return launch_fwd<T, 128>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
-    case 64: return launch_fwd<T, 64>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+    case 256: return launch_fwd<T, 256, 0>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+    case 128: return launch_fwd<T, 128, 0>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+    case 64: return launch_fwd<T, 64, 0>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
     default: return RAYEN_E_UNSUPPORTED;
   }
 }
