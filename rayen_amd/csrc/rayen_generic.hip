@@ -31,6 +31,11 @@ template <> struct Num<double> {
   __device__ static double tiny() { return 1.0e-290; }
 };
 
+// 1/x for the Sturm recurrence: only the SIGN sequence of q matters there, so the 1-ulp hardware
+// reciprocal is enough in fp32 (fp64 keeps the exact division)
+__device__ __forceinline__ float sturm_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double sturm_rcp(double x) { return 1.0 / x; }
+
 template <typename T> __device__ __forceinline__ T fma_(T a, T b, T c);
 template <> __device__ __forceinline__ float fma_(float a, float b, float c) { return fmaf(a, b, c); }
 template <> __device__ __forceinline__ double fma_(double a, double b, double c) { return fma(a, b, c); }
@@ -142,7 +147,7 @@ __device__ T lambda_max_packed(T* lm, int r) {
     int below = q < T(0);
     for (int i = 1; i < r; ++i) {
       if (fabs(q) < pivmin) q = -pivmin;
-      q = dd[(size_t)i * BLOCK] - mid - e2[(size_t)(i - 1) * BLOCK] / q;
+      q = dd[(size_t)i * BLOCK] - mid - e2[(size_t)(i - 1) * BLOCK] * sturm_rcp(q);
       below += q < T(0);
     }
     if (below == r) hi = mid; else lo = mid;  // all eigenvalues < mid  ->  lambda_max < mid
@@ -218,7 +223,7 @@ __device__ __forceinline__ T lambda_max_regs(T (&a)[R * (R + 1) / 2]) {
 #pragma unroll
     for (int i = 1; i < R; ++i) {
       if (fabs(q) < pivmin) q = -pivmin;
-      q = dd[i] - mid - e2[i - 1] / q;
+      q = dd[i] - mid - e2[i - 1] * sturm_rcp(q);
       below += q < T(0);
     }
     if (below == R) hi = mid; else lo = mid;
