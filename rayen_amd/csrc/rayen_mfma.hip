@@ -107,30 +107,9 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_fwd_kern
   const int64_t wave_id = (int64_t)blockIdx.x * kMfmaWaves + wave;
   const int64_t wave_stride = (int64_t)gridDim.x * kMfmaWaves;
   bool bad = false;
-#if defined(RAYEN_MFMA_STAGGER) && RAYEN_MFMA_STAGGER > 0
-  // waves w and w+4 of a workgroup share a SIMD: start the second one a fraction of a group later,
-  // so that the pair never sits at a group boundary (HBM burst, no MFMA work) at the same time
-  if (__builtin_amdgcn_readfirstlane(wave) >= kMfmaWaves / 2)
-    for (int i = 0; i < RAYEN_MFMA_STAGGER; ++i) __builtin_amdgcn_s_sleep(16);  // 16 x 64 cycles each
-#endif
-#ifdef RAYEN_MFMA_PRIO
-  // waves w and w+4 of a workgroup share a SIMD: give one of each pair static priority so the two
-  // do not drift into lockstep (MFMA phases on top of each other, epilogues on top of each other)
-  if (__builtin_amdgcn_readfirstlane(wave) >= kMfmaWaves / 2) __builtin_amdgcn_s_setprio(RAYEN_MFMA_PRIO);
-#endif
 
-#ifdef RAYEN_TIMING
-  // developer instrumentation: lane 0 of one wave logs s_memtime stamps into LDS, dumped at the end
-  __shared__ unsigned ts_lds[256];
-  int ts_n = 0;
-  const bool ts_on = (blockIdx.x == RAYEN_TIMING) && (threadIdx.x == 0);
-#define TS() do { __builtin_amdgcn_sched_barrier(0); if (ts_on && ts_n < 256) { ts_lds[ts_n++] = (unsigned)__builtin_amdgcn_s_memtime(); } __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define TS() do {} while (0)
-#endif
   // persistent walk over groups of NT*32 samples (no workgroup barriers anywhere)
   for (int64_t grp = wave_id; grp < n_groups; grp += wave_stride) {
-  TS();
   const int64_t s_base = grp * (NT * 32);
 
   // ---- this lane's half of v for each of its samples, as B operands
@@ -145,12 +124,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_fwd_kern
     for (int q = 0; q < NQ; ++q) {
       const int c0 = 8 * q + 4 * hi;
       f32x4 x = {0.f, 0.f, 0.f, 0.f};
-#if defined(RAYEN_ABL) && (RAYEN_ABL & 8)
-      x = f32x4{0.001f * (float)(lane + q), -0.002f * (float)(col + t), 0.25f, -0.125f};
-      if (false) {
-#else
       if (live[t]) {
-#endif
         if (vec_in && c0 + 3 < n) {
           x = *reinterpret_cast<const f32x4*>(row + c0);
         } else {
@@ -167,11 +141,6 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_fwd_kern
     }
   }
 
-#if defined(RAYEN_TIMING) && defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-  for (int t = 0; t < NT; ++t) asm volatile("" ::"v"(vr[t][0]), "v"(vr[t][KK - 1]));
-#endif
-  TS();
   float kap[NT], part[NT], scale[NT];
   int aseg[NT], arow[NT];
 #pragma unroll
@@ -185,13 +154,8 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_fwd_kern
   const f32x4* wp = Wimg + lane;
   f32x4 buf_a[NQ], buf_b[NQ];
   auto fetch_tile = [&](f32x4 (&buf)[NQ]) {
-#if defined(RAYEN_ABL) && (RAYEN_ABL & 4)
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) buf[q] = f32x4{0.5f, -0.25f, 0.125f, 1.f};
-#else
 #pragma unroll
     for (int q = 0; q < NQ; ++q) buf[q] = wp[q * 64];
-#endif
     wp += NQ * 64;
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -203,12 +167,6 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_fwd_kern
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
-#if defined(RAYEN_ABL) && (RAYEN_ABL & 2)
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t][q & 15] += a[q][0] * vr[t][4 * q];
-#else
 #pragma unroll
     for (int qb = 0; qb < NKK; ++qb) {  // one 32-column block = 4 k-groups
       if (4 * qb < qbegin) continue;    // wave-uniform: the block was folded into its transpose
@@ -220,7 +178,6 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_fwd_kern
           for (int t = 0; t < NT; ++t)
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][c], vr[t][4 * q + c], acc[t], 0, 0, 0);
     }
-#endif
   };
 
   auto finish_kappa = [&]() {
@@ -243,12 +200,6 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_fwd_kern
     // rows of NA_E come last: kappa is final once the first of those tiles is reached
     if (item.type == MI_OUT && (item.flags & MF_FIRST)) finish_kappa();
     run_tile(acc, a, item.qbegin);
-    TS();
-#if defined(RAYEN_ABL) && (RAYEN_ABL & 1) && defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-    for (int t = 0; t < NT; ++t) asm volatile("" ::"v"(acc[t]));
-    if (item.type != MI_OUT) return;
-#endif
     if (item.type == MI_LIN) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -362,17 +313,11 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_fwd_kern
   for (int it = 0; it < n_items; it += 2) {  // n_items is even (padded with a no-op tile)
     fetch_tile(buf_b);
     process(items[it], buf_a);
-    TS();
     fetch_tile(buf_a);
     process(items[it + 1], buf_b);
-    TS();
   }
 
-#if defined(RAYEN_ABL) && (RAYEN_ABL & 16)
-  if (identity && kap[0] == 12345.678f) {
-#else
   if (identity) {
-#endif
     finish_kappa();
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -408,11 +353,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_fwd_kern
       if (TRACK) { active_out[2 * s] = aseg[t]; active_out[2 * s + 1] = arow[t]; }
     }
   }
-  TS();
   }  // persistent loop over sample groups
-#ifdef RAYEN_TIMING
-  if (ts_on) for (int i = 0; i < ts_n; ++i) nan_flag[16 + i] = (int32_t)ts_lds[i];
-#endif
   if (nan_flag && bad) atomicOr(nan_flag, 1);
 }
 

@@ -91,6 +91,34 @@ def test_against_oracle(name, B, dtype, tol):
     assert oracle.max_violation(raw, y) <= max(floor, 3 * oracle.max_violation(raw, y_ref))
 
 
+def _wide_cases():
+    """Shapes that exercise the wider MFMA instantiations (n_pad = 96, 128) and non-identity outputs."""
+    rng = np.random.default_rng(40)
+    a = workloads.random_lin_quad_soc(k=96, m=200, n_quad=3, n_soc=2, seed=41)
+    b = workloads.random_lin_quad_soc(k=128, m=64, n_quad=2, n_soc=1, r_M=40, seed=42)
+    c = workloads.random_lin_quad_soc(k=100, m=150, n_quad=2, n_soc=2, r_M=100, seed=43)   # + equalities: n = 70
+    c["A2"] = rng.uniform(-1, 1, size=(30, 100))
+    c["b2"] = np.zeros((30, 1))
+    d = workloads.corridor_like(k=80, n_eq=10, m=100, n_quad=40, rank=6, seed=44)        # rank-7 factors: quad pairs
+    return {"k96": a, "k128": b, "k100_n70": c, "k80_pairs": d}
+
+
+@pytest.mark.parametrize("name", ["k96", "k128", "k100_n70", "k80_pairs"])
+def test_wide_shapes_against_oracle(name):
+    raw = _wide_cases()[name]
+    cs, layer = _layer(raw, torch.float32)
+    gen = torch.Generator().manual_seed(6)
+    x = torch.empty(3000, cs.n, 1).uniform_(-1, 1, generator=gen)
+    y = layer(x.cuda()).cpu().numpy()[:, :, 0]
+    y_ref = _oracle_forward(cs, x, torch.float32)
+    assert np.max(rel_err_rows(y, y_ref)) <= FP32_TOL
+    assert oracle.max_violation(raw, y) <= max(VIOLATION_TOL, 3 * oracle.max_violation(raw, y_ref))
+    dp, _ = layer.device_pack(torch.device("cuda", 0))
+    yg, _, _ = ops.project_raw(x.reshape(3000, -1).cuda(), dp, force_generic=True)
+    assert np.max(rel_err_rows(yg.cpu().numpy(), y_ref)) <= FP32_TOL
+    assert dp.info().mfma_f32 == 1
+
+
 # --------------------------------------------------------------------------- closed-form answers
 def _run(layer, v):
     return layer(torch.tensor(v, dtype=torch.float32).unsqueeze(2).cuda()).cpu().numpy()[:, :, 0].astype(np.float64)
