@@ -1,6 +1,7 @@
 // C-ABI entry points of librayen_hip.so (declared in include/rayen_hip.h).
 #include "rayen_internal.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -131,6 +132,10 @@ int rayen_pack_create(const RayenPackDesc* desc, RayenPack** out) {
   p->n = desc->n;
   p->n_rows = desc->n_rows;
   p->out_identity = desc->out_identity ? 1 : 0;
+  {
+    const char* env = std::getenv("RAYEN_SPLIT_BF16");
+    p->split_bf16 = (env != nullptr && env[0] == '1') ? 1 : 0;
+  }
   p->W.assign(desc->W, desc->W + (size_t)desc->n_rows * desc->n);
   p->y0.assign(desc->y0, desc->y0 + desc->k);
   p->NA_E.assign((size_t)desc->k * desc->n, 0.0);

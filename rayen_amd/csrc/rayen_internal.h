@@ -52,6 +52,7 @@ struct RayenPack {
   int device = -1;
   int k = 0, n = 0, n_rows = 0;
   int out_identity = 0;
+  int split_bf16 = 0;            // fp32 MFMA path on split bf16 operands (see rayen_mfma.hip)
   std::vector<double> W;         // host copy [n_rows, n]
   std::vector<double> NA_E;      // host copy [k, n] (identity materialised)
   std::vector<double> y0;        // host copy [k]

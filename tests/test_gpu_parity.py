@@ -300,3 +300,20 @@ def test_hip_graph_capture_replays_the_projection():
         torch.cuda.synchronize()
         y_ref = _oracle_forward(cs, x, torch.float32)
         assert np.max(rel_err_rows(static_y.cpu().numpy()[:, :, 0], y_ref)) <= FP32_TOL
+
+
+@pytest.mark.parametrize("name,B", [("c2", 4096), ("c3", 8192), ("c5", 8192)])
+def test_split_bf16_operand_mode(name, B, monkeypatch):
+    """Opt-in MFMA mode on bf16 operand triples (6 partial products, fp32 accumulate): same parity bar."""
+    monkeypatch.setenv("RAYEN_SPLIT_BF16", "1")          # read by rayen_pack_create
+    raw = workloads.make_raw(name, seed=51)
+    cs, layer = _layer(raw)
+    gen = torch.Generator().manual_seed(8)
+    x = torch.empty(B, cs.n, 1).uniform_(-1, 1, generator=gen)
+    x[:4] *= 1e-4
+    x[4] = 0
+    y = layer(x.cuda()).cpu().numpy()[:, :, 0]
+    y_ref = _oracle_forward(cs, x, torch.float32)
+    assert np.max(rel_err_rows(y, y_ref)) <= FP32_TOL
+    assert oracle.max_violation(raw, y) <= max(VIOLATION_TOL, 3 * oracle.max_violation(raw, y_ref))
+    assert np.allclose(y[4], cs.y0[:, 0], atol=1e-6)      # v = 0 -> y0
