@@ -18,8 +18,8 @@
 //     those registers, again as float4s.
 // W is stored in fragment order ([tile][k-group][lane] float4): each A fetch is
 // one contiguous 1 KiB global_load_dwordx4 per wave, served by L2 (the image is
-// <= a few hundred KiB and shared by every wave), software-prefetched one
-// k-group (4 MFMAs x NT) ahead.  No LDS staging, no workgroup barriers.
+// <= a few hundred KiB and shared by every wave), prefetched a whole tile ahead into a
+// second register buffer.  No LDS staging of W, no workgroup barriers in the tile walk.
 //
 // HBM traffic per sample: n loads + k stores, the algorithmic minimum.
 #include "rayen_internal.h"
@@ -100,6 +100,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_fwd_kern
   using C = MfmaCfg<NKK>;
   constexpr int NT = C::NT, NQ = C::NQ, KK = C::KK;
   __shared__ float aux_lds[kMfmaWaves][NT][32][32];  // [wave][sample tile][aux row][sample]
+  __shared__ __attribute__((aligned(16))) float y0_lds[NKK * 32];  // output offset for the NA_E = I write-out
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -109,6 +110,8 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_fwd_kern
   const int64_t wave_id = (int64_t)blockIdx.x * kMfmaWaves + wave;
   const int64_t wave_stride = (int64_t)gridDim.x * kMfmaWaves;
   bool bad = false;
+  for (int i = threadIdx.x; i < NKK * 32; i += kMfmaWaves * 64) y0_lds[i] = y0[i];  // y0 is zero-padded
+  __syncthreads();  // the only workgroup barrier; from here on the waves are independent
 
   // persistent walk over groups of NT*32 samples (no workgroup barriers anywhere)
   for (int64_t grp = wave_id; grp < n_groups; grp += wave_stride) {
@@ -321,26 +324,39 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_fwd_kern
 
   if (identity) {
     finish_kappa();
+    // y = y0 + v / max(1, kappa), straight from the B-operand registers.  y0 comes from LDS (a
+    // global load per piece would put an L2 round trip in front of every store).
+    if (vec_out && (k & 3) == 0) {  // wave-uniform fast path: whole float4 pieces, no per-piece branches
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      if (!live[t]) continue;
-      float* yrow = y + (s_base + t * 32 + col) * ldy;
+      for (int t = 0; t < NT; ++t) {
+        if (!live[t]) continue;
+        float* yrow = y + (s_base + t * 32 + col) * ldy;
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int c0 = 8 * q + 4 * hi;
-        if (c0 >= k) continue;
-        f32x4 o;
+        for (int q = 0; q < NQ; ++q) {
+          const int c0 = 8 * q + 4 * hi;
+          const f32x4 off = *reinterpret_cast<const f32x4*>(&y0_lds[c0]);
+          f32x4 o;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          o[c] = fmaf(vr[t][4 * q + c], scale[t], y0[c0 + c]);
-          bad |= (o[c] != o[c]) && (c0 + c < k);
+          for (int c = 0; c < 4; ++c) {
+            o[c] = fmaf(vr[t][4 * q + c], scale[t], off[c]);
+            bad |= (o[c] != o[c]);
+          }
+          if (c0 < k) *reinterpret_cast<f32x4*>(yrow + c0) = o;
         }
-        if (vec_out && c0 + 3 < k) {
-          *reinterpret_cast<f32x4*>(yrow + c0) = o;
-        } else {
+      }
+    } else {
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
-            if (c0 + c < k) yrow[c0 + c] = o[c];
+      for (int t = 0; t < NT; ++t) {
+        if (!live[t]) continue;
+        float* yrow = y + (s_base + t * 32 + col) * ldy;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int c0 = 8 * q + 4 * hi;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float o = fmaf(vr[t][4 * q + c], scale[t], y0_lds[c0 + c]);
+            if (c0 + c < k) { bad |= (o != o); yrow[c0 + c] = o; }
+          }
         }
       }
     }
