@@ -101,6 +101,13 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_fwd_kern
   constexpr int NT = C::NT, NQ = C::NQ, KK = C::KK;
   __shared__ float aux_lds[kMfmaWaves][NT][32][32];  // [wave][sample tile][aux row][sample]
   __shared__ __attribute__((aligned(16))) float y0_lds[NKK * 32];  // output offset for the NA_E = I write-out
+  // Transposition patch for v and y (one sample tile per wave at a time).  A lane needs 16-byte
+  // pieces of ITS sample's row (fragment-shaped access: 32 B per 128-B line per instruction); going
+  // through LDS lets every global load/store instruction move four whole rows (1 KiB, full lines).
+  // Row stride n_pad + 4 floats keeps both the row-wise and the fragment-wise LDS accesses conflict-free.
+  constexpr bool kLines = NKK <= 2;  // LDS budget: 8 waves x 32 x (n_pad + 4) floats next to aux_lds
+  constexpr int LSTR = NKK * 32 + 4;
+  __shared__ __attribute__((aligned(16))) float line_lds[kLines ? kMfmaWaves : 1][kLines ? 32 : 1][kLines ? LSTR : 4];
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -120,29 +127,61 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_fwd_kern
   // ---- this lane's half of v for each of its samples, as B operands
   float vr[NT][KK];
   bool live[NT];
+  const bool lines_in = kLines && vec_in && n == NKK * 32;   // wave-uniform
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int64_t s = s_base + t * 32 + col;
-    live[t] = s < B;
-    const float* row = v + (live[t] ? s : 0) * ldv;
+  for (int t = 0; t < NT; ++t) live[t] = (s_base + t * 32 + col) < B;
+  if (lines_in) {
+    f32x4 piece[NT][NQ];  // piece idx = lane + 64 j of the [32 rows][n/4 pieces] tile: row idx / (n/4)
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int c0 = 8 * q + 4 * hi;
-      f32x4 x = {0.f, 0.f, 0.f, 0.f};
-      if (live[t]) {
-        if (vec_in && c0 + 3 < n) {
-          x = *reinterpret_cast<const f32x4*>(row + c0);
-        } else {
-          if (c0 + 0 < n) x[0] = row[c0 + 0];
-          if (c0 + 1 < n) x[1] = row[c0 + 1];
-          if (c0 + 2 < n) x[2] = row[c0 + 2];
-          if (c0 + 3 < n) x[3] = row[c0 + 3];
-        }
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const int idx = lane + 64 * j;
+        const int64_t s = s_base + t * 32 + idx / (NKK * 8);
+        piece[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (s < B) piece[t][j] = *reinterpret_cast<const f32x4*>(v + s * ldv + 4 * (idx % (NKK * 8)));
       }
-      vr[t][4 * q + 0] = x[0];
-      vr[t][4 * q + 1] = x[1];
-      vr[t][4 * q + 2] = x[2];
-      vr[t][4 * q + 3] = x[3];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const int idx = lane + 64 * j;
+        *reinterpret_cast<f32x4*>(&line_lds[wave][idx / (NKK * 8)][4 * (idx % (NKK * 8))]) = piece[t][j];
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(&line_lds[wave][col][8 * q + 4 * hi]);
+        vr[t][4 * q + 0] = x[0];
+        vr[t][4 * q + 1] = x[1];
+        vr[t][4 * q + 2] = x[2];
+        vr[t][4 * q + 3] = x[3];
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float* row = v + (live[t] ? (s_base + t * 32 + col) : 0) * ldv;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int c0 = 8 * q + 4 * hi;
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        if (live[t]) {
+          if (vec_in && c0 + 3 < n) {
+            x = *reinterpret_cast<const f32x4*>(row + c0);
+          } else {
+            if (c0 + 0 < n) x[0] = row[c0 + 0];
+            if (c0 + 1 < n) x[1] = row[c0 + 1];
+            if (c0 + 2 < n) x[2] = row[c0 + 2];
+            if (c0 + 3 < n) x[3] = row[c0 + 3];
+          }
+        }
+        vr[t][4 * q + 0] = x[0];
+        vr[t][4 * q + 1] = x[1];
+        vr[t][4 * q + 2] = x[2];
+        vr[t][4 * q + 3] = x[3];
+      }
     }
   }
 
@@ -326,7 +365,31 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_fwd_kern
     finish_kappa();
     // y = y0 + v / max(1, kappa), straight from the B-operand registers.  y0 comes from LDS (a
     // global load per piece would put an L2 round trip in front of every store).
-    if (vec_out && (k & 3) == 0) {  // wave-uniform fast path: whole float4 pieces, no per-piece branches
+    if (kLines && vec_out && k == NKK * 32) {  // wave-uniform: full-line stores through the LDS patch
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const f32x4 off = *reinterpret_cast<const f32x4*>(&y0_lds[8 * q + 4 * hi]);
+          f32x4 o;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            o[c] = fmaf(vr[t][4 * q + c], scale[t], off[c]);
+            bad |= live[t] && (o[c] != o[c]);
+          }
+          *reinterpret_cast<f32x4*>(&line_lds[wave][col][8 * q + 4 * hi]) = o;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+          const int idx = lane + 64 * j;
+          const int64_t s = s_base + t * 32 + idx / (NKK * 8);
+          const f32x4 o = *reinterpret_cast<const f32x4*>(&line_lds[wave][idx / (NKK * 8)][4 * (idx % (NKK * 8))]);
+          if (s < B) *reinterpret_cast<f32x4*>(y + s * ldy + 4 * (idx % (NKK * 8))) = o;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    } else if (vec_out && (k & 3) == 0) {  // whole float4 pieces, no per-piece branches
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         if (!live[t]) continue;
