@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp64"])
     ap.add_argument("--gather", action="store_true", help="all-gather y across ranks inside the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed even for one rank (exercises the multi-GPU code path)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -98,9 +100,12 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from rayen_amd import workloads
     from rayen_amd.constraint_module import ConstraintModule
@@ -118,7 +123,7 @@ def main():
     rng = workloads.CONFIGS[args.config][3]
     gen = torch.Generator(device=device).manual_seed(1000 + rank)
     x = torch.empty(B, cs.n, 1, device=device, dtype=dtype).uniform_(-rng, rng, generator=gen)
-    gathered = torch.empty(world * B, cs.k, 1, device=device, dtype=dtype) if (args.gather and world > 1) else None
+    gathered = torch.empty(world * B, cs.k, 1, device=device, dtype=dtype) if (args.gather and use_dist) else None
 
     def step():
         y = layer(x)
@@ -130,7 +135,7 @@ def main():
         for _ in range(args.warmup):
             y = step()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -140,14 +145,14 @@ def main():
             y = step()
         ev1.record()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1) / args.steps    # HIP events on the launch stream
 
     t = torch.tensor([elapsed, dev_ms], device=device, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, dev_ms = float(t[0]), float(t[1])
 
@@ -210,7 +215,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(raw, cs, B, dtype, args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
