@@ -32,6 +32,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector = FP32 MFMA peak (spec)
+PEAK_FP64_TFLOPS = 78.6    # MI355X datasheet: FP64 vector = FP64 matrix (v_mfma_f64_16x16x4_f64)
 PEAK_HBM_GBS = 8000.0      # HBM3E spec (≈6.3 TB/s achievable)
 
 
@@ -169,10 +170,11 @@ def main():
         tflops = flops_pp * B / kern_s / 1e12
         gbs = bytes_pp * B / kern_s / 1e9
         ai = flops_pp / bytes_pp
-        ridge = PEAK_FP32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
-        if ai > ridge and dtype == torch.float32:
-            roof = {"bound": "mfma", "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": tflops / PEAK_FP32_TFLOPS, "traffic": None}
+        peak_tf = PEAK_FP32_TFLOPS if dtype == torch.float32 else PEAK_FP64_TFLOPS
+        ridge = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
+        if ai > ridge:
+            roof = {"bound": "mfma", "achieved": tflops, "peak": peak_tf, "unit": "TFLOP/s",
+                    "frac": tflops / peak_tf, "traffic": None}
         else:
             roof = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": gbs / PEAK_HBM_GBS, "traffic": None}
@@ -189,7 +191,7 @@ def main():
                 roof["traffic_source"] = os.path.relpath(found[-1], REPO)
         roof.update({"kernel_ms": dev_ms, "algorithmic_flops_per_projection": flops_pp,
                      "algorithmic_bytes_per_projection": bytes_pp, "hbm_GBps": gbs,
-                     "hbm_frac": gbs / PEAK_HBM_GBS, "fp32_TFLOPs": tflops})
+                     "hbm_frac": gbs / PEAK_HBM_GBS, "TFLOPs": tflops})
         info = layer.device_pack(device)[0].info()
         out = {
             "metric": "feasible projections/sec at k=64, 128 lin+4 quad+2 SOC; max violation"
@@ -206,7 +208,8 @@ def main():
                                    f"batch {B} per GPU, v~U(-{rng:g},{rng:g})",
                        "batch_per_gpu": B, "global_batch": world * B,
                        "parallelism": f"batch-sharded x{world}" + (" + all-gather(y)" if gathered is not None else ""),
-                       "kernel": "mfma_f32" if info.mfma_f32 and dtype == torch.float32 else "generic"},
+                       "kernel": ("mfma_f32" if info.mfma_f32 else "generic") if dtype == torch.float32
+                       else ("mfma_f64" if info.mfma_f64 else "generic")},
             "max_violation": max_violation,
             "violations_gt_1e-6": int(max_violation > 1e-6),
             "roofline": roof,

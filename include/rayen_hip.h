@@ -94,7 +94,7 @@ typedef struct RayenPackInfo {
   int32_t device;               /* HIP device ordinal the pack lives on */
   int32_t mfma_f32;             /* 1: the fp32 MFMA path serves this pack */
   int32_t generic_block;        /* workgroup size the generic path uses for fp32 (0 = unsupported) */
-  int32_t reserved;
+  int32_t mfma_f64;             /* 1: the fp64 MFMA path serves this pack */
   int64_t device_bytes;         /* bytes of device memory the pack holds so far */
 } RayenPackInfo;
 
@@ -129,6 +129,9 @@ int rayen_ray_project_f64(const RayenPack* pack, const double* v, int64_t B, int
  * parity tests to cover both implementations on every shape. */
 int rayen_ray_project_generic_f32(const RayenPack* pack, const float* v, int64_t B, int64_t ldv,
                                   float* y, int64_t ldy, float* kappa, int32_t* active,
+                                  int32_t* nan_flag, void* stream);
+int rayen_ray_project_generic_f64(const RayenPack* pack, const double* v, int64_t B, int64_t ldv,
+                                  double* y, int64_t ldy, double* kappa, int32_t* active,
                                   int32_t* nan_flag, void* stream);
 
 /* Backward of y w.r.t. v (vector-Jacobian product):

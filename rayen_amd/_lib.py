@@ -18,7 +18,8 @@ SEG_LIN, SEG_QUAD_SYM, SEG_QUAD_FAC, SEG_SOC, SEG_LMI = range(5)
 EXPORTS = (
     "rayen_abi_version", "rayen_strerror", "rayen_pack_create", "rayen_pack_destroy",
     "rayen_pack_info", "rayen_ray_project_f32", "rayen_ray_project_f64",
-    "rayen_ray_project_generic_f32", "rayen_ray_project_bwd_f32", "rayen_ray_project_bwd_f64",
+    "rayen_ray_project_generic_f32", "rayen_ray_project_generic_f64", "rayen_ray_project_bwd_f32",
+    "rayen_ray_project_bwd_f64",
 )
 
 
@@ -42,7 +43,7 @@ class RayenPackInfo(ctypes.Structure):
     _fields_ = [("k", ctypes.c_int32), ("n", ctypes.c_int32), ("n_rows", ctypes.c_int32),
                 ("n_segments", ctypes.c_int32), ("device", ctypes.c_int32),
                 ("mfma_f32", ctypes.c_int32), ("generic_block", ctypes.c_int32),
-                ("reserved", ctypes.c_int32), ("device_bytes", ctypes.c_int64)]
+                ("mfma_f64", ctypes.c_int32), ("device_bytes", ctypes.c_int64)]
 
 
 class RayenError(RuntimeError):
@@ -80,7 +81,8 @@ def load():
     lib.rayen_pack_info.restype = ctypes.c_int
     lib.rayen_pack_info.argtypes = [p, ctypes.POINTER(RayenPackInfo)]
     fwd = [p, p, i64, i64, p, i64, p, i32p, i32p, p]
-    for name in ("rayen_ray_project_f32", "rayen_ray_project_f64", "rayen_ray_project_generic_f32"):
+    for name in ("rayen_ray_project_f32", "rayen_ray_project_f64", "rayen_ray_project_generic_f32",
+                 "rayen_ray_project_generic_f64"):
         getattr(lib, name).restype = ctypes.c_int
         getattr(lib, name).argtypes = fwd
     bwd = [p, p, i64, i64, p, i32p, p, i64, p, i64, p]

@@ -70,6 +70,20 @@ int ensure_mfma(const RayenPack* p) {
   return RAYEN_OK;
 }
 
+int ensure_mfma64(const RayenPack* p) {
+  std::lock_guard<std::mutex> lock(p->mu);
+  if (p->m64_tried) return RAYEN_OK;
+  p->m64_tried = true;
+  if (!mfma64_eligible(p)) return RAYEN_OK;
+  int64_t bytes = 0;
+  Mfma64Image* img = nullptr;
+  const int rc = mfma64_build(p, &img, &bytes);
+  if (rc != RAYEN_OK) return rc;
+  p->m64 = img;
+  p->device_bytes += bytes;
+  return RAYEN_OK;
+}
+
 template <typename T>
 int project_generic(const RayenPack* p, const T* v, int64_t B, int64_t ldv, T* y, int64_t ldy, T* kappa,
                     int32_t* active, int32_t* nan_flag, void* stream) {
@@ -157,6 +171,7 @@ void rayen_pack_destroy(RayenPack* p) {
   generic_free<float>(&p->g32);
   generic_free<double>(&p->g64);
   if (p->m32) mfma_free(p->m32);
+  if (p->m64) mfma64_free(p->m64);
   if (switched) (void)hipSetDevice(prev);
   delete p;
 }
@@ -170,6 +185,7 @@ int rayen_pack_info(const RayenPack* p, RayenPackInfo* info) {
   info->n_segments = (int32_t)p->segs.size();
   info->device = p->device;
   info->mfma_f32 = mfma_eligible(p) ? 1 : 0;
+  info->mfma_f64 = mfma64_eligible(p) ? 1 : 0;
   int lmi_words = 0;
   for (const RayenSegment& g : p->segs)
     if (g.type == RAYEN_SEG_LMI && g.nrows + 4 * g.dim > lmi_words) lmi_words = g.nrows + 4 * g.dim;
@@ -200,8 +216,23 @@ int rayen_ray_project_f32(const RayenPack* p, const float* v, int64_t B, int64_t
   return project_generic<float>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
 }
 
+int rayen_ray_project_generic_f64(const RayenPack* p, const double* v, int64_t B, int64_t ldv, double* y,
+                                  int64_t ldy, double* kappa, int32_t* active, int32_t* nan_flag,
+                                  void* stream) {
+  return project_generic<double>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+}
+
 int rayen_ray_project_f64(const RayenPack* p, const double* v, int64_t B, int64_t ldv, double* y,
                           int64_t ldy, double* kappa, int32_t* active, int32_t* nan_flag, void* stream) {
+  if (p == nullptr || B < 0 || (B > 0 && v == nullptr) || ldv < p->n || (y != nullptr && ldy < p->k))
+    return RAYEN_E_BAD_ARG;
+  int rc = check_device(p);
+  if (rc) return rc;
+  rc = ensure_mfma64(p);
+  if (rc) return rc;
+  if (p->m64 != nullptr && y != nullptr)
+    return mfma64_forward(p, p->m64, v, B, ldv, y, ldy, kappa, active, nan_flag,
+                          static_cast<hipStream_t>(stream));
   return project_generic<double>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
 }
 

@@ -44,7 +44,8 @@ struct GenericImage {
   int64_t bytes = 0;
 };
 
-struct MfmaImage;  // rayen_mfma.hip
+struct MfmaImage;    // rayen_mfma.hip
+struct Mfma64Image;  // rayen_mfma_f64.hip
 
 }  // namespace rayen
 
@@ -62,6 +63,8 @@ struct RayenPack {
   mutable rayen::GenericImage<double> g64;
   mutable rayen::MfmaImage* m32 = nullptr;
   mutable bool m32_tried = false;
+  mutable rayen::Mfma64Image* m64 = nullptr;
+  mutable bool m64_tried = false;
   mutable int64_t device_bytes = 0;
 };
 
@@ -90,5 +93,13 @@ void mfma_free(MfmaImage* img);
 int mfma_forward(const RayenPack* p, const MfmaImage* img, const float* v, int64_t B, int64_t ldv,
                  float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
                  hipStream_t stream);
+
+// fp64 MFMA path (rayen_mfma_f64.hip)
+bool mfma64_eligible(const RayenPack* p);
+int mfma64_build(const RayenPack* p, Mfma64Image** out, int64_t* bytes);
+void mfma64_free(Mfma64Image* img);
+int mfma64_forward(const RayenPack* p, const Mfma64Image* img, const double* v, int64_t B, int64_t ldv,
+                   double* y, int64_t ldy, double* kappa, int32_t* active, int32_t* nan_flag,
+                   hipStream_t stream);
 
 }  // namespace rayen

@@ -58,7 +58,7 @@ def _stream():
 
 _FWD = {(torch.float32, False): "rayen_ray_project_f32", (torch.float64, False): "rayen_ray_project_f64",
         (torch.float32, True): "rayen_ray_project_generic_f32",
-        (torch.float64, True): "rayen_ray_project_f64"}
+        (torch.float64, True): "rayen_ray_project_generic_f64"}
 
 
 def project_raw(v, pack, want_y=True, force_generic=False, want_active=True):

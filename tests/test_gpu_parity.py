@@ -317,3 +317,24 @@ def test_split_bf16_operand_mode(name, B, monkeypatch):
     assert np.max(rel_err_rows(y, y_ref)) <= FP32_TOL
     assert oracle.max_violation(raw, y) <= max(VIOLATION_TOL, 3 * oracle.max_violation(raw, y_ref))
     assert np.allclose(y[4], cs.y0[:, 0], atol=1e-6)      # v = 0 -> y0
+
+
+@pytest.mark.parametrize("name,B", [("c2", 4096), ("c3", 4096), ("k100_n70", 2000)])
+def test_fp64_mfma_and_generic_paths_agree(name, B):
+    """fp64: the MFMA kernel (v_mfma_f64_16x16x4_f64) and the generic kernel against the fp64 oracle."""
+    raw = _wide_cases()[name] if name.startswith("k") else workloads.make_raw(name, seed=61)
+    cs, layer = _layer(raw, torch.float64)
+    gen = torch.Generator().manual_seed(10)
+    x = torch.empty(B, cs.n, 1, dtype=torch.float64).uniform_(-1, 1, generator=gen)
+    x[:3] *= 1e-4
+    dp, _ = layer.device_pack(torch.device("cuda", 0))
+    y_ref = _oracle_forward(cs, x, torch.float64)
+    xf = x.reshape(B, -1).cuda()
+    y_auto, kap_auto, act_auto = ops.project_raw(xf, dp)
+    y_gen, kap_gen, _ = ops.project_raw(xf, dp, force_generic=True)
+    assert np.max(rel_err_rows(y_auto.cpu().numpy(), y_ref)) <= FP64_TOL
+    assert np.max(rel_err_rows(y_gen.cpu().numpy(), y_ref)) <= FP64_TOL
+    assert torch.allclose(kap_auto, kap_gen, rtol=1e-10, atol=1e-12)
+    assert oracle.max_violation(raw, y_auto.cpu().numpy()) <= 1e-11
+    if cs.n <= 64:
+        assert dp.info().mfma_f64 == 1
