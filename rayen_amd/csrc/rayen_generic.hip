@@ -570,8 +570,8 @@ int generic_forward(const RayenPack* p, const GenericImage<T>& img, const T* v, 
 // Same lane = sample layout.  grad kappa is evaluated on the active constraint only (the one the
 // forward recorded), which is what autograd gives for rayen/constraint_module.py:351-474: max ->
 // its arg-max, relu, sqrt, the SOC root (implicit differentiation of a'x^2+b'x+c'=0) and
-// eigvalsh -> x x' for the top eigenvector.  The segment loop stays wave-uniform; a wave skips a
-// segment none of its lanes is active in.
+// eigvalsh -> x x' for the top eigenvector.  Each lane evaluates the gradient of its own active
+// constraint only.
 // ---------------------------------------------------------------------------------------------
 
 // u_j += sum_r Wg[rb][j][r] * w[r]   (W' w for one row block), masked per lane
@@ -695,10 +695,12 @@ __global__ __launch_bounds__(BLOCK) void generic_bwd_kernel(
   const bool clipped = live && kap > T(1) && aseg >= 0;
   const T sc = T(1) / fmax(T(1), kap);
 
-  for (int s = 0; s < n_gseg; ++s) {
-    const GSeg sg = segs[s];
-    const bool on = clipped && aseg == sg.seg;
-    if (!__any(on)) continue;  // wave-uniform skip
+  // Every lane walks ONLY the constraint that set its kappa: its own segment record, its own row
+  // blocks (the reads of W become per-lane loads; lanes that share a segment share the addresses).
+  // A wave pays for the distinct constraint TYPES among its lanes, not for the whole constraint set.
+  if (clipped) {
+    const GSeg sg = segs[aseg];
+    const bool on = true;
     if (sg.type == RAYEN_SEG_LIN) {
       if (on) {
         const int r = arow - sg.row0;
