@@ -24,6 +24,7 @@ using f64x2 = double __attribute__((ext_vector_type(2)));
 struct Mfma64Image {
   f64x2* W = nullptr;   // [tile][step pair][row half][lane] x 2 doubles
   MItem* items = nullptr;
+  MPack* packs = nullptr;
   double* y0 = nullptr;  // [k_pad]
   int n_items = 0;
   int nkk = 0;
@@ -42,7 +43,7 @@ __device__ __forceinline__ T xq32(T x) { return __shfl_xor(x, 32); }
 template <int NKK, bool TRACK>
 __global__ __launch_bounds__(k64Waves * 64, 2) void mfma64_fwd_kernel(
     const f64x2* __restrict__ Wimg, const MItem* __restrict__ items, int n_items,
-    const double* __restrict__ y0, int identity, int k, int n, const double* __restrict__ v, int64_t B,
+    const MPack* __restrict__ packs, const double* __restrict__ y0, int identity, int k, int n, const double* __restrict__ v, int64_t B,
     int64_t ldv, double* __restrict__ y, int64_t ldy, double* __restrict__ kappa_out,
     int32_t* __restrict__ active_out, int32_t* __restrict__ nan_flag) {
   constexpr int NS = NKK * 8;   // K-steps (4 columns each) per tile
@@ -186,6 +187,33 @@ __global__ __launch_bounds__(k64Waves * 64, 2) void mfma64_fwd_kernel(
               }
             }
         }
+      } else if (item.type == MI_PACK) {
+        // eight small factor segments per tile: quad m = rows 4m..4m+3 = register (rh = m>>2, g = m&3)
+        // of the four lane groups, so ||U v||^2 of a quad is one square summed across the groups
+        const MPack pk = packs[item.aux];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const bool pair = (item.row0 >> a) & 1;
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            double qs[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int m = 2 * a + h;
+              double sq = acc[m >> 2][c][m & 3] * acc[m >> 2][c][m & 3];
+              sq += xq16(sq);
+              sq += xq32(sq);
+              qs[h] = sq;
+            }
+            if (pair) { qs[0] += qs[1]; qs[1] = qs[0]; }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int sid = pk.seg[a][h];
+              const double kc = aux_lds[wave][c][pk.aux[a][h] & 31][j] + sqrt(qs[h]);
+              if (sid >= 0 && kc > kap[c]) { kap[c] = kc; aseg[c] = sid; arow[c] = 0; }
+            }
+          }
+        }
       } else {
         // symmetric form (acc . v), or factor rows (acc . acc); closed on the segment's last tile
 #pragma unroll
@@ -276,7 +304,7 @@ bool mfma64_eligible(const RayenPack* p) {
   for (const RayenSegment& g : p->segs)
     if (g.type == RAYEN_SEG_LMI) return false;
   TileLayout b(p->n);
-  if (layout_tiles(p, b, /*allow_pack=*/false) != RAYEN_OK || b.items.empty()) return false;
+  if (layout_tiles(p, b, /*allow_pack=*/true) != RAYEN_OK || b.items.empty()) return false;
   const int64_t padded = (int64_t)b.items.size() * 32;
   return b.useful_rows * 2 >= padded && p->n * 2 >= b.n_pad;
 }
@@ -285,13 +313,14 @@ void mfma64_free(Mfma64Image* img) {
   if (img == nullptr) return;
   if (img->W) (void)hipFree(img->W);
   if (img->items) (void)hipFree(img->items);
+  if (img->packs) (void)hipFree(img->packs);
   if (img->y0) (void)hipFree(img->y0);
   delete img;
 }
 
 int mfma64_build(const RayenPack* p, Mfma64Image** out, int64_t* bytes) {
   TileLayout b(p->n);
-  const int rc = layout_tiles(p, b, /*allow_pack=*/false);
+  const int rc = layout_tiles(p, b, /*allow_pack=*/true);
   if (rc != RAYEN_OK) return rc;
   // SOC constants in full precision (MItem carries them as float for the fp32 kernels)
   for (MItem& it : b.items) {
@@ -299,6 +328,7 @@ int mfma64_build(const RayenPack* p, Mfma64Image** out, int64_t* bytes) {
     it.f1d = it.type == MI_SOC ? p->segs[it.seg].f1 : 0.0;
   }
   b.add_tile({}, p->n);  // spare tile: the prefetch runs one tile past the end
+  if (b.packs.empty()) b.packs.push_back(MPack());
   const int nt = b.n_tiles(), ns = b.n_pad / 4;
   // [tile][step pair sg][row half rh][lane l][2]: W[16 rh + (l&15)][4 (2 sg + e) + (l>>4)], e = 0, 1
   std::vector<double> frag((size_t)nt * (ns / 2) * 2 * 64 * 2, 0.0);
@@ -328,7 +358,9 @@ int mfma64_build(const RayenPack* p, Mfma64Image** out, int64_t* bytes) {
       hipMalloc(&img->y0, y0.size() * sizeof(double)) == hipSuccess &&
       hipMemcpy(img->y0, y0.data(), y0.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
       hipMalloc(&img->items, b.items.size() * sizeof(MItem)) == hipSuccess &&
-      hipMemcpy(img->items, b.items.data(), b.items.size() * sizeof(MItem), hipMemcpyHostToDevice) == hipSuccess;
+      hipMemcpy(img->items, b.items.data(), b.items.size() * sizeof(MItem), hipMemcpyHostToDevice) == hipSuccess &&
+      hipMalloc(&img->packs, b.packs.size() * sizeof(MPack)) == hipSuccess &&
+      hipMemcpy(img->packs, b.packs.data(), b.packs.size() * sizeof(MPack), hipMemcpyHostToDevice) == hipSuccess;
   if (!ok) { mfma64_free(img); return RAYEN_E_ALLOC; }
   img->bytes = (int64_t)(frag.size() * sizeof(double) + y0.size() * sizeof(double) + b.items.size() * sizeof(MItem));
   *bytes = img->bytes;
@@ -348,11 +380,11 @@ static int launch64(const RayenPack* p, const Mfma64Image* img, const double* v,
   const int64_t grid = (waves + k64Waves - 1) / k64Waves;
   if (active != nullptr) {
     hipLaunchKernelGGL((mfma64_fwd_kernel<NKK, true>), dim3((unsigned)grid), dim3(k64Waves * 64), 0, stream,
-                       img->W, img->items, img->n_items, img->y0, img->identity, p->k, p->n, v, B, ldv, y, ldy,
+                       img->W, img->items, img->n_items, img->packs, img->y0, img->identity, p->k, p->n, v, B, ldv, y, ldy,
                        kappa, active, nan_flag);
   } else {
     hipLaunchKernelGGL((mfma64_fwd_kernel<NKK, false>), dim3((unsigned)grid), dim3(k64Waves * 64), 0, stream,
-                       img->W, img->items, img->n_items, img->y0, img->identity, p->k, p->n, v, B, ldv, y, ldy,
+                       img->W, img->items, img->n_items, img->packs, img->y0, img->identity, p->k, p->n, v, B, ldv, y, ldy,
                        kappa, active, nan_flag);
   }
   return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;

@@ -319,7 +319,7 @@ def test_split_bf16_operand_mode(name, B, monkeypatch):
     assert np.allclose(y[4], cs.y0[:, 0], atol=1e-6)      # v = 0 -> y0
 
 
-@pytest.mark.parametrize("name,B", [("c2", 4096), ("c3", 4096), ("k100_n70", 2000)])
+@pytest.mark.parametrize("name,B", [("c2", 4096), ("c3", 4096), ("c5", 4096), ("k100_n70", 2000)])
 def test_fp64_mfma_and_generic_paths_agree(name, B):
     """fp64: the MFMA kernel (v_mfma_f64_16x16x4_f64) and the generic kernel against the fp64 oracle."""
     raw = _wide_cases()[name] if name.startswith("k") else workloads.make_raw(name, seed=61)
