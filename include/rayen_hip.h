@@ -93,7 +93,7 @@ typedef struct RayenPackInfo {
   int32_t k, n, n_rows, n_segments;
   int32_t device;               /* HIP device ordinal the pack lives on */
   int32_t mfma_f32;             /* 1: the fp32 MFMA path serves this pack */
-  int32_t generic_block;        /* workgroup size the generic path uses for fp32 (0 = unsupported) */
+  int32_t generic_block;        /* fp32 generic path: workgroup size with v staged in LDS; 0 = v read from global memory */
   int32_t mfma_f64;             /* 1: the fp64 MFMA path serves this pack */
   int64_t device_bytes;         /* bytes of device memory the pack holds so far */
 } RayenPackInfo;

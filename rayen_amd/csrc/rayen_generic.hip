@@ -231,34 +231,38 @@ __device__ __forceinline__ T lambda_max_regs(T (&a)[R * (R + 1) / 2]) {
   return T(0.5) * (lo + hi);
 }
 
-template <typename T, int BLOCK, int RREG>
+// VG = true: directions are read straight from global memory by each lane (no LDS tile), for
+// subspace dimensions too large to stage; slower (uncoalesced, cache-served) but size-independent.
+template <typename T, int BLOCK, int RREG, bool VG>
 __global__ __launch_bounds__(BLOCK) void generic_fwd_kernel(
     const T* __restrict__ Wg, const T* __restrict__ Ng, const T* __restrict__ y0,
     const GSeg* __restrict__ segs, int n_gseg, int out_nrb, int k, int n, int lmi_words,
     const T* __restrict__ v, int64_t B, int64_t ldv, T* __restrict__ y, int64_t ldy,
     T* __restrict__ kappa_out, int32_t* __restrict__ active_out, int32_t* __restrict__ nan_flag) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  constexpr int LD = BLOCK + 1;
+  constexpr int LD = VG ? 1 : BLOCK + 1;
   const int n_pad = (n + kRowBlock - 1) / kRowBlock * kRowBlock;
-  T* vT = reinterpret_cast<T*>(smem_raw);  // [n_pad][LD]
-  T* sc = vT + (size_t)n_pad * LD;         // [BLOCK] clip factor
+  T* vT = reinterpret_cast<T*>(smem_raw);  // [n_pad][LD]  (absent when VG)
+  T* sc = vT + (VG ? 0 : (size_t)n_pad * LD);  // [BLOCK] clip factor
   T* lmi = sc + BLOCK;                     // [lmi_words][BLOCK]
 
   const int tid = threadIdx.x;
   const int64_t b0 = (int64_t)blockIdx.x * BLOCK;
   const int nb = (int)((B - b0) < (int64_t)BLOCK ? (B - b0) : (int64_t)BLOCK);
 
-  // coalesced fill of the transposed tile (zero for the tail samples and the pad rows)
-  for (int idx = tid; idx < BLOCK * n_pad; idx += BLOCK) {
-    const int bl = idx / n_pad;
-    const int j = idx - bl * n_pad;
-    T x = T(0);
-    if (bl < nb && j < n) x = v[(b0 + bl) * ldv + j];
-    vT[j * LD + bl] = x;
+  if (!VG) {
+    // coalesced fill of the transposed tile (zero for the tail samples and the pad rows)
+    for (int idx = tid; idx < BLOCK * n_pad; idx += BLOCK) {
+      const int bl = idx / n_pad;
+      const int j = idx - bl * n_pad;
+      T x = T(0);
+      if (bl < nb && j < n) x = v[(b0 + bl) * ldv + j];
+      vT[j * LD + bl] = x;
+    }
+    __syncthreads();
   }
-  __syncthreads();
 
-  const T* vcol = vT + tid;
+  const T* vcol = VG ? (v + (tid < nb ? (b0 + tid) : b0) * ldv) : (vT + tid);
   T kap = T(0);
   int aseg = -1, arow = 0;
   T acc[kRowBlock];
@@ -281,7 +285,10 @@ __global__ __launch_bounds__(BLOCK) void generic_fwd_kernel(
         dot8<T, LD>(Wg, sg.rb0 + b, n, vcol, acc);
         if (sg.type == RAYEN_SEG_QUAD_SYM) {
 #pragma unroll
-          for (int r = 0; r < kRowBlock; ++r) qf = fma_(acc[r], vcol[(b * kRowBlock + r) * LD], qf);
+          for (int r = 0; r < kRowBlock; ++r) {
+            const int jj = b * kRowBlock + r;  // rows of G beyond n are zero padding
+            qf = fma_(acc[r], (!VG || jj < n) ? vcol[jj * LD] : T(0), qf);
+          }
         } else {
 #pragma unroll
           for (int r = 0; r < kRowBlock; ++r) qf = fma_(acc[r], acc[r], qf);
@@ -358,7 +365,14 @@ __global__ __launch_bounds__(BLOCK) void generic_fwd_kernel(
   if (y == nullptr) return;
 
   bool bad = false;
-  if (Ng == nullptr) {
+  if (Ng == nullptr && VG) {
+    if (live)
+      for (int jj = 0; jj < n; ++jj) {
+        const T val = fma_(vcol[jj], scale, y0[jj]);
+        bad |= (val != val);
+        y[(b0 + tid) * ldy + jj] = val;
+      }
+  } else if (Ng == nullptr) {
     // NA_E = I: y = y0 + v * scale, written coalesced from the staged tile
     sc[tid] = scale;
     __syncthreads();
@@ -508,13 +522,15 @@ int generic_block_for(const RayenPack* p, const GenericImage<T>& img) {
   return 0;
 }
 
-template <typename T, int BLOCK, int RREG>
+template <typename T, int BLOCK, int RREG, bool VG = false>
 static int launch_fwd(const RayenPack* p, const GenericImage<T>& img, const T* v, int64_t B,
                       int64_t ldv, T* y, int64_t ldy, T* kappa, int32_t* active, int32_t* nan_flag,
                       hipStream_t stream) {
   const int lmi_words = RREG > 0 ? 0 : img.lmi_words;  // the register path needs no LDS scratch
-  const size_t lds = generic_lds_bytes<T>(p->n, lmi_words, BLOCK);
-  auto kern = generic_fwd_kernel<T, BLOCK, RREG>;
+  const size_t lds = VG ? sizeof(T) * ((size_t)BLOCK + (size_t)lmi_words * BLOCK)
+                        : generic_lds_bytes<T>(p->n, lmi_words, BLOCK);
+  if (lds > kLdsHard) return RAYEN_E_UNSUPPORTED;
+  auto kern = generic_fwd_kernel<T, BLOCK, RREG, VG>;
   if (lds > 48 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -560,7 +576,8 @@ int generic_forward(const RayenPack* p, const GenericImage<T>& img, const T* v, 
     case 256: return launch_fwd<T, 256, 0>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
     case 128: return launch_fwd<T, 128, 0>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
     case 64: return launch_fwd<T, 64, 0>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
-    default: return RAYEN_E_UNSUPPORTED;
+    default:  // n too large for an LDS tile: directions straight from global memory
+      return launch_fwd<T, 64, 0, true>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
   }
 }
 

@@ -338,3 +338,18 @@ def test_fp64_mfma_and_generic_paths_agree(name, B):
     assert oracle.max_violation(raw, y_auto.cpu().numpy()) <= 1e-11
     if cs.n <= 64:
         assert dp.info().mfma_f64 == 1
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, FP32_TOL), (torch.float64, FP64_TOL)])
+def test_large_subspace_dimension(dtype, tol):
+    """n = 800: beyond the LDS tile and the MFMA register budget -> directions read from global memory."""
+    raw = workloads.random_lin_quad_soc(k=800, m=120, n_quad=2, n_soc=1, r_M=50, seed=71)
+    cs, layer = _layer(raw, dtype)
+    gen = torch.Generator().manual_seed(12)
+    x = torch.empty(300, cs.n, 1, dtype=torch.float32).uniform_(-1, 1, generator=gen).to(dtype)
+    x[0] = 0
+    y = layer(x.cuda()).cpu().numpy()[:, :, 0]
+    y_ref = _oracle_forward(cs, x, dtype)
+    assert np.max(rel_err_rows(y, y_ref)) <= tol
+    floor = VIOLATION_TOL if dtype == torch.float32 else 1e-10
+    assert oracle.max_violation(raw, y) <= max(floor, 3 * oracle.max_violation(raw, y_ref))
