@@ -353,3 +353,25 @@ def test_large_subspace_dimension(dtype, tol):
     assert np.max(rel_err_rows(y, y_ref)) <= tol
     floor = VIOLATION_TOL if dtype == torch.float32 else 1e-10
     assert oracle.max_violation(raw, y) <= max(floor, 3 * oracle.max_violation(raw, y_ref))
+
+
+def test_config5_full_two_million_batch():
+    """BASELINE.json config 5 at its full size on ONE device (the 8-GPU run shards exactly this batch)."""
+    B = workloads.CONFIGS["c5"][2]
+    assert B == 2097152
+    raw = workloads.make_raw("c5", seed=0)
+    cs, layer = _layer(raw)
+    layer.check_nan = False
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.empty(B, cs.n, 1, device="cuda").uniform_(-1, 1, generator=gen)
+    y = layer(x)
+    assert y.shape == (B, cs.k, 1)
+    assert bool(torch.isfinite(y).all())
+    sub = y[::64, :, 0].cpu().numpy()                      # residuals of 32768 evenly spaced samples
+    assert oracle.max_violation(raw, sub) <= 5e-5          # unnormalised residuals, |P| ~ 1e2 (see c5 above)
+    # the same rows in a small batch give the same bits (no dependence on the launch geometry)
+    y_small = layer(x[:4096])
+    assert torch.equal(y_small, y[:4096])
+    from rayen_amd.dist import shard_bounds
+    lo, hi = shard_bounds(B, 8, 3)                         # rank 3's shard of the 8-GPU run
+    assert torch.equal(layer(x[lo:hi]), y[lo:hi])
