@@ -81,9 +81,9 @@ def _install_stubs():
 
 
 _install_stubs()
-sys.path.insert(0, REF)
+sys.path.insert(0, REF)                                   # the reference's own `rayen` package wins
 sys.path.insert(0, os.path.join(REF, "examples"))
-sys.path.insert(0, REPO)
+sys.path.append(REPO)                                      # rayen_amd.workloads (raw synthetic data only)
 
 from rayen import constraints as ref_constraints          # noqa: E402  (the reference)
 from rayen import constraint_module as ref_module         # noqa: E402

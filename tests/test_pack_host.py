@@ -134,3 +134,14 @@ def test_state_dict_and_pickle_roundtrip():
     again = torch.load(blob, weights_only=False)
     assert torch.equal(again.all_delta, layer.all_delta)
     assert again.getDimAfterMap() == layer.getDimAfterMap()
+
+
+def test_reference_import_names_resolve_to_this_build():
+    """`from rayen import constraints, constraint_module` (the reference's import line) works here."""
+    import rayen
+    from rayen import constraint_module as cm, constraints as cons
+    from rayen.constraint_module import ConstraintModule as CM2
+    import rayen_amd
+    assert cm.ConstraintModule is rayen_amd.constraint_module.ConstraintModule is CM2
+    assert cons.ConvexConstraints is rayen_amd.constraints.ConvexConstraints
+    assert rayen.utils.verify is rayen_amd.utils.verify
