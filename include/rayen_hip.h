@@ -147,6 +147,26 @@ int rayen_ray_project_bwd_f64(const RayenPack* pack, const double* v, int64_t B,
                               const double* grad_y, int64_t ldg,
                               double* grad_v, int64_t ldgv, void* stream);
 
+/* The RAYEN_old head (rayen/constraint_module.py:460-466, forwardForRAYENOld): the input carries one
+ * more column, beta = v[:, n] (so ldv >= n + 1), and the step is 1/(exp(beta) + kappa(v_bar)) along
+ * v_bar = v/||v||:   y = y0 + NA_E v / (||v|| exp(beta) + kappa(v))   (y = y0 when v = 0).
+ * kappa / active / nan_flag as above.  The backward writes n + 1 columns (ldgv >= n + 1):
+ *   grad_v = s N'g - s^2 (g . N v) (exp(beta) v/||v|| + grad kappa(v)),  grad_beta = -s^2 (g . N v) ||v|| exp(beta). */
+int rayen_ray_project_old_f32(const RayenPack* pack, const float* v, int64_t B, int64_t ldv,
+                              float* y, int64_t ldy, float* kappa, int32_t* active,
+                              int32_t* nan_flag, void* stream);
+int rayen_ray_project_old_f64(const RayenPack* pack, const double* v, int64_t B, int64_t ldv,
+                              double* y, int64_t ldy, double* kappa, int32_t* active,
+                              int32_t* nan_flag, void* stream);
+int rayen_ray_project_old_bwd_f32(const RayenPack* pack, const float* v, int64_t B, int64_t ldv,
+                                  const float* kappa, const int32_t* active,
+                                  const float* grad_y, int64_t ldg,
+                                  float* grad_v, int64_t ldgv, void* stream);
+int rayen_ray_project_old_bwd_f64(const RayenPack* pack, const double* v, int64_t B, int64_t ldv,
+                                  const double* kappa, const int32_t* active,
+                                  const double* grad_y, int64_t ldg,
+                                  double* grad_v, int64_t ldgv, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

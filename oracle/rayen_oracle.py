@@ -23,6 +23,7 @@ Function -> reference lines it follows (CM = rayen/constraint_module.py):
 * ``solve_second_order`` CM:339-348
 * ``compute_kappa``   CM:351-458
 * ``forward_rayen``   CM:468-474 with ``getyFromz`` CM:512-514
+* ``forward_rayen_old`` CM:460-466
 * ``forward``         CM:520-533 with ``create_map=False`` (identity mapper)
 """
 from __future__ import annotations
@@ -141,10 +142,21 @@ def forward_rayen(buf: dict, q: torch.Tensor) -> torch.Tensor:
     return buf["NA_E"] @ (buf["z0"] + alpha * v_bar) + buf["yp"]
 
 
-def forward(buf: dict, x: torch.Tensor) -> torch.Tensor:
+def forward_rayen_old(buf: dict, q: torch.Tensor) -> torch.Tensor:
+    """``q [B, >=n+1, 1] -> y [B,k,1]``: the ``RAYEN_old`` head, step ``1/(exp(beta)+kappa)`` (CM:460-466)."""
+    n = buf["NA_E"].shape[1]
+    v = q[:, 0:n, 0:1]
+    v_bar = torch.nn.functional.normalize(v, dim=1)
+    kappa = compute_kappa(buf, v_bar)
+    beta = q[:, n:(n + 1), 0:1]
+    alpha = 1 / (torch.exp(beta) + kappa)
+    return buf["NA_E"] @ (buf["z0"] + alpha * v_bar) + buf["yp"]
+
+
+def forward(buf: dict, x: torch.Tensor, method: str = "RAYEN") -> torch.Tensor:
     """Layer forward with the identity mapper (CM:520-533, ``create_map=False``)."""
     q = torch.flatten(x, 1).unsqueeze(2)  # == x.view(B, -1), and defined for B = 0
-    y = forward_rayen(buf, q)
+    y = forward_rayen(buf, q) if method == "RAYEN" else forward_rayen_old(buf, q)
     assert not torch.isnan(y).any()
     return y
 

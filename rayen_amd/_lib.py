@@ -19,7 +19,8 @@ EXPORTS = (
     "rayen_abi_version", "rayen_strerror", "rayen_pack_create", "rayen_pack_destroy",
     "rayen_pack_info", "rayen_ray_project_f32", "rayen_ray_project_f64",
     "rayen_ray_project_generic_f32", "rayen_ray_project_generic_f64", "rayen_ray_project_bwd_f32",
-    "rayen_ray_project_bwd_f64",
+    "rayen_ray_project_bwd_f64", "rayen_ray_project_old_f32", "rayen_ray_project_old_f64",
+    "rayen_ray_project_old_bwd_f32", "rayen_ray_project_old_bwd_f64",
 )
 
 
@@ -82,11 +83,12 @@ def load():
     lib.rayen_pack_info.argtypes = [p, ctypes.POINTER(RayenPackInfo)]
     fwd = [p, p, i64, i64, p, i64, p, i32p, i32p, p]
     for name in ("rayen_ray_project_f32", "rayen_ray_project_f64", "rayen_ray_project_generic_f32",
-                 "rayen_ray_project_generic_f64"):
+                 "rayen_ray_project_generic_f64", "rayen_ray_project_old_f32", "rayen_ray_project_old_f64"):
         getattr(lib, name).restype = ctypes.c_int
         getattr(lib, name).argtypes = fwd
     bwd = [p, p, i64, i64, p, i32p, p, i64, p, i64, p]
-    for name in ("rayen_ray_project_bwd_f32", "rayen_ray_project_bwd_f64"):
+    for name in ("rayen_ray_project_bwd_f32", "rayen_ray_project_bwd_f64",
+                 "rayen_ray_project_old_bwd_f32", "rayen_ray_project_old_bwd_f64"):
         getattr(lib, name).restype = ctypes.c_int
         getattr(lib, name).argtypes = bwd
     if lib.rayen_abi_version() != ABI_VERSION:

@@ -11,9 +11,9 @@ PyTorch ops and 10 host syncs per call, one hand-written gfx950 kernel computes
 (the homogeneity identity of SURVEY.md §0, equal to :468-474 for every ``v``).
 The layer only runs on an MI355X: CPU tensors raise (no fallback path exists).
 
-Only ``method='RAYEN'`` (the default) is the hot path this package accelerates;
-``'UU'`` is the identity and kept because it is free; the paper baselines
-(``RAYEN_old, UP, PP, DC3, Bar``) are out of scope and raise
+``method='RAYEN'`` (the default) is the hot path this package accelerates; its older step rule
+``'RAYEN_old'`` (:460-466) runs on the same kernels; ``'UU'`` is the identity and kept because it
+is free; the paper baselines (``UP, PP, DC3, Bar``) are out of scope and raise
 ``NotImplementedError``.
 
 Documented deviation: for an SOC whose ray never meets the cone (negative
@@ -36,8 +36,8 @@ class ConstraintModule(torch.nn.Module):
         super().__init__()
 
         self.method = method
-        if method not in ('RAYEN', 'UU'):
-            if method in ('RAYEN_old', 'UP', 'PP', 'DC3', 'Bar'):
+        if method not in ('RAYEN', 'RAYEN_old', 'UU'):
+            if method in ('UP', 'PP', 'DC3', 'Bar'):
                 raise NotImplementedError(
                     f"method '{method}' is one of the reference's comparison baselines; rayen_amd "
                     "implements the RAYEN projection only")
@@ -102,6 +102,9 @@ class ConstraintModule(torch.nn.Module):
         if self.method == 'RAYEN':
             self.forwardForMethod = self.forwardForRAYEN
             self.dim_after_map = self.n
+        elif self.method == 'RAYEN_old':
+            self.forwardForMethod = self.forwardForRAYENOld
+            self.dim_after_map = self.n + 1
         else:  # 'UU'
             self.forwardForMethod = self.forwardForUU
             self.dim_after_map = self.k
@@ -159,10 +162,11 @@ class ConstraintModule(torch.nn.Module):
 
     def __setstate__(self, state):
         super().__setstate__(state)
-        self.forwardForMethod = self.forwardForRAYEN if self.method == 'RAYEN' else self.forwardForUU
+        self.forwardForMethod = {'RAYEN': self.forwardForRAYEN, 'RAYEN_old': self.forwardForRAYENOld,
+                                 'UU': self.forwardForUU}[self.method]
 
     # ------------------------------------------------------------------ the projection
-    def _project(self, q):
+    def _project(self, q, old_head=False):
         """``q [B, >=n, 1]`` (or ``[B, >=n]``) -> ``(y [B,k], kappa [B])`` through the fused HIP op."""
         v = torch.flatten(q, 1)
         if not v.is_cuda:
@@ -171,7 +175,7 @@ class ConstraintModule(torch.nn.Module):
                 f"{v.device} tensor. Call .to('cuda') on the model and the input.")
         _, pack_id = self.device_pack(v.device)
         need_active = torch.is_grad_enabled() and v.requires_grad
-        y, kappa, _ = torch.ops.rayen_amd.ray_project(v, pack_id, need_active)
+        y, kappa, _ = torch.ops.rayen_amd.ray_project(v, pack_id, need_active, old_head)
         return y, kappa
 
     def computeKappa(self, v_bar):
@@ -183,6 +187,11 @@ class ConstraintModule(torch.nn.Module):
 
     def forwardForRAYEN(self, q):
         y, _ = self._project(q)
+        return y.unsqueeze(2)
+
+    def forwardForRAYENOld(self, q):
+        # step 1/(exp(beta) + kappa) with beta = q[:, n] (rayen/constraint_module.py:460-466)
+        y, _ = self._project(q, old_head=True)
         return y.unsqueeze(2)
 
     def forwardForUU(self, q):
@@ -208,7 +217,7 @@ class ConstraintModule(torch.nn.Module):
 
         y = self.forwardForMethod(q)
 
-        if (__debug__ and self.check_nan and self.method == 'RAYEN'
+        if (__debug__ and self.check_nan and self.method in ('RAYEN', 'RAYEN_old')
                 and not torch.cuda.is_current_stream_capturing()):  # the flag read is a host sync
             dp, _ = self.device_pack(y.device)
             if int(dp.nan_flag.item()) != 0:

@@ -86,28 +86,31 @@ int ensure_mfma64(const RayenPack* p) {
 
 template <typename T>
 int project_generic(const RayenPack* p, const T* v, int64_t B, int64_t ldv, T* y, int64_t ldy, T* kappa,
-                    int32_t* active, int32_t* nan_flag, void* stream) {
-  if (p == nullptr || B < 0 || (B > 0 && v == nullptr) || ldv < p->n || (y != nullptr && ldy < p->k))
+                    int32_t* active, int32_t* nan_flag, void* stream, int old_mode = 0) {
+  if (p == nullptr || B < 0 || (B > 0 && v == nullptr) || ldv < p->n + old_mode ||
+      (y != nullptr && ldy < p->k))
     return RAYEN_E_BAD_ARG;
   int rc = check_device(p);
   if (rc) return rc;
   rc = ensure_generic<T>(p);
   if (rc) return rc;
-  return generic_forward<T>(p, image_of<T>(p), v, B, ldv, y, ldy, kappa, active, nan_flag,
+  return generic_forward<T>(p, image_of<T>(p), v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode,
                             static_cast<hipStream_t>(stream));
 }
 
 template <typename T>
 int project_bwd(const RayenPack* p, const T* v, int64_t B, int64_t ldv, const T* kappa,
-                const int32_t* active, const T* grad_y, int64_t ldg, T* grad_v, int64_t ldgv, void* stream) {
-  if (p == nullptr || B < 0 || ldv < p->n || ldg < p->k || ldgv < p->n) return RAYEN_E_BAD_ARG;
+                const int32_t* active, const T* grad_y, int64_t ldg, T* grad_v, int64_t ldgv, void* stream,
+                int old_mode = 0) {
+  if (p == nullptr || B < 0 || ldv < p->n + old_mode || ldg < p->k || ldgv < p->n + old_mode)
+    return RAYEN_E_BAD_ARG;
   if (B > 0 && (!v || !kappa || !active || !grad_y || !grad_v)) return RAYEN_E_BAD_ARG;
   int rc = check_device(p);
   if (rc) return rc;
   rc = ensure_generic<T>(p);
   if (rc) return rc;
   return generic_backward<T>(p, image_of<T>(p), v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv,
-                             static_cast<hipStream_t>(stream));
+                             old_mode, static_cast<hipStream_t>(stream));
 }
 
 }  // namespace
@@ -202,18 +205,29 @@ int rayen_ray_project_generic_f32(const RayenPack* p, const float* v, int64_t B,
   return project_generic<float>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
 }
 
-int rayen_ray_project_f32(const RayenPack* p, const float* v, int64_t B, int64_t ldv, float* y,
-                          int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag, void* stream) {
-  if (p == nullptr || B < 0 || (B > 0 && v == nullptr) || ldv < p->n || (y != nullptr && ldy < p->k))
+static int project_f32(const RayenPack* p, const float* v, int64_t B, int64_t ldv, float* y, int64_t ldy,
+                       float* kappa, int32_t* active, int32_t* nan_flag, void* stream, int old_mode) {
+  if (p == nullptr || B < 0 || (B > 0 && v == nullptr) || ldv < p->n + old_mode ||
+      (y != nullptr && ldy < p->k))
     return RAYEN_E_BAD_ARG;
   int rc = check_device(p);
   if (rc) return rc;
   rc = ensure_mfma(p);
   if (rc) return rc;
   if (p->m32 != nullptr && y != nullptr)
-    return mfma_forward(p, p->m32, v, B, ldv, y, ldy, kappa, active, nan_flag,
+    return mfma_forward(p, p->m32, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode,
                         static_cast<hipStream_t>(stream));
-  return project_generic<float>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+  return project_generic<float>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, old_mode);
+}
+
+int rayen_ray_project_f32(const RayenPack* p, const float* v, int64_t B, int64_t ldv, float* y,
+                          int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag, void* stream) {
+  return project_f32(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, 0);
+}
+
+int rayen_ray_project_old_f32(const RayenPack* p, const float* v, int64_t B, int64_t ldv, float* y,
+                              int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag, void* stream) {
+  return project_f32(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, 1);
 }
 
 int rayen_ray_project_generic_f64(const RayenPack* p, const double* v, int64_t B, int64_t ldv, double* y,
@@ -222,18 +236,29 @@ int rayen_ray_project_generic_f64(const RayenPack* p, const double* v, int64_t B
   return project_generic<double>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
 }
 
-int rayen_ray_project_f64(const RayenPack* p, const double* v, int64_t B, int64_t ldv, double* y,
-                          int64_t ldy, double* kappa, int32_t* active, int32_t* nan_flag, void* stream) {
-  if (p == nullptr || B < 0 || (B > 0 && v == nullptr) || ldv < p->n || (y != nullptr && ldy < p->k))
+static int project_f64(const RayenPack* p, const double* v, int64_t B, int64_t ldv, double* y, int64_t ldy,
+                       double* kappa, int32_t* active, int32_t* nan_flag, void* stream, int old_mode) {
+  if (p == nullptr || B < 0 || (B > 0 && v == nullptr) || ldv < p->n + old_mode ||
+      (y != nullptr && ldy < p->k))
     return RAYEN_E_BAD_ARG;
   int rc = check_device(p);
   if (rc) return rc;
   rc = ensure_mfma64(p);
   if (rc) return rc;
   if (p->m64 != nullptr && y != nullptr)
-    return mfma64_forward(p, p->m64, v, B, ldv, y, ldy, kappa, active, nan_flag,
+    return mfma64_forward(p, p->m64, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode,
                           static_cast<hipStream_t>(stream));
-  return project_generic<double>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+  return project_generic<double>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, old_mode);
+}
+
+int rayen_ray_project_f64(const RayenPack* p, const double* v, int64_t B, int64_t ldv, double* y,
+                          int64_t ldy, double* kappa, int32_t* active, int32_t* nan_flag, void* stream) {
+  return project_f64(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, 0);
+}
+
+int rayen_ray_project_old_f64(const RayenPack* p, const double* v, int64_t B, int64_t ldv, double* y,
+                              int64_t ldy, double* kappa, int32_t* active, int32_t* nan_flag, void* stream) {
+  return project_f64(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, 1);
 }
 
 int rayen_ray_project_bwd_f32(const RayenPack* p, const float* v, int64_t B, int64_t ldv,
@@ -246,6 +271,18 @@ int rayen_ray_project_bwd_f64(const RayenPack* p, const double* v, int64_t B, in
                               const double* kappa, const int32_t* active, const double* grad_y,
                               int64_t ldg, double* grad_v, int64_t ldgv, void* stream) {
   return project_bwd<double>(p, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, stream);
+}
+
+int rayen_ray_project_old_bwd_f32(const RayenPack* p, const float* v, int64_t B, int64_t ldv,
+                                  const float* kappa, const int32_t* active, const float* grad_y,
+                                  int64_t ldg, float* grad_v, int64_t ldgv, void* stream) {
+  return project_bwd<float>(p, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, stream, 1);
+}
+
+int rayen_ray_project_old_bwd_f64(const RayenPack* p, const double* v, int64_t B, int64_t ldv,
+                                  const double* kappa, const int32_t* active, const double* grad_y,
+                                  int64_t ldg, double* grad_v, int64_t ldgv, void* stream) {
+  return project_bwd<double>(p, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, stream, 1);
 }
 
 }  // extern "C"

@@ -238,7 +238,8 @@ __global__ __launch_bounds__(BLOCK) void generic_fwd_kernel(
     const T* __restrict__ Wg, const T* __restrict__ Ng, const T* __restrict__ y0,
     const GSeg* __restrict__ segs, int n_gseg, int out_nrb, int k, int n, int lmi_words,
     const T* __restrict__ v, int64_t B, int64_t ldv, T* __restrict__ y, int64_t ldy,
-    T* __restrict__ kappa_out, int32_t* __restrict__ active_out, int32_t* __restrict__ nan_flag) {
+    T* __restrict__ kappa_out, int32_t* __restrict__ active_out, int32_t* __restrict__ nan_flag,
+    int old_mode) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int LD = VG ? 1 : BLOCK + 1;
   const int n_pad = (n + kRowBlock - 1) / kRowBlock * kRowBlock;
@@ -356,8 +357,17 @@ __global__ __launch_bounds__(BLOCK) void generic_fwd_kernel(
     }
   }
 
-  const T scale = T(1) / fmax(T(1), kap);
   const bool live = tid < nb;
+  T scale = T(1) / fmax(T(1), kap);
+  if (old_mode) {
+    // RAYEN_old head (rayen/constraint_module.py:460-466): step 1/(exp(beta) + kappa(v_bar)) along
+    // v_bar = v/||v||, i.e. y = y0 + N v / (||v|| exp(beta) + kappa(v)); beta is column n of the input
+    T nrm2 = T(0);
+    for (int jj = 0; jj < n; ++jj) nrm2 = fma_(vcol[jj * LD], vcol[jj * LD], nrm2);
+    const T beta = live ? v[(b0 + tid) * ldv + n] : T(0);
+    const T nrm = sqrt(nrm2);
+    scale = nrm > T(0) ? T(1) / (nrm * exp(beta) + kap) : T(0);
+  }
   if (live) {
     if (kappa_out) kappa_out[b0 + tid] = kap;
     if (active_out) { active_out[2 * (b0 + tid)] = aseg; active_out[2 * (b0 + tid) + 1] = arow; }
@@ -525,7 +535,7 @@ int generic_block_for(const RayenPack* p, const GenericImage<T>& img) {
 template <typename T, int BLOCK, int RREG, bool VG = false>
 static int launch_fwd(const RayenPack* p, const GenericImage<T>& img, const T* v, int64_t B,
                       int64_t ldv, T* y, int64_t ldy, T* kappa, int32_t* active, int32_t* nan_flag,
-                      hipStream_t stream) {
+                      int old_mode, hipStream_t stream) {
   const int lmi_words = RREG > 0 ? 0 : img.lmi_words;  // the register path needs no LDS scratch
   const size_t lds = VG ? sizeof(T) * ((size_t)BLOCK + (size_t)lmi_words * BLOCK)
                         : generic_lds_bytes<T>(p->n, lmi_words, BLOCK);
@@ -539,7 +549,7 @@ static int launch_fwd(const RayenPack* p, const GenericImage<T>& img, const T* v
   const int64_t grid = (B + BLOCK - 1) / BLOCK;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), lds, stream, img.Wg, img.Ng, img.y0,
                      img.segs, img.n_gseg, img.out_nrb, p->k, p->n, lmi_words, v, B, ldv, y, ldy,
-                     kappa, active, nan_flag);
+                     kappa, active, nan_flag, old_mode);
   return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
 }
 
@@ -557,27 +567,27 @@ static int lmi_reg_class(const RayenPack* p) {
 template <typename T>
 int generic_forward(const RayenPack* p, const GenericImage<T>& img, const T* v, int64_t B,
                     int64_t ldv, T* y, int64_t ldy, T* kappa, int32_t* active, int32_t* nan_flag,
-                    hipStream_t stream) {
+                    int old_mode, hipStream_t stream) {
   if (B == 0) return RAYEN_OK;
   if constexpr (std::is_same<T, float>::value) {
     if (generic_lds_bytes<T>(p->n, 0, 64) <= kLdsHard) {
       switch (lmi_reg_class<T>(p)) {
-        case 4: return launch_fwd<T, 64, 4>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
-        case 8: return launch_fwd<T, 64, 8>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
-        case 12: return launch_fwd<T, 64, 12>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
-        case 16: return launch_fwd<T, 64, 16>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
-        case 20: return launch_fwd<T, 64, 20>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
-        case 24: return launch_fwd<T, 64, 24>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+        case 4: return launch_fwd<T, 64, 4>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream);
+        case 8: return launch_fwd<T, 64, 8>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream);
+        case 12: return launch_fwd<T, 64, 12>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream);
+        case 16: return launch_fwd<T, 64, 16>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream);
+        case 20: return launch_fwd<T, 64, 20>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream);
+        case 24: return launch_fwd<T, 64, 24>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream);
         default: break;
       }
     }
   }
   switch (generic_block_for<T>(p, img)) {
-    case 256: return launch_fwd<T, 256, 0>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
-    case 128: return launch_fwd<T, 128, 0>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
-    case 64: return launch_fwd<T, 64, 0>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+    case 256: return launch_fwd<T, 256, 0>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream);
+    case 128: return launch_fwd<T, 128, 0>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream);
+    case 64: return launch_fwd<T, 64, 0>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream);
     default:  // n too large for an LDS tile: directions straight from global memory
-      return launch_fwd<T, 64, 0, true>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+      return launch_fwd<T, 64, 0, true>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream);
   }
 }
 
@@ -654,7 +664,7 @@ __global__ __launch_bounds__(BLOCK) void generic_bwd_kernel(
     const T* __restrict__ Wg, const T* __restrict__ NTg, const GSeg* __restrict__ segs, int n_gseg,
     int k, int n, int w_rows, int lmi_words, const T* __restrict__ v, int64_t B, int64_t ldv,
     const T* __restrict__ kappa, const int32_t* __restrict__ active, const T* __restrict__ grad_y,
-    int64_t ldg, T* __restrict__ grad_v, int64_t ldgv) {
+    int64_t ldg, T* __restrict__ grad_v, int64_t ldgv, int old_mode) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int LD = BLOCK + 1;
   const int n_pad = (n + kRowBlock - 1) / kRowBlock * kRowBlock;
@@ -709,8 +719,17 @@ __global__ __launch_bounds__(BLOCK) void generic_bwd_kernel(
   const T kap = live ? kappa[b0 + tid] : T(0);
   const int aseg = live ? active[2 * (b0 + tid)] : -1;
   const int arow = live ? active[2 * (b0 + tid) + 1] : 0;
-  const bool clipped = live && kap > T(1) && aseg >= 0;
-  const T sc = T(1) / fmax(T(1), kap);
+  // RAYEN: s = 1/max(1,kappa), so kappa only matters once it clips.  RAYEN_old (old_mode):
+  // s = 1/(r e^beta + kappa) with r = ||v||: kappa always matters, and r, beta get gradients too.
+  T r_nrm = T(0), e_beta = T(0);
+  if (old_mode) {
+    T nrm2 = T(0);
+    for (int j = 0; j < n; ++j) nrm2 = fma_(vcol[j * LD], vcol[j * LD], nrm2);
+    r_nrm = sqrt(nrm2);
+    e_beta = live ? exp(v[(b0 + tid) * ldv + n]) : T(0);
+  }
+  const bool clipped = old_mode ? (live && aseg >= 0 && r_nrm > T(0)) : (live && kap > T(1) && aseg >= 0);
+  const T sc = old_mode ? (r_nrm > T(0) ? T(1) / (r_nrm * e_beta + kap) : T(0)) : T(1) / fmax(T(1), kap);
 
   // Every lane walks ONLY the constraint that set its kappa: its own segment record, its own row
   // blocks (the reads of W become per-lane loads; lanes that share a segment share the addresses).
@@ -811,8 +830,17 @@ __global__ __launch_bounds__(BLOCK) void generic_bwd_kernel(
   }
 
   // grad_v = s t - [clipped] s^2 (t.v) u
-  const T coef = clipped ? sc * sc * tv : T(0);
-  for (int j = 0; j < n; ++j) tcol[j * LD] = sc * tcol[j * LD] - coef * ucol[j * LD];
+  if (!old_mode) {
+    const T coef = clipped ? sc * sc * tv : T(0);
+    for (int j = 0; j < n; ++j) tcol[j * LD] = sc * tcol[j * LD] - coef * ucol[j * LD];
+  } else {
+    // grad_v = s t - s^2 (t.v) (e^beta v / r + grad kappa),  grad_beta = -s^2 (t.v) r e^beta
+    const T coef = sc * sc * tv;
+    const T dir = r_nrm > T(0) ? e_beta / r_nrm : T(0);
+    for (int j = 0; j < n; ++j)
+      tcol[j * LD] = sc * tcol[j * LD] - coef * (dir * vcol[j * LD] + (clipped ? ucol[j * LD] : T(0)));
+    if (live) grad_v[(b0 + tid) * ldgv + n] = -coef * r_nrm * e_beta;
+  }
   __syncthreads();
   for (int idx = tid; idx < nb * n; idx += BLOCK) {
     const int bl = idx / n, j = idx - bl * n;
@@ -844,7 +872,7 @@ static size_t bwd_lds_bytes(const RayenPack* p, int w_rows, int lmi_words, int b
 template <typename T, int BLOCK>
 static int launch_bwd(const RayenPack* p, const GenericImage<T>& img, int w_rows, int lmi_words, const T* v,
                       int64_t B, int64_t ldv, const T* kappa, const int32_t* active, const T* grad_y,
-                      int64_t ldg, T* grad_v, int64_t ldgv, hipStream_t stream) {
+                      int64_t ldg, T* grad_v, int64_t ldgv, int old_mode, hipStream_t stream) {
   const size_t lds = bwd_lds_bytes<T>(p, w_rows, lmi_words, BLOCK);
   auto kern = generic_bwd_kernel<T, BLOCK>;
   if (lds > 48 * 1024 &&
@@ -854,14 +882,14 @@ static int launch_bwd(const RayenPack* p, const GenericImage<T>& img, int w_rows
   const int64_t grid = (B + BLOCK - 1) / BLOCK;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), lds, stream, img.Wg, img.NTg, img.segs,
                      img.n_gseg, p->k, p->n, w_rows, lmi_words, v, B, ldv, kappa, active, grad_y, ldg, grad_v,
-                     ldgv);
+                     ldgv, old_mode);
   return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
 }
 
 template <typename T>
 int generic_backward(const RayenPack* p, const GenericImage<T>& img, const T* v, int64_t B, int64_t ldv,
                      const T* kappa, const int32_t* active, const T* grad_y, int64_t ldg, T* grad_v,
-                     int64_t ldgv, hipStream_t stream) {
+                     int64_t ldgv, int old_mode, hipStream_t stream) {
   if (B == 0) return RAYEN_OK;
   int w_rows, lmi_words;
   bwd_shape<T>(p, img, &w_rows, &lmi_words);
@@ -870,9 +898,9 @@ int generic_backward(const RayenPack* p, const GenericImage<T>& img, const T* v,
     if (bwd_lds_bytes<T>(p, w_rows, lmi_words, cand) <= kLdsSoft) { block = cand; break; }
   if (block == 0 && bwd_lds_bytes<T>(p, w_rows, lmi_words, 64) <= kLdsHard) block = 64;
   switch (block) {
-    case 256: return launch_bwd<T, 256>(p, img, w_rows, lmi_words, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, stream);
-    case 128: return launch_bwd<T, 128>(p, img, w_rows, lmi_words, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, stream);
-    case 64: return launch_bwd<T, 64>(p, img, w_rows, lmi_words, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, stream);
+    case 256: return launch_bwd<T, 256>(p, img, w_rows, lmi_words, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode, stream);
+    case 128: return launch_bwd<T, 128>(p, img, w_rows, lmi_words, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode, stream);
+    case 64: return launch_bwd<T, 64>(p, img, w_rows, lmi_words, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode, stream);
     default: return RAYEN_E_UNSUPPORTED;
   }
 }
@@ -882,10 +910,10 @@ int generic_backward(const RayenPack* p, const GenericImage<T>& img, const T* v,
   template void generic_free<T>(GenericImage<T>*);                                                  \
   template int generic_block_for<T>(const RayenPack*, const GenericImage<T>&);                      \
   template int generic_forward<T>(const RayenPack*, const GenericImage<T>&, const T*, int64_t,      \
-                                  int64_t, T*, int64_t, T*, int32_t*, int32_t*, hipStream_t);       \
+                                  int64_t, T*, int64_t, T*, int32_t*, int32_t*, int, hipStream_t);  \
   template int generic_backward<T>(const RayenPack*, const GenericImage<T>&, const T*, int64_t,     \
                                    int64_t, const T*, const int32_t*, const T*, int64_t, T*,        \
-                                   int64_t, hipStream_t);
+                                   int64_t, int, hipStream_t);
 RAYEN_INSTANTIATE(float)
 RAYEN_INSTANTIATE(double)
 

@@ -80,11 +80,11 @@ int generic_block_for(const RayenPack* p, const GenericImage<T>& img);
 template <typename T>
 int generic_forward(const RayenPack* p, const GenericImage<T>& img, const T* v, int64_t B,
                     int64_t ldv, T* y, int64_t ldy, T* kappa, int32_t* active, int32_t* nan_flag,
-                    hipStream_t stream);
+                    int old_mode, hipStream_t stream);
 template <typename T>
 int generic_backward(const RayenPack* p, const GenericImage<T>& img, const T* v, int64_t B,
                      int64_t ldv, const T* kappa, const int32_t* active, const T* grad_y,
-                     int64_t ldg, T* grad_v, int64_t ldgv, hipStream_t stream);
+                     int64_t ldg, T* grad_v, int64_t ldgv, int old_mode, hipStream_t stream);
 
 // fp32 MFMA path (rayen_mfma.hip)
 bool mfma_eligible(const RayenPack* p);
@@ -92,7 +92,7 @@ int mfma_build(const RayenPack* p, MfmaImage** out, int64_t* bytes);
 void mfma_free(MfmaImage* img);
 int mfma_forward(const RayenPack* p, const MfmaImage* img, const float* v, int64_t B, int64_t ldv,
                  float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
-                 hipStream_t stream);
+                 int old_mode, hipStream_t stream);
 
 // fp64 MFMA path (rayen_mfma_f64.hip)
 bool mfma64_eligible(const RayenPack* p);
@@ -100,6 +100,6 @@ int mfma64_build(const RayenPack* p, Mfma64Image** out, int64_t* bytes);
 void mfma64_free(Mfma64Image* img);
 int mfma64_forward(const RayenPack* p, const Mfma64Image* img, const double* v, int64_t B, int64_t ldv,
                    double* y, int64_t ldy, double* kappa, int32_t* active, int32_t* nan_flag,
-                   hipStream_t stream);
+                   int old_mode, hipStream_t stream);
 
 }  // namespace rayen

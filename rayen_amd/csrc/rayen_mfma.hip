@@ -75,7 +75,8 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_fwd_kern
     const f32x4* __restrict__ Wimg, const MItem* __restrict__ items, int n_items,
     const MPack* __restrict__ packs, const float* __restrict__ y0, int identity, int k, int n, const float* __restrict__ v, int64_t B,
     int64_t ldv, int vec_in, float* __restrict__ y, int64_t ldy, int vec_out,
-    float* __restrict__ kappa_out, int32_t* __restrict__ active_out, int32_t* __restrict__ nan_flag) {
+    float* __restrict__ kappa_out, int32_t* __restrict__ active_out, int32_t* __restrict__ nan_flag,
+    int old_mode) {
   using C = MfmaCfg<NKK>;
   constexpr int NT = C::NT, NQ = C::NQ, KK = C::KK;
   __shared__ float aux_lds[kMfmaWaves][NT][32][32];  // [wave][sample tile][aux row][sample]
@@ -164,6 +165,22 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_fwd_kern
     }
   }
 
+  // RAYEN_old head (rayen/constraint_module.py:460-466): y = y0 + N v / (||v|| e^beta + kappa(v)),
+  // beta = column n of the input
+  float old_den[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) old_den[t] = 0.f;
+  if (old_mode) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float nrm2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < KK; ++i) nrm2 = fmaf(vr[t][i], vr[t][i], nrm2);
+      nrm2 += xhalf(nrm2);
+      const float beta = live[t] ? v[(s_base + t * 32 + col) * ldv + n] : 0.f;
+      old_den[t] = sqrtf(nrm2) * __expf(beta);   // ||v|| e^beta (0 exactly when v = 0)
+    }
+  }
   float kap[NT], part[NT], scale[NT];
   int aseg[NT], arow[NT];
 #pragma unroll
@@ -214,6 +231,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_fwd_kern
       }
       kap[t] = fmaxf(kap[t], other);
       scale[t] = 1.0f / fmaxf(1.0f, kap[t]);
+      if (old_mode) scale[t] = old_den[t] > 0.f ? 1.0f / (old_den[t] + kap[t]) : 0.f;
     }
   };
 
@@ -840,7 +858,7 @@ void mfma_free(MfmaImage* img) {
 template <int NKK>
 static int launch_mfma(const RayenPack* p, const MfmaImage* img, const float* v, int64_t B, int64_t ldv,
                        float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
-                       hipStream_t stream) {
+                       int old_mode, hipStream_t stream) {
   // persistent waves: at most `slots` waves are resident (VGPR-limited waves per SIMD x SIMDs);
   // give every wave the same number of sample groups so that no SIMD idles in a ragged last round
   constexpr int per_wave = MfmaCfg<NKK>::NT * 32;
@@ -854,11 +872,11 @@ static int launch_mfma(const RayenPack* p, const MfmaImage* img, const float* v,
   if (active != nullptr) {
     hipLaunchKernelGGL((mfma_fwd_kernel<NKK, true>), dim3((unsigned)grid), dim3(kMfmaWaves * 64), 0, stream,
                        img->W, img->items, img->n_items, img->packs, img->y0, img->identity, p->k, p->n, v, B, ldv,
-                       vec_in, y, ldy, vec_out, kappa, active, nan_flag);
+                       vec_in, y, ldy, vec_out, kappa, active, nan_flag, old_mode);
   } else {
     hipLaunchKernelGGL((mfma_fwd_kernel<NKK, false>), dim3((unsigned)grid), dim3(kMfmaWaves * 64), 0, stream,
                        img->W, img->items, img->n_items, img->packs, img->y0, img->identity, p->k, p->n, v, B, ldv,
-                       vec_in, y, ldy, vec_out, kappa, active, nan_flag);
+                       vec_in, y, ldy, vec_out, kappa, active, nan_flag, old_mode);
   }
   return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
 }
@@ -888,17 +906,18 @@ static int launch_split(const RayenPack* p, const MfmaImage* img, const float* v
 }
 
 int mfma_forward(const RayenPack* p, const MfmaImage* img, const float* v, int64_t B, int64_t ldv, float* y,
-                 int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream) {
+                 int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag, int old_mode,
+                 hipStream_t stream) {
   if (B == 0) return RAYEN_OK;
-  if (img->Wb != nullptr) {
+  if (img->Wb != nullptr && !old_mode) {
     if (img->nkk == 1) return launch_split<1>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
     if (img->nkk == 2) return launch_split<2>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
   }
   switch (img->nkk) {
-    case 1: return launch_mfma<1>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
-    case 2: return launch_mfma<2>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
-    case 3: return launch_mfma<3>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
-    case 4: return launch_mfma<4>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+    case 1: return launch_mfma<1>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream);
+    case 2: return launch_mfma<2>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream);
+    case 3: return launch_mfma<3>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream);
+    case 4: return launch_mfma<4>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream);
     default: return RAYEN_E_UNSUPPORTED;
   }
 }

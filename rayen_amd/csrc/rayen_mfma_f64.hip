@@ -45,7 +45,7 @@ __global__ __launch_bounds__(k64Waves * 64, 2) void mfma64_fwd_kernel(
     const f64x2* __restrict__ Wimg, const MItem* __restrict__ items, int n_items,
     const MPack* __restrict__ packs, const double* __restrict__ y0, int identity, int k, int n, const double* __restrict__ v, int64_t B,
     int64_t ldv, double* __restrict__ y, int64_t ldy, double* __restrict__ kappa_out,
-    int32_t* __restrict__ active_out, int32_t* __restrict__ nan_flag) {
+    int32_t* __restrict__ active_out, int32_t* __restrict__ nan_flag, int old_mode) {
   constexpr int NS = NKK * 8;   // K-steps (4 columns each) per tile
   __shared__ double aux_lds[k64Waves][2][32][16];  // [wave][column block][aux row][sample]
 
@@ -73,6 +73,20 @@ __global__ __launch_bounds__(k64Waves * 64, 2) void mfma64_fwd_kernel(
       for (int st = 0; st < NS; ++st) vb[c][st] = (live[c] && 4 * st + q < n) ? row[4 * st + q] : 0.0;
     }
 
+    // RAYEN_old head (rayen/constraint_module.py:460-466): y = y0 + N v / (||v|| e^beta + kappa(v))
+    double old_den[2] = {0.0, 0.0};
+    if (old_mode) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        double nrm2 = 0.0;
+#pragma unroll
+        for (int st = 0; st < NS; ++st) nrm2 = fma(vb[c][st], vb[c][st], nrm2);
+        nrm2 += xq16(nrm2);
+        nrm2 += xq32(nrm2);
+        const double beta = live[c] ? v[(s_base + 16 * c + j) * ldv + n] : 0.0;
+        old_den[c] = sqrt(nrm2) * exp(beta);
+      }
+    }
     double kap[2], part[2], scale[2];
     int aseg[2], arow[2];
 #pragma unroll
@@ -107,6 +121,7 @@ __global__ __launch_bounds__(k64Waves * 64, 2) void mfma64_fwd_kernel(
           if (ok > kap[c] || (ok == kap[c] && owho < who)) { kap[c] = ok; who = owho; aseg[c] = oseg; arow[c] = orow; }
         }
         scale[c] = 1.0 / fmax(1.0, kap[c]);
+        if (old_mode) scale[c] = old_den[c] > 0.0 ? 1.0 / (old_den[c] + kap[c]) : 0.0;
       }
     };
 
@@ -371,7 +386,7 @@ int mfma64_build(const RayenPack* p, Mfma64Image** out, int64_t* bytes) {
 template <int NKK>
 static int launch64(const RayenPack* p, const Mfma64Image* img, const double* v, int64_t B, int64_t ldv,
                     double* y, int64_t ldy, double* kappa, int32_t* active, int32_t* nan_flag,
-                    hipStream_t stream) {
+                    int old_mode, hipStream_t stream) {
   // persistent, balanced: 2 waves per SIMD, every wave the same number of 32-sample groups
   const int64_t n_groups = (B + 31) / 32;
   const int64_t slots = (int64_t)img->n_simd * 2;
@@ -381,21 +396,21 @@ static int launch64(const RayenPack* p, const Mfma64Image* img, const double* v,
   if (active != nullptr) {
     hipLaunchKernelGGL((mfma64_fwd_kernel<NKK, true>), dim3((unsigned)grid), dim3(k64Waves * 64), 0, stream,
                        img->W, img->items, img->n_items, img->packs, img->y0, img->identity, p->k, p->n, v, B, ldv, y, ldy,
-                       kappa, active, nan_flag);
+                       kappa, active, nan_flag, old_mode);
   } else {
     hipLaunchKernelGGL((mfma64_fwd_kernel<NKK, false>), dim3((unsigned)grid), dim3(k64Waves * 64), 0, stream,
                        img->W, img->items, img->n_items, img->packs, img->y0, img->identity, p->k, p->n, v, B, ldv, y, ldy,
-                       kappa, active, nan_flag);
+                       kappa, active, nan_flag, old_mode);
   }
   return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
 }
 
 int mfma64_forward(const RayenPack* p, const Mfma64Image* img, const double* v, int64_t B, int64_t ldv,
                    double* y, int64_t ldy, double* kappa, int32_t* active, int32_t* nan_flag,
-                   hipStream_t stream) {
+                   int old_mode, hipStream_t stream) {
   if (B == 0) return RAYEN_OK;
-  if (img->nkk == 1) return launch64<1>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
-  if (img->nkk == 2) return launch64<2>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+  if (img->nkk == 1) return launch64<1>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream);
+  if (img->nkk == 2) return launch64<2>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream);
   return RAYEN_E_UNSUPPORTED;
 }
 

@@ -59,11 +59,19 @@ def _stream():
 _FWD = {(torch.float32, False): "rayen_ray_project_f32", (torch.float64, False): "rayen_ray_project_f64",
         (torch.float32, True): "rayen_ray_project_generic_f32",
         (torch.float64, True): "rayen_ray_project_generic_f64"}
+_FWD_OLD = {torch.float32: "rayen_ray_project_old_f32", torch.float64: "rayen_ray_project_old_f64"}
+_BWD = {(torch.float32, False): "rayen_ray_project_bwd_f32", (torch.float64, False): "rayen_ray_project_bwd_f64",
+        (torch.float32, True): "rayen_ray_project_old_bwd_f32",
+        (torch.float64, True): "rayen_ray_project_old_bwd_f64"}
 
 
-def project_raw(v, pack, want_y=True, force_generic=False, want_active=True):
-    """Direct call of the C ABI on an existing ``DevicePack``; returns (y|None, kappa, active|None)."""
+def project_raw(v, pack, want_y=True, force_generic=False, want_active=True, old_head=False):
+    """Direct call of the C ABI on an existing ``DevicePack``; returns (y|None, kappa, active|None).
+
+    ``old_head``: the ``RAYEN_old`` step rule; ``v`` then carries ``beta`` in column ``n``."""
     _check_input(v, pack)
+    if old_head and v.shape[1] < pack.consts.n + 1:
+        raise RuntimeError(f"rayen_amd: RAYEN_old needs {pack.consts.n + 1} input columns, got {v.shape[1]}")
     if v.stride(1) != 1:
         v = v.contiguous()
     B = v.shape[0]
@@ -71,7 +79,8 @@ def project_raw(v, pack, want_y=True, force_generic=False, want_active=True):
     y = torch.empty((B, k), dtype=v.dtype, device=v.device) if want_y else None
     kappa = torch.empty((B,), dtype=v.dtype, device=v.device)
     active = torch.empty((B, 2), dtype=torch.int32, device=v.device) if want_active else None
-    fn = getattr(_lib.load(), _FWD[(v.dtype, bool(force_generic))])
+    name = _FWD_OLD[v.dtype] if old_head else _FWD[(v.dtype, bool(force_generic))]
+    fn = getattr(_lib.load(), name)
     with torch.cuda.device(v.device):
         code = fn(pack.handle, _ptr(v), B, v.stride(0) if B else pack.consts.n, _ptr(y), k,
                   _ptr(kappa), _ptr(active), _ptr(pack.nan_flag), _stream())
@@ -80,17 +89,18 @@ def project_raw(v, pack, want_y=True, force_generic=False, want_active=True):
 
 
 @torch.library.custom_op("rayen_amd::ray_project", mutates_args=())
-def ray_project(v: torch.Tensor, pack_id: int, need_active: bool) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+def ray_project(v: torch.Tensor, pack_id: int, need_active: bool, old_head: bool = False) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """``need_active``: also record which constraint set kappa (only the backward reads it; without
-    it the kernels skip the arg-max bookkeeping and ``active`` comes back empty)."""
-    y, kappa, active = project_raw(v, _pack(pack_id), want_active=need_active)
+    it the kernels skip the arg-max bookkeeping and ``active`` comes back empty).
+    ``old_head``: the ``RAYEN_old`` step rule (``v[:, n]`` is ``beta``)."""
+    y, kappa, active = project_raw(v, _pack(pack_id), want_active=need_active, old_head=old_head)
     if active is None:
         active = torch.empty((0, 2), dtype=torch.int32, device=v.device)
     return y, kappa, active
 
 
 @ray_project.register_fake
-def _(v, pack_id, need_active):
+def _(v, pack_id, need_active, old_head=False):
     pack = _pack(pack_id)
     B = v.shape[0]
     return (v.new_empty((B, pack.consts.k)), v.new_empty((B,)),
@@ -99,7 +109,7 @@ def _(v, pack_id, need_active):
 
 @torch.library.custom_op("rayen_amd::ray_project_bwd", mutates_args=())
 def ray_project_bwd(v: torch.Tensor, kappa: torch.Tensor, active: torch.Tensor,
-                    grad_y: torch.Tensor, pack_id: int) -> torch.Tensor:
+                    grad_y: torch.Tensor, pack_id: int, old_head: bool = False) -> torch.Tensor:
     pack = _pack(pack_id)
     _check_input(v, pack)
     if v.stride(1) != 1:
@@ -107,7 +117,7 @@ def ray_project_bwd(v: torch.Tensor, kappa: torch.Tensor, active: torch.Tensor,
     grad_y = grad_y.contiguous()
     B = v.shape[0]
     grad_v = torch.zeros_like(v)
-    name = "rayen_ray_project_bwd_f32" if v.dtype == torch.float32 else "rayen_ray_project_bwd_f64"
+    name = _BWD[(v.dtype, bool(old_head))]
     with torch.cuda.device(v.device):
         code = getattr(_lib.load(), name)(pack.handle, _ptr(v), B, v.stride(0) if B else pack.consts.n,
                                           _ptr(kappa), _ptr(active), _ptr(grad_y), grad_y.shape[1],
@@ -118,12 +128,13 @@ def ray_project_bwd(v: torch.Tensor, kappa: torch.Tensor, active: torch.Tensor,
 
 
 @ray_project_bwd.register_fake
-def _(v, kappa, active, grad_y, pack_id):
+def _(v, kappa, active, grad_y, pack_id, old_head=False):
     return torch.empty_like(v)
 
 
 def _setup_context(ctx, inputs, output):
-    v, pack_id, need_active = inputs
+    v, pack_id, need_active, old_head = inputs
+    ctx.old_head = old_head
     if not need_active:
         raise RuntimeError("rayen_amd::ray_project was called with need_active=False on an input that "
                            "requires grad")
@@ -135,8 +146,9 @@ def _setup_context(ctx, inputs, output):
 def _backward(ctx, grad_y, grad_kappa, grad_active):
     v, kappa, active = ctx.saved_tensors
     if grad_y is None:
-        return torch.zeros_like(v), None, None
-    return torch.ops.rayen_amd.ray_project_bwd(v, kappa, active, grad_y, ctx.pack_id), None, None
+        return torch.zeros_like(v), None, None, None
+    return (torch.ops.rayen_amd.ray_project_bwd(v, kappa, active, grad_y, ctx.pack_id, ctx.old_head),
+            None, None, None)
 
 
 ray_project.register_autograd(_backward, setup_context=_setup_context)

@@ -164,6 +164,15 @@ def _run_reference(cs, x32):
             for name in ("D", "all_phi", "all_delta", "L"):
                 if hasattr(layer, name):
                     out[f"buf_{name}{tag}"] = getattr(layer, name).numpy()
+            # the RAYEN_old head on the same directions plus a step column beta (CM:460-466)
+            old = ref_module.ConstraintModule(cs, method="RAYEN_old", create_map=False)
+            old.eval()
+            gen = torch.Generator().manual_seed(77)
+            beta = torch.empty(x32.shape[0], 1, 1, dtype=torch.float32).uniform_(-2.0, 2.0, generator=gen)
+            with torch.no_grad():
+                y_old = old(torch.cat((x, beta.to(dtype)), dim=1))
+            out["beta"] = beta.numpy()
+            out["y_old" + tag] = y_old.numpy()[:, :, 0]
         finally:
             torch.set_default_dtype(torch.float32)
     return out

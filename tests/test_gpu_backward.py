@@ -88,3 +88,33 @@ def test_training_step_through_a_model():
     assert losses[-1] < losses[0]
     for p in model.parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all()
+
+
+@pytest.mark.parametrize("name", ["c2", "c3", "c4", "mixed"])
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-6), (torch.float32, 5e-3)])
+def test_backward_rayen_old_head(name, dtype, tol):
+    """Gradients w.r.t. the direction AND the step column beta of method='RAYEN_old'."""
+    raw = _cases()[name]
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        cs = workloads.build_constraints(raw)
+        layer = ConstraintModule(cs, method="RAYEN_old", create_map=False).cuda()
+    finally:
+        torch.set_default_dtype(prev)
+    B = 400
+    gen = torch.Generator().manual_seed(5)
+    x = torch.empty(B, cs.n + 1, 1).uniform_(-1, 1, generator=gen).to(dtype)
+    G = torch.empty(B, cs.k).uniform_(-1, 1, generator=gen).to(dtype)
+    xg = x.cuda().requires_grad_(True)
+    (layer(xg)[:, :, 0] * G.cuda()).sum().backward()
+    got = xg.grad[:, :, 0].cpu().double().numpy()
+
+    buf = oracle.precompute(csd_from_cs(cs), torch.float64)
+    xr = x.double().clone().requires_grad_(True)
+    (oracle.forward(buf, xr, method="RAYEN_old")[:, :, 0] * G.double()).sum().backward()
+    want = xr.grad[:, :, 0].numpy()
+    assert np.all(np.isfinite(got))
+    err = np.max(np.abs(got - want), axis=1) / np.maximum(np.max(np.abs(want), axis=1), 1e-12)
+    assert np.mean(err <= tol) >= (0.999 if dtype == torch.float64 else 0.99), np.sort(err)[-5:]
+    assert np.median(err) <= tol / 10

@@ -375,3 +375,23 @@ def test_config5_full_two_million_batch():
     from rayen_amd.dist import shard_bounds
     lo, hi = shard_bounds(B, 8, 3)                         # rank 3's shard of the 8-GPU run
     assert torch.equal(layer(x[lo:hi]), y[lo:hi])
+
+
+@pytest.mark.parametrize("name", golden_names())
+@pytest.mark.parametrize("tag,dtype,tol", [("32", torch.float32, FP32_TOL), ("64", torch.float64, FP64_TOL)])
+def test_golden_rayen_old_head(name, tag, dtype, tol):
+    """method='RAYEN_old' (constraint_module.py:460-466) against the reference's own outputs."""
+    raw, csd, z = load_golden(name)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        cs = workloads.build_constraints(raw)
+        layer = ConstraintModule(cs, method="RAYEN_old", create_map=False).cuda()
+    finally:
+        torch.set_default_dtype(prev)
+    assert layer.getDimAfterMap() == cs.n + 1
+    x = torch.cat((_to_my_basis(cs, csd, z["x"], dtype), torch.tensor(z["beta"]).to(dtype)), dim=1)
+    y = layer(x.cuda()).cpu().numpy()[:, :, 0]
+    assert np.max(rel_err_rows(y, z["y_old" + tag])) <= tol
+    assert oracle.max_violation(raw, y) <= max(VIOLATION_TOL if tag == "32" else 1e-11,
+                                               3 * oracle.max_violation(raw, z["y_old" + tag]))

@@ -51,3 +51,13 @@ def test_interior_rows_are_unclipped():
     assert np.allclose(z["y64"][500], y0)
     step = z["x"][501, :, 0]
     assert np.allclose(z["y64"][501], y0 + csd["NA_E"] @ step, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", golden_names())
+@pytest.mark.parametrize("tag,dtype,tol", [("64", torch.float64, 1e-12), ("32", torch.float32, 2e-6)])
+def test_oracle_rayen_old_matches_reference(name, tag, dtype, tol):
+    raw, csd, z = load_golden(name)
+    buf = oracle.precompute(csd, dtype=dtype)
+    x = torch.cat((torch.tensor(z["x"]), torch.tensor(z["beta"])), dim=1).to(dtype)
+    y = oracle.forward(buf, x, method="RAYEN_old").numpy()[:, :, 0]
+    assert np.max(rel_err_rows(y, z["y_old" + tag])) <= tol

@@ -114,6 +114,7 @@ def test_unsupported_methods_and_cpu_input_fail_loudly():
     cs = workloads.build_constraints(workloads.cube())
     with pytest.raises(NotImplementedError):
         ConstraintModule(cs, method="DC3", create_map=False)
+    assert ConstraintModule(cs, method="RAYEN_old", create_map=False).getDimAfterMap() == cs.n + 1
     with pytest.raises(RuntimeError):
         ConstraintModule(cs, create_map=True)              # input_dim missing (utils.verify)
     layer = ConstraintModule(cs, create_map=False)
