@@ -39,8 +39,8 @@ PEAK_HBM_GBS = 8000.0      # HBM3E spec (≈6.3 TB/s achievable)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c3", choices=["c1", "c2", "c3", "c4", "c5"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0 = the BASELINE.json size)")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp64"])
@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed even for one rank (exercises the multi-GPU code path)")
+    ap.add_argument("--mapper", type=int, default=0, metavar="D",
+                    help="put the module's nn.Linear(D, n) mapper in front (create_map=True); 0 = identity mapper")
+    ap.add_argument("--no-fuse", action="store_true", help="with --mapper: run the mapper as its own GEMM")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -116,14 +119,19 @@ def main():
     torch.set_default_dtype(dtype)
     raw = workloads.make_raw(args.config, seed=0)
     cs = workloads.build_constraints(raw)
-    layer = ConstraintModule(cs, method="RAYEN", create_map=False).to(device)
+    if args.mapper:
+        torch.manual_seed(0)
+        layer = ConstraintModule(cs, input_dim=args.mapper, method="RAYEN", create_map=True).to(device)
+        layer.fuse_mapper = not args.no_fuse
+    else:
+        layer = ConstraintModule(cs, method="RAYEN", create_map=False).to(device)
     layer.check_nan = False                      # no host sync inside the timed region
     B = args.batch or workloads.CONFIGS[args.config][2]
     if args.config == "c5" and not args.batch:
         B = B // 8                               # 2M over 8 GPUs -> 262144 per GPU
     rng = workloads.CONFIGS[args.config][3]
     gen = torch.Generator(device=device).manual_seed(1000 + rank)
-    x = torch.empty(B, cs.n, 1, device=device, dtype=dtype).uniform_(-rng, rng, generator=gen)
+    x = torch.empty(B, args.mapper or cs.n, 1, device=device, dtype=dtype).uniform_(-rng, rng, generator=gen)
     gathered = torch.empty(world * B, cs.k, 1, device=device, dtype=dtype) if (args.gather and use_dist) else None
 
     def step():
@@ -164,6 +172,9 @@ def main():
 
     if rank == 0:
         bytes_pp, flops_pp = workloads.algorithmic_work(cs)
+        if args.mapper:
+            bytes_pp += 4 * (args.mapper - cs.n)
+            flops_pp += 2 * args.mapper * cs.n
         if dtype == torch.float64:
             bytes_pp *= 2
         kern_s = dev_ms * 1e-3
@@ -214,7 +225,9 @@ def main():
             "violations_gt_1e-6": int(max_violation > 1e-6),
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if args.mapper:
+            out["config"]["mapper"] = f"nn.Linear({args.mapper}, {cs.n}) " + ("as its own GEMM" if args.no_fuse else "fused into the projection kernel")
+        if world == 1 and not args.no_cpu_baseline and not args.mapper:
             out["cpu_baseline"] = cpu_baseline(raw, cs, B, dtype, args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))

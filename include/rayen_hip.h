@@ -167,6 +167,20 @@ int rayen_ray_project_old_bwd_f64(const RayenPack* pack, const double* v, int64_
                                   const double* grad_y, int64_t ldg,
                                   double* grad_v, int64_t ldgv, void* stream);
 
+/* The module's mapper fused in front of the projection (rayen/constraint_module.py:259-263 creates
+ * mapper = nn.Linear(input_dim, n); :525 applies it before forwardForRAYEN):
+ *     v = Wm x + bias,   y = y0 + NA_E v / max(1, kappa(v))
+ * in ONE launch; v is kept in registers and reaches memory only when v_out != NULL (the backward
+ * needs it).  x [B, ldx] (first in_dim columns read), Wm [n, ldw] row-major (= Linear.weight, rows
+ * 16-byte aligned), bias [n] or NULL.  rayen_mapper_fusable() says whether this pack and input width
+ * are served (fp32 MFMA path, in_dim a multiple of 4 and <= 64); otherwise the call returns
+ * RAYEN_E_UNSUPPORTED and the caller runs its GEMM followed by rayen_ray_project_f32. */
+int rayen_mapper_fusable(const RayenPack* pack, int32_t in_dim);
+int rayen_ray_project_mapped_f32(const RayenPack* pack, const float* x, int64_t B, int64_t ldx,
+                                 int32_t in_dim, const float* Wm, int64_t ldw, const float* bias,
+                                 float* v_out, int64_t ldvo, float* y, int64_t ldy, float* kappa,
+                                 int32_t* active, int32_t* nan_flag, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

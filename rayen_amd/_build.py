@@ -12,7 +12,7 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 INCLUDE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
-SOURCES = ["rayen_abi.hip", "rayen_generic.hip", "rayen_mfma.hip", "rayen_mfma_f64.hip"]
+SOURCES = ["rayen_abi.hip", "rayen_generic.hip", "rayen_mfma.hip", "rayen_mfma_mapped.hip", "rayen_mfma_f64.hip"]
 LIBRARY = os.environ.get("RAYEN_HIP_LIBRARY") or os.path.join(CSRC, "librayen_hip.so")
 
 
@@ -33,18 +33,34 @@ def is_stale():
 
 
 def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950 into ``csrc/librayen_hip.so``; returns its path."""
+    """Compile every HIP source for gfx950 into ``csrc/librayen_hip.so``; returns its path.
+
+    Translation units are compiled side by side (objects under ``csrc/_obj``, git-ignored), then linked."""
     if not force and not is_stale():
         return LIBRARY
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I", INCLUDE, "-I", CSRC]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", LIBRARY + ".tmp"]
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(CSRC, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC]
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc_path(), *flags, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        proc = subprocess.run(cmd, capture_output=True, text=True)
+        if proc.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n" + proc.stdout + proc.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+        objects = list(pool.map(compile_one, SOURCES))
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", *objects, "-o", LIBRARY + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + proc.stdout + proc.stderr)
+        raise RuntimeError("hipcc link failed:\n" + proc.stdout + proc.stderr)
     os.replace(LIBRARY + ".tmp", LIBRARY)
     return LIBRARY
 

@@ -21,6 +21,7 @@ EXPORTS = (
     "rayen_ray_project_generic_f32", "rayen_ray_project_generic_f64", "rayen_ray_project_bwd_f32",
     "rayen_ray_project_bwd_f64", "rayen_ray_project_old_f32", "rayen_ray_project_old_f64",
     "rayen_ray_project_old_bwd_f32", "rayen_ray_project_old_bwd_f64",
+    "rayen_mapper_fusable", "rayen_ray_project_mapped_f32",
 )
 
 
@@ -91,6 +92,11 @@ def load():
                  "rayen_ray_project_old_bwd_f32", "rayen_ray_project_old_bwd_f64"):
         getattr(lib, name).restype = ctypes.c_int
         getattr(lib, name).argtypes = bwd
+    lib.rayen_mapper_fusable.restype = ctypes.c_int
+    lib.rayen_mapper_fusable.argtypes = [p, ctypes.c_int32]
+    lib.rayen_ray_project_mapped_f32.restype = ctypes.c_int
+    lib.rayen_ray_project_mapped_f32.argtypes = [p, p, i64, i64, ctypes.c_int32, p, i64, p, p, i64, p, i64,
+                                                 p, i32p, i32p, p]
     if lib.rayen_abi_version() != ABI_VERSION:
         raise RuntimeError(f"librayen_hip.so ABI {lib.rayen_abi_version()} != binding ABI {ABI_VERSION}")
     _lib = lib

@@ -117,6 +117,9 @@ class ConstraintModule(torch.nn.Module):
 
         # fused NaN check: the kernel raises a device flag instead of re-reading y (:531)
         self.check_nan = True
+        # evaluate the mapper inside the projection kernel when the shapes allow it (one launch, v
+        # never written to memory in inference); False = always run nn.Linear as its own GEMM
+        self.fuse_mapper = True
         self._device_packs = {}
         self._consts = None
 
@@ -210,12 +213,28 @@ class ConstraintModule(torch.nn.Module):
     def getzFromy(self, y):
         return self.NA_E.T @ (y - self.yp)
 
+    def _forward_fused_mapper(self, x2):
+        """mapper + projection as ONE kernel launch (``rayen_amd::ray_project_mapped``) or ``None`` when
+        the fused kernel does not serve this layer/input (then the two-op path below runs)."""
+        if (self.method != 'RAYEN' or not getattr(self, "fuse_mapper", True)
+                or not isinstance(self.mapper, nn.Linear) or not x2.is_cuda or x2.dtype != torch.float32):
+            return None
+        dp, pack_id = self.device_pack(x2.device)
+        weight, bias = self.mapper.weight, self.mapper.bias
+        if not ops.mapper_fusable(x2, weight, bias, dp):
+            return None
+        need_grad = torch.is_grad_enabled() and (x2.requires_grad or weight.requires_grad
+                                                 or (bias is not None and bias.requires_grad))
+        y, _, _, _ = torch.ops.rayen_amd.ray_project_mapped(x2, weight, bias, pack_id, need_grad)
+        return y.unsqueeze(2)
+
     def forward(self, x):
         # x: [nsib, numel_input_mapper, 1]; after the mapper q is [nsib, numel_output_mapper, 1]
-        q = self.mapper(torch.flatten(x, 1))  # == x.view(B, -1), and defined for B = 0
-        q = torch.unsqueeze(q, dim=2)
-
-        y = self.forwardForMethod(q)
+        x2 = torch.flatten(x, 1)  # == x.view(B, -1), and defined for B = 0
+        y = self._forward_fused_mapper(x2)
+        if y is None:
+            q = torch.unsqueeze(self.mapper(x2), dim=2)
+            y = self.forwardForMethod(q)
 
         if (__debug__ and self.check_nan and self.method in ('RAYEN', 'RAYEN_old')
                 and not torch.cuda.is_current_stream_capturing()):  # the flag read is a host sync

@@ -230,6 +230,27 @@ int rayen_ray_project_old_f32(const RayenPack* p, const float* v, int64_t B, int
   return project_f32(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, 1);
 }
 
+int rayen_mapper_fusable(const RayenPack* p, int32_t in_dim) {
+  if (p == nullptr || check_device(p) != RAYEN_OK || ensure_mfma(p) != RAYEN_OK) return 0;
+  return (p->m32 != nullptr && mfma_mapper_fusable(p, p->m32, in_dim)) ? 1 : 0;
+}
+
+int rayen_ray_project_mapped_f32(const RayenPack* p, const float* x, int64_t B, int64_t ldx, int32_t in_dim,
+                                 const float* Wm, int64_t ldw, const float* bias, float* v_out,
+                                 int64_t ldvo, float* y, int64_t ldy, float* kappa, int32_t* active,
+                                 int32_t* nan_flag, void* stream) {
+  if (p == nullptr || B < 0 || in_dim <= 0 || ldx < in_dim || ldw < in_dim || Wm == nullptr || y == nullptr ||
+      ldy < p->k || (B > 0 && x == nullptr) || (v_out != nullptr && ldvo < p->n))
+    return RAYEN_E_BAD_ARG;
+  int rc = check_device(p);
+  if (rc) return rc;
+  rc = ensure_mfma(p);
+  if (rc) return rc;
+  if (p->m32 == nullptr) return RAYEN_E_UNSUPPORTED;
+  return mfma_forward_mapped(p, p->m32, x, B, ldx, in_dim, Wm, ldw, bias, v_out, ldvo, y, ldy, kappa,
+                             active, nan_flag, static_cast<hipStream_t>(stream));
+}
+
 int rayen_ray_project_generic_f64(const RayenPack* p, const double* v, int64_t B, int64_t ldv, double* y,
                                   int64_t ldy, double* kappa, int32_t* active, int32_t* nan_flag,
                                   void* stream) {

@@ -94,6 +94,13 @@ int mfma_forward(const RayenPack* p, const MfmaImage* img, const float* v, int64
                  float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
                  int old_mode, hipStream_t stream);
 
+// fp32 MFMA path with the mapper v = Wm x + b fused in front (rayen_mfma_mapped.hip)
+bool mfma_mapper_fusable(const RayenPack* p, const MfmaImage* img, int in_dim);
+int mfma_forward_mapped(const RayenPack* p, const MfmaImage* img, const float* x, int64_t B, int64_t ldx,
+                        int in_dim, const float* w, int64_t ldw, const float* bias, float* v_out,
+                        int64_t ldvo, float* y, int64_t ldy, float* kappa, int32_t* active,
+                        int32_t* nan_flag, hipStream_t stream);
+
 // fp64 MFMA path (rayen_mfma_f64.hip)
 bool mfma64_eligible(const RayenPack* p);
 int mfma64_build(const RayenPack* p, Mfma64Image** out, int64_t* bytes);

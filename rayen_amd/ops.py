@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes
 import weakref
+from typing import Optional
 
 import torch
 
@@ -152,3 +153,81 @@ def _backward(ctx, grad_y, grad_kappa, grad_active):
 
 
 ray_project.register_autograd(_backward, setup_context=_setup_context)
+
+
+# ------------------------------------------------------------------------------------------------
+# mapper + projection in one launch (rayen/constraint_module.py:525 followed by :468-474)
+# ------------------------------------------------------------------------------------------------
+
+def mapper_fusable(x, weight, bias, pack):
+    """Can ``ray_project_mapped`` serve this call?  (fp32, contiguous rows, the pack on the MFMA path and
+    an input width the fused kernel holds in registers.)"""
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 2
+            and weight.dim() == 2 and weight.shape[0] == pack.consts.n and x.shape[1] == weight.shape[1]
+            and weight.is_contiguous() and weight.data_ptr() % 16 == 0
+            and (bias is None or (bias.dtype == torch.float32 and bias.is_contiguous()))
+            and pack.mapper_fusable(weight.shape[1]))
+
+
+@torch.library.custom_op("rayen_amd::ray_project_mapped", mutates_args=())
+def ray_project_mapped(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], pack_id: int,
+                       need_grad: bool) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """``(y, kappa, active, v)`` with ``v = x weight' + bias`` evaluated inside the projection kernel.
+
+    ``need_grad``: also write ``v`` and the active-constraint record (the backward's inputs); without it
+    ``v`` never reaches memory and both come back empty."""
+    pack = _pack(pack_id)
+    if not mapper_fusable(x, weight, bias, pack):
+        raise RuntimeError("rayen_amd::ray_project_mapped: unsupported mapper (check ops.mapper_fusable first)")
+    if x.device.index != pack.device_index:
+        raise RuntimeError("rayen_amd: input and constant pack live on different devices")
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    B, in_dim = x.shape
+    k, n = pack.consts.k, pack.consts.n
+    y = torch.empty((B, k), dtype=x.dtype, device=x.device)
+    kappa = torch.empty((B,), dtype=x.dtype, device=x.device)
+    active = torch.empty((B if need_grad else 0, 2), dtype=torch.int32, device=x.device)
+    v = torch.empty((B if need_grad else 0, n), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        code = _lib.load().rayen_ray_project_mapped_f32(
+            pack.handle, _ptr(x), B, x.stride(0) if B else in_dim, in_dim, _ptr(weight), weight.stride(0),
+            _ptr(bias), _ptr(v) if need_grad else None, n, _ptr(y), k, _ptr(kappa),
+            _ptr(active) if need_grad else None, _ptr(pack.nan_flag), _stream())
+    _lib.check(code, "rayen_ray_project_mapped")
+    return y, kappa, active, v
+
+
+@ray_project_mapped.register_fake
+def _(x, weight, bias, pack_id, need_grad):
+    pack = _pack(pack_id)
+    B = x.shape[0]
+    rows = B if need_grad else 0
+    return (x.new_empty((B, pack.consts.k)), x.new_empty((B,)),
+            x.new_empty((rows, 2), dtype=torch.int32), x.new_empty((rows, pack.consts.n)))
+
+
+def _mapped_setup_context(ctx, inputs, output):
+    x, weight, bias, pack_id, need_grad = inputs
+    if not need_grad:
+        raise RuntimeError("rayen_amd::ray_project_mapped was called with need_grad=False on inputs that "
+                           "require grad")
+    _, kappa, active, v = output
+    ctx.pack_id = pack_id
+    ctx.has_bias = bias is not None
+    ctx.save_for_backward(x, weight, v, kappa, active)
+
+
+def _mapped_backward(ctx, grad_y, grad_kappa, grad_active, grad_v_out):
+    x, weight, v, kappa, active = ctx.saved_tensors
+    if grad_y is None:
+        return None, None, None, None, None
+    # d y / d v on the HIP backward kernel; the three mapper products are plain GEMMs (rocBLAS via torch)
+    grad_v = torch.ops.rayen_amd.ray_project_bwd(v, kappa, active, grad_y, ctx.pack_id, False)
+    grad_x = grad_v @ weight if ctx.needs_input_grad[0] else None
+    grad_w = grad_v.t() @ x if ctx.needs_input_grad[1] else None
+    grad_b = grad_v.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+    return grad_x, grad_w, grad_b, None, None
+
+
+ray_project_mapped.register_autograd(_mapped_backward, setup_context=_mapped_setup_context)

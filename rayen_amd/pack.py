@@ -187,6 +187,15 @@ class DevicePack:
         _lib.check(_lib.load().rayen_pack_info(self.handle, ctypes.byref(out)), "rayen_pack_info")
         return out
 
+    def mapper_fusable(self, in_dim):
+        """True when ``rayen_ray_project_mapped_f32`` serves this pack with an ``in_dim``-wide mapper."""
+        import torch
+        cache = self.__dict__.setdefault("_fusable", {})
+        if in_dim not in cache:
+            with torch.cuda.device(self.device_index):
+                cache[in_dim] = bool(_lib.load().rayen_mapper_fusable(self.handle, int(in_dim)))
+        return cache[in_dim]
+
     def close(self):
         if getattr(self, "handle", None):
             _lib.load().rayen_pack_destroy(self.handle)

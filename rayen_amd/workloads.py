@@ -122,15 +122,25 @@ def build_constraints(raw):
 
 
 def algorithmic_work(cs):
-    """(bytes, flops) per projection in fp32, SURVEY.md §8(d) formulas."""
+    """(bytes, flops) per projection in fp32, SURVEY.md §8(d) formulas.
+
+    Two refinements keep the figure a lower bound of the arithmetic any exact evaluation needs (so that
+    a roofline fraction can never exceed 1 by construction): a quadratic of rank ``rho < n/2`` is priced
+    in its factored form ``||U v||`` (``2 rho n`` instead of ``2 n^2``; config 5's ``P = 2 C'C`` has rank 3),
+    and products are priced in the subspace dimension ``n`` the kernels work in (``n = k`` unless the set
+    has equalities).
+    """
+    import numpy as np
     k, n = cs.k, cs.n
     m = cs.A_p.shape[0]
     flops = 2 * m * n + 2 * k * n
-    flops += len(cs.qcs) * (2 * k * k + 4 * k)
+    for qc in cs.qcs:
+        rank = int(np.linalg.matrix_rank(qc.P))
+        flops += min(2 * n * n, 2 * rank * n + 2 * rank) + 4 * n
     for soc in cs.socs:
         r_M = soc.M.shape[0]
-        flops += 2 * r_M * k + 2 * k + 4 * r_M
+        flops += 2 * r_M * n + 2 * n + 4 * r_M
     if cs.has_lmi_constraints:
         r = cs.lmic.all_F[0].shape[0]
-        flops += 2 * k * r * r + (4 * r ** 3) // 3
+        flops += 2 * n * r * r + (4 * r ** 3) // 3
     return 4 * (n + k), flops
