@@ -84,6 +84,20 @@ int ensure_mfma64(const RayenPack* p) {
   return RAYEN_OK;
 }
 
+int ensure_mfma_bwd(const RayenPack* p) {
+  std::lock_guard<std::mutex> lock(p->mu);
+  if (p->mb32_tried) return RAYEN_OK;
+  p->mb32_tried = true;
+  if (!mfma_bwd_eligible(p)) return RAYEN_OK;
+  int64_t bytes = 0;
+  MfmaBwdImage* img = nullptr;
+  const int rc = mfma_bwd_build(p, &img, &bytes);
+  if (rc != RAYEN_OK) return rc;
+  p->mb32 = img;
+  p->device_bytes += bytes;
+  return RAYEN_OK;
+}
+
 template <typename T>
 int project_generic(const RayenPack* p, const T* v, int64_t B, int64_t ldv, T* y, int64_t ldy, T* kappa,
                     int32_t* active, int32_t* nan_flag, void* stream, int old_mode = 0) {
@@ -101,12 +115,21 @@ int project_generic(const RayenPack* p, const T* v, int64_t B, int64_t ldv, T* y
 template <typename T>
 int project_bwd(const RayenPack* p, const T* v, int64_t B, int64_t ldv, const T* kappa,
                 const int32_t* active, const T* grad_y, int64_t ldg, T* grad_v, int64_t ldgv, void* stream,
-                int old_mode = 0) {
+                int old_mode = 0, bool force_generic = false) {
   if (p == nullptr || B < 0 || ldv < p->n + old_mode || ldg < p->k || ldgv < p->n + old_mode)
     return RAYEN_E_BAD_ARG;
   if (B > 0 && (!v || !kappa || !active || !grad_y || !grad_v)) return RAYEN_E_BAD_ARG;
   int rc = check_device(p);
   if (rc) return rc;
+  if constexpr (sizeof(T) == 4) {
+    if (!force_generic) {
+      rc = ensure_mfma_bwd(p);
+      if (rc) return rc;
+      if (p->mb32 != nullptr)
+        return mfma_backward(p, p->mb32, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode,
+                             static_cast<hipStream_t>(stream));
+    }
+  }
   rc = ensure_generic<T>(p);
   if (rc) return rc;
   return generic_backward<T>(p, image_of<T>(p), v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv,
@@ -175,6 +198,7 @@ void rayen_pack_destroy(RayenPack* p) {
   generic_free<double>(&p->g64);
   if (p->m32) mfma_free(p->m32);
   if (p->m64) mfma64_free(p->m64);
+  if (p->mb32) mfma_bwd_free(p->mb32);
   if (switched) (void)hipSetDevice(prev);
   delete p;
 }
@@ -286,6 +310,12 @@ int rayen_ray_project_bwd_f32(const RayenPack* p, const float* v, int64_t B, int
                               const float* kappa, const int32_t* active, const float* grad_y,
                               int64_t ldg, float* grad_v, int64_t ldgv, void* stream) {
   return project_bwd<float>(p, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, stream);
+}
+
+int rayen_ray_project_bwd_generic_f32(const RayenPack* p, const float* v, int64_t B, int64_t ldv,
+                                      const float* kappa, const int32_t* active, const float* grad_y,
+                                      int64_t ldg, float* grad_v, int64_t ldgv, void* stream) {
+  return project_bwd<float>(p, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, stream, 0, true);
 }
 
 int rayen_ray_project_bwd_f64(const RayenPack* p, const double* v, int64_t B, int64_t ldv,

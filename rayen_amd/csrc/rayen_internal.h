@@ -46,6 +46,7 @@ struct GenericImage {
 
 struct MfmaImage;    // rayen_mfma.hip
 struct Mfma64Image;  // rayen_mfma_f64.hip
+struct MfmaBwdImage; // rayen_mfma_bwd.hip
 
 }  // namespace rayen
 
@@ -65,6 +66,8 @@ struct RayenPack {
   mutable bool m32_tried = false;
   mutable rayen::Mfma64Image* m64 = nullptr;
   mutable bool m64_tried = false;
+  mutable rayen::MfmaBwdImage* mb32 = nullptr;
+  mutable bool mb32_tried = false;
   mutable int64_t device_bytes = 0;
 };
 
@@ -100,6 +103,14 @@ int mfma_forward_mapped(const RayenPack* p, const MfmaImage* img, const float* x
                         int in_dim, const float* w, int64_t ldw, const float* bias, float* v_out,
                         int64_t ldvo, float* y, int64_t ldy, float* kappa, int32_t* active,
                         int32_t* nan_flag, hipStream_t stream);
+
+// fp32 MFMA backward (rayen_mfma_bwd.hip)
+bool mfma_bwd_eligible(const RayenPack* p);
+int mfma_bwd_build(const RayenPack* p, MfmaBwdImage** out, int64_t* bytes);
+void mfma_bwd_free(MfmaBwdImage* img);
+int mfma_backward(const RayenPack* p, const MfmaBwdImage* img, const float* v, int64_t B, int64_t ldv,
+                  const float* kappa, const int32_t* active, const float* grad_y, int64_t ldg, float* grad_v,
+                  int64_t ldgv, int old_mode, hipStream_t stream);
 
 // fp64 MFMA path (rayen_mfma_f64.hip)
 bool mfma64_eligible(const RayenPack* p);

@@ -1,0 +1,348 @@
+// fp32 MFMA backward of the projection (packs with NA_E = I, n <= 64, no LMI):
+//
+//   grad_v = s g - [kappa > 1] s^2 (g . v) grad kappa(v),        s = 1 / max(1, kappa)
+//
+// which is what autograd produces for rayen/constraint_module.py:351-474 (max -> arg-max, relu); the
+// RAYEN_old head (:460-466) adds the terms of its step column.  grad kappa belongs to the ONE
+// constraint that set kappa (`active`, recorded by the forward):
+//   linear row i          D_i                                              (:353)
+//   quadratic             phi + S v / sqrt(v'S v),   S = G  or  U'U        (:374)
+//   second-order cone     implicit derivative of the root of a'x^2 + b'x + c' = 0 (:383-399, 339-348):
+//                         -(2 S v + (-2 c.v - 2 tau kappa) c + 2 kappa M'beta) / (2 a' kappa + b'),  S = M'M
+// The generic backward lets every lane walk its own constraint (per-lane gathers of an n x n matrix).
+// Here S_s v is evaluated for EVERY quadratic / cone s on the matrix cores -- one dense 32-row tile walk
+// like the forward's, the same v-in-registers B operands -- and each lane keeps the rows of its own
+// segment with a select; the linear case is a gather of one row.  A wave owns 32 samples (v, g and
+// the gradient of kappa live in registers, n/2 VGPRs each).
+#include "rayen_mfma_kernel.h"
+
+#include <cstring>
+#include <vector>
+
+namespace rayen {
+
+enum : int32_t { BI_NOP = 0, BI_QUAD = 1, BI_SOC = 2 };
+
+struct BItem {
+  int32_t type;
+  int32_t flags;    // MF_FIRST | MF_LAST of the segment's row tiles
+  int32_t seg;      // caller's segment index (what `active` holds)
+  int32_t tp;       // row tile of S (rows 32 tp .. 32 tp + 31 = elements of v)
+  int32_t aux_row;  // W row of phi | c (M'beta is the next row)
+  int32_t reserved;
+  float f0, f1;     // SOC: tau, a'
+};
+
+struct MfmaBwdImage {
+  f32x4* S = nullptr;      // [n_items + 1][NQ][64] float4, fragment order, one dense n_pad x n_pad form per segment
+  BItem* items = nullptr;
+  float* Wrow = nullptr;   // [n_rows][n_pad] row-major copy of W (gathers: linear rows, phi, c, M'beta)
+  int n_items = 0;
+  int nkk = 0;
+  int n_simd = 1024;
+  int64_t bytes = 0;
+};
+
+template <int NKK>
+__global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwd_kernel(
+    const f32x4* __restrict__ Simg, const BItem* __restrict__ items, int n_items,
+    const float* __restrict__ Wrow, int n, const float* __restrict__ v, int64_t B, int64_t ldv, int vec_v,
+    const float* __restrict__ kappa, const int32_t* __restrict__ active, const float* __restrict__ gy,
+    int64_t ldg, int vec_g, float* __restrict__ gv, int64_t ldgv, int vec_o, int old_mode) {
+  constexpr int NT = 1, NQ = NKK * 4, KK = NKK * 16, NP = NKK * 32, LSTR = NKK * 32 + 4;
+  __shared__ __attribute__((aligned(16))) float line_lds[kMfmaWaves][32][LSTR];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int col = lane & 31;
+  const int hi = lane >> 5;
+  const int64_t n_groups = (B + 31) / 32;
+  const int64_t wave_id = (int64_t)blockIdx.x * kMfmaWaves + wave;
+  const int64_t wave_stride = (int64_t)gridDim.x * kMfmaWaves;
+  float (*patch)[LSTR] = line_lds[wave];
+
+  for (int64_t grp = wave_id; grp < n_groups; grp += wave_stride) {
+    const int64_t s_base = grp * 32;
+    const int64_t smp = s_base + col;
+    bool live[NT];
+    live[0] = smp < B;
+    float vr[NT][KK], tr[NT][KK];
+    load_rows<NT, NKK, LSTR, true>(vr, v, ldv, n, vec_v, s_base, B, live, patch, lane);
+    load_rows<NT, NKK, LSTR, true>(tr, gy, ldg, n, vec_g, s_base, B, live, patch, lane);
+    const float kap = live[0] ? kappa[smp] : 0.f;
+    const int aseg = live[0] ? active[2 * smp] : -1;
+    const int arow = live[0] ? active[2 * smp + 1] : 0;
+
+    float tv = 0.f;
+#pragma unroll
+    for (int i = 0; i < KK; ++i) tv = fmaf(tr[0][i], vr[0][i], tv);
+    tv += xhalf(tv);
+    // RAYEN: s = 1/max(1,kappa), kappa matters once it clips.  RAYEN_old: s = 1/(r e^beta + kappa),
+    // r = ||v||: kappa always matters, and r, beta get gradients too.
+    float r_nrm = 0.f, e_beta = 0.f;
+    if (old_mode) {
+      float nrm2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < KK; ++i) nrm2 = fmaf(vr[0][i], vr[0][i], nrm2);
+      nrm2 += xhalf(nrm2);
+      r_nrm = sqrtf(nrm2);
+      e_beta = live[0] ? __expf(v[smp * ldv + n]) : 0.f;
+    }
+    const bool clipped = old_mode ? (live[0] && aseg >= 0 && r_nrm > 0.f) : (live[0] && kap > 1.f && aseg >= 0);
+    const float sc = old_mode ? (r_nrm > 0.f ? 1.f / (r_nrm * e_beta + kap) : 0.f) : 1.f / fmaxf(1.f, kap);
+
+    float ur[KK];
+#pragma unroll
+    for (int i = 0; i < KK; ++i) ur[i] = 0.f;
+
+    if (__ballot(clipped) != 0) {  // wave-uniform: a wave of interior samples skips the walk
+      bool matched = false;
+      float part = 0.f;
+      const f32x4* wp = Simg + lane;
+      f32x4 buf_a[NQ], buf_b[NQ];
+      auto fetch_tile = [&](f32x4 (&buf)[NQ]) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) buf[q] = wp[q * 64];
+        wp += NQ * 64;
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto process = [&](const BItem item, const f32x4 (&a)[NQ]) {
+        if (item.type == BI_NOP) return;
+        f32x16 acc;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][c], vr[0][4 * q + c], acc, 0, 0, 0);
+        const bool sel = clipped && aseg == item.seg;
+        float sum = (item.flags & MF_FIRST) ? 0.f : part;
+#pragma unroll
+        for (int tp = 0; tp < NKK; ++tp)
+          if (item.tp == tp) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+              sum = fmaf(acc[g], vr[0][16 * tp + g], sum);
+              ur[16 * tp + g] = sel ? acc[g] : ur[16 * tp + g];
+            }
+          }
+        part = sum;
+        if ((item.flags & MF_LAST) && __ballot(sel) != 0) {
+          const float total = part + xhalf(part);  // v'S v
+          const float* ax = Wrow + (int64_t)item.aux_row * NP + 4 * hi;
+          float cw, c0, c1 = 0.f;
+          if (item.type == BI_QUAD) {
+            cw = total > 0.f ? 1.f / sqrtf(total) : 0.f;
+            c0 = 1.f;
+          } else {
+            float cr = 0.f, br = 0.f;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+              const f32x4 x0 = *reinterpret_cast<const f32x4*>(ax + 8 * q);
+              const f32x4 x1 = *reinterpret_cast<const f32x4*>(ax + NP + 8 * q);
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                cr = fmaf(x0[c], vr[0][4 * q + c], cr);
+                br = fmaf(x1[c], vr[0][4 * q + c], br);
+              }
+            }
+            cr += xhalf(cr);
+            br += xhalf(br);
+            const float tau = item.f0, ap = item.f1;
+            const float bp = 2.f * br - 2.f * cr * tau;
+            const float den = 2.f * ap * kap + bp;  // dF/dkappa at the root
+            const float inv = den != 0.f ? -1.f / den : 0.f;
+            cw = 2.f * inv;                          // d c'/dv = 2 M'Mv - 2 (c.v) c
+            c0 = inv * (-2.f * cr - 2.f * tau * kap);
+            c1 = inv * 2.f * kap;                    // kappa * d b'/dv = kappa (2 M'beta - 2 tau c)
+          }
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(ax + 8 * q);
+            f32x4 x1 = {0.f, 0.f, 0.f, 0.f};
+            if (item.type == BI_SOC) x1 = *reinterpret_cast<const f32x4*>(ax + NP + 8 * q);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const float u = fmaf(cw, ur[4 * q + c], fmaf(c0, x0[c], c1 * x1[c]));
+              ur[4 * q + c] = sel ? u : ur[4 * q + c];
+            }
+          }
+          matched |= sel;
+        }
+      };
+      if (n_items > 0) {
+        fetch_tile(buf_a);
+        for (int it = 0; it < n_items; it += 2) {  // n_items is even (padded with a no-op tile)
+          fetch_tile(buf_b);
+          process(items[it], buf_a);
+          fetch_tile(buf_a);
+          process(items[it + 1], buf_b);
+        }
+      }
+      // every quadratic / cone is in the item list: what is left is a linear row
+      if (clipped && !matched) {
+        const float* row = Wrow + (int64_t)arow * NP + 4 * hi;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const f32x4 x = *reinterpret_cast<const f32x4*>(row + 8 * q);
+          ur[4 * q + 0] = x[0];
+          ur[4 * q + 1] = x[1];
+          ur[4 * q + 2] = x[2];
+          ur[4 * q + 3] = x[3];
+        }
+      }
+    }
+
+    float one[NT];
+    one[0] = 1.f;
+    if (!old_mode) {
+      const float coef = clipped ? sc * sc * tv : 0.f;
+#pragma unroll
+      for (int i = 0; i < KK; ++i) tr[0][i] = fmaf(sc, tr[0][i], -coef * ur[i]);
+    } else {
+      // grad_v = s t - s^2 (t.v) (e^beta v / r + grad kappa),  grad_beta = -s^2 (t.v) r e^beta
+      const float coef = sc * sc * tv;
+      const float dir = r_nrm > 0.f ? e_beta / r_nrm : 0.f;
+#pragma unroll
+      for (int i = 0; i < KK; ++i) tr[0][i] = fmaf(sc, tr[0][i], -coef * fmaf(dir, vr[0][i], ur[i]));
+      if (live[0] && hi == 0) gv[smp * ldgv + n] = -coef * r_nrm * e_beta;
+    }
+    (void)store_rows<NT, NKK, LSTR, true>(tr, one, nullptr, gv, ldgv, n, vec_o, s_base, B, live, patch, lane);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------
+
+static bool quad_like(const RayenSegment& g) {
+  return g.type == RAYEN_SEG_QUAD_SYM || g.type == RAYEN_SEG_QUAD_FAC || g.type == RAYEN_SEG_SOC;
+}
+
+bool mfma_bwd_eligible(const RayenPack* p) {
+  if (!p->out_identity || p->n > 64 || !mfma_eligible(p)) return false;
+  int64_t tiles = 0;
+  for (const RayenSegment& g : p->segs) {
+    if (g.type == RAYEN_SEG_LMI) return false;
+    if (quad_like(g)) tiles += n_pad_of(p->n) / 32;
+  }
+  // the walk is dense (one n x n form per quadratic / cone): sets made of very many small low-rank
+  // quadratics are cheaper on the per-lane generic backward
+  return tiles <= 64;
+}
+
+int mfma_bwd_build(const RayenPack* p, MfmaBwdImage** out, int64_t* bytes) {
+  const int n = p->n, np = n_pad_of(n), nkk = np / 32;
+  TileLayout b(n);
+  std::vector<BItem> items;
+  const double* W = p->W.data();
+  for (size_t s = 0; s < p->segs.size(); ++s) {
+    const RayenSegment& g = p->segs[s];
+    if (!quad_like(g)) continue;
+    std::vector<double> S((size_t)n * n, 0.0);
+    if (g.type == RAYEN_SEG_QUAD_SYM) {
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) S[(size_t)i * n + j] = W[(size_t)(g.row0 + i) * n + j];
+    } else {  // U'U or M'M
+      for (int r = 0; r < g.nrows; ++r) {
+        const double* row = W + (size_t)(g.row0 + r) * n;
+        for (int i = 0; i < n; ++i) {
+          if (row[i] == 0.0) continue;
+          for (int j = 0; j < n; ++j) S[(size_t)i * n + j] += row[i] * row[j];
+        }
+      }
+    }
+    for (int tp = 0; tp < nkk; ++tp) {
+      std::vector<const double*> rows;
+      for (int r = 32 * tp; r < 32 * tp + 32 && r < n; ++r) rows.push_back(S.data() + (size_t)r * n);
+      b.add_tile(rows, n);
+      BItem it;
+      std::memset(&it, 0, sizeof(it));
+      it.type = g.type == RAYEN_SEG_SOC ? BI_SOC : BI_QUAD;
+      it.flags = (tp == 0 ? MF_FIRST : 0) | (tp == nkk - 1 ? MF_LAST : 0);
+      it.seg = (int32_t)s;
+      it.tp = tp;
+      it.aux_row = g.aux_row;
+      it.f0 = (float)g.f0;
+      it.f1 = (float)g.f1;
+      items.push_back(it);
+    }
+  }
+  if (items.size() % 2) {
+    BItem it;
+    std::memset(&it, 0, sizeof(it));
+    it.type = BI_NOP;
+    items.push_back(it);
+    b.add_tile({}, n);
+  }
+  b.add_tile({}, n);  // spare tile: the prefetch runs one tile past the end
+  const std::vector<float> frag = b.fragments_f32();
+  std::vector<float> wrow((size_t)(p->n_rows + 2) * np, 0.f);  // (+2: an aux pair may be read past a last row)
+  for (int r = 0; r < p->n_rows; ++r)
+    for (int j = 0; j < n; ++j) wrow[(size_t)r * np + j] = (float)W[(size_t)r * n + j];
+  const int n_real = (int)items.size();
+  if (items.empty()) {
+    BItem it;
+    std::memset(&it, 0, sizeof(it));
+    items.push_back(it);  // never read (n_items = 0), keeps the allocation non-empty
+  }
+
+  MfmaBwdImage* img = new MfmaBwdImage();
+  img->nkk = nkk;
+  img->n_items = n_real;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0)
+      img->n_simd = prop.multiProcessorCount * 4;
+  }
+  const bool ok =
+      hipMalloc(&img->S, frag.size() * sizeof(float)) == hipSuccess &&
+      hipMemcpy(img->S, frag.data(), frag.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
+      hipMalloc(&img->items, items.size() * sizeof(BItem)) == hipSuccess &&
+      hipMemcpy(img->items, items.data(), items.size() * sizeof(BItem), hipMemcpyHostToDevice) == hipSuccess &&
+      hipMalloc(&img->Wrow, wrow.size() * sizeof(float)) == hipSuccess &&
+      hipMemcpy(img->Wrow, wrow.data(), wrow.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) { mfma_bwd_free(img); return RAYEN_E_ALLOC; }
+  img->bytes = (int64_t)(frag.size() * sizeof(float) + items.size() * sizeof(BItem) + wrow.size() * sizeof(float));
+  *bytes = img->bytes;
+  *out = img;
+  return RAYEN_OK;
+}
+
+void mfma_bwd_free(MfmaBwdImage* img) {
+  if (img == nullptr) return;
+  if (img->S) (void)hipFree(img->S);
+  if (img->items) (void)hipFree(img->items);
+  if (img->Wrow) (void)hipFree(img->Wrow);
+  delete img;
+}
+
+template <int NKK>
+static int launch_bwd(const RayenPack* p, const MfmaBwdImage* img, const float* v, int64_t B, int64_t ldv,
+                      const float* kappa, const int32_t* active, const float* gy, int64_t ldg, float* gv,
+                      int64_t ldgv, int old_mode, hipStream_t stream) {
+  const int64_t n_groups = (B + 31) / 32;
+  const int64_t slots = (int64_t)img->n_simd * kMfmaWavesPerSimd;
+  const int64_t rounds = (n_groups + slots - 1) / slots;
+  const int64_t waves = (n_groups + rounds - 1) / rounds;
+  const int64_t grid = (waves + kMfmaWaves - 1) / kMfmaWaves;
+  auto aligned = [](const void* ptr, int64_t ld) { return (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(ptr) & 15) == 0); };
+  hipLaunchKernelGGL((mfma_bwd_kernel<NKK>), dim3((unsigned)grid), dim3(kMfmaWaves * 64), 0, stream, img->S,
+                     img->items, img->n_items, img->Wrow, p->n, v, B, ldv, aligned(v, ldv) ? 1 : 0, kappa, active,
+                     gy, ldg, aligned(gy, ldg) ? 1 : 0, gv, ldgv, aligned(gv, ldgv) ? 1 : 0, old_mode);
+  return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
+}
+
+int mfma_backward(const RayenPack* p, const MfmaBwdImage* img, const float* v, int64_t B, int64_t ldv,
+                  const float* kappa, const int32_t* active, const float* grad_y, int64_t ldg, float* grad_v,
+                  int64_t ldgv, int old_mode, hipStream_t stream) {
+  if (B == 0) return RAYEN_OK;
+  switch (img->nkk) {
+    case 1: return launch_bwd<1>(p, img, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode, stream);
+    case 2: return launch_bwd<2>(p, img, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode, stream);
+    default: return RAYEN_E_UNSUPPORTED;
+  }
+}
+
+}  // namespace rayen

@@ -108,10 +108,9 @@ def _(v, pack_id, need_active, old_head=False):
             v.new_empty((B if need_active else 0, 2), dtype=torch.int32))
 
 
-@torch.library.custom_op("rayen_amd::ray_project_bwd", mutates_args=())
-def ray_project_bwd(v: torch.Tensor, kappa: torch.Tensor, active: torch.Tensor,
-                    grad_y: torch.Tensor, pack_id: int, old_head: bool = False) -> torch.Tensor:
-    pack = _pack(pack_id)
+def backward_raw(v, kappa, active, grad_y, pack, old_head=False, force_generic=False):
+    """Direct call of the backward entry points; ``force_generic`` (fp32 only) pins the lane-per-sample
+    kernel where ``rayen_ray_project_bwd_f32`` would pick the matrix-core one."""
     _check_input(v, pack)
     if v.stride(1) != 1:
         v = v.contiguous()
@@ -119,6 +118,10 @@ def ray_project_bwd(v: torch.Tensor, kappa: torch.Tensor, active: torch.Tensor,
     B = v.shape[0]
     grad_v = torch.zeros_like(v)
     name = _BWD[(v.dtype, bool(old_head))]
+    if force_generic:
+        if v.dtype != torch.float32 or old_head:
+            raise RuntimeError("force_generic selects between the two fp32 RAYEN backward kernels only")
+        name = "rayen_ray_project_bwd_generic_f32"
     with torch.cuda.device(v.device):
         code = getattr(_lib.load(), name)(pack.handle, _ptr(v), B, v.stride(0) if B else pack.consts.n,
                                           _ptr(kappa), _ptr(active), _ptr(grad_y), grad_y.shape[1],
@@ -126,6 +129,12 @@ def ray_project_bwd(v: torch.Tensor, kappa: torch.Tensor, active: torch.Tensor,
                                           _stream())
     _lib.check(code, "rayen_ray_project_bwd")
     return grad_v
+
+
+@torch.library.custom_op("rayen_amd::ray_project_bwd", mutates_args=())
+def ray_project_bwd(v: torch.Tensor, kappa: torch.Tensor, active: torch.Tensor,
+                    grad_y: torch.Tensor, pack_id: int, old_head: bool = False) -> torch.Tensor:
+    return backward_raw(v, kappa, active, grad_y, _pack(pack_id), old_head)
 
 
 @ray_project_bwd.register_fake

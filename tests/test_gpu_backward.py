@@ -118,3 +118,61 @@ def test_backward_rayen_old_head(name, dtype, tol):
     err = np.max(np.abs(got - want), axis=1) / np.maximum(np.max(np.abs(want), axis=1), 1e-12)
     assert np.mean(err <= tol) >= (0.999 if dtype == torch.float64 else 0.99), np.sort(err)[-5:]
     assert np.median(err) <= tol / 10
+
+
+# ---------------------------------------------------------------------------------------------
+# matrix-core backward (rayen_mfma_bwd.hip) against the lane-per-sample backward on the same inputs
+# ---------------------------------------------------------------------------------------------
+
+def _bwd_sets():
+    rng = np.random.default_rng(3)
+    k = 40
+    lowrank = workloads.random_lin_quad_soc(k=k, m=64, n_quad=0, n_soc=1, r_M=12, seed=61)   # short cone block
+    for _ in range(3):                                                                        # rank-12 quadratics
+        U = rng.uniform(-1, 1, size=(12, k))
+        lowrank["P"].append(U.T @ U)
+        lowrank["q"].append(rng.uniform(-1, 1, size=(k, 1)))
+        lowrank["r"].append(rng.uniform(-1, 0, size=(1, 1)))
+    return {
+        "c2": workloads.make_raw("c2", seed=51),
+        "c3": workloads.make_raw("c3", seed=52),
+        "lin": workloads.random_lin_quad_soc(k=48, m=200, n_quad=0, n_soc=0, seed=53),
+        "soc_only": workloads.random_lin_quad_soc(k=32, m=0, n_quad=0, n_soc=3, seed=54),
+        "lowrank": lowrank,
+    }
+
+
+@pytest.mark.parametrize("name", ["c2", "c3", "lin", "soc_only", "lowrank"])
+@pytest.mark.parametrize("old_head", [False, True])
+def test_matrix_core_backward_matches_lane_backward(name, old_head):
+    from rayen_amd import ops
+    cs = workloads.build_constraints(_bwd_sets()[name])
+    layer = ConstraintModule(cs, create_map=False, method="RAYEN_old" if old_head else "RAYEN").cuda()
+    dp, _ = layer.device_pack(torch.device("cuda", 0))
+    B = 1237                                                  # ragged: not a multiple of 32
+    gen = torch.Generator().manual_seed(9)
+    width = cs.n + (1 if old_head else 0)
+    v = torch.empty(B, width).uniform_(-1.5, 1.5, generator=gen)
+    v[:40] *= 1e-3                                            # interior: unclipped
+    if not old_head:
+        v[40:44] = 0.0                                        # (autograd through v/||v|| is NaN at 0 for RAYEN_old)
+    g = torch.empty(B, cs.k).uniform_(-1, 1, generator=gen)
+    v, g = v.cuda(), g.cuda()
+    _, kappa, active = ops.project_raw(v, dp, want_active=True, old_head=old_head)
+    got = ops.backward_raw(v, kappa, active, g, dp, old_head=old_head)
+    assert torch.isfinite(got).all()
+    if old_head:
+        # no forced-generic entry point for the old head: compare with autograd through the fp64 oracle
+        buf = oracle.precompute(csd_from_cs(cs), torch.float64)
+        xr = v.cpu().double().unsqueeze(2).requires_grad_(True)
+        y = oracle.forward(buf, xr, method="RAYEN_old")
+        (y[:, :, 0] * g.cpu().double()).sum().backward()
+        want = xr.grad[:, :, 0]
+    else:
+        want = ops.backward_raw(v, kappa, active, g, dp, force_generic=True).cpu().double()
+    got = got.cpu().double()
+    scale = want.abs().amax(1).clamp_min(1e-12)
+    err = (got - want).abs().amax(1) / scale
+    tol = 5e-3 if old_head else 2e-4
+    assert (err <= tol).double().mean() >= (0.99 if old_head else 0.999), torch.sort(err).values[-5:]
+    assert float(err.median()) <= tol / 10
