@@ -146,12 +146,16 @@ int rayen_ray_project_bwd_f64(const RayenPack* pack, const double* v, int64_t B,
                               const double* kappa, const int32_t* active,
                               const double* grad_y, int64_t ldg,
                               double* grad_v, int64_t ldgv, void* stream);
-/* Same contract, forced through the lane-per-sample backward (rayen_ray_project_bwd_f32 picks the
+/* Same contract, forced through the lane-per-sample backward (rayen_ray_project_bwd_f32/_f64 pick the
  * matrix-core backward when the pack allows it); used by the tests to cover both. */
 int rayen_ray_project_bwd_generic_f32(const RayenPack* pack, const float* v, int64_t B, int64_t ldv,
                                       const float* kappa, const int32_t* active,
                                       const float* grad_y, int64_t ldg,
                                       float* grad_v, int64_t ldgv, void* stream);
+int rayen_ray_project_bwd_generic_f64(const RayenPack* pack, const double* v, int64_t B, int64_t ldv,
+                                      const double* kappa, const int32_t* active,
+                                      const double* grad_y, int64_t ldg,
+                                      double* grad_v, int64_t ldgv, void* stream);
 
 /* The RAYEN_old head (rayen/constraint_module.py:460-466, forwardForRAYENOld): the input carries one
  * more column, beta = v[:, n] (so ldv >= n + 1), and the step is 1/(exp(beta) + kappa(v_bar)) along

@@ -22,6 +22,7 @@ EXPORTS = (
     "rayen_ray_project_bwd_f64", "rayen_ray_project_old_f32", "rayen_ray_project_old_f64",
     "rayen_ray_project_old_bwd_f32", "rayen_ray_project_old_bwd_f64",
     "rayen_mapper_fusable", "rayen_ray_project_mapped_f32", "rayen_ray_project_bwd_generic_f32",
+    "rayen_ray_project_bwd_generic_f64",
 )
 
 
@@ -89,6 +90,7 @@ def load():
         getattr(lib, name).argtypes = fwd
     bwd = [p, p, i64, i64, p, i32p, p, i64, p, i64, p]
     for name in ("rayen_ray_project_bwd_f32", "rayen_ray_project_bwd_f64", "rayen_ray_project_bwd_generic_f32",
+                 "rayen_ray_project_bwd_generic_f64",
                  "rayen_ray_project_old_bwd_f32", "rayen_ray_project_old_bwd_f64"):
         getattr(lib, name).restype = ctypes.c_int
         getattr(lib, name).argtypes = bwd

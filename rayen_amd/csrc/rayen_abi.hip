@@ -98,6 +98,20 @@ int ensure_mfma_bwd(const RayenPack* p) {
   return RAYEN_OK;
 }
 
+int ensure_mfma64_bwd(const RayenPack* p) {
+  std::lock_guard<std::mutex> lock(p->mu);
+  if (p->mb64_tried) return RAYEN_OK;
+  p->mb64_tried = true;
+  if (!mfma64_bwd_eligible(p)) return RAYEN_OK;
+  int64_t bytes = 0;
+  Mfma64BwdImage* img = nullptr;
+  const int rc = mfma64_bwd_build(p, &img, &bytes);
+  if (rc != RAYEN_OK) return rc;
+  p->mb64 = img;
+  p->device_bytes += bytes;
+  return RAYEN_OK;
+}
+
 template <typename T>
 int project_generic(const RayenPack* p, const T* v, int64_t B, int64_t ldv, T* y, int64_t ldy, T* kappa,
                     int32_t* active, int32_t* nan_flag, void* stream, int old_mode = 0) {
@@ -128,6 +142,15 @@ int project_bwd(const RayenPack* p, const T* v, int64_t B, int64_t ldv, const T*
       if (p->mb32 != nullptr)
         return mfma_backward(p, p->mb32, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode,
                              static_cast<hipStream_t>(stream));
+    }
+  }
+  if constexpr (sizeof(T) == 8) {
+    if (!force_generic) {
+      rc = ensure_mfma64_bwd(p);
+      if (rc) return rc;
+      if (p->mb64 != nullptr)
+        return mfma64_backward(p, p->mb64, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode,
+                               static_cast<hipStream_t>(stream));
     }
   }
   rc = ensure_generic<T>(p);
@@ -199,6 +222,7 @@ void rayen_pack_destroy(RayenPack* p) {
   if (p->m32) mfma_free(p->m32);
   if (p->m64) mfma64_free(p->m64);
   if (p->mb32) mfma_bwd_free(p->mb32);
+  if (p->mb64) mfma64_bwd_free(p->mb64);
   if (switched) (void)hipSetDevice(prev);
   delete p;
 }
@@ -316,6 +340,12 @@ int rayen_ray_project_bwd_generic_f32(const RayenPack* p, const float* v, int64_
                                       const float* kappa, const int32_t* active, const float* grad_y,
                                       int64_t ldg, float* grad_v, int64_t ldgv, void* stream) {
   return project_bwd<float>(p, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, stream, 0, true);
+}
+
+int rayen_ray_project_bwd_generic_f64(const RayenPack* p, const double* v, int64_t B, int64_t ldv,
+                                      const double* kappa, const int32_t* active, const double* grad_y,
+                                      int64_t ldg, double* grad_v, int64_t ldgv, void* stream) {
+  return project_bwd<double>(p, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, stream, 0, true);
 }
 
 int rayen_ray_project_bwd_f64(const RayenPack* p, const double* v, int64_t B, int64_t ldv,

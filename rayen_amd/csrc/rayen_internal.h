@@ -47,6 +47,7 @@ struct GenericImage {
 struct MfmaImage;    // rayen_mfma.hip
 struct Mfma64Image;  // rayen_mfma_f64.hip
 struct MfmaBwdImage; // rayen_mfma_bwd.hip
+struct Mfma64BwdImage;  // rayen_mfma_bwd64.hip
 
 }  // namespace rayen
 
@@ -68,6 +69,8 @@ struct RayenPack {
   mutable bool m64_tried = false;
   mutable rayen::MfmaBwdImage* mb32 = nullptr;
   mutable bool mb32_tried = false;
+  mutable rayen::Mfma64BwdImage* mb64 = nullptr;
+  mutable bool mb64_tried = false;
   mutable int64_t device_bytes = 0;
 };
 
@@ -111,6 +114,14 @@ void mfma_bwd_free(MfmaBwdImage* img);
 int mfma_backward(const RayenPack* p, const MfmaBwdImage* img, const float* v, int64_t B, int64_t ldv,
                   const float* kappa, const int32_t* active, const float* grad_y, int64_t ldg, float* grad_v,
                   int64_t ldgv, int old_mode, hipStream_t stream);
+
+// fp64 MFMA backward (rayen_mfma_bwd64.hip)
+bool mfma64_bwd_eligible(const RayenPack* p);
+int mfma64_bwd_build(const RayenPack* p, Mfma64BwdImage** out, int64_t* bytes);
+void mfma64_bwd_free(Mfma64BwdImage* img);
+int mfma64_backward(const RayenPack* p, const Mfma64BwdImage* img, const double* v, int64_t B, int64_t ldv,
+                    const double* kappa, const int32_t* active, const double* grad_y, int64_t ldg,
+                    double* grad_v, int64_t ldgv, int old_mode, hipStream_t stream);
 
 // fp64 MFMA path (rayen_mfma_f64.hip)
 bool mfma64_eligible(const RayenPack* p);

@@ -15,23 +15,12 @@
 // segment with a select; the linear case is a gather of one row.  A wave owns 32 samples (v, g and
 // the gradient of kappa live in registers, n/2 VGPRs each).
 #include "rayen_mfma_kernel.h"
+#include "rayen_bwd_tiles.h"
 
 #include <cstring>
 #include <vector>
 
 namespace rayen {
-
-enum : int32_t { BI_NOP = 0, BI_QUAD = 1, BI_SOC = 2 };
-
-struct BItem {
-  int32_t type;
-  int32_t flags;    // MF_FIRST | MF_LAST of the segment's row tiles
-  int32_t seg;      // caller's segment index (what `active` holds)
-  int32_t tp;       // row tile of S (rows 32 tp .. 32 tp + 31 = elements of v)
-  int32_t aux_row;  // W row of phi | c (M'beta is the next row)
-  int32_t reserved;
-  float f0, f1;     // SOC: tau, a'
-};
 
 struct MfmaBwdImage {
   f32x4* S = nullptr;      // [n_items + 1][NQ][64] float4, fragment order, one dense n_pad x n_pad form per segment
@@ -216,77 +205,19 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwd_kern
 // host
 // ---------------------------------------------------------------------------------------------
 
-static bool quad_like(const RayenSegment& g) {
-  return g.type == RAYEN_SEG_QUAD_SYM || g.type == RAYEN_SEG_QUAD_FAC || g.type == RAYEN_SEG_SOC;
-}
-
 bool mfma_bwd_eligible(const RayenPack* p) {
-  if (!p->out_identity || p->n > 64 || !mfma_eligible(p)) return false;
-  int64_t tiles = 0;
-  for (const RayenSegment& g : p->segs) {
-    if (g.type == RAYEN_SEG_LMI) return false;
-    if (quad_like(g)) tiles += n_pad_of(p->n) / 32;
-  }
-  // the walk is dense (one n x n form per quadratic / cone): sets made of very many small low-rank
-  // quadratics are cheaper on the per-lane generic backward
-  return tiles <= 64;
+  return mfma_eligible(p) && bwd_tiles_eligible(p);
 }
 
 int mfma_bwd_build(const RayenPack* p, MfmaBwdImage** out, int64_t* bytes) {
   const int n = p->n, np = n_pad_of(n), nkk = np / 32;
   TileLayout b(n);
   std::vector<BItem> items;
-  const double* W = p->W.data();
-  for (size_t s = 0; s < p->segs.size(); ++s) {
-    const RayenSegment& g = p->segs[s];
-    if (!quad_like(g)) continue;
-    std::vector<double> S((size_t)n * n, 0.0);
-    if (g.type == RAYEN_SEG_QUAD_SYM) {
-      for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) S[(size_t)i * n + j] = W[(size_t)(g.row0 + i) * n + j];
-    } else {  // U'U or M'M
-      for (int r = 0; r < g.nrows; ++r) {
-        const double* row = W + (size_t)(g.row0 + r) * n;
-        for (int i = 0; i < n; ++i) {
-          if (row[i] == 0.0) continue;
-          for (int j = 0; j < n; ++j) S[(size_t)i * n + j] += row[i] * row[j];
-        }
-      }
-    }
-    for (int tp = 0; tp < nkk; ++tp) {
-      std::vector<const double*> rows;
-      for (int r = 32 * tp; r < 32 * tp + 32 && r < n; ++r) rows.push_back(S.data() + (size_t)r * n);
-      b.add_tile(rows, n);
-      BItem it;
-      std::memset(&it, 0, sizeof(it));
-      it.type = g.type == RAYEN_SEG_SOC ? BI_SOC : BI_QUAD;
-      it.flags = (tp == 0 ? MF_FIRST : 0) | (tp == nkk - 1 ? MF_LAST : 0);
-      it.seg = (int32_t)s;
-      it.tp = tp;
-      it.aux_row = g.aux_row;
-      it.f0 = (float)g.f0;
-      it.f1 = (float)g.f1;
-      items.push_back(it);
-    }
-  }
-  if (items.size() % 2) {
-    BItem it;
-    std::memset(&it, 0, sizeof(it));
-    it.type = BI_NOP;
-    items.push_back(it);
-    b.add_tile({}, n);
-  }
-  b.add_tile({}, n);  // spare tile: the prefetch runs one tile past the end
+  const int n_real = layout_bwd_tiles(p, b, items);
   const std::vector<float> frag = b.fragments_f32();
   std::vector<float> wrow((size_t)(p->n_rows + 2) * np, 0.f);  // (+2: an aux pair may be read past a last row)
   for (int r = 0; r < p->n_rows; ++r)
-    for (int j = 0; j < n; ++j) wrow[(size_t)r * np + j] = (float)W[(size_t)r * n + j];
-  const int n_real = (int)items.size();
-  if (items.empty()) {
-    BItem it;
-    std::memset(&it, 0, sizeof(it));
-    items.push_back(it);  // never read (n_items = 0), keeps the allocation non-empty
-  }
+    for (int j = 0; j < n; ++j) wrow[(size_t)r * np + j] = (float)p->W[(size_t)r * n + j];
 
   MfmaBwdImage* img = new MfmaBwdImage();
   img->nkk = nkk;

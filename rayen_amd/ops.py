@@ -109,8 +109,8 @@ def _(v, pack_id, need_active, old_head=False):
 
 
 def backward_raw(v, kappa, active, grad_y, pack, old_head=False, force_generic=False):
-    """Direct call of the backward entry points; ``force_generic`` (fp32 only) pins the lane-per-sample
-    kernel where ``rayen_ray_project_bwd_f32`` would pick the matrix-core one."""
+    """Direct call of the backward entry points; ``force_generic`` pins the lane-per-sample kernel
+    where ``rayen_ray_project_bwd_f32/_f64`` would pick the matrix-core one."""
     _check_input(v, pack)
     if v.stride(1) != 1:
         v = v.contiguous()
@@ -119,9 +119,9 @@ def backward_raw(v, kappa, active, grad_y, pack, old_head=False, force_generic=F
     grad_v = torch.zeros_like(v)
     name = _BWD[(v.dtype, bool(old_head))]
     if force_generic:
-        if v.dtype != torch.float32 or old_head:
-            raise RuntimeError("force_generic selects between the two fp32 RAYEN backward kernels only")
-        name = "rayen_ray_project_bwd_generic_f32"
+        if old_head:
+            raise RuntimeError("force_generic selects between the two RAYEN backward kernels only")
+        name = "rayen_ray_project_bwd_generic_f32" if v.dtype == torch.float32 else "rayen_ray_project_bwd_generic_f64"
     with torch.cuda.device(v.device):
         code = getattr(_lib.load(), name)(pack.handle, _ptr(v), B, v.stride(0) if B else pack.consts.n,
                                           _ptr(kappa), _ptr(active), _ptr(grad_y), grad_y.shape[1],

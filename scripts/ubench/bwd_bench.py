@@ -25,6 +25,8 @@ def time_call(fn, reps=30):
     return e0.elapsed_time(e1) / reps
 
 
+DTYPE = torch.float64 if os.environ.get("BWD_FP64") else torch.float32
+torch.set_default_dtype(DTYPE)
 for name in sys.argv[1:] or ["c2", "c3", "c5"]:
     cs = workloads.build_constraints(workloads.make_raw(name, seed=0))
     layer = ConstraintModule(cs, create_map=False).cuda()
@@ -36,5 +38,7 @@ for name in sys.argv[1:] or ["c2", "c3", "c5"]:
     row = {"config": name, "B": B, "clipped_frac": float((kappa > 1).float().mean()),
            "fwd_track_ms": time_call(lambda: ops.project_raw(v, dp, want_active=True)),
            "bwd_ms": time_call(lambda: ops.backward_raw(v, kappa, active, g, dp)),
-           "bwd_generic_ms": time_call(lambda: ops.backward_raw(v, kappa, active, g, dp, force_generic=True))}
+           "dtype": str(DTYPE)}
+    if DTYPE == torch.float32:
+        row["bwd_generic_ms"] = time_call(lambda: ops.backward_raw(v, kappa, active, g, dp, force_generic=True))
     print(json.dumps(row))
