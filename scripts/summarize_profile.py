@@ -8,7 +8,7 @@ import sys
 tag, out_path = sys.argv[1], sys.argv[2]
 note = sys.argv[3] if len(sys.argv) > 3 else ""
 base = f"gpurun_out/prof_{tag}"
-out = {"command": "rocprofv3 --kernel-trace --stats / --pmc ... -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline",
+out = {"command": "rocprofv3 --kernel-trace --stats / --pmc ... -- python bench.py --steps 200 --warmup 20 --no-cpu-baseline",
        "note": note, "kernel_stats": [], "pmc": {}}
 con = sqlite3.connect(f"{base}/stats/stats_results.db")
 for r in con.execute("select name,total_calls,total_duration,average,percentage from top_kernels limit 4"):
