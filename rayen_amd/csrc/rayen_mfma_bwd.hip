@@ -12,8 +12,8 @@
 // The generic backward lets every lane walk its own constraint (per-lane gathers of an n x n matrix).
 // Here S_s v is evaluated for EVERY quadratic / cone s on the matrix cores -- one dense 32-row tile walk
 // like the forward's, the same v-in-registers B operands -- and each lane keeps the rows of its own
-// segment with a select; the linear case is a gather of one row.  A wave owns 32 samples (v, g and
-// the gradient of kappa live in registers, n/2 VGPRs each).
+// segment with a select; the linear case is a gather of one row.  A wave owns 64 samples (v and the
+// gradient of kappa live in registers, n/2 VGPRs per 32 samples each).
 #include "rayen_mfma_kernel.h"
 #include "rayen_bwd_tiles.h"
 
@@ -21,6 +21,10 @@
 #include <vector>
 
 namespace rayen {
+
+#ifndef RAYEN_BWD_NT
+#define RAYEN_BWD_NT 2
+#endif
 
 struct MfmaBwdImage {
   f32x4* S = nullptr;      // [n_items + 1][NQ][64] float4, fragment order, one dense n_pad x n_pad form per segment
@@ -38,55 +42,72 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwd_kern
     const float* __restrict__ Wrow, int n, const float* __restrict__ v, int64_t B, int64_t ldv, int vec_v,
     const float* __restrict__ kappa, const int32_t* __restrict__ active, const float* __restrict__ gy,
     int64_t ldg, int vec_g, float* __restrict__ gv, int64_t ldgv, int vec_o, int old_mode) {
-  constexpr int NT = 1, NQ = NKK * 4, KK = NKK * 16, NP = NKK * 32, LSTR = NKK * 32 + 4;
+  // two sample tiles per wave (every A fetch feeds two MFMA chains); grad_y is read twice -- once for
+  // g.v, once for the final combination -- instead of occupying n/2 VGPRs per tile during the walk
+  constexpr int NT = RAYEN_BWD_NT, NQ = NKK * 4, KK = NKK * 16, NP = NKK * 32, LSTR = NKK * 32 + 4;
   __shared__ __attribute__((aligned(16))) float line_lds[kMfmaWaves][32][LSTR];
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int col = lane & 31;
   const int hi = lane >> 5;
-  const int64_t n_groups = (B + 31) / 32;
+  const int64_t n_groups = (B + NT * 32 - 1) / (NT * 32);
   const int64_t wave_id = (int64_t)blockIdx.x * kMfmaWaves + wave;
   const int64_t wave_stride = (int64_t)gridDim.x * kMfmaWaves;
   float (*patch)[LSTR] = line_lds[wave];
 
   for (int64_t grp = wave_id; grp < n_groups; grp += wave_stride) {
-    const int64_t s_base = grp * 32;
-    const int64_t smp = s_base + col;
-    bool live[NT];
-    live[0] = smp < B;
-    float vr[NT][KK], tr[NT][KK];
+    const int64_t s_base = grp * (NT * 32);
+    bool live[NT], clipped[NT], matched[NT];
+    float vr[NT][KK], ur[NT][KK];
+    float kap[NT], tv[NT], sc[NT], r_nrm[NT], e_beta[NT], part[NT];
+    int aseg[NT], arow[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) live[t] = (s_base + t * 32 + col) < B;
     load_rows<NT, NKK, LSTR, true>(vr, v, ldv, n, vec_v, s_base, B, live, patch, lane);
-    load_rows<NT, NKK, LSTR, true>(tr, gy, ldg, n, vec_g, s_base, B, live, patch, lane);
-    const float kap = live[0] ? kappa[smp] : 0.f;
-    const int aseg = live[0] ? active[2 * smp] : -1;
-    const int arow = live[0] ? active[2 * smp + 1] : 0;
-
-    float tv = 0.f;
+    {
+      float tr[NT][KK];
+      load_rows<NT, NKK, LSTR, true>(tr, gy, ldg, n, vec_g, s_base, B, live, patch, lane);
 #pragma unroll
-    for (int i = 0; i < KK; ++i) tv = fmaf(tr[0][i], vr[0][i], tv);
-    tv += xhalf(tv);
-    // RAYEN: s = 1/max(1,kappa), kappa matters once it clips.  RAYEN_old: s = 1/(r e^beta + kappa),
-    // r = ||v||: kappa always matters, and r, beta get gradients too.
-    float r_nrm = 0.f, e_beta = 0.f;
-    if (old_mode) {
-      float nrm2 = 0.f;
+      for (int t = 0; t < NT; ++t) {
+        float dot = 0.f;
 #pragma unroll
-      for (int i = 0; i < KK; ++i) nrm2 = fmaf(vr[0][i], vr[0][i], nrm2);
-      nrm2 += xhalf(nrm2);
-      r_nrm = sqrtf(nrm2);
-      e_beta = live[0] ? __expf(v[smp * ldv + n]) : 0.f;
+        for (int i = 0; i < KK; ++i) dot = fmaf(tr[t][i], vr[t][i], dot);
+        tv[t] = dot + xhalf(dot);
+      }
     }
-    const bool clipped = old_mode ? (live[0] && aseg >= 0 && r_nrm > 0.f) : (live[0] && kap > 1.f && aseg >= 0);
-    const float sc = old_mode ? (r_nrm > 0.f ? 1.f / (r_nrm * e_beta + kap) : 0.f) : 1.f / fmaxf(1.f, kap);
-
-    float ur[KK];
+    bool any = false;
 #pragma unroll
-    for (int i = 0; i < KK; ++i) ur[i] = 0.f;
+    for (int t = 0; t < NT; ++t) {
+      const int64_t smp = s_base + t * 32 + col;
+      kap[t] = live[t] ? kappa[smp] : 0.f;
+      aseg[t] = live[t] ? active[2 * smp] : -1;
+      arow[t] = live[t] ? active[2 * smp + 1] : 0;
+      matched[t] = false;
+      part[t] = 0.f;
+      // RAYEN: s = 1/max(1,kappa), kappa matters once it clips.  RAYEN_old: s = 1/(r e^beta + kappa),
+      // r = ||v||: kappa always matters, and r, beta get gradients too.
+      r_nrm[t] = 0.f;
+      e_beta[t] = 0.f;
+      if (old_mode) {
+        float nrm2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < KK; ++i) nrm2 = fmaf(vr[t][i], vr[t][i], nrm2);
+        nrm2 += xhalf(nrm2);
+        r_nrm[t] = sqrtf(nrm2);
+        e_beta[t] = live[t] ? __expf(v[smp * ldv + n]) : 0.f;
+        clipped[t] = live[t] && aseg[t] >= 0 && r_nrm[t] > 0.f;
+        sc[t] = r_nrm[t] > 0.f ? 1.f / (r_nrm[t] * e_beta[t] + kap[t]) : 0.f;
+      } else {
+        clipped[t] = live[t] && kap[t] > 1.f && aseg[t] >= 0;
+        sc[t] = 1.f / fmaxf(1.f, kap[t]);
+      }
+      any |= clipped[t];
+#pragma unroll
+      for (int i = 0; i < KK; ++i) ur[t][i] = 0.f;
+    }
 
-    if (__ballot(clipped) != 0) {  // wave-uniform: a wave of interior samples skips the walk
-      bool matched = false;
-      float part = 0.f;
+    if (__ballot(any) != 0) {  // wave-uniform: a wave of interior samples skips the walk
       const f32x4* wp = Simg + lane;
       f32x4 buf_a[NQ], buf_b[NQ];
       auto fetch_tile = [&](f32x4 (&buf)[NQ]) {
@@ -97,54 +118,73 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwd_kern
       };
       auto process = [&](const BItem item, const f32x4 (&a)[NQ]) {
         if (item.type == BI_NOP) return;
-        f32x16 acc;
+        f32x16 acc[NT];
 #pragma unroll
-        for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
           for (int c = 0; c < 4; ++c)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][c], vr[0][4 * q + c], acc, 0, 0, 0);
-        const bool sel = clipped && aseg == item.seg;
-        float sum = (item.flags & MF_FIRST) ? 0.f : part;
 #pragma unroll
-        for (int tp = 0; tp < NKK; ++tp)
-          if (item.tp == tp) {
+            for (int t = 0; t < NT; ++t)
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][c], vr[t][4 * q + c], acc[t], 0, 0, 0);
+        bool sel[NT], any_sel = false;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-              sum = fmaf(acc[g], vr[0][16 * tp + g], sum);
-              ur[16 * tp + g] = sel ? acc[g] : ur[16 * tp + g];
+        for (int t = 0; t < NT; ++t) {
+          sel[t] = clipped[t] && aseg[t] == item.seg;
+          any_sel |= sel[t];
+          float sum = (item.flags & MF_FIRST) ? 0.f : part[t];
+#pragma unroll
+          for (int tp = 0; tp < NKK; ++tp)
+            if (item.tp == tp) {
+#pragma unroll
+              for (int g = 0; g < 16; ++g) {
+                sum = fmaf(acc[t][g], vr[t][16 * tp + g], sum);
+                ur[t][16 * tp + g] = sel[t] ? acc[t][g] : ur[t][16 * tp + g];
+              }
             }
-          }
-        part = sum;
-        if ((item.flags & MF_LAST) && __ballot(sel) != 0) {
-          const float total = part + xhalf(part);  // v'S v
+          part[t] = sum;
+        }
+        if ((item.flags & MF_LAST) && __ballot(any_sel) != 0) {
           const float* ax = Wrow + (int64_t)item.aux_row * NP + 4 * hi;
-          float cw, c0, c1 = 0.f;
+          float cw[NT], c0[NT], c1[NT];
           if (item.type == BI_QUAD) {
-            cw = total > 0.f ? 1.f / sqrtf(total) : 0.f;
-            c0 = 1.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              const float total = part[t] + xhalf(part[t]);  // v'S v
+              cw[t] = total > 0.f ? 1.f / sqrtf(total) : 0.f;
+              c0[t] = 1.f;
+              c1[t] = 0.f;
+            }
           } else {
-            float cr = 0.f, br = 0.f;
+            float cr[NT], br[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { cr[t] = 0.f; br[t] = 0.f; }
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
               const f32x4 x0 = *reinterpret_cast<const f32x4*>(ax + 8 * q);
               const f32x4 x1 = *reinterpret_cast<const f32x4*>(ax + NP + 8 * q);
 #pragma unroll
-              for (int c = 0; c < 4; ++c) {
-                cr = fmaf(x0[c], vr[0][4 * q + c], cr);
-                br = fmaf(x1[c], vr[0][4 * q + c], br);
-              }
+              for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                  cr[t] = fmaf(x0[c], vr[t][4 * q + c], cr[t]);
+                  br[t] = fmaf(x1[c], vr[t][4 * q + c], br[t]);
+                }
             }
-            cr += xhalf(cr);
-            br += xhalf(br);
-            const float tau = item.f0, ap = item.f1;
-            const float bp = 2.f * br - 2.f * cr * tau;
-            const float den = 2.f * ap * kap + bp;  // dF/dkappa at the root
-            const float inv = den != 0.f ? -1.f / den : 0.f;
-            cw = 2.f * inv;                          // d c'/dv = 2 M'Mv - 2 (c.v) c
-            c0 = inv * (-2.f * cr - 2.f * tau * kap);
-            c1 = inv * 2.f * kap;                    // kappa * d b'/dv = kappa (2 M'beta - 2 tau c)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              const float crs = cr[t] + xhalf(cr[t]), brs = br[t] + xhalf(br[t]);
+              const float tau = item.f0, ap = item.f1;
+              const float bp = 2.f * brs - 2.f * crs * tau;
+              const float den = 2.f * ap * kap[t] + bp;  // dF/dkappa at the root
+              const float inv = den != 0.f ? -1.f / den : 0.f;
+              cw[t] = 2.f * inv;                            // d c'/dv = 2 M'Mv - 2 (c.v) c
+              c0[t] = inv * (-2.f * crs - 2.f * tau * kap[t]);
+              c1[t] = inv * 2.f * kap[t];                   // kappa * d b'/dv = kappa (2 M'beta - 2 tau c)
+            }
           }
 #pragma unroll
           for (int q = 0; q < NQ; ++q) {
@@ -152,12 +192,15 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwd_kern
             f32x4 x1 = {0.f, 0.f, 0.f, 0.f};
             if (item.type == BI_SOC) x1 = *reinterpret_cast<const f32x4*>(ax + NP + 8 * q);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              const float u = fmaf(cw, ur[4 * q + c], fmaf(c0, x0[c], c1 * x1[c]));
-              ur[4 * q + c] = sel ? u : ur[4 * q + c];
-            }
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+              for (int t = 0; t < NT; ++t) {
+                const float u = fmaf(cw[t], ur[t][4 * q + c], fmaf(c0[t], x0[c], c1[t] * x1[c]));
+                ur[t][4 * q + c] = sel[t] ? u : ur[t][4 * q + c];
+              }
           }
-          matched |= sel;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) matched[t] |= sel[t];
         }
       };
       if (n_items > 0) {
@@ -170,34 +213,45 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwd_kern
         }
       }
       // every quadratic / cone is in the item list: what is left is a linear row
-      if (clipped && !matched) {
-        const float* row = Wrow + (int64_t)arow * NP + 4 * hi;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          const f32x4 x = *reinterpret_cast<const f32x4*>(row + 8 * q);
-          ur[4 * q + 0] = x[0];
-          ur[4 * q + 1] = x[1];
-          ur[4 * q + 2] = x[2];
-          ur[4 * q + 3] = x[3];
+      for (int t = 0; t < NT; ++t)
+        if (clipped[t] && !matched[t]) {
+          const float* row = Wrow + (int64_t)arow[t] * NP + 4 * hi;
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(row + 8 * q);
+            ur[t][4 * q + 0] = x[0];
+            ur[t][4 * q + 1] = x[1];
+            ur[t][4 * q + 2] = x[2];
+            ur[t][4 * q + 3] = x[3];
+          }
+        }
+    }
+
+    // grad_v = s g - coef grad kappa (in place in ur), with g read a second time
+    {
+      float tr[NT][KK];
+      load_rows<NT, NKK, LSTR, true>(tr, gy, ldg, n, vec_g, s_base, B, live, patch, lane);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (!old_mode) {
+          const float coef = clipped[t] ? sc[t] * sc[t] * tv[t] : 0.f;
+#pragma unroll
+          for (int i = 0; i < KK; ++i) ur[t][i] = fmaf(sc[t], tr[t][i], -coef * ur[t][i]);
+        } else {
+          // grad_v = s t - s^2 (t.v) (e^beta v / r + grad kappa),  grad_beta = -s^2 (t.v) r e^beta
+          const float coef = sc[t] * sc[t] * tv[t];
+          const float dir = r_nrm[t] > 0.f ? e_beta[t] / r_nrm[t] : 0.f;
+#pragma unroll
+          for (int i = 0; i < KK; ++i) ur[t][i] = fmaf(sc[t], tr[t][i], -coef * fmaf(dir, vr[t][i], ur[t][i]));
+          if (live[t] && hi == 0) gv[(s_base + t * 32 + col) * ldgv + n] = -coef * r_nrm[t] * e_beta[t];
         }
       }
     }
-
     float one[NT];
-    one[0] = 1.f;
-    if (!old_mode) {
-      const float coef = clipped ? sc * sc * tv : 0.f;
 #pragma unroll
-      for (int i = 0; i < KK; ++i) tr[0][i] = fmaf(sc, tr[0][i], -coef * ur[i]);
-    } else {
-      // grad_v = s t - s^2 (t.v) (e^beta v / r + grad kappa),  grad_beta = -s^2 (t.v) r e^beta
-      const float coef = sc * sc * tv;
-      const float dir = r_nrm > 0.f ? e_beta / r_nrm : 0.f;
-#pragma unroll
-      for (int i = 0; i < KK; ++i) tr[0][i] = fmaf(sc, tr[0][i], -coef * fmaf(dir, vr[0][i], ur[i]));
-      if (live[0] && hi == 0) gv[smp * ldgv + n] = -coef * r_nrm * e_beta;
-    }
-    (void)store_rows<NT, NKK, LSTR, true>(tr, one, nullptr, gv, ldgv, n, vec_o, s_base, B, live, patch, lane);
+    for (int t = 0; t < NT; ++t) one[t] = 1.f;
+    (void)store_rows<NT, NKK, LSTR, true>(ur, one, nullptr, gv, ldgv, n, vec_o, s_base, B, live, patch, lane);
   }
 }
 
@@ -253,7 +307,7 @@ template <int NKK>
 static int launch_bwd(const RayenPack* p, const MfmaBwdImage* img, const float* v, int64_t B, int64_t ldv,
                       const float* kappa, const int32_t* active, const float* gy, int64_t ldg, float* gv,
                       int64_t ldgv, int old_mode, hipStream_t stream) {
-  const int64_t n_groups = (B + 31) / 32;
+  const int64_t n_groups = (B + RAYEN_BWD_NT * 32 - 1) / (RAYEN_BWD_NT * 32);
   const int64_t slots = (int64_t)img->n_simd * kMfmaWavesPerSimd;
   const int64_t rounds = (n_groups + slots - 1) / slots;
   const int64_t waves = (n_groups + rounds - 1) / rounds;
