@@ -84,6 +84,30 @@ int ensure_mfma64(const RayenPack* p) {
   return RAYEN_OK;
 }
 
+int ensure_quad32(const RayenPack* p) {
+  std::lock_guard<std::mutex> lock(p->mu);
+  if (p->q32_tried) return RAYEN_OK;
+  p->q32_tried = true;
+  if (!lmi_quad_eligible_f32(p)) return RAYEN_OK;
+  int64_t bytes = 0;
+  const int rc = lmi_quad_build_f32(p, &p->q32, &bytes);
+  if (rc != RAYEN_OK) return rc;
+  p->device_bytes += bytes;
+  return RAYEN_OK;
+}
+
+int ensure_quad64(const RayenPack* p) {
+  std::lock_guard<std::mutex> lock(p->mu);
+  if (p->q64_tried) return RAYEN_OK;
+  p->q64_tried = true;
+  if (!lmi_quad_eligible_f64(p)) return RAYEN_OK;
+  int64_t bytes = 0;
+  const int rc = lmi_quad_build_f64(p, &p->q64, &bytes);
+  if (rc != RAYEN_OK) return rc;
+  p->device_bytes += bytes;
+  return RAYEN_OK;
+}
+
 int ensure_mfma_bwd(const RayenPack* p) {
   std::lock_guard<std::mutex> lock(p->mu);
   if (p->mb32_tried) return RAYEN_OK;
@@ -223,6 +247,8 @@ void rayen_pack_destroy(RayenPack* p) {
   if (p->m64) mfma64_free(p->m64);
   if (p->mb32) mfma_bwd_free(p->mb32);
   if (p->mb64) mfma64_bwd_free(p->mb64);
+  if (p->q32) lmi_quad_free(p->q32);
+  if (p->q64) lmi_quad_free(p->q64);
   if (switched) (void)hipSetDevice(prev);
   delete p;
 }
@@ -265,6 +291,15 @@ static int project_f32(const RayenPack* p, const float* v, int64_t B, int64_t ld
   if (p->m32 != nullptr && y != nullptr)
     return mfma_forward(p, p->m32, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode,
                         static_cast<hipStream_t>(stream));
+  // four lanes per sample pay off while one lane per sample cannot fill the chip (B/64 waves on
+  // 1024 SIMDs x 2); beyond that the lane-per-sample kernel has the higher throughput in fp32
+  if (y != nullptr && !old_mode && B <= 65536) {
+    rc = ensure_quad32(p);
+    if (rc) return rc;
+    if (p->q32 != nullptr)
+      return lmi_quad_forward_f32(p, p->q32, v, B, ldv, y, ldy, kappa, active, nan_flag,
+                                  static_cast<hipStream_t>(stream));
+  }
   return project_generic<float>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, old_mode);
 }
 
@@ -317,6 +352,13 @@ static int project_f64(const RayenPack* p, const double* v, int64_t B, int64_t l
   if (p->m64 != nullptr && y != nullptr)
     return mfma64_forward(p, p->m64, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode,
                           static_cast<hipStream_t>(stream));
+  if (y != nullptr && !old_mode) {
+    rc = ensure_quad64(p);
+    if (rc) return rc;
+    if (p->q64 != nullptr)
+      return lmi_quad_forward_f64(p, p->q64, v, B, ldv, y, ldy, kappa, active, nan_flag,
+                                  static_cast<hipStream_t>(stream));
+  }
   return project_generic<double>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, old_mode);
 }
 

@@ -48,6 +48,7 @@ struct MfmaImage;    // rayen_mfma.hip
 struct Mfma64Image;  // rayen_mfma_f64.hip
 struct MfmaBwdImage; // rayen_mfma_bwd.hip
 struct Mfma64BwdImage;  // rayen_mfma_bwd64.hip
+struct LmiQuadImage;    // rayen_lmi_quad.h
 
 }  // namespace rayen
 
@@ -71,6 +72,9 @@ struct RayenPack {
   mutable bool mb32_tried = false;
   mutable rayen::Mfma64BwdImage* mb64 = nullptr;
   mutable bool mb64_tried = false;
+  mutable rayen::LmiQuadImage* q32 = nullptr;
+  mutable rayen::LmiQuadImage* q64 = nullptr;
+  mutable bool q32_tried = false, q64_tried = false;
   mutable int64_t device_bytes = 0;
 };
 
@@ -114,6 +118,19 @@ void mfma_bwd_free(MfmaBwdImage* img);
 int mfma_backward(const RayenPack* p, const MfmaBwdImage* img, const float* v, int64_t B, int64_t ldv,
                   const float* kappa, const int32_t* active, const float* grad_y, int64_t ldg, float* grad_v,
                   int64_t ldgv, int old_mode, hipStream_t stream);
+
+// four-lanes-per-sample LMI kernels (rayen_lmi_quad32.hip / rayen_lmi_quad64.hip)
+bool lmi_quad_eligible_f32(const RayenPack* p);
+bool lmi_quad_eligible_f64(const RayenPack* p);
+int lmi_quad_build_f32(const RayenPack* p, LmiQuadImage** out, int64_t* bytes);
+int lmi_quad_build_f64(const RayenPack* p, LmiQuadImage** out, int64_t* bytes);
+void lmi_quad_free(LmiQuadImage* img);
+int lmi_quad_forward_f32(const RayenPack* p, const LmiQuadImage* img, const float* v, int64_t B, int64_t ldv,
+                         float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
+                         hipStream_t stream);
+int lmi_quad_forward_f64(const RayenPack* p, const LmiQuadImage* img, const double* v, int64_t B, int64_t ldv,
+                         double* y, int64_t ldy, double* kappa, int32_t* active, int32_t* nan_flag,
+                         hipStream_t stream);
 
 // fp64 MFMA backward (rayen_mfma_bwd64.hip)
 bool mfma64_bwd_eligible(const RayenPack* p);

@@ -1,0 +1,420 @@
+// LMI path with FOUR lanes per sample (a DPP quad), fp32 and fp64 -- shared by rayen_lmi_quad32.hip
+// and rayen_lmi_quad64.hip (one translation unit per element type so that they compile side by side).
+//
+// kappa_LMI(v) = relu(lambda_max(sum_a v_a G_a)),  G_a = -L'F_a L folded with NA_E
+// (rayen/constraint_module.py:43-52, 401-449: einsum, L' S L, eigvalsh, max, relu).
+//
+// The lane-per-sample kernels keep a whole r x r matrix per lane: at config 4's batch (16384) that is
+// 256 waves on 1024 SIMDs, each running ~30k dependent instructions, and in fp64 the matrix does not
+// fit the register file at all.  Here the four lanes of a quad share one sample: lane `sub` owns rows
+// i = 4t + sub of the (full, symmetric) matrix, a quarter of the registers and a quarter of the work,
+// and every exchange is a DPP quad permutation (no LDS, no barriers):
+//   * S = sum_a v_a G_a      each lane forms its rows from an LDS image of the full G_a;
+//   * Householder tridiagonalisation, distributed: column norm and u'p by quad sums, A u and the rank-2
+//     update with the other lanes' u_j, w_j read through quad_perm broadcasts;
+//   * lambda_max of the tridiagonal by MULTI-section on the Sturm count: each lane evaluates two
+//     shifts per round (eight section points per quad), so the bracket shrinks 9x per round.
+// Same numerics as lambda_max_regs of rayen_generic.hip (Householder formulas, Gershgorin bracket,
+// pivmin guard); rows/columns beyond the true size are decoupled and far below every eigenvalue.
+// Linear rows (if any) are split over the four lanes as well.  Serves packs = [linear rows] + one LMI.
+#pragma once
+
+#include <type_traits>
+#include <vector>
+
+#include "rayen_internal.h"
+
+namespace rayen {
+
+struct LmiQuadImage {
+  void* data = nullptr;   // device: [Wf n*R*R | Wlin m*n | N k*n (absent when identity) | y0 k] of T
+  int32_t* lin_id = nullptr;  // device: [m][2] (segment, W row) of every linear row
+  int r = 0, R = 0, n = 0, k = 0, m = 0, identity = 0, lmi_seg = 0;
+  int64_t elems = 0;      // number of T elements in `data`
+  int64_t bytes = 0;
+};
+
+namespace lq {
+
+template <int I, int N, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    sfor<I + 1, N>(f);
+  }
+}
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_(float x) { return __int_as_float(dpp_<CTRL>(__float_as_int(x))); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_(double x) {
+  const int lo = dpp_<CTRL>(__double2loint(x)), hi = dpp_<CTRL>(__double2hiint(x));
+  return __hiloint2double(hi, lo);
+}
+// value of lane M of the quad
+template <int M, typename U>
+__device__ __forceinline__ U qb(U x) { return dpp_<M * 0x55>(x); }
+template <typename U>
+__device__ __forceinline__ U qsum(U x) {
+  x += dpp_<0xB1>(x);  // lanes [1,0,3,2]
+  x += dpp_<0x4E>(x);  // lanes [2,3,0,1]
+  return x;
+}
+template <typename U>
+__device__ __forceinline__ U qmax(U x) {
+  x = fmax(x, dpp_<0xB1>(x));
+  return fmax(x, dpp_<0x4E>(x));
+}
+template <typename U>
+__device__ __forceinline__ U qmin(U x) {
+  x = fmin(x, dpp_<0xB1>(x));
+  return fmin(x, dpp_<0x4E>(x));
+}
+
+template <typename T> struct Lim;
+template <> struct Lim<float> {
+  static constexpr int rounds = 11;  // 9^-11 < 2^-32 (the lane kernels run 32 bisections)
+  __device__ static float tiny() { return 1.0e-30f; }
+  __device__ static float rcp(float x) { return __builtin_amdgcn_rcpf(x); }  // only the SIGN sequence of q matters
+};
+template <> struct Lim<double> {
+  static constexpr int rounds = 19;  // 9^-19 < 2^-60 (60 bisections)
+  __device__ static double tiny() { return 1.0e-290; }
+  __device__ static double rcp(double x) { return 1.0 / x; }
+};
+
+template <typename T> __device__ __forceinline__ T fma_(T a, T b, T c);
+template <> __device__ __forceinline__ float fma_(float a, float b, float c) { return fmaf(a, b, c); }
+template <> __device__ __forceinline__ double fma_(double a, double b, double c) { return fma(a, b, c); }
+
+// One Householder step on column C of the distributed matrix (a[t][j] = A[4t + sub][j]).
+template <typename T, int R4, int C>
+__device__ __forceinline__ void hh_step(T (&a)[R4][4 * R4], T (&dd)[4 * R4], T (&e2)[4 * R4], const int sub) {
+  constexpr int R = 4 * R4, I1 = C + 1;
+  constexpr int T0 = I1 / 4;  // first row group with a live row (rows >= I1)
+  const T x0 = qb<(I1 & 3)>(a[I1 >> 2][C]);
+  T sig = T(0);
+  sfor<0, R4>([&](auto it) {
+    constexpr int t = decltype(it)::value;
+    if constexpr (4 * t + 3 >= C + 2) {
+      const T x = a[t][C];
+      const bool on = (4 * t >= C + 2) || (4 * t + sub >= C + 2);
+      sig += on ? x * x : T(0);
+    }
+  });
+  sig = qsum(sig);
+  const T mu = sqrt(fma_(x0, x0, sig));
+  const bool act = sig > T(0);
+  const T v0 = (x0 <= T(0)) ? (x0 - mu) : (-sig / (x0 + mu));
+  const T beta = act ? (T(2) * v0 * v0 / (sig + v0 * v0)) : T(0);
+  const T inv_v0 = act ? (T(1) / v0) : T(0);
+  dd[C] = qb<(C & 3)>(a[C >> 2][C]);
+  e2[C] = act ? (mu * mu) : (x0 * x0);
+
+  T hv[R4], p[R4];
+  sfor<0, R4>([&](auto it) {
+    constexpr int t = decltype(it)::value;
+    const int i = 4 * t + sub;
+    hv[t] = T(0);
+    p[t] = T(0);
+    if constexpr (t >= T0) hv[t] = (i == I1) ? T(1) : ((i >= C + 2) ? a[t][C] * inv_v0 : T(0));
+  });
+  // p = beta A u over the live block
+  sfor<I1, R>([&](auto ij) {
+    constexpr int j = decltype(ij)::value;
+    const T hj = qb<(j & 3)>(hv[j >> 2]);
+    sfor<T0, R4>([&](auto it) {
+      constexpr int t = decltype(it)::value;
+      p[t] = fma_(a[t][j], hj, p[t]);
+    });
+  });
+  T pv = T(0);
+  sfor<T0, R4>([&](auto it) {
+    constexpr int t = decltype(it)::value;
+    p[t] = (4 * t + sub >= I1) ? p[t] * beta : T(0);
+    pv = fma_(p[t], hv[t], pv);
+  });
+  pv = qsum(pv);
+  const T K = T(0.5) * beta * pv;
+  sfor<T0, R4>([&](auto it) {
+    constexpr int t = decltype(it)::value;
+    p[t] -= K * hv[t];  // now w
+  });
+  // A -= u w' + w u'
+  sfor<I1, R>([&](auto ij) {
+    constexpr int j = decltype(ij)::value;
+    const T hj = qb<(j & 3)>(hv[j >> 2]);
+    const T wj = qb<(j & 3)>(p[j >> 2]);
+    sfor<T0, R4>([&](auto it) {
+      constexpr int t = decltype(it)::value;
+      a[t][j] -= hv[t] * wj + p[t] * hj;
+    });
+  });
+}
+
+// lambda_max of the symmetric R x R matrix spread over a quad; every lane returns the same value.
+template <typename T, int R4>
+__device__ __forceinline__ T lambda_max_quad(T (&a)[R4][4 * R4], const int sub) {
+  constexpr int R = 4 * R4;
+  T dd[R], e2[R];
+  sfor<0, R - 2>([&](auto ic) {
+    constexpr int c = decltype(ic)::value;
+    hh_step<T, R4, c>(a, dd, e2, sub);
+  });
+  dd[R - 2] = qb<((R - 2) & 3)>(a[(R - 2) >> 2][R - 2]);
+  dd[R - 1] = qb<((R - 1) & 3)>(a[(R - 1) >> 2][R - 1]);
+  {
+    const T e = qb<((R - 1) & 3)>(a[(R - 1) >> 2][R - 2]);
+    e2[R - 2] = e * e;
+  }
+  e2[R - 1] = T(0);
+
+  // Gershgorin bracket of lambda_max: max diag <= lambda_max <= max(d_i + |e_{i-1}| + |e_i|)
+  T lo = dd[0], hi = dd[0] + sqrt(e2[0]), emax = T(0), eprev = T(0);
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const T enext = (i + 1 < R) ? sqrt(e2[i]) : T(0);
+    lo = (i == 0) ? dd[i] : fmax(lo, dd[i]);
+    hi = (i == 0) ? hi : fmax(hi, dd[i] + eprev + enext);
+    emax = fmax(emax, enext);
+    eprev = enext;
+  }
+  const T pivmin = Lim<T>::tiny() * fmax(T(1), emax * emax);
+  // eight section points per round: lane `sub` takes points 2 sub and 2 sub + 1 (two independent
+  // recurrences in flight per lane)
+  for (int it = 0; it < Lim<T>::rounds; ++it) {
+    const T w = (hi - lo) * T(1.0 / 9.0);
+    const T xa = fma_(w, T(2 * sub + 1), lo), xb = fma_(w, T(2 * sub + 2), lo);
+    T qa = dd[0] - xa, qb_ = dd[0] - xb;
+    int na = qa < T(0), nb = qb_ < T(0);
+#pragma unroll
+    for (int i = 1; i < R; ++i) {
+      if (fabs(qa) < pivmin) qa = -pivmin;
+      if (fabs(qb_) < pivmin) qb_ = -pivmin;
+      qa = dd[i] - xa - e2[i - 1] * Lim<T>::rcp(qa);
+      qb_ = dd[i] - xb - e2[i - 1] * Lim<T>::rcp(qb_);
+      na += qa < T(0);
+      nb += qb_ < T(0);
+    }
+    // all eigenvalues below x  ->  lambda_max < x
+    T lo_c = lo, hi_c = hi;
+    if (na == R) hi_c = fmin(hi_c, xa); else lo_c = fmax(lo_c, xa);
+    if (nb == R) hi_c = fmin(hi_c, xb); else lo_c = fmax(lo_c, xb);
+    lo = qmax(lo_c);
+    hi = fmax(qmin(hi_c), lo);
+  }
+  return T(0.5) * (lo + hi);
+}
+
+template <typename T, int R4>
+__global__ __launch_bounds__(256) void lmi_quad_kernel(
+    const T* __restrict__ image, const int32_t* __restrict__ lin_id, int r, int n, int k, int m, int identity,
+    int lmi_seg, int64_t elems, const T* __restrict__ v, int64_t B, int64_t ldv, T* __restrict__ y, int64_t ldy,
+    T* __restrict__ kappa_out, int32_t* __restrict__ active_out, int32_t* __restrict__ nan_flag) {
+  constexpr int R = 4 * R4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* img = reinterpret_cast<T*>(smem_raw);               // the whole constant image
+  const T* Wf = img;                                      // [n][R][R]
+  const T* Wlin = Wf + (size_t)n * R * R;                 // [m][n]
+  const T* Nmat = Wlin + (size_t)m * n;                   // [k][n] (absent when identity)
+  const T* y0 = Nmat + (identity ? 0 : (size_t)k * n);    // [k]
+  T* vt = img + elems;                                    // [64][n + 1]
+  const int LDV = n + 1;
+
+  const int tid = threadIdx.x;
+  const int sl = tid >> 2, sub = tid & 3;
+  const int64_t b0 = (int64_t)blockIdx.x * 64;
+  const int nb = (int)((B - b0) < 64 ? (B - b0) : 64);
+  for (int64_t i = tid; i < elems; i += 256) img[i] = image[i];
+  for (int idx = tid; idx < 64 * n; idx += 256) {
+    const int bl = idx / n, j = idx - bl * n;
+    vt[bl * LDV + j] = bl < nb ? v[(b0 + bl) * ldv + j] : T(0);
+  }
+  __syncthreads();
+  const T* vs = vt + sl * LDV;
+  const bool live = sl < nb;
+
+  // ---- S = sum_a v_a G_a, this lane's rows (padding rows/columns decoupled, far below the spectrum)
+  T a[R4][R];
+#pragma unroll
+  for (int t = 0; t < R4; ++t)
+#pragma unroll
+    for (int j = 0; j < R; ++j) a[t][j] = (4 * t + sub == j && j >= r) ? T(-1e18) : T(0);
+  for (int aa = 0; aa < n; ++aa) {
+    const T va = vs[aa];
+    const T* wa = Wf + (size_t)aa * R * R + sub * R;
+#pragma unroll
+    for (int t = 0; t < R4; ++t)
+#pragma unroll
+      for (int j = 0; j < R; ++j) a[t][j] = fma_(wa[4 * t * R + j], va, a[t][j]);
+  }
+
+  // ---- linear rows, split over the quad
+  T kap = T(0);
+  int aseg = -1, arow = 0;
+  for (int rho = sub; rho < m; rho += 4) {
+    T acc = T(0);
+    for (int aa = 0; aa < n; ++aa) acc = fma_(Wlin[rho * n + aa], vs[aa], acc);
+    if (acc > kap) { kap = acc; aseg = lin_id[2 * rho]; arow = lin_id[2 * rho + 1]; }
+  }
+  if (m > 0) {
+    // quad arg-max; ties go to the lower lane so that all four agree
+    int who = sub;
+    {
+      const T ok = dpp_<0xB1>(kap);
+      const int ow = dpp_<0xB1>(who), os = dpp_<0xB1>(aseg), orow = dpp_<0xB1>(arow);
+      if (ok > kap || (ok == kap && ow < who)) { kap = ok; who = ow; aseg = os; arow = orow; }
+    }
+    {
+      const T ok = dpp_<0x4E>(kap);
+      const int ow = dpp_<0x4E>(who), os = dpp_<0x4E>(aseg), orow = dpp_<0x4E>(arow);
+      if (ok > kap || (ok == kap && ow < who)) { kap = ok; who = ow; aseg = os; arow = orow; }
+    }
+  }
+
+  const T lam = lambda_max_quad<T, R4>(a, sub);
+  if (lam > kap) { kap = lam; aseg = lmi_seg; arow = 0; }
+
+  const T scale = T(1) / fmax(T(1), kap);
+  if (live && sub == 0) {
+    if (kappa_out) kappa_out[b0 + sl] = kap;
+    if (active_out) { active_out[2 * (b0 + sl)] = aseg; active_out[2 * (b0 + sl) + 1] = arow; }
+  }
+  bool bad = false;
+  if (live) {
+    T* yrow = y + (b0 + sl) * ldy;
+    for (int i = sub; i < k; i += 4) {
+      T val;
+      if (identity) {
+        val = fma_(vs[i], scale, y0[i]);
+      } else {
+        T acc = T(0);
+        for (int aa = 0; aa < n; ++aa) acc = fma_(Nmat[i * n + aa], vs[aa], acc);
+        val = fma_(acc, scale, y0[i]);
+      }
+      bad |= (val != val);
+      yrow[i] = val;
+    }
+  }
+  if (nan_flag && bad) atomicOr(nan_flag, 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------
+
+template <typename T>
+inline int quad_size_class(int r) {  // padded size R (multiple of 4) the kernels are instantiated for
+  for (int R : {8, 16, 20, 24, 32})
+    if (r <= R) return (R == 32 && sizeof(T) == 8) ? 0 : R;  // fp64: a quarter of a 32 x 32 matrix spills
+  return 0;
+}
+
+template <typename T>
+size_t quad_lds_bytes(const RayenPack* p, int R, int m) {
+  const size_t elems = (size_t)p->n * R * R + (size_t)m * p->n + (p->out_identity ? 0 : (size_t)p->k * p->n) + p->k;
+  return sizeof(T) * (elems + 64 * (size_t)(p->n + 1));
+}
+
+template <typename T>
+bool lmi_quad_eligible_t(const RayenPack* p) {
+  int n_lmi = 0, r = 0, m = 0;
+  for (const RayenSegment& g : p->segs) {
+    if (g.type == RAYEN_SEG_LMI) { ++n_lmi; r = g.dim; }
+    else if (g.type == RAYEN_SEG_LIN) m += g.nrows;
+    else return false;
+  }
+  if (n_lmi != 1 || r < 2) return false;
+  const int R = quad_size_class<T>(r);
+  return R != 0 && p->n <= 64 && p->k <= 256 && quad_lds_bytes<T>(p, R, m) <= 64 * 1024;
+}
+
+template <typename T>
+int lmi_quad_build_t(const RayenPack* p, LmiQuadImage** out, int64_t* bytes) {
+  LmiQuadImage* img = new LmiQuadImage();
+  const int n = p->n, k = p->k;
+  const RayenSegment* lmi = nullptr;
+  std::vector<int32_t> ids;
+  std::vector<const double*> lin_rows;
+  for (size_t s = 0; s < p->segs.size(); ++s) {
+    const RayenSegment& g = p->segs[s];
+    if (g.type == RAYEN_SEG_LMI) { lmi = &g; img->lmi_seg = (int)s; }
+    if (g.type == RAYEN_SEG_LIN)
+      for (int rr = 0; rr < g.nrows; ++rr) {
+        lin_rows.push_back(p->W.data() + (size_t)(g.row0 + rr) * n);
+        ids.push_back((int32_t)s);
+        ids.push_back(g.row0 + rr);
+      }
+  }
+  const int r = lmi->dim, R = quad_size_class<T>(r), m = (int)lin_rows.size();
+  img->r = r; img->R = R; img->n = n; img->k = k; img->m = m; img->identity = p->out_identity;
+  std::vector<T> host((size_t)n * R * R + (size_t)m * n + (p->out_identity ? 0 : (size_t)k * n) + k, T(0));
+  for (int a = 0; a < n; ++a)
+    for (int i = 0; i < r; ++i)
+      for (int j = 0; j < r; ++j) {
+        const int hi = i > j ? i : j, lo = i > j ? j : i;
+        host[((size_t)a * R + i) * R + j] = (T)p->W[(size_t)(lmi->row0 + hi * (hi + 1) / 2 + lo) * n + a];
+      }
+  size_t off = (size_t)n * R * R;
+  for (int rr = 0; rr < m; ++rr)
+    for (int a = 0; a < n; ++a) host[off + (size_t)rr * n + a] = (T)lin_rows[rr][a];
+  off += (size_t)m * n;
+  if (!p->out_identity) {
+    for (size_t i = 0; i < (size_t)k * n; ++i) host[off + i] = (T)p->NA_E[i];
+    off += (size_t)k * n;
+  }
+  for (int i = 0; i < k; ++i) host[off + i] = (T)p->y0[i];
+  if (ids.empty()) ids.assign(2, 0);
+  img->elems = (int64_t)host.size();
+  const bool ok = hipMalloc(&img->data, host.size() * sizeof(T)) == hipSuccess &&
+                  hipMemcpy(img->data, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMalloc(&img->lin_id, ids.size() * sizeof(int32_t)) == hipSuccess &&
+                  hipMemcpy(img->lin_id, ids.data(), ids.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) {
+    if (img->data) (void)hipFree(img->data);
+    if (img->lin_id) (void)hipFree(img->lin_id);
+    delete img;
+    return RAYEN_E_ALLOC;
+  }
+  img->bytes = (int64_t)(host.size() * sizeof(T) + ids.size() * sizeof(int32_t));
+  *bytes = img->bytes;
+  *out = img;
+  return RAYEN_OK;
+}
+
+template <typename T, int R4>
+int launch_quad(const RayenPack* p, const LmiQuadImage* img, const T* v, int64_t B, int64_t ldv, T* y, int64_t ldy,
+                T* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream) {
+  const size_t lds = quad_lds_bytes<T>(p, img->R, img->m);
+  auto kern = lmi_quad_kernel<T, R4>;
+  if (lds > 48 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) !=
+          hipSuccess)
+    return RAYEN_E_LAUNCH;
+  const int64_t grid = (B + 63) / 64;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, static_cast<const T*>(img->data), img->lin_id,
+                     img->r, img->n, img->k, img->m, img->identity, img->lmi_seg, img->elems, v, B, ldv, y, ldy, kappa,
+                     active, nan_flag);
+  return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
+}
+
+template <typename T>
+int lmi_quad_forward_t(const RayenPack* p, const LmiQuadImage* img, const T* v, int64_t B, int64_t ldv, T* y,
+                       int64_t ldy, T* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream) {
+  if (B == 0) return RAYEN_OK;
+  switch (img->R) {
+    case 8: return launch_quad<T, 2>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+    case 16: return launch_quad<T, 4>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+    case 20: return launch_quad<T, 5>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+    case 24: return launch_quad<T, 6>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+    case 32:
+      if constexpr (sizeof(T) == 4) return launch_quad<T, 8>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+      return RAYEN_E_UNSUPPORTED;
+    default: return RAYEN_E_UNSUPPORTED;
+  }
+}
+
+}  // namespace lq
+}  // namespace rayen

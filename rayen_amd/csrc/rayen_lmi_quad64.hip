@@ -1,0 +1,16 @@
+// fp64 instances of the four-lanes-per-sample LMI kernel (see rayen_lmi_quad.h).
+#include "rayen_lmi_quad.h"
+
+namespace rayen {
+
+bool lmi_quad_eligible_f64(const RayenPack* p) { return lq::lmi_quad_eligible_t<double>(p); }
+int lmi_quad_build_f64(const RayenPack* p, LmiQuadImage** out, int64_t* bytes) {
+  return lq::lmi_quad_build_t<double>(p, out, bytes);
+}
+int lmi_quad_forward_f64(const RayenPack* p, const LmiQuadImage* img, const double* v, int64_t B, int64_t ldv,
+                         double* y, int64_t ldy, double* kappa, int32_t* active, int32_t* nan_flag,
+                         hipStream_t stream) {
+  return lq::lmi_quad_forward_t<double>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+}
+
+}  // namespace rayen
