@@ -34,16 +34,23 @@ int main() {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int zero = 0; zero < 2; ++zero) {
     if (zero) hipMemset(in, 0, n * 4);
+    for (int nacc = 1; nacc <= 4; nacc *= 2)
     for (int wps = 1; wps <= 4; ++wps) {
       const int blocks = 256 * wps;  // 4 waves per block -> wps waves per SIMD
       const int iters = 20000;
-      k<2><<<blocks, 256>>>(in, out, 100);
+      auto run = [&](int it) {
+        if (nacc == 1) k<1><<<blocks, 256>>>(in, out, it);
+        else if (nacc == 2) k<2><<<blocks, 256>>>(in, out, it);
+        else k<4><<<blocks, 256>>>(in, out, it);
+      };
+      run(100);
       hipDeviceSynchronize();
       hipEventRecord(e0);
-      k<2><<<blocks, 256>>>(in, out, iters);
+      run(iters);
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
-      const double mfma_per_wave = (double)iters * 16;
+      const double mfma_per_wave = (double)iters * 8 * nacc;
+      printf("chains/wave %d  ", nacc);
       const double flops = mfma_per_wave * blocks * 4 * (2.0 * 32 * 32 * 2);
       const double cyc_per_simd = mfma_per_wave * wps * 64;  // if the pipe were always busy
       printf("%s operands, %d waves/SIMD: %.3f ms  %.1f TFLOP/s  implied clock if pipe 100%% busy %.3f GHz\n",
