@@ -116,7 +116,9 @@ def backward_raw(v, kappa, active, grad_y, pack, old_head=False, force_generic=F
         v = v.contiguous()
     grad_y = grad_y.contiguous()
     B = v.shape[0]
-    grad_v = torch.zeros_like(v)
+    # the kernels write the first n (+1 for the old head) columns of every row; wider inputs keep zeros
+    used = pack.consts.n + (1 if old_head else 0)
+    grad_v = torch.empty_like(v) if v.shape[1] == used else torch.zeros_like(v)
     name = _BWD[(v.dtype, bool(old_head))]
     if force_generic:
         if old_head:
