@@ -30,6 +30,8 @@
 // HBM traffic per sample: n loads + k stores, the algorithmic minimum.
 #pragma once
 
+#include <type_traits>
+
 #include "rayen_internal.h"
 #include "rayen_tiles.h"
 
@@ -370,22 +372,31 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_fwd_kern
   };
   fetch_tile(buf_a);
 
-  // one 32-row tile: NQ k-groups of 4 MFMA steps on every sample tile
+  // one 32-row tile: NQ k-groups of 4 MFMA steps on every sample tile.  FB = first 32-column block
+  // the tile needs (the blocks before it were folded into their transposes).  The first MFMA of a
+  // chain takes the constant 0 as its C operand: no accumulator initialisation instructions (VALU
+  // work and MFMA issue of a SIMD are serial).
+  auto run_from = [&](f32x16 (&acc)[NT], const f32x4 (&a)[NQ], auto fb_tag) {
+    constexpr int FB = decltype(fb_tag)::value;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 4 * FB; q < NQ; ++q)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][c], vr[t][4 * q + c],
+                                                        (q == 4 * FB && c == 0) ? zero : acc[t], 0, 0, 0);
+  };
   auto run_tile = [&](f32x16 (&acc)[NT], const f32x4 (&a)[NQ], const int qbegin) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
-#pragma unroll
-    for (int qb = 0; qb < NKK; ++qb) {  // one 32-column block = 4 k-groups
-      if (4 * qb < qbegin) continue;    // wave-uniform: the block was folded into its transpose
-#pragma unroll
-      for (int q = 4 * qb; q < 4 * qb + 4; ++q)
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-          for (int t = 0; t < NT; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][c], vr[t][4 * q + c], acc[t], 0, 0, 0);
+    if (qbegin == 0) {
+      run_from(acc, a, std::integral_constant<int, 0>{});
+    } else if (NKK > 1 && qbegin == 4) {
+      run_from(acc, a, std::integral_constant<int, (NKK > 1 ? 1 : 0)>{});
+    } else if (NKK > 2 && qbegin == 8) {
+      run_from(acc, a, std::integral_constant<int, (NKK > 2 ? 2 : 0)>{});
+    } else {
+      run_from(acc, a, std::integral_constant<int, (NKK > 3 ? 3 : 0)>{});
     }
   };
 
