@@ -119,17 +119,15 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwd_kern
       auto process = [&](const BItem item, const f32x4 (&a)[NQ]) {
         if (item.type == BI_NOP) return;
         f32x16 acc[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-          for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
           for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-              acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][c], vr[t][4 * q + c], acc[t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t)  // the first MFMA of a chain starts from the constant 0
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][c], vr[t][4 * q + c],
+                                                            (q == 0 && c == 0) ? zero : acc[t], 0, 0, 0);
         bool sel[NT], any_sel = false;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {

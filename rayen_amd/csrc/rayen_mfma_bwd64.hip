@@ -111,10 +111,7 @@ __global__ __launch_bounds__(kB64Waves * 64, 2) void mfma64_bwd_kernel(
           fetch_half(buf_hi);
           continue;
         }
-#pragma unroll
-        for (int rh = 0; rh < 2; ++rh)
-#pragma unroll
-          for (int c = 0; c < 2; ++c) acc[rh][c] = f64x4{0.0, 0.0, 0.0, 0.0};
+        const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int p = 0; p < NS / 4; ++p)
 #pragma unroll
@@ -122,8 +119,9 @@ __global__ __launch_bounds__(kB64Waves * 64, 2) void mfma64_bwd_kernel(
 #pragma unroll
             for (int rh = 0; rh < 2; ++rh)
 #pragma unroll
-              for (int c = 0; c < 2; ++c)
-                acc[rh][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(buf_lo[p][rh][e], vb[c][2 * p + e], acc[rh][c], 0, 0, 0);
+              for (int c = 0; c < 2; ++c)  // the first MFMA of a chain starts from the constant 0
+                acc[rh][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(buf_lo[p][rh][e], vb[c][2 * p + e],
+                                                                  (p == 0 && e == 0) ? zero4 : acc[rh][c], 0, 0, 0);
         fetch_half(buf_lo);
 #pragma unroll
         for (int p = 0; p < NS / 4; ++p)

@@ -134,34 +134,47 @@ __global__ __launch_bounds__(k64Waves * 64, 2) void mfma64_fwd_kernel(
         continue;
       }
       if (item.type == MI_OUT && (item.flags & MF_FIRST)) finish_kappa();
-#pragma unroll
-      for (int rh = 0; rh < 2; ++rh)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) acc[rh][c] = f64x4{0.0, 0.0, 0.0, 0.0};
       const int sbegin = 2 * item.qbegin;  // qbegin counts 8-column groups, a K-step is 4 columns
-      // first half of the K range out of buf_lo, then refill it for the next tile
+      // The first MFMA of each of the four chains takes the constant 0 as its C operand (no accumulator
+      // initialisation: VALU work and MFMA issue of a SIMD are serial).  Whole 32-column blocks before
+      // sbegin were folded into their transposes (wave-uniform): with NKK = 2 that is the buf_lo half.
+      const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
+      const bool skip_lo = (NKK == 2) && sbegin >= 8;
+      if (!skip_lo) {
 #pragma unroll
-      for (int p = 0; p < NS / 4; ++p) {
-        if (((2 * p) & ~7) < sbegin) continue;  // whole 32-column blocks folded away (wave-uniform)
+        for (int p = 0; p < NS / 4; ++p)
 #pragma unroll
-        for (int e = 0; e < 2; ++e)
+          for (int e = 0; e < 2; ++e)
 #pragma unroll
-          for (int rh = 0; rh < 2; ++rh)
+            for (int rh = 0; rh < 2; ++rh)
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
-              acc[rh][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(buf_lo[p][rh][e], vb[c][2 * p + e], acc[rh][c], 0, 0, 0);
+              for (int c = 0; c < 2; ++c)
+                acc[rh][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(buf_lo[p][rh][e], vb[c][2 * p + e],
+                                                                  (p == 0 && e == 0) ? zero4 : acc[rh][c], 0, 0, 0);
       }
       fetch_half(buf_lo);
+      if (skip_lo) {
 #pragma unroll
-      for (int p = 0; p < NS / 4; ++p) {
-        if (((NS / 2 + 2 * p) & ~7) < sbegin) continue;
+        for (int p = 0; p < NS / 4; ++p)
 #pragma unroll
-        for (int e = 0; e < 2; ++e)
+          for (int e = 0; e < 2; ++e)
 #pragma unroll
-          for (int rh = 0; rh < 2; ++rh)
+            for (int rh = 0; rh < 2; ++rh)
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
-              acc[rh][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(buf_hi[p][rh][e], vb[c][NS / 2 + 2 * p + e], acc[rh][c], 0, 0, 0);
+              for (int c = 0; c < 2; ++c)
+                acc[rh][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(buf_hi[p][rh][e], vb[c][NS / 2 + 2 * p + e],
+                                                                  (p == 0 && e == 0) ? zero4 : acc[rh][c], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int p = 0; p < NS / 4; ++p)
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+              for (int c = 0; c < 2; ++c)
+                acc[rh][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(buf_hi[p][rh][e], vb[c][NS / 2 + 2 * p + e],
+                                                                  acc[rh][c], 0, 0, 0);
       }
       fetch_half(buf_hi);
 
