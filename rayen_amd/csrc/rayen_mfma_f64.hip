@@ -140,6 +140,38 @@ __global__ __launch_bounds__(k64Waves * 64, 2) void mfma64_fwd_kernel(
       // sbegin were folded into their transposes (wave-uniform): with NKK = 2 that is the buf_lo half.
       const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
       const bool skip_lo = (NKK == 2) && sbegin >= 8;
+      if constexpr (TRACK) {
+        // (with the arg-max bookkeeping the second copy of the buf_hi block costs more registers than the
+        // initialisation saves: explicit zeroes, one copy of each block)
+#pragma unroll
+        for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) acc[rh][c] = zero4;
+#pragma unroll
+        for (int p = 0; p < NS / 4; ++p) {
+          if (((2 * p) & ~7) < sbegin) continue;
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+              for (int c = 0; c < 2; ++c)
+                acc[rh][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(buf_lo[p][rh][e], vb[c][2 * p + e], acc[rh][c], 0, 0, 0);
+        }
+        fetch_half(buf_lo);
+#pragma unroll
+        for (int p = 0; p < NS / 4; ++p) {
+          if (((NS / 2 + 2 * p) & ~7) < sbegin) continue;
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+              for (int c = 0; c < 2; ++c)
+                acc[rh][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(buf_hi[p][rh][e], vb[c][NS / 2 + 2 * p + e], acc[rh][c], 0, 0, 0);
+        }
+        fetch_half(buf_hi);
+      } else {
       if (!skip_lo) {
 #pragma unroll
         for (int p = 0; p < NS / 4; ++p)
@@ -177,6 +209,7 @@ __global__ __launch_bounds__(k64Waves * 64, 2) void mfma64_fwd_kernel(
                                                                   acc[rh][c], 0, 0, 0);
       }
       fetch_half(buf_hi);
+      }
 
       // ---- epilogue: this lane holds rows 16 rh + 4 g + q of the tile for its two samples
       if (item.type == MI_LIN) {
