@@ -229,7 +229,11 @@ __device__ __forceinline__ bool store_rows(const float (&val)[NT][NK * 16], cons
   return bad;
 }
 
-template <int NKK, int NKX, bool TRACK>
+// STAGED: the NA_E output tiles leave through an LDS transposition (row-coalesced stores).  Packs with
+// NA_E = I never execute that code and are launched with STAGED = false, which keeps their instance
+// exactly the code the headline numbers were tuned on (hipcc's register allocation of this kernel is
+// sensitive to code it never runs).
+template <int NKK, int NKX, bool TRACK, bool STAGED>
 __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_fwd_kernel(
     const f32x4* __restrict__ Wimg, const MItem* __restrict__ items, int n_items,
     const MPack* __restrict__ packs, const float* __restrict__ y0, int identity, int k, int n, const float* __restrict__ v, int64_t B,
@@ -444,7 +448,33 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_fwd_kern
         for (int g = 0; g < 16; ++g)
           aux_lds[wave][t][(g & 3) + 8 * (g >> 2) + 4 * hi][col] = acc[t][g];
       __builtin_amdgcn_wave_barrier();
-    } else if (item.type == MI_OUT) {
+    } else if (STAGED && item.type == MI_OUT) {
+      // rows of NA_E: the 32 x 32 result block goes through this wave's aux patch (dead by now: every
+      // segment has closed), XOR-swizzled so that both the fragment-shaped writes and the row-shaped
+      // reads are conflict-free, and leaves as row-coalesced stores (two samples x 32 consecutive
+      // outputs per instruction instead of 64 scattered words)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        float* stage = &aux_lds[wave][t][0][0];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int r = (g & 3) + 8 * (g >> 2) + 4 * hi;
+          const float o = fmaf(acc[t][g], scale[t], y0[item.row0 + r]);  // y0 is padded to a tile multiple
+          bad |= live[t] && (item.row0 + r < k) && (o != o);
+          stage[col * 32 + (r ^ col)] = o;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int orow = item.row0 + col;
+        float* ybase = y + (s_base + t * 32 + hi) * ldy + orow;
+#pragma unroll 4
+        for (int j = 0; j < 16; ++j) {
+          const int sm = 2 * j + hi;
+          const float o = stage[sm * 32 + (col ^ sm)];
+          if (s_base + t * 32 + sm < B && orow < k) ybase[(int64_t)(2 * j) * ldy] = o;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    } else if (!STAGED && item.type == MI_OUT) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         if (!live[t]) continue;
@@ -572,14 +602,17 @@ static int launch_mfma(const RayenPack* p, const MfmaImage* img, const float* v,
   const int64_t grid = (waves + kMfmaWaves - 1) / kMfmaWaves;
   const int vec_in = (ldv % 4 == 0) && ((reinterpret_cast<uintptr_t>(v) & 15) == 0);
   const int vec_out = (ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
-  if (active != nullptr) {
-    hipLaunchKernelGGL((mfma_fwd_kernel<NKK, NKX, true>), dim3((unsigned)grid), dim3(kMfmaWaves * 64), 0, stream,
-                       img->W, img->items, img->n_items, img->packs, img->y0, img->identity, p->k, p->n, v, B, ldv,
-                       vec_in, y, ldy, vec_out, kappa, active, nan_flag, old_mode, mp);
+  auto go = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kMfmaWaves * 64), 0, stream, img->W, img->items,
+                       img->n_items, img->packs, img->y0, img->identity, p->k, p->n, v, B, ldv, vec_in, y, ldy,
+                       vec_out, kappa, active, nan_flag, old_mode, mp);
+  };
+  if (img->identity) {
+    if (active != nullptr) go(mfma_fwd_kernel<NKK, NKX, true, false>);
+    else go(mfma_fwd_kernel<NKK, NKX, false, false>);
   } else {
-    hipLaunchKernelGGL((mfma_fwd_kernel<NKK, NKX, false>), dim3((unsigned)grid), dim3(kMfmaWaves * 64), 0, stream,
-                       img->W, img->items, img->n_items, img->packs, img->y0, img->identity, p->k, p->n, v, B, ldv,
-                       vec_in, y, ldy, vec_out, kappa, active, nan_flag, old_mode, mp);
+    if (active != nullptr) go(mfma_fwd_kernel<NKK, NKX, true, true>);
+    else go(mfma_fwd_kernel<NKK, NKX, false, true>);
   }
   return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
 }
