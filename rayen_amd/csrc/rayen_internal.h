@@ -48,6 +48,7 @@ struct MfmaImage;    // rayen_mfma.hip
 struct Mfma64Image;  // rayen_mfma_f64.hip
 struct MfmaBwdImage; // rayen_mfma_bwd.hip
 struct Mfma64BwdImage;  // rayen_mfma_bwd64.hip
+struct MfmaBwdgImage;   // rayen_mfma_bwdg.hip
 struct LmiQuadImage;    // rayen_lmi_quad.h
 
 }  // namespace rayen
@@ -72,6 +73,8 @@ struct RayenPack {
   mutable bool mb32_tried = false;
   mutable rayen::Mfma64BwdImage* mb64 = nullptr;
   mutable bool mb64_tried = false;
+  mutable rayen::MfmaBwdgImage* mbg32 = nullptr;
+  mutable bool mbg32_tried = false;
   mutable rayen::LmiQuadImage* q32 = nullptr;
   mutable rayen::LmiQuadImage* q64 = nullptr;
   mutable bool q32_tried = false, q64_tried = false;
@@ -131,6 +134,14 @@ int lmi_quad_forward_f32(const RayenPack* p, const LmiQuadImage* img, const floa
 int lmi_quad_forward_f64(const RayenPack* p, const LmiQuadImage* img, const double* v, int64_t B, int64_t ldv,
                          double* y, int64_t ldy, double* kappa, int32_t* active, int32_t* nan_flag,
                          hipStream_t stream);
+
+// fp32 MFMA backward for sets with equalities / packed low-rank quadratics (rayen_mfma_bwdg.hip)
+bool mfma_bwdg_eligible(const RayenPack* p);
+int mfma_bwdg_build(const RayenPack* p, MfmaBwdgImage** out, int64_t* bytes);
+void mfma_bwdg_free(MfmaBwdgImage* img);
+int mfma_bwdg_backward(const RayenPack* p, const MfmaBwdgImage* img, const float* v, int64_t B, int64_t ldv,
+                       const float* kappa, const int32_t* active, const float* grad_y, int64_t ldg,
+                       float* grad_v, int64_t ldgv, int old_mode, hipStream_t stream);
 
 // fp64 MFMA backward (rayen_mfma_bwd64.hip)
 bool mfma64_bwd_eligible(const RayenPack* p);

@@ -1,0 +1,542 @@
+// fp32 matrix-core backward, general shapes: sets with equality constraints (NA_E != I, so the incoming
+// gradient is first pulled back, t = NA_E' g, on the matrix cores) and sets with many small low-rank
+// quadratics (the packed tiles of the forward).  rayen_mfma_bwd.hip keeps the tuned kernel for NA_E = I with
+// dense forms only; this one serves what that one declines when n <= 32 and k <= 64 (no LMI): with two
+// 32-column blocks of v the masked product's extra accumulators no longer fit the register file.
+//
+//   grad_v = s t - [kappa > 1] s^2 (t . v) grad kappa(v),   t = NA_E' g,   s = 1 / max(1, kappa)
+//
+// Packed low-rank quadratics (kappa = phi.v + ||U v||, rank <= 8, eight half-quads of rows per tile as in
+// the forward): a per-lane matrix gather is avoided with a MASKED two-step product --
+//   step 1   w = U_tile v                    one tile walk step, all eight segments of the tile at once;
+//            every lane zeroes the quads that do not belong to ITS active segment and scales the rest by
+//            1 / ||U v||  (a 4-register sum, plus one half-wave exchange when the segment spans both halves);
+//   step 2   u += U_tile' w                  the transposed tile as A operand, w -- which already sits in
+//            the registers an MFMA B operand needs -- as B operand, accumulated over the pack tiles.
+// Only the lane's own segment survives the mask, so u = U_s'(U_s v)/||U_s v||; phi_s is a row gather.
+#include "rayen_bwd_tiles.h"
+#include "rayen_mfma_kernel.h"
+
+#include <cstring>
+#include <vector>
+
+namespace rayen {
+
+enum : int32_t { BI_PACK1 = 3, BI_PACK2 = 4 };
+
+struct BPack {
+  int32_t seg[4][2];   // [quad a][half]: caller's segment index sitting there, -1 = empty
+  int32_t pair_bits;   // bit a: the segment of quad a spans both halves (rank 5..8)
+  int32_t reserved;
+};
+
+struct MfmaBwdgImage {
+  f32x4* S = nullptr;        // item tiles, fragment order, NQ float4 per lane and tile
+  f32x4* NT = nullptr;       // NA_E' as [NKK tiles][NQG][64] float4 (K = k_pad), null when NA_E = I
+  BItem* items = nullptr;
+  BPack* packs = nullptr;
+  int32_t* seg_aux = nullptr;  // [n_segments] W row of phi for factor segments, -1 otherwise
+  float* Wrow = nullptr;     // [n_rows + 2][n_pad]
+  int n_items = 0, nkk = 0, nkg = 0, n_simd = 1024;
+  int64_t bytes = 0;
+};
+
+template <int NKK, int NKG>
+__global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwdg_kernel(
+    const f32x4* __restrict__ Simg, const f32x4* __restrict__ NTimg, const BItem* __restrict__ items, int n_items,
+    const BPack* __restrict__ packs, const int32_t* __restrict__ seg_aux, const float* __restrict__ Wrow, int n,
+    int k, const float* __restrict__ v, int64_t B, int64_t ldv, int vec_v, const float* __restrict__ kappa,
+    const int32_t* __restrict__ active, const float* __restrict__ gy, int64_t ldg, int vec_g,
+    float* __restrict__ gv, int64_t ldgv, int vec_o, int old_mode) {
+  constexpr int NT = 2, NQ = NKK * 4, KK = NKK * 16, NP = NKK * 32;
+  constexpr int NKL = NKG > NKK ? NKG : NKK, LSTR = NKL * 32 + 4;
+  constexpr int NQG = NKG * 4, KG = NKG > 0 ? NKG * 16 : 1;
+  __shared__ __attribute__((aligned(16))) float line_lds[kMfmaWaves][32][LSTR];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int col = lane & 31;
+  const int hi = lane >> 5;
+  const int64_t n_groups = (B + NT * 32 - 1) / (NT * 32);
+  const int64_t wave_id = (int64_t)blockIdx.x * kMfmaWaves + wave;
+  const int64_t wave_stride = (int64_t)gridDim.x * kMfmaWaves;
+  float (*patch)[LSTR] = line_lds[wave];
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  for (int64_t grp = wave_id; grp < n_groups; grp += wave_stride) {
+    const int64_t s_base = grp * (NT * 32);
+    bool live[NT], clipped[NT], matched[NT], pmatched[NT];
+    float vr[NT][KK];
+    f32x16 u16[NT][NKK];
+    float kap[NT], tv[NT], sc[NT], r_nrm[NT], e_beta[NT], part[NT];
+    int aseg[NT], arow[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) live[t] = (s_base + t * 32 + col) < B;
+    load_rows<NT, NKK, LSTR, true>(vr, v, ldv, n, vec_v, s_base, B, live, patch, lane);
+
+    // t = NA_E' g (or g itself), in the register layout of v
+    auto pull_back = [&](float (&tr)[NT][KK]) {
+      if constexpr (NKG == 0) {
+        load_rows<NT, NKK, LSTR, true>(tr, gy, ldg, n, vec_g, s_base, B, live, patch, lane);
+      } else {
+        float gr[NT][KG];
+        load_rows<NT, NKG, LSTR, true>(gr, gy, ldg, k, vec_g, s_base, B, live, patch, lane);
+#pragma unroll
+        for (int tp = 0; tp < NKK; ++tp) {
+          f32x4 a[NQG];
+#pragma unroll
+          for (int q = 0; q < NQG; ++q) a[q] = NTimg[((size_t)tp * NQG + q) * 64 + lane];
+          f32x16 acc[NT];
+#pragma unroll
+          for (int q = 0; q < NQG; ++q)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+              for (int t = 0; t < NT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][c], gr[t][4 * q + c],
+                                                              (q == 0 && c == 0) ? zero : acc[t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) tr[t][16 * tp + g] = acc[t][g];
+        }
+      }
+    };
+    {
+      float tr[NT][KK];
+      pull_back(tr);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < KK; ++i) dot = fmaf(tr[t][i], vr[t][i], dot);
+        tv[t] = dot + xhalf(dot);
+      }
+    }
+    bool any = false;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int64_t smp = s_base + t * 32 + col;
+      kap[t] = live[t] ? kappa[smp] : 0.f;
+      aseg[t] = live[t] ? active[2 * smp] : -1;
+      arow[t] = live[t] ? active[2 * smp + 1] : 0;
+      matched[t] = false;
+      pmatched[t] = false;
+      part[t] = 0.f;
+      r_nrm[t] = 0.f;
+      e_beta[t] = 0.f;
+      if (old_mode) {  // RAYEN_old: s = 1/(r e^beta + kappa), r = ||v||
+        float nrm2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < KK; ++i) nrm2 = fmaf(vr[t][i], vr[t][i], nrm2);
+        nrm2 += xhalf(nrm2);
+        r_nrm[t] = sqrtf(nrm2);
+        e_beta[t] = live[t] ? __expf(v[smp * ldv + n]) : 0.f;
+        clipped[t] = live[t] && aseg[t] >= 0 && r_nrm[t] > 0.f;
+        sc[t] = r_nrm[t] > 0.f ? 1.f / (r_nrm[t] * e_beta[t] + kap[t]) : 0.f;
+      } else {
+        clipped[t] = live[t] && kap[t] > 1.f && aseg[t] >= 0;
+        sc[t] = 1.f / fmaxf(1.f, kap[t]);
+      }
+      any |= clipped[t];
+#pragma unroll
+      for (int tp = 0; tp < NKK; ++tp) u16[t][tp] = zero;
+    }
+
+    if (__ballot(any) != 0 && n_items > 0) {  // wave-uniform: a wave of interior samples skips the walk
+      const f32x4* wp = Simg + lane;
+      f32x4 buf_a[NQ], buf_b[NQ];
+      f32x16 wreg[NT];  // step-1 result of a packed tile, masked and scaled: the B operand of step 2
+      auto fetch_tile = [&](f32x4 (&buf)[NQ]) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) buf[q] = wp[q * 64];
+        wp += NQ * 64;
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto process = [&](const BItem item, const f32x4 (&a)[NQ]) {
+        if (item.type == BI_NOP) return;
+        if (item.type == BI_PACK2) {
+          // u += U_tile' w : row tile tp of the transposed tile sits in k-groups 4 tp .. 4 tp + 3
+#pragma unroll
+          for (int tp = 0; tp < NKK; ++tp)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                  u16[t][tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * tp + q][c], wreg[t][4 * q + c], u16[t][tp], 0, 0, 0);
+          return;
+        }
+        f32x16 acc[NT];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][c], vr[t][4 * q + c],
+                                                            (q == 0 && c == 0) ? zero : acc[t], 0, 0, 0);
+        if (item.type == BI_PACK1) {
+          const BPack pk = packs[item.aux_row];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            bool got = false;
+#pragma unroll
+            for (int a4 = 0; a4 < 4; ++a4) {
+              const int sid = hi ? pk.seg[a4][1] : pk.seg[a4][0];
+              const bool mine = clipped[t] && sid >= 0 && sid == aseg[t];
+              float qs = 0.f;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) qs = fmaf(acc[t][4 * a4 + c], acc[t][4 * a4 + c], qs);
+              qs = mine ? qs : 0.f;
+              if ((pk.pair_bits >> a4) & 1) qs += xhalf(qs);  // the segment's other rows sit in the other half
+              const float cw = (mine && qs > 0.f) ? 1.f / sqrtf(qs) : 0.f;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) wreg[t][4 * a4 + c] = acc[t][4 * a4 + c] * cw;
+              got |= mine;
+            }
+            const int both = (got ? 1 : 0) | __shfl_xor(got ? 1 : 0, 32);
+            pmatched[t] |= both != 0;
+          }
+          return;
+        }
+        bool sel[NT], any_sel = false;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          sel[t] = clipped[t] && aseg[t] == item.seg;
+          any_sel |= sel[t];
+          float sum = (item.flags & MF_FIRST) ? 0.f : part[t];
+#pragma unroll
+          for (int tp = 0; tp < NKK; ++tp)
+            if (item.tp == tp) {
+#pragma unroll
+              for (int g = 0; g < 16; ++g) {
+                sum = fmaf(acc[t][g], vr[t][16 * tp + g], sum);
+                u16[t][tp][g] = sel[t] ? acc[t][g] : u16[t][tp][g];
+              }
+            }
+          part[t] = sum;
+        }
+        if ((item.flags & MF_LAST) && __ballot(any_sel) != 0) {
+          const float* ax = Wrow + (int64_t)item.aux_row * NP + 4 * hi;
+          float cw[NT], c0[NT], c1[NT];
+          if (item.type == BI_QUAD) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              const float total = part[t] + xhalf(part[t]);  // v'S v
+              cw[t] = total > 0.f ? 1.f / sqrtf(total) : 0.f;
+              c0[t] = 1.f;
+              c1[t] = 0.f;
+            }
+          } else {
+            float cr[NT], br[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { cr[t] = 0.f; br[t] = 0.f; }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+              const f32x4 x0 = *reinterpret_cast<const f32x4*>(ax + 8 * q);
+              const f32x4 x1 = *reinterpret_cast<const f32x4*>(ax + NP + 8 * q);
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                  cr[t] = fmaf(x0[c], vr[t][4 * q + c], cr[t]);
+                  br[t] = fmaf(x1[c], vr[t][4 * q + c], br[t]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              const float crs = cr[t] + xhalf(cr[t]), brs = br[t] + xhalf(br[t]);
+              const float tau = item.f0, ap = item.f1;
+              const float bp = 2.f * brs - 2.f * crs * tau;
+              const float den = 2.f * ap * kap[t] + bp;  // dF/dkappa at the root
+              const float inv = den != 0.f ? -1.f / den : 0.f;
+              cw[t] = 2.f * inv;
+              c0[t] = inv * (-2.f * crs - 2.f * tau * kap[t]);
+              c1[t] = inv * 2.f * kap[t];
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(ax + 8 * q);
+            f32x4 x1 = {0.f, 0.f, 0.f, 0.f};
+            if (item.type == BI_SOC) x1 = *reinterpret_cast<const f32x4*>(ax + NP + 8 * q);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+              for (int t = 0; t < NT; ++t) {
+                const int i = 4 * q + c;
+                const float u = fmaf(cw[t], u16[t][i / 16][i % 16], fmaf(c0[t], x0[c], c1[t] * x1[c]));
+                u16[t][i / 16][i % 16] = sel[t] ? u : u16[t][i / 16][i % 16];
+              }
+          }
+#pragma unroll
+          for (int t = 0; t < NT; ++t) matched[t] |= sel[t];
+        }
+      };
+      fetch_tile(buf_a);
+      for (int it = 0; it < n_items; it += 2) {  // n_items is even (padded with a no-op tile)
+        fetch_tile(buf_b);
+        process(items[it], buf_a);
+        fetch_tile(buf_a);
+        process(items[it + 1], buf_b);
+      }
+    }
+    // a packed quadratic still needs its phi; what matched nothing at all is a linear row
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (!clipped[t] || matched[t]) continue;
+      const int rowi = pmatched[t] ? seg_aux[aseg[t]] : arow[t];
+      const float* row = Wrow + (int64_t)rowi * NP + 4 * hi;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(row + 8 * q);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int i = 4 * q + c;
+          u16[t][i / 16][i % 16] = pmatched[t] ? u16[t][i / 16][i % 16] + x[c] : x[c];
+        }
+      }
+    }
+
+    // grad_v = s t - coef grad kappa, with t formed a second time
+    float out[NT][KK];
+    {
+      float tr[NT][KK];
+      pull_back(tr);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (!old_mode) {
+          const float coef = clipped[t] ? sc[t] * sc[t] * tv[t] : 0.f;
+#pragma unroll
+          for (int i = 0; i < KK; ++i) out[t][i] = fmaf(sc[t], tr[t][i], -coef * u16[t][i / 16][i % 16]);
+        } else {
+          // grad_v = s t - s^2 (t.v) (e^beta v / r + grad kappa),  grad_beta = -s^2 (t.v) r e^beta
+          const float coef = sc[t] * sc[t] * tv[t];
+          const float dir = r_nrm[t] > 0.f ? e_beta[t] / r_nrm[t] : 0.f;
+#pragma unroll
+          for (int i = 0; i < KK; ++i)
+            out[t][i] = fmaf(sc[t], tr[t][i], -coef * fmaf(dir, vr[t][i], u16[t][i / 16][i % 16]));
+          if (live[t] && hi == 0) gv[(s_base + t * 32 + col) * ldgv + n] = -coef * r_nrm[t] * e_beta[t];
+        }
+      }
+    }
+    float one[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) one[t] = 1.f;
+    (void)store_rows<NT, NKK, LSTR, true>(out, one, nullptr, gv, ldgv, n, vec_o, s_base, B, live, patch, lane);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------
+
+bool mfma_bwdg_eligible(const RayenPack* p) {
+  if (p->n > 32 || p->k > 64 || !mfma_eligible(p)) return false;
+  int64_t tiles = 0;
+  int small = 0;
+  for (const RayenSegment& g : p->segs) {
+    if (g.type == RAYEN_SEG_LMI) return false;
+    if (!bwd_quad_like(g)) continue;
+    if (is_small_factor(g)) ++small;
+    else tiles += n_pad_of(p->n) / 32;
+  }
+  tiles += 2 * ((small + 3) / 4);  // at least four (rank 5..8) and at most eight segments per packed tile pair
+  return tiles <= 96;
+}
+
+void mfma_bwdg_free(MfmaBwdgImage* img) {
+  if (img == nullptr) return;
+  if (img->S) (void)hipFree(img->S);
+  if (img->NT) (void)hipFree(img->NT);
+  if (img->items) (void)hipFree(img->items);
+  if (img->packs) (void)hipFree(img->packs);
+  if (img->seg_aux) (void)hipFree(img->seg_aux);
+  if (img->Wrow) (void)hipFree(img->Wrow);
+  delete img;
+}
+
+template <typename T>
+static bool upload_vec(const std::vector<T>& host, T** dev, int64_t* bytes) {
+  if (hipMalloc(dev, host.size() * sizeof(T)) != hipSuccess) return false;
+  if (hipMemcpy(*dev, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return false;
+  *bytes += (int64_t)(host.size() * sizeof(T));
+  return true;
+}
+
+int mfma_bwdg_build(const RayenPack* p, MfmaBwdgImage** out, int64_t* bytes) {
+  const int n = p->n, k = p->k, np = n_pad_of(n), nkk = np / 32;
+  const double* W = p->W.data();
+  TileLayout b(n);
+  std::vector<BItem> items;
+  std::vector<BPack> packs;
+  std::vector<int32_t> seg_aux(p->segs.size() + 1, -1);
+  auto blank = [](int type) { BItem it; std::memset(&it, 0, sizeof(it)); it.type = type; return it; };
+
+  // ---- dense forms for everything that is not a small factor (same as rayen_bwd_tiles.h)
+  for (size_t s = 0; s < p->segs.size(); ++s) {
+    const RayenSegment& g = p->segs[s];
+    if (g.type == RAYEN_SEG_QUAD_FAC) seg_aux[s] = g.aux_row;
+    if (!bwd_quad_like(g) || is_small_factor(g)) continue;
+    std::vector<double> S((size_t)n * n, 0.0);
+    if (g.type == RAYEN_SEG_QUAD_SYM) {
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) S[(size_t)i * n + j] = W[(size_t)(g.row0 + i) * n + j];
+    } else {
+      for (int r = 0; r < g.nrows; ++r) {
+        const double* row = W + (size_t)(g.row0 + r) * n;
+        for (int i = 0; i < n; ++i) {
+          if (row[i] == 0.0) continue;
+          for (int j = 0; j < n; ++j) S[(size_t)i * n + j] += row[i] * row[j];
+        }
+      }
+    }
+    for (int tp = 0; tp < nkk; ++tp) {
+      std::vector<const double*> rows;
+      for (int r = 32 * tp; r < 32 * tp + 32 && r < n; ++r) rows.push_back(S.data() + (size_t)r * n);
+      b.add_tile(rows, n);
+      BItem it = blank(g.type == RAYEN_SEG_SOC ? BI_SOC : BI_QUAD);
+      it.flags = (tp == 0 ? MF_FIRST : 0) | (tp == nkk - 1 ? MF_LAST : 0);
+      it.seg = (int32_t)s;
+      it.tp = tp;
+      it.aux_row = g.aux_row;
+      it.f0 = (float)g.f0;
+      it.f1 = (float)g.f1;
+      items.push_back(it);
+    }
+  }
+  // ---- small factors: eight half-quads of rows per tile (placement of rayen_tiles.h), each tile followed
+  // by its transpose
+  {
+    std::vector<const double*> rows(32, nullptr);
+    BPack pk;
+    int used = 0;
+    auto reset = [&]() {
+      std::fill(rows.begin(), rows.end(), nullptr);
+      std::memset(&pk, 0, sizeof(pk));
+      for (int a = 0; a < 4; ++a) for (int h = 0; h < 2; ++h) pk.seg[a][h] = -1;
+      used = 0;
+    };
+    auto flush = [&]() {
+      if (used == 0) return;
+      BItem it1 = blank(BI_PACK1);
+      it1.aux_row = (int32_t)packs.size();
+      items.push_back(it1);
+      b.add_tile(rows, n);
+      // transposed: raw2[r][32 tp + kk] = tile[kk][32 tp + r]
+      std::vector<std::vector<double>> tr(32, std::vector<double>(np, 0.0));
+      for (int kk = 0; kk < 32; ++kk) {
+        if (rows[kk] == nullptr) continue;
+        for (int e = 0; e < n; ++e) tr[e % 32][32 * (e / 32) + kk] = rows[kk][e];
+      }
+      std::vector<const double*> trp;
+      for (auto& r : tr) trp.push_back(r.data());
+      BItem it2 = blank(BI_PACK2);
+      items.push_back(it2);
+      b.add_tile(trp, np);
+      packs.push_back(pk);
+      reset();
+    };
+    reset();
+    for (size_t s = 0; s < p->segs.size(); ++s) {
+      const RayenSegment& g = p->segs[s];
+      if (!is_small_factor(g)) continue;
+      const bool pair = g.nrows > 4;
+      if (pair && (used & 1)) ++used;
+      if (used + (pair ? 2 : 1) > 8) flush();
+      const int a = used / 2, h = used & 1;
+      for (int r = 0; r < g.nrows; ++r) rows[8 * a + 4 * h + r] = W + (size_t)(g.row0 + r) * n;
+      pk.seg[a][h] = (int32_t)s;
+      if (pair) { pk.seg[a][1] = (int32_t)s; pk.pair_bits |= 1 << a; }
+      used += pair ? 2 : 1;
+    }
+    flush();
+  }
+  // a PACK1 / PACK2 pair must not straddle the kernel's (it, it+1) unrolling in a way that matters: the
+  // kernel keeps wreg across process() calls, so any order works; only the count must be even
+  if (items.size() % 2) {
+    items.push_back(blank(BI_NOP));
+    b.add_tile({}, n);
+  }
+  b.add_tile({}, n);  // spare tile for the prefetch
+  const int n_real = (int)items.size();
+  if (items.empty()) items.push_back(blank(BI_NOP));
+  if (packs.empty()) { BPack pk; std::memset(&pk, 0, sizeof(pk)); packs.push_back(pk); }
+
+  MfmaBwdgImage* img = new MfmaBwdgImage();
+  img->nkk = nkk;
+  img->nkg = p->out_identity ? 0 : n_pad_of(k) / 32;
+  img->n_items = n_real;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0)
+      img->n_simd = prop.multiProcessorCount * 4;
+  }
+  const std::vector<float> frag = b.fragments_f32();
+  std::vector<float> wrow((size_t)(p->n_rows + 2) * np, 0.f);
+  for (int r = 0; r < p->n_rows; ++r)
+    for (int j = 0; j < n; ++j) wrow[(size_t)r * np + j] = (float)W[(size_t)r * n + j];
+  bool ok = true;
+  {
+    float* d = nullptr;
+    ok = ok && upload_vec(frag, &d, &img->bytes);
+    img->S = reinterpret_cast<f32x4*>(d);
+  }
+  ok = ok && upload_vec(wrow, &img->Wrow, &img->bytes) && upload_vec(items, &img->items, &img->bytes) &&
+       upload_vec(packs, &img->packs, &img->bytes) && upload_vec(seg_aux, &img->seg_aux, &img->bytes);
+  if (ok && !p->out_identity) {
+    // NA_E' : rows = the n subspace coordinates, K = the k ambient coordinates
+    TileLayout bn(k);
+    std::vector<std::vector<double>> nt(n, std::vector<double>(k, 0.0));
+    for (int i = 0; i < k; ++i)
+      for (int e = 0; e < n; ++e) nt[e][i] = p->NA_E[(size_t)i * n + e];
+    for (int tp = 0; tp < nkk; ++tp) {
+      std::vector<const double*> rows;
+      for (int r = 32 * tp; r < 32 * tp + 32 && r < n; ++r) rows.push_back(nt[r].data());
+      bn.add_tile(rows, k);
+    }
+    const std::vector<float> fn = bn.fragments_f32();
+    float* d = nullptr;
+    ok = upload_vec(fn, &d, &img->bytes);
+    img->NT = reinterpret_cast<f32x4*>(d);
+  }
+  if (!ok) { mfma_bwdg_free(img); return RAYEN_E_ALLOC; }
+  *bytes = img->bytes;
+  *out = img;
+  return RAYEN_OK;
+}
+
+template <int NKK, int NKG>
+static int launch_bwdg(const RayenPack* p, const MfmaBwdgImage* img, const float* v, int64_t B, int64_t ldv,
+                       const float* kappa, const int32_t* active, const float* gy, int64_t ldg, float* gv,
+                       int64_t ldgv, int old_mode, hipStream_t stream) {
+  const int64_t n_groups = (B + 63) / 64;
+  const int64_t slots = (int64_t)img->n_simd * kMfmaWavesPerSimd;
+  const int64_t rounds = (n_groups + slots - 1) / slots;
+  const int64_t waves = (n_groups + rounds - 1) / rounds;
+  const int64_t grid = (waves + kMfmaWaves - 1) / kMfmaWaves;
+  auto aligned = [](const void* ptr, int64_t ld) { return (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(ptr) & 15) == 0); };
+  hipLaunchKernelGGL((mfma_bwdg_kernel<NKK, NKG>), dim3((unsigned)grid), dim3(kMfmaWaves * 64), 0, stream, img->S,
+                     img->NT, img->items, img->n_items, img->packs, img->seg_aux, img->Wrow, p->n, p->k, v, B, ldv,
+                     aligned(v, ldv) ? 1 : 0, kappa, active, gy, ldg, aligned(gy, ldg) ? 1 : 0, gv, ldgv,
+                     aligned(gv, ldgv) ? 1 : 0, old_mode);
+  return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
+}
+
+int mfma_bwdg_backward(const RayenPack* p, const MfmaBwdgImage* img, const float* v, int64_t B, int64_t ldv,
+                       const float* kappa, const int32_t* active, const float* grad_y, int64_t ldg,
+                       float* grad_v, int64_t ldgv, int old_mode, hipStream_t stream) {
+  if (B == 0) return RAYEN_OK;
+#define RAYEN_BWDG_CASE(A, G) \
+  if (img->nkk == A && img->nkg == G) \
+    return launch_bwdg<A, G>(p, img, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode, stream);
+  RAYEN_BWDG_CASE(1, 0)
+  RAYEN_BWDG_CASE(1, 1)
+  RAYEN_BWDG_CASE(1, 2)
+#undef RAYEN_BWDG_CASE
+  return RAYEN_E_UNSUPPORTED;
+}
+
+}  // namespace rayen

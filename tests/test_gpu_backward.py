@@ -133,7 +133,32 @@ def _bwd_sets():
         lowrank["P"].append(U.T @ U)
         lowrank["q"].append(rng.uniform(-1, 1, size=(k, 1)))
         lowrank["r"].append(rng.uniform(-1, 0, size=(1, 1)))
+    eq_dense = workloads.corridor_like(k=40, n_eq=10, m=96, n_quad=0, rank=3, seed=62)     # equalities, n = 30
+    for _ in range(2):                                                                      # + dense quadratics
+        T = rng.uniform(-1, 1, size=(40, 40))
+        P = T @ T.T
+        q = rng.uniform(-1, 1, size=(40, 1))
+        g0 = 0.5 * eq_dense["y0"].T @ P @ eq_dense["y0"] + q.T @ eq_dense["y0"]
+        eq_dense["P"].append(P)
+        eq_dense["q"].append(q)
+        eq_dense["r"].append(-g0 - rng.uniform(0.1, 1.0, size=(1, 1)))
+    packed_identity = workloads.random_lin_quad_soc(k=32, m=64, n_quad=0, n_soc=0, seed=63)  # NA_E = I, packed factors
+    for r_ in (2, 3, 6, 8, 4, 1, 7, 3, 5, 2):
+        U = rng.uniform(-1, 1, size=(r_, 32))
+        packed_identity["P"].append(U.T @ U)
+        packed_identity["q"].append(rng.uniform(-1, 1, size=(32, 1)))
+        packed_identity["r"].append(rng.uniform(-1, 0, size=(1, 1)))
+    many_packed = workloads.random_lin_quad_soc(k=32, m=64, n_quad=0, n_soc=0, seed=64)      # NA_E = I, 70 small factors:
+    for i in range(70):                                                                       # too many for the dense walk
+        U = rng.uniform(-1, 1, size=(1 + i % 5, 32))
+        many_packed["P"].append(U.T @ U)
+        many_packed["q"].append(rng.uniform(-1, 1, size=(32, 1)))
+        many_packed["r"].append(rng.uniform(-1, 0, size=(1, 1)))
     return {
+        "many_packed": many_packed,
+        "c5": workloads.make_raw("c5", seed=55),                  # equalities + 72 packed rank-3 quadratics
+        "eq_dense": eq_dense,
+        "packed_identity": packed_identity,
         "c2": workloads.make_raw("c2", seed=51),
         "c3": workloads.make_raw("c3", seed=52),
         "lin": workloads.random_lin_quad_soc(k=48, m=200, n_quad=0, n_soc=0, seed=53),
@@ -142,7 +167,8 @@ def _bwd_sets():
     }
 
 
-@pytest.mark.parametrize("name", ["c2", "c3", "lin", "soc_only", "lowrank"])
+@pytest.mark.parametrize("name", ["c2", "c3", "lin", "soc_only", "lowrank", "c5", "eq_dense", "packed_identity",
+                                  "many_packed"])
 @pytest.mark.parametrize("old_head", [False, True])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_matrix_core_backward_matches_lane_backward(name, old_head, dtype):
