@@ -136,6 +136,20 @@ int ensure_mfma_bwdg(const RayenPack* p) {
   return RAYEN_OK;
 }
 
+int ensure_mfma64_bwdg(const RayenPack* p) {
+  std::lock_guard<std::mutex> lock(p->mu);
+  if (p->mbg64_tried) return RAYEN_OK;
+  p->mbg64_tried = true;
+  if (!mfma64_bwdg_eligible(p)) return RAYEN_OK;
+  int64_t bytes = 0;
+  Mfma64BwdgImage* img = nullptr;
+  const int rc = mfma64_bwdg_build(p, &img, &bytes);
+  if (rc != RAYEN_OK) return rc;
+  p->mbg64 = img;
+  p->device_bytes += bytes;
+  return RAYEN_OK;
+}
+
 int ensure_mfma64_bwd(const RayenPack* p) {
   std::lock_guard<std::mutex> lock(p->mu);
   if (p->mb64_tried) return RAYEN_OK;
@@ -194,6 +208,11 @@ int project_bwd(const RayenPack* p, const T* v, int64_t B, int64_t ldv, const T*
       if (p->mb64 != nullptr)
         return mfma64_backward(p, p->mb64, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode,
                                static_cast<hipStream_t>(stream));
+      rc = ensure_mfma64_bwdg(p);
+      if (rc) return rc;
+      if (p->mbg64 != nullptr)
+        return mfma64_bwdg_backward(p, p->mbg64, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode,
+                                    static_cast<hipStream_t>(stream));
     }
   }
   rc = ensure_generic<T>(p);
@@ -267,6 +286,7 @@ void rayen_pack_destroy(RayenPack* p) {
   if (p->mb32) mfma_bwd_free(p->mb32);
   if (p->mb64) mfma64_bwd_free(p->mb64);
   if (p->mbg32) mfma_bwdg_free(p->mbg32);
+  if (p->mbg64) mfma64_bwdg_free(p->mbg64);
   if (p->q32) lmi_quad_free(p->q32);
   if (p->q64) lmi_quad_free(p->q64);
   if (switched) (void)hipSetDevice(prev);

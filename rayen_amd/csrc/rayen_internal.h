@@ -49,6 +49,7 @@ struct Mfma64Image;  // rayen_mfma_f64.hip
 struct MfmaBwdImage; // rayen_mfma_bwd.hip
 struct Mfma64BwdImage;  // rayen_mfma_bwd64.hip
 struct MfmaBwdgImage;   // rayen_mfma_bwdg.hip
+struct Mfma64BwdgImage; // rayen_mfma_bwdg64.hip
 struct LmiQuadImage;    // rayen_lmi_quad.h
 
 }  // namespace rayen
@@ -75,6 +76,8 @@ struct RayenPack {
   mutable bool mb64_tried = false;
   mutable rayen::MfmaBwdgImage* mbg32 = nullptr;
   mutable bool mbg32_tried = false;
+  mutable rayen::Mfma64BwdgImage* mbg64 = nullptr;
+  mutable bool mbg64_tried = false;
   mutable rayen::LmiQuadImage* q32 = nullptr;
   mutable rayen::LmiQuadImage* q64 = nullptr;
   mutable bool q32_tried = false, q64_tried = false;
@@ -142,6 +145,14 @@ void mfma_bwdg_free(MfmaBwdgImage* img);
 int mfma_bwdg_backward(const RayenPack* p, const MfmaBwdgImage* img, const float* v, int64_t B, int64_t ldv,
                        const float* kappa, const int32_t* active, const float* grad_y, int64_t ldg,
                        float* grad_v, int64_t ldgv, int old_mode, hipStream_t stream);
+
+// its fp64 twin (rayen_mfma_bwdg64.hip)
+bool mfma64_bwdg_eligible(const RayenPack* p);
+int mfma64_bwdg_build(const RayenPack* p, Mfma64BwdgImage** out, int64_t* bytes);
+void mfma64_bwdg_free(Mfma64BwdgImage* img);
+int mfma64_bwdg_backward(const RayenPack* p, const Mfma64BwdgImage* img, const double* v, int64_t B, int64_t ldv,
+                         const double* kappa, const int32_t* active, const double* grad_y, int64_t ldg,
+                         double* grad_v, int64_t ldgv, int old_mode, hipStream_t stream);
 
 // fp64 MFMA backward (rayen_mfma_bwd64.hip)
 bool mfma64_bwd_eligible(const RayenPack* p);

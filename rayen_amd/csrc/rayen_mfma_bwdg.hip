@@ -22,14 +22,6 @@
 
 namespace rayen {
 
-enum : int32_t { BI_PACK1 = 3, BI_PACK2 = 4 };
-
-struct BPack {
-  int32_t seg[4][2];   // [quad a][half]: caller's segment index sitting there, -1 = empty
-  int32_t pair_bits;   // bit a: the segment of quad a spans both halves (rank 5..8)
-  int32_t reserved;
-};
-
 struct MfmaBwdgImage {
   f32x4* S = nullptr;        // item tiles, fragment order, NQ float4 per lane and tile
   f32x4* NT = nullptr;       // NA_E' as [NKK tiles][NQG][64] float4 (K = k_pad), null when NA_E = I
@@ -333,19 +325,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwdg_ker
 // host
 // ---------------------------------------------------------------------------------------------
 
-bool mfma_bwdg_eligible(const RayenPack* p) {
-  if (p->n > 32 || p->k > 64 || !mfma_eligible(p)) return false;
-  int64_t tiles = 0;
-  int small = 0;
-  for (const RayenSegment& g : p->segs) {
-    if (g.type == RAYEN_SEG_LMI) return false;
-    if (!bwd_quad_like(g)) continue;
-    if (is_small_factor(g)) ++small;
-    else tiles += n_pad_of(p->n) / 32;
-  }
-  tiles += 2 * ((small + 3) / 4);  // at least four (rank 5..8) and at most eight segments per packed tile pair
-  return tiles <= 96;
-}
+bool mfma_bwdg_eligible(const RayenPack* p) { return mfma_eligible(p) && bwdg_tiles_eligible(p); }
 
 void mfma_bwdg_free(MfmaBwdgImage* img) {
   if (img == nullptr) return;
@@ -372,98 +352,8 @@ int mfma_bwdg_build(const RayenPack* p, MfmaBwdgImage** out, int64_t* bytes) {
   TileLayout b(n);
   std::vector<BItem> items;
   std::vector<BPack> packs;
-  std::vector<int32_t> seg_aux(p->segs.size() + 1, -1);
-  auto blank = [](int type) { BItem it; std::memset(&it, 0, sizeof(it)); it.type = type; return it; };
-
-  // ---- dense forms for everything that is not a small factor (same as rayen_bwd_tiles.h)
-  for (size_t s = 0; s < p->segs.size(); ++s) {
-    const RayenSegment& g = p->segs[s];
-    if (g.type == RAYEN_SEG_QUAD_FAC) seg_aux[s] = g.aux_row;
-    if (!bwd_quad_like(g) || is_small_factor(g)) continue;
-    std::vector<double> S((size_t)n * n, 0.0);
-    if (g.type == RAYEN_SEG_QUAD_SYM) {
-      for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) S[(size_t)i * n + j] = W[(size_t)(g.row0 + i) * n + j];
-    } else {
-      for (int r = 0; r < g.nrows; ++r) {
-        const double* row = W + (size_t)(g.row0 + r) * n;
-        for (int i = 0; i < n; ++i) {
-          if (row[i] == 0.0) continue;
-          for (int j = 0; j < n; ++j) S[(size_t)i * n + j] += row[i] * row[j];
-        }
-      }
-    }
-    for (int tp = 0; tp < nkk; ++tp) {
-      std::vector<const double*> rows;
-      for (int r = 32 * tp; r < 32 * tp + 32 && r < n; ++r) rows.push_back(S.data() + (size_t)r * n);
-      b.add_tile(rows, n);
-      BItem it = blank(g.type == RAYEN_SEG_SOC ? BI_SOC : BI_QUAD);
-      it.flags = (tp == 0 ? MF_FIRST : 0) | (tp == nkk - 1 ? MF_LAST : 0);
-      it.seg = (int32_t)s;
-      it.tp = tp;
-      it.aux_row = g.aux_row;
-      it.f0 = (float)g.f0;
-      it.f1 = (float)g.f1;
-      items.push_back(it);
-    }
-  }
-  // ---- small factors: eight half-quads of rows per tile (placement of rayen_tiles.h), each tile followed
-  // by its transpose
-  {
-    std::vector<const double*> rows(32, nullptr);
-    BPack pk;
-    int used = 0;
-    auto reset = [&]() {
-      std::fill(rows.begin(), rows.end(), nullptr);
-      std::memset(&pk, 0, sizeof(pk));
-      for (int a = 0; a < 4; ++a) for (int h = 0; h < 2; ++h) pk.seg[a][h] = -1;
-      used = 0;
-    };
-    auto flush = [&]() {
-      if (used == 0) return;
-      BItem it1 = blank(BI_PACK1);
-      it1.aux_row = (int32_t)packs.size();
-      items.push_back(it1);
-      b.add_tile(rows, n);
-      // transposed: raw2[r][32 tp + kk] = tile[kk][32 tp + r]
-      std::vector<std::vector<double>> tr(32, std::vector<double>(np, 0.0));
-      for (int kk = 0; kk < 32; ++kk) {
-        if (rows[kk] == nullptr) continue;
-        for (int e = 0; e < n; ++e) tr[e % 32][32 * (e / 32) + kk] = rows[kk][e];
-      }
-      std::vector<const double*> trp;
-      for (auto& r : tr) trp.push_back(r.data());
-      BItem it2 = blank(BI_PACK2);
-      items.push_back(it2);
-      b.add_tile(trp, np);
-      packs.push_back(pk);
-      reset();
-    };
-    reset();
-    for (size_t s = 0; s < p->segs.size(); ++s) {
-      const RayenSegment& g = p->segs[s];
-      if (!is_small_factor(g)) continue;
-      const bool pair = g.nrows > 4;
-      if (pair && (used & 1)) ++used;
-      if (used + (pair ? 2 : 1) > 8) flush();
-      const int a = used / 2, h = used & 1;
-      for (int r = 0; r < g.nrows; ++r) rows[8 * a + 4 * h + r] = W + (size_t)(g.row0 + r) * n;
-      pk.seg[a][h] = (int32_t)s;
-      if (pair) { pk.seg[a][1] = (int32_t)s; pk.pair_bits |= 1 << a; }
-      used += pair ? 2 : 1;
-    }
-    flush();
-  }
-  // a PACK1 / PACK2 pair must not straddle the kernel's (it, it+1) unrolling in a way that matters: the
-  // kernel keeps wreg across process() calls, so any order works; only the count must be even
-  if (items.size() % 2) {
-    items.push_back(blank(BI_NOP));
-    b.add_tile({}, n);
-  }
-  b.add_tile({}, n);  // spare tile for the prefetch
-  const int n_real = (int)items.size();
-  if (items.empty()) items.push_back(blank(BI_NOP));
-  if (packs.empty()) { BPack pk; std::memset(&pk, 0, sizeof(pk)); packs.push_back(pk); }
+  std::vector<int32_t> seg_aux;
+  const int n_real = layout_bwdg_tiles(p, b, items, packs, seg_aux);
 
   MfmaBwdgImage* img = new MfmaBwdgImage();
   img->nkk = nkk;
