@@ -395,3 +395,61 @@ def test_golden_rayen_old_head(name, tag, dtype, tol):
     assert np.max(rel_err_rows(y, z["y_old" + tag])) <= tol
     assert oracle.max_violation(raw, y) <= max(VIOLATION_TOL if tag == "32" else 1e-11,
                                                3 * oracle.max_violation(raw, z["y_old" + tag]))
+
+
+# --------------------------------------------------------------------------- LMI sets of the quad kernel's family
+def _lmi_cases():
+    rng = np.random.default_rng(12)
+
+    def lmi(k, r):
+        F = []
+        for _ in range(k):
+            T = rng.uniform(-1, 1, size=(r, r))
+            F.append((T + T.T) / 2)
+        T = rng.uniform(-1, 1, size=(r, r))
+        F.append(T @ T.T + 0.5 * np.eye(r))
+        return F
+
+    cases = {}
+    for name, k, r, m, n_eq in (("r3_lin", 5, 3, 12, 0), ("r7", 6, 7, 0, 0), ("r12_lin_eq", 9, 12, 20, 3),
+                                ("r16", 8, 16, 0, 0), ("r24_lin", 6, 24, 9, 0), ("r30_eq", 7, 30, 0, 2)):
+        raw = workloads.random_lmi(k, r, seed=0)
+        raw["F"] = lmi(k, r)
+        if m:
+            raw["A1"] = rng.uniform(-1, 1, size=(m, k))
+            raw["b1"] = rng.uniform(0.1, 1.0, size=(m, 1))
+        if n_eq:
+            raw["A2"] = rng.uniform(-1, 1, size=(n_eq, k))
+            raw["b2"] = np.zeros((n_eq, 1))                     # y0 = 0 satisfies them
+        cases[name] = raw
+    return cases
+
+
+@pytest.mark.parametrize("name", ["r3_lin", "r7", "r12_lin_eq", "r16", "r24_lin", "r30_eq"])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, FP32_TOL), (torch.float64, FP64_TOL)])
+def test_lmi_with_linear_rows_and_equalities(name, dtype, tol):
+    """[linear rows] + one LMI, with and without equality constraints, every size class of the four-lanes-per-
+    sample kernel (fp64 above 24 x 24 falls to the lane-per-sample kernel); small and ragged batches."""
+    from rayen_amd._lib import RayenError
+    raw = _lmi_cases()[name]
+    cs, layer = _layer(raw, dtype)
+    gen = torch.Generator().manual_seed(6)
+    if dtype == torch.float64 and name == "r30_eq":
+        # 30 x 30 in fp64 fits neither the quad kernel's registers nor a lane's LDS column: refused, loudly
+        with pytest.raises(RayenError):
+            layer(torch.zeros(4, cs.n, 1, dtype=dtype).cuda())
+        return
+    for B in (1, 67, 1500):
+        x = torch.empty(B, cs.n, 1, dtype=torch.float32).uniform_(-2.0, 2.0, generator=gen).to(dtype)
+        x[: min(B, 2)] *= 1e-3
+        y = layer(x.cuda()).cpu().numpy()[:, :, 0]
+        y_ref = _oracle_forward(cs, x, dtype)
+        # lambda_max of a 30 x 30 matrix in fp32: the oracle's eigvalsh and the Sturm bracket agree to ~1e-5 of kappa
+        assert np.max(rel_err_rows(y, y_ref)) <= (tol if dtype == torch.float64 or cs.lmic.all_F[0].shape[0] < 20 else 3e-5)
+        dp, _ = layer.device_pack(torch.device("cuda", 0))
+        try:
+            y_gen, _, _ = ops.project_raw(x[:, :, 0].cuda(), dp, force_generic=True)
+        except RayenError:                                      # fp64 beyond ~21 x 21 has no lane-per-sample kernel
+            assert dtype == torch.float64 and cs.lmic.all_F[0].shape[0] > 20
+            continue
+        assert np.max(rel_err_rows(y, y_gen.cpu().numpy())) <= (1e-5 if dtype == torch.float32 else 1e-9)
