@@ -213,9 +213,11 @@ inline int layout_bwdg_tiles(const RayenPack* p, TileLayout& b, std::vector<BIte
 
 }
 
-// Shape test of the general backward kernels: n <= 32 (one 32-column block of v), k <= 64, no LMI.
+constexpr int kBwdgMaxN = 64;
+
+// Shape test of the general backward kernels: n, k <= 64, no LMI (the fp64 twin adds n <= 32).
 inline bool bwdg_tiles_eligible(const RayenPack* p) {
-  if (p->n > 32 || p->k > 64) return false;
+  if (p->n > kBwdgMaxN || p->k > 64) return false;
   int64_t tiles = 0;
   int small = 0;
   for (const RayenSegment& g : p->segs) {

@@ -1,8 +1,8 @@
 // fp32 matrix-core backward, general shapes: sets with equality constraints (NA_E != I, so the incoming
 // gradient is first pulled back, t = NA_E' g, on the matrix cores) and sets with many small low-rank
 // quadratics (the packed tiles of the forward).  rayen_mfma_bwd.hip keeps the tuned kernel for NA_E = I with
-// dense forms only; this one serves what that one declines when n <= 32 and k <= 64 (no LMI): with two
-// 32-column blocks of v the masked product's extra accumulators no longer fit the register file.
+// dense forms only; this one serves what that one declines (n, k <= 64, no LMI); with two 32-column blocks
+// of v a wave takes one sample tile instead of two (and still spills: 1.6x the lane-per-sample backward).
 //
 //   grad_v = s t - [kappa > 1] s^2 (t . v) grad kappa(v),   t = NA_E' g,   s = 1 / max(1, kappa)
 //
@@ -40,7 +40,8 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwdg_ker
     int k, const float* __restrict__ v, int64_t B, int64_t ldv, int vec_v, const float* __restrict__ kappa,
     const int32_t* __restrict__ active, const float* __restrict__ gy, int64_t ldg, int vec_g,
     float* __restrict__ gv, int64_t ldgv, int vec_o, int old_mode) {
-  constexpr int NT = 2, NQ = NKK * 4, KK = NKK * 16, NP = NKK * 32;
+  constexpr int NT = NKK == 1 ? 2 : 1;  // two 32-column blocks of v leave registers for one sample tile only
+  constexpr int NQ = NKK * 4, KK = NKK * 16, NP = NKK * 32;
   constexpr int NKL = NKG > NKK ? NKG : NKK, LSTR = NKL * 32 + 4;
   constexpr int NQG = NKG * 4, KG = NKG > 0 ? NKG * 16 : 1;
   __shared__ __attribute__((aligned(16))) float line_lds[kMfmaWaves][32][LSTR];
@@ -402,7 +403,8 @@ template <int NKK, int NKG>
 static int launch_bwdg(const RayenPack* p, const MfmaBwdgImage* img, const float* v, int64_t B, int64_t ldv,
                        const float* kappa, const int32_t* active, const float* gy, int64_t ldg, float* gv,
                        int64_t ldgv, int old_mode, hipStream_t stream) {
-  const int64_t n_groups = (B + 63) / 64;
+  constexpr int per_wave = NKK == 1 ? 64 : 32;
+  const int64_t n_groups = (B + per_wave - 1) / per_wave;
   const int64_t slots = (int64_t)img->n_simd * kMfmaWavesPerSimd;
   const int64_t rounds = (n_groups + slots - 1) / slots;
   const int64_t waves = (n_groups + rounds - 1) / rounds;
@@ -425,6 +427,8 @@ int mfma_bwdg_backward(const RayenPack* p, const MfmaBwdgImage* img, const float
   RAYEN_BWDG_CASE(1, 0)
   RAYEN_BWDG_CASE(1, 1)
   RAYEN_BWDG_CASE(1, 2)
+  RAYEN_BWDG_CASE(2, 0)
+  RAYEN_BWDG_CASE(2, 2)
 #undef RAYEN_BWDG_CASE
   return RAYEN_E_UNSUPPORTED;
 }

@@ -335,7 +335,7 @@ __global__ __launch_bounds__(kG64Waves * 64, 2) void mfma64_bwdg_kernel(
 // host
 // ---------------------------------------------------------------------------------------------
 
-bool mfma64_bwdg_eligible(const RayenPack* p) { return mfma64_eligible(p) && bwdg_tiles_eligible(p); }
+bool mfma64_bwdg_eligible(const RayenPack* p) { return p->n <= 32 && mfma64_eligible(p) && bwdg_tiles_eligible(p); }
 
 void mfma64_bwdg_free(Mfma64BwdgImage* img) {
   if (img == nullptr) return;

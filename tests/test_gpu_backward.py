@@ -155,6 +155,7 @@ def _bwd_sets():
         many_packed["q"].append(rng.uniform(-1, 1, size=(32, 1)))
         many_packed["r"].append(rng.uniform(-1, 0, size=(1, 1)))
     return {
+        "eq_packed_n50": workloads.corridor_like(k=60, n_eq=10, m=96, n_quad=20, rank=3, seed=65),   # two blocks of v
         "many_packed": many_packed,
         "c5": workloads.make_raw("c5", seed=55),                  # equalities + 72 packed rank-3 quadratics
         "eq_dense": eq_dense,
@@ -168,7 +169,7 @@ def _bwd_sets():
 
 
 @pytest.mark.parametrize("name", ["c2", "c3", "lin", "soc_only", "lowrank", "c5", "eq_dense", "packed_identity",
-                                  "many_packed"])
+                                  "many_packed", "eq_packed_n50"])
 @pytest.mark.parametrize("old_head", [False, True])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_matrix_core_backward_matches_lane_backward(name, old_head, dtype):
