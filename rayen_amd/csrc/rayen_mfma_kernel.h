@@ -512,7 +512,10 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_fwd_kern
 #pragma unroll
           for (int c = 1; c < 4; ++c) qs = fmaf(acc[t][4 * a + c], acc[t][4 * a + c], qs);
           if (pair) qs += xhalf(qs);
-          const float kc = aux_lds[wave][t][slot & 31][col] + sqrtf(qs);
+          // (v_sqrt_f32, 1 ulp: the IEEE-exact sqrtf costs ~10 more VALU instructions per constraint, and
+          // VALU work is serial with the MFMA stream; 72 small constraints per group in config 5)
+          // (kept to the general-shape instance so that the NA_E = I instances stay the code they were tuned as)
+          const float kc = aux_lds[wave][t][slot & 31][col] + (STAGED ? __builtin_amdgcn_sqrtf(qs) : sqrtf(qs));
           if (sid >= 0 && kc > kap[t]) { kap[t] = kc; aseg[t] = sid; arow[t] = 0; }
         }
       }
