@@ -671,10 +671,14 @@ __global__ __launch_bounds__(BLOCK) void generic_bwd_kernel(
   const int k_pad = (k + kRowBlock - 1) / kRowBlock * kRowBlock;
   T* vT = reinterpret_cast<T*>(smem_raw);  // [n_pad][LD]
   T* tT = vT + (size_t)n_pad * LD;         // [n_pad][LD]  N'g, finally the result
-  T* uT = tT + (size_t)n_pad * LD;         // [n_pad][LD]  grad kappa
-  T* gT = uT + (size_t)n_pad * LD;         // [k_pad][LD]  grad_y (unused when NA_E = I)
-  T* wT = gT + (size_t)(NTg ? k_pad : 0) * LD;  // [w_rows][LD]  U v / M v of the active segment
-  T* lmi = wT + (size_t)w_rows * LD;       // [lmi_words][BLOCK]
+  // One region serves grad_y first ([k_pad][LD], only until t = NA_E' g is formed) and then grad kappa
+  // ([n_pad][LD]) followed by U v / M v of the active segment ([w_rows][LD]): after the fill every lane
+  // touches its own column only, so the hand-over needs no barrier.
+  T* gT = tT + (size_t)n_pad * LD;
+  T* uT = gT;
+  T* wT = uT + (size_t)n_pad * LD;
+  const int shared_rows = (NTg != nullptr && k_pad > n_pad + w_rows) ? k_pad : n_pad + w_rows;
+  T* lmi = gT + (size_t)shared_rows * LD;  // [lmi_words][BLOCK]
 
   const int tid = threadIdx.x;
   const int64_t b0 = (int64_t)blockIdx.x * BLOCK;
@@ -689,7 +693,6 @@ __global__ __launch_bounds__(BLOCK) void generic_bwd_kernel(
     }
     vT[j * LD + bl] = x;
     tT[j * LD + bl] = g;
-    uT[j * LD + bl] = T(0);
   }
   if (NTg != nullptr) {
     for (int idx = tid; idx < BLOCK * k_pad; idx += BLOCK) {
@@ -713,6 +716,7 @@ __global__ __launch_bounds__(BLOCK) void generic_bwd_kernel(
       for (int r = 0; r < kRowBlock; ++r) tcol[(b * kRowBlock + r) * LD] = acc[r];
     }
   }
+  for (int j = 0; j < n_pad; ++j) ucol[j * LD] = T(0);  // (the region held this lane's grad_y column until here)
   T tv = T(0);
   for (int j = 0; j < n; ++j) tv = fma_(tcol[j * LD], vcol[j * LD], tv);
 
@@ -866,7 +870,8 @@ template <typename T>
 static size_t bwd_lds_bytes(const RayenPack* p, int w_rows, int lmi_words, int block) {
   const int n_pad = (p->n + kRowBlock - 1) / kRowBlock * kRowBlock;
   const int k_pad = p->out_identity ? 0 : (p->k + kRowBlock - 1) / kRowBlock * kRowBlock;
-  return sizeof(T) * ((size_t)(3 * n_pad + k_pad + w_rows) * (block + 1) + (size_t)lmi_words * block);
+  const int shared_rows = k_pad > n_pad + w_rows ? k_pad : n_pad + w_rows;  // grad_y, then grad kappa + U v
+  return sizeof(T) * ((size_t)(2 * n_pad + shared_rows) * (block + 1) + (size_t)lmi_words * block);
 }
 
 template <typename T, int BLOCK>

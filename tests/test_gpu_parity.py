@@ -453,3 +453,137 @@ def test_lmi_with_linear_rows_and_equalities(name, dtype, tol):
             assert dtype == torch.float64 and cs.lmic.all_F[0].shape[0] > 20
             continue
         assert np.max(rel_err_rows(y, y_gen.cpu().numpy())) <= (1e-5 if dtype == torch.float32 else 1e-9)
+
+
+# --------------------------------------------------------------------------- randomised constraint sets
+def _random_set(seed):
+    """A random mix of families, sizes, ranks and equality constraints around a random interior point."""
+    rng = np.random.default_rng(seed)
+    k = int(rng.choice([3, 5, 8, 13, 16, 24, 31, 32, 33, 40, 48, 64, 70]))
+    n_eq = int(rng.integers(0, max(1, k // 4) + 1)) if rng.random() < 0.5 else 0
+    raw = workloads._empty(k)
+    y0 = rng.uniform(-1, 1, size=(k, 1))
+    raw["y0"] = y0
+    if n_eq:
+        raw["A2"] = rng.uniform(-1, 1, size=(n_eq, k))
+        raw["b2"] = raw["A2"] @ y0
+    m = int(rng.choice([0, 1, 7, 32, 45, 130]))
+    if m:
+        raw["A1"] = rng.uniform(-1, 1, size=(m, k))
+        raw["b1"] = raw["A1"] @ y0 + rng.uniform(0.1, 1.0, size=(m, 1))
+    for _ in range(int(rng.choice([0, 1, 2, 5, 11, 40]))):
+        rank = int(rng.choice([1, 2, 3, 4, 5, 8, 9, max(1, k // 2), k]))
+        C = rng.uniform(-1, 1, size=(min(rank, k), k))
+        P = C.T @ C
+        q = rng.uniform(-1, 1, size=(k, 1))
+        g0 = 0.5 * y0.T @ P @ y0 + q.T @ y0
+        raw["P"].append(P)
+        raw["q"].append(q)
+        raw["r"].append(-g0 - rng.uniform(0.1, 1.0, size=(1, 1)))
+    r_M = int(rng.choice([1, 3, k, k + 5]))                     # (like the reference, one block shape per set)
+    for _ in range(int(rng.choice([0, 0, 1, 3]))):
+        M = rng.uniform(-1, 1, size=(r_M, k))
+        s = rng.uniform(-1, 1, size=(r_M, 1))
+        c = rng.uniform(-1, 1, size=(k, 1))
+        d = np.linalg.norm(M @ y0 + s) - c.T @ y0 + rng.uniform(0.2, 1.0, size=(1, 1))
+        raw["M"].append(M); raw["s"].append(s); raw["c"].append(c); raw["d"].append(d)
+    if rng.random() < 0.3 and k <= 16:
+        r = int(rng.choice([2, 3, 6, 11]))
+        F = []
+        for _ in range(k):
+            T = rng.uniform(-1, 1, size=(r, r))
+            F.append((T + T.T) / 2)
+        T = rng.uniform(-1, 1, size=(r, r))
+        H = T @ T.T + 0.5 * np.eye(r)
+        F.append(H - sum(y0[i, 0] * F[i] for i in range(k)))     # sum y0_i F_i + F_k = H > 0
+        raw["F"] = F
+    if m == 0 and not raw["P"] and not raw["M"] and not len(raw["F"]):
+        raw["A1"] = rng.uniform(-1, 1, size=(4, k))
+        raw["b1"] = raw["A1"] @ y0 + rng.uniform(0.1, 1.0, size=(4, 1))
+    return raw
+
+
+def _relative_violation(raw, y):
+    """max over constraints and samples of residual / (sum of |terms|)."""
+    y = np.asarray(y, dtype=np.float64)
+    ay = np.abs(y)
+    worst = 0.0
+    if raw["A1"] is not None:
+        res = y @ raw["A1"].T - raw["b1"].T
+        worst = max(worst, float(np.max(res / (ay @ np.abs(raw["A1"]).T + np.abs(raw["b1"]).T))))
+    if raw["A2"] is not None:
+        res = np.abs(y @ raw["A2"].T - raw["b2"].T)
+        worst = max(worst, float(np.max(res / (ay @ np.abs(raw["A2"]).T + np.abs(raw["b2"]).T + 1e-300))))
+    for P, q, r in zip(raw["P"], raw["q"], raw["r"]):
+        res = 0.5 * np.einsum("bi,ij,bj->b", y, P, y) + y @ q[:, 0] + r[0, 0]
+        mag = 0.5 * np.einsum("bi,ij,bj->b", ay, np.abs(P), ay) + ay @ np.abs(q[:, 0]) + abs(r[0, 0])
+        worst = max(worst, float(np.max(res / mag)))
+    for M, s_, c, d in zip(raw["M"], raw["s"], raw["c"], raw["d"]):
+        res = np.linalg.norm(y @ M.T + s_.T, axis=1) - y @ c[:, 0] - d[0, 0]
+        mag = np.linalg.norm(ay @ np.abs(M).T + np.abs(s_).T, axis=1) + ay @ np.abs(c[:, 0]) + abs(d[0, 0])
+        worst = max(worst, float(np.max(res / mag)))
+    if len(raw["F"]):
+        F = raw["F"]
+        S = np.einsum("bi,ijk->bjk", y, np.array(F[:-1])) + F[-1]
+        lam = np.linalg.eigvalsh(S)[:, 0]
+        mag = np.einsum("bi,i->b", ay, np.array([np.linalg.norm(Fi, 2) for Fi in F[:-1]])) + np.linalg.norm(F[-1], 2)
+        worst = max(worst, float(np.max(-lam / mag)))
+    return worst
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("RAYEN_FUZZ_SEEDS", "100")))))
+def test_random_constraint_sets(seed):
+    """Every kernel that serves the set agrees with the oracle (fp32 1e-5, fp64 1e-9), the outputs are feasible,
+    and the tracked forward + backward agree with the lane-per-sample backward."""
+    raw = _random_set(1000 + seed)
+    rng = np.random.default_rng(seed)
+    B = int(rng.choice([1, 31, 64, 65, 1000, 4099]))
+    for dtype, tol in ((torch.float32, FP32_TOL), (torch.float64, FP64_TOL)):
+        cs, layer = _layer(raw, dtype)
+        gen = torch.Generator().manual_seed(seed)
+        x = torch.empty(B, cs.n, 1, dtype=torch.float32).uniform_(-2.0, 2.0, generator=gen).to(dtype)
+        y = layer(x.cuda()).cpu().numpy()[:, :, 0]
+        assert np.all(np.isfinite(y))
+        try:
+            y_ref = _oracle_forward(cs, x, dtype)
+        except AssertionError:
+            # the reference op sequence asserts (NaN) when a ray never meets a cone (negative discriminant,
+            # CM:342); the kernels give that cone kappa = 0, its exact value: only feasibility can be checked
+            assert _relative_violation(raw, y) <= (1e-5 if dtype == torch.float32 else 1e-13), (seed, dtype)
+            continue
+        lmi_fp32 = dtype == torch.float32 and len(raw["F"]) > 0
+        if dtype == torch.float32:
+            # random sets can be ill-conditioned in fp32 (cancellation in a radicand).  Judge both fp32 results
+            # against the fp64 truth; the yardsticks are the reference's own fp32 arithmetic (which varies with
+            # the host's summation order) and the error that the fp32 ROUNDING OF THE CONSTANTS alone causes
+            # (the packed constants evaluated in fp64 arithmetic, tests/packed_eval.py)
+            import packed_eval
+            y_true = _oracle_forward(cs, x.double(), torch.float64)
+            ours, theirs = rel_err_rows(y, y_true).max(), rel_err_rows(y_ref, y_true).max()
+            y_const, _, _ = packed_eval.evaluate(layer.packed_constants(), x[:, :, 0].double().numpy())
+            inherent = rel_err_rows(y_const, y_true).max()
+            bound = max(3e-5 if lmi_fp32 else tol, 4.0 * theirs, 8.0 * inherent)
+            assert ours <= bound, (seed, ours, theirs, inherent)
+        else:
+            assert np.max(rel_err_rows(y, y_ref)) <= tol, (seed, dtype)
+        # feasibility relative to each constraint's own magnitude (sum of the absolute values of its terms): random
+        # sets have |P| up to ~30 k, where one fp32 ulp of y already moves the residual by 1e-3
+        if dtype == torch.float32:
+            rel_bound = max(5e-6, 4 * _relative_violation(raw, y_ref), 8 * _relative_violation(raw, y_const))
+            assert _relative_violation(raw, y) <= min(rel_bound, 1e-4), (seed, dtype)
+        else:
+            assert _relative_violation(raw, y) <= 1e-13, (seed, dtype)
+        dp, _ = layer.device_pack(torch.device("cuda", 0))
+        v = x[:, :, 0].cuda()
+        y_gen, _, _ = ops.project_raw(v, dp, force_generic=True)
+        if dtype == torch.float32:
+            assert rel_err_rows(y_gen.cpu().numpy(), y_true).max() <= bound
+        else:
+            assert np.max(rel_err_rows(y, y_gen.cpu().numpy())) <= 10 * tol
+        _, kappa, active = ops.project_raw(v, dp, want_active=True)
+        g = torch.empty(B, cs.k, dtype=dtype).uniform_(-1, 1, generator=gen).cuda()
+        got = ops.backward_raw(v, kappa, active, g, dp).cpu().double()
+        want = ops.backward_raw(v, kappa, active, g, dp, force_generic=True).cpu().double()
+        scale = want.abs().amax(1).clamp_min(1e-12)
+        err = (got - want).abs().amax(1) / scale
+        assert float((err <= (1e-3 if dtype == torch.float32 else 1e-8)).double().mean()) >= 0.99, (seed, dtype, err.max())
