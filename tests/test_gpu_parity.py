@@ -587,3 +587,51 @@ def test_random_constraint_sets(seed):
         scale = want.abs().amax(1).clamp_min(1e-12)
         err = (got - want).abs().amax(1) / scale
         assert float((err <= (1e-3 if dtype == torch.float32 else 1e-8)).double().mean()) >= 0.99, (seed, dtype, err.max())
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("RAYEN_FUZZ_SEEDS", "100")) // 2)))
+def test_random_modules(seed):
+    """Random set x head (RAYEN / RAYEN_old) x mapper (none / nn.Linear of a random width, fused when it can be) x
+    batch: the module against the oracle fed with the same mapper output, in fp32 and fp64."""
+    raw = _random_set(5000 + seed)
+    rng = np.random.default_rng(7000 + seed)
+    method = "RAYEN_old" if rng.random() < 0.35 else "RAYEN"
+    input_dim = int(rng.choice([0, 0, 4, 8, 20, 33, 64, 100]))
+    B = int(rng.choice([1, 33, 64, 127, 2000]))
+    for dtype, tol in ((torch.float32, FP32_TOL), (torch.float64, FP64_TOL)):
+        prev = torch.get_default_dtype()
+        torch.set_default_dtype(dtype)
+        try:
+            cs = workloads.build_constraints(raw)
+            torch.manual_seed(seed)
+            layer = ConstraintModule(cs, input_dim=input_dim or None, method=method, create_map=bool(input_dim)).cuda()
+        finally:
+            torch.set_default_dtype(prev)
+        gen = torch.Generator().manual_seed(seed)
+        width = input_dim or layer.getDimAfterMap()
+        x = torch.empty(B, width, dtype=torch.float32).uniform_(-1.5, 1.5, generator=gen).to(dtype)
+        with torch.no_grad():
+            y = layer(x.cuda()).cpu().numpy()[:, :, 0]
+            q = layer.mapper(x.cuda()).cpu() if input_dim else x          # what the projection was fed with
+        assert y.shape == (B, cs.k) and np.all(np.isfinite(y))
+        buf = oracle.precompute(csd_from_cs(cs), torch.float64)
+        try:
+            y_true = oracle.forward(buf, q.double().unsqueeze(2), method=method).numpy()[:, :, 0]
+        except AssertionError:                                         # a ray that never meets a cone (see above)
+            continue
+        err = rel_err_rows(y, y_true).max()
+        if dtype == torch.float64:
+            assert err <= 1e-8, (seed, method, input_dim, err)
+        else:
+            import packed_eval
+            try:
+                y32 = oracle.forward(oracle.precompute(csd_from_cs(cs), torch.float32), q.float().unsqueeze(2),
+                                     method=method).numpy()[:, :, 0]
+                theirs = rel_err_rows(y32, y_true).max()
+            except AssertionError:                                     # (only the fp32 discriminant went negative)
+                theirs = 0.0
+            bound = max(3e-5 if len(raw["F"]) else tol, 4.0 * theirs)
+            if method == "RAYEN":
+                y_const, _, _ = packed_eval.evaluate(layer.packed_constants(), q.double().numpy()[:, :cs.n])
+                bound = max(bound, 8.0 * rel_err_rows(y_const, y_true).max())
+            assert err <= bound, (seed, method, input_dim, err, theirs)
