@@ -209,3 +209,44 @@ def test_matrix_core_backward_matches_lane_backward(name, old_head, dtype):
     tol = (5e-3 if old_head else 2e-4) if dtype == torch.float32 else (1e-6 if old_head else 1e-9)
     assert (err <= tol).double().mean() >= (0.99 if old_head and dtype == torch.float32 else 0.999), torch.sort(err).values[-5:]
     assert float(err.median()) <= tol / 10
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("RAYEN_FUZZ_SEEDS", "100")) // 3)))
+def test_random_sets_gradients_match_oracle_autograd(seed):
+    """fp64 gradients of random constraint sets (whatever backward kernel serves them) against autograd through
+    the fp64 oracle; both heads."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("_parity", os.path.join(os.path.dirname(__file__), "test_gpu_parity.py"))
+    parity = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(parity)
+    raw = parity._random_set(9000 + seed)
+    rng = np.random.default_rng(seed)
+    method = "RAYEN_old" if rng.random() < 0.3 else "RAYEN"
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        cs = workloads.build_constraints(raw)
+        layer = ConstraintModule(cs, create_map=False, method=method).cuda()
+    finally:
+        torch.set_default_dtype(prev)
+    B = int(rng.choice([17, 64, 500]))
+    gen = torch.Generator().manual_seed(seed)
+    width = layer.getDimAfterMap()
+    x = torch.empty(B, width, 1, dtype=torch.float64).uniform_(-1.5, 1.5, generator=gen)
+    G = torch.empty(B, cs.k, dtype=torch.float64).uniform_(-1, 1, generator=gen)
+    buf = oracle.precompute(csd_from_cs(cs), torch.float64)
+    xr = x.clone().requires_grad_(True)
+    try:
+        y_ref = oracle.forward(buf, xr, method=method)
+    except AssertionError:
+        pytest.skip("the reference asserts on this set (a ray that never meets a cone)")
+    (y_ref[:, :, 0] * G).sum().backward()
+    want = xr.grad[:, :, 0]
+    xg = x.cuda().requires_grad_(True)
+    (layer(xg)[:, :, 0] * G.cuda()).sum().backward()
+    got = xg.grad[:, :, 0].cpu()
+    assert torch.isfinite(got).all()
+    scale = want.abs().amax(1).clamp_min(1e-12)
+    err = (got - want).abs().amax(1) / scale
+    # a sample on a kink of kappa (two constraints tie) may take the other one-sided derivative
+    assert float((err <= 1e-6).double().mean()) >= 0.98, (seed, method, torch.sort(err).values[-5:])
