@@ -188,6 +188,13 @@ int project_bwd(const RayenPack* p, const T* v, int64_t B, int64_t ldv, const T*
   int rc = check_device(p);
   if (rc) return rc;
   if constexpr (sizeof(T) == 4) {
+    if (!force_generic && !old_mode) {
+      rc = ensure_quad32(p);
+      if (rc) return rc;
+      if (p->q32 != nullptr && lmi_quad_bwd_serves_f32(p, p->q32))
+        return lmi_quad_backward_f32(p, p->q32, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv,
+                                     static_cast<hipStream_t>(stream));
+    }
     if (!force_generic) {
       rc = ensure_mfma_bwd(p);
       if (rc) return rc;
@@ -202,6 +209,13 @@ int project_bwd(const RayenPack* p, const T* v, int64_t B, int64_t ldv, const T*
     }
   }
   if constexpr (sizeof(T) == 8) {
+    if (!force_generic && !old_mode) {
+      rc = ensure_quad64(p);
+      if (rc) return rc;
+      if (p->q64 != nullptr && lmi_quad_bwd_serves_f64(p, p->q64))
+        return lmi_quad_backward_f64(p, p->q64, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv,
+                                     static_cast<hipStream_t>(stream));
+    }
     if (!force_generic) {
       rc = ensure_mfma64_bwd(p);
       if (rc) return rc;

@@ -154,6 +154,15 @@ int mfma64_bwdg_backward(const RayenPack* p, const Mfma64BwdgImage* img, const d
                          const double* kappa, const int32_t* active, const double* grad_y, int64_t ldg,
                          double* grad_v, int64_t ldgv, int old_mode, hipStream_t stream);
 
+bool lmi_quad_bwd_serves_f32(const RayenPack* p, const LmiQuadImage* img);
+bool lmi_quad_bwd_serves_f64(const RayenPack* p, const LmiQuadImage* img);
+int lmi_quad_backward_f32(const RayenPack* p, const LmiQuadImage* img, const float* v, int64_t B, int64_t ldv,
+                          const float* kappa, const int32_t* active, const float* grad_y, int64_t ldg,
+                          float* grad_v, int64_t ldgv, hipStream_t stream);
+int lmi_quad_backward_f64(const RayenPack* p, const LmiQuadImage* img, const double* v, int64_t B, int64_t ldv,
+                          const double* kappa, const int32_t* active, const double* grad_y, int64_t ldg,
+                          double* grad_v, int64_t ldgv, hipStream_t stream);
+
 // fp64 MFMA backward (rayen_mfma_bwd64.hip)
 bool mfma64_bwd_eligible(const RayenPack* p);
 int mfma64_bwd_build(const RayenPack* p, Mfma64BwdImage** out, int64_t* bytes);

@@ -29,6 +29,7 @@ namespace rayen {
 struct LmiQuadImage {
   void* data = nullptr;   // device: [Wf n*R*R | Wlin m*n | N k*n (absent when identity) | y0 k] of T
   int32_t* lin_id = nullptr;  // device: [m][2] (segment, W row) of every linear row
+  void* wrow = nullptr;       // device: [n_rows][n] of T, row-major W (backward: the active linear row)
   int r = 0, R = 0, n = 0, k = 0, m = 0, identity = 0, lmi_seg = 0;
   int64_t elems = 0;      // number of T elements in `data`
   int64_t bytes = 0;
@@ -90,8 +91,12 @@ template <> __device__ __forceinline__ float fma_(float a, float b, float c) { r
 template <> __device__ __forceinline__ double fma_(double a, double b, double c) { return fma(a, b, c); }
 
 // One Householder step on column C of the distributed matrix (a[t][j] = A[4t + sub][j]).
-template <typename T, int R4, int C>
-__device__ __forceinline__ void hh_step(T (&a)[R4][4 * R4], T (&dd)[4 * R4], T (&e2)[4 * R4], const int sub) {
+// KEEP (backward): the reflector H_C = I - beta u u', u = (1, hv...) on rows >= C+1, is kept -- hv in the
+// column it has just annihilated (rows >= C+2 of column C, never touched again), beta in e2[C + R]'s place
+// (the caller passes arrays of 2R) -- and e2[C] holds the SIGNED sub-diagonal entry instead of its square.
+template <typename T, int R4, int C, bool KEEP = false>
+__device__ __forceinline__ void hh_step(T (&a)[R4][4 * R4], T (&dd)[4 * R4], T (&e2)[KEEP ? 8 * R4 : 4 * R4],
+                                        const int sub) {
   constexpr int R = 4 * R4, I1 = C + 1;
   constexpr int T0 = I1 / 4;  // first row group with a live row (rows >= I1)
   const T x0 = qb<(I1 & 3)>(a[I1 >> 2][C]);
@@ -111,7 +116,12 @@ __device__ __forceinline__ void hh_step(T (&a)[R4][4 * R4], T (&dd)[4 * R4], T (
   const T beta = act ? (T(2) * v0 * v0 / (sig + v0 * v0)) : T(0);
   const T inv_v0 = act ? (T(1) / v0) : T(0);
   dd[C] = qb<(C & 3)>(a[C >> 2][C]);
-  e2[C] = act ? (mu * mu) : (x0 * x0);
+  if constexpr (KEEP) {
+    e2[C] = act ? mu : x0;   // H x = mu e_1 (mu = ||x|| > 0); untouched column when sigma = 0
+    e2[R + C] = beta;
+  } else {
+    e2[C] = act ? (mu * mu) : (x0 * x0);
+  }
 
   T hv[R4], p[R4];
   sfor<0, R4>([&](auto it) {
@@ -120,6 +130,7 @@ __device__ __forceinline__ void hh_step(T (&a)[R4][4 * R4], T (&dd)[4 * R4], T (
     hv[t] = T(0);
     p[t] = T(0);
     if constexpr (t >= T0) hv[t] = (i == I1) ? T(1) : ((i >= C + 2) ? a[t][C] * inv_v0 : T(0));
+    if constexpr (KEEP && t >= T0) a[t][C] = (i >= C + 2) ? hv[t] : a[t][C];
   });
   // p = beta A u over the live block
   sfor<I1, R>([&](auto ij) {
@@ -302,6 +313,190 @@ __global__ __launch_bounds__(256) void lmi_quad_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Backward with the same four-lanes-per-sample layout:
+//   grad_v = s t - [kappa > 1] s^2 (t . v) grad kappa(v),   t = NA_E' g,   s = 1 / max(1, kappa)
+// When the LMI is the active constraint, grad kappa_b = x' G_b x for the unit eigenvector x of lambda_max
+// (what autograd gives for eigvalsh + max, rayen/constraint_module.py:424-425).  The quad repeats the
+// forward's S and Householder sweep but keeps the reflectors (in the columns they annihilate), gets the
+// eigenvector z of the tridiagonal matrix by inverse iteration on (lambda + shift) I - T -- positive definite,
+// so a plain LDL' without pivoting, O(R) per solve, done redundantly by the four lanes --, maps it back
+// through the reflectors, x = H_0 H_1 ... z (quad sums for the dot products), and contracts x with the
+// generators straight from the LDS image.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int R4>
+__device__ __forceinline__ void top_eigenvector_quad(T (&a)[R4][4 * R4], const T lam, T (&xr)[R4], const int sub) {
+  constexpr int R = 4 * R4;
+  T dd[R], eb[2 * R];  // eb[0..R): signed sub-diagonal, eb[R..2R): reflector scales
+  sfor<0, R - 2>([&](auto ic) {
+    constexpr int c = decltype(ic)::value;
+    hh_step<T, R4, c, true>(a, dd, eb, sub);
+  });
+  dd[R - 2] = qb<((R - 2) & 3)>(a[(R - 2) >> 2][R - 2]);
+  dd[R - 1] = qb<((R - 1) & 3)>(a[(R - 1) >> 2][R - 1]);
+  eb[R - 2] = qb<((R - 1) & 3)>(a[(R - 1) >> 2][R - 2]);
+  eb[R - 1] = T(0);
+
+  // M = (lam + shift) I - T, tridiagonal and positive definite; padding rows (d = -1e18) are decoupled
+  T scale = fabs(lam);
+#pragma unroll
+  for (int i = 0; i < R; ++i) scale = fmax(scale, dd[i] > T(-1e17) ? fabs(dd[i]) : T(0));
+  const T shift = (sizeof(T) == 4 ? T(2e-4) : T(1e-9)) * fmax(scale, Lim<T>::tiny());
+  T Dg[R], l[R];  // M = L D L', unit lower bidiagonal L with sub-diagonal l[i] (row i), i >= 1
+  Dg[0] = fmax(lam + shift - dd[0], shift * T(1e-3));
+  l[0] = T(0);
+#pragma unroll
+  for (int i = 1; i < R; ++i) {
+    l[i] = -eb[i - 1] / Dg[i - 1];
+    Dg[i] = fmax(lam + shift - dd[i] + l[i] * eb[i - 1], shift * T(1e-3));
+  }
+  T z[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) z[i] = T(1) + T(0.01) * T(i);  // not orthogonal to anything special
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+#pragma unroll
+    for (int i = 1; i < R; ++i) z[i] = fma_(-l[i], z[i - 1], z[i]);   // L y = b
+    T nrm = T(0);
+    z[R - 1] = z[R - 1] / Dg[R - 1];
+    nrm = z[R - 1] * z[R - 1];
+#pragma unroll
+    for (int i = R - 2; i >= 0; --i) {                                 // D L' z = y
+      z[i] = fma_(-l[i + 1], z[i + 1], z[i] / Dg[i]);
+      nrm = fma_(z[i], z[i], nrm);
+    }
+    const T inv = T(1) / sqrt(fmax(nrm, Lim<T>::tiny()));
+#pragma unroll
+    for (int i = 0; i < R; ++i) z[i] *= inv;
+  }
+  // x = H_0 H_1 ... H_{R-3} z, this lane's rows
+  sfor<0, R4>([&](auto it) {
+    constexpr int t = decltype(it)::value;
+    xr[t] = T(0);
+    sfor<0, 4>([&](auto is) {
+      constexpr int q = decltype(is)::value;
+      if (sub == q) xr[t] = z[4 * t + q];
+    });
+  });
+  sfor<0, R - 2>([&](auto ic) {
+    constexpr int c = R - 3 - decltype(ic)::value;
+    constexpr int I1 = c + 1, T0 = I1 / 4;
+    T dot = T(0);
+    sfor<T0, R4>([&](auto it) {
+      constexpr int t = decltype(it)::value;
+      const int i = 4 * t + sub;
+      const T u = (i == I1) ? T(1) : ((i >= c + 2) ? a[t][c] : T(0));
+      dot = fma_(u, xr[t], dot);
+    });
+    dot = qsum(dot) * eb[R + c];
+    sfor<T0, R4>([&](auto it) {
+      constexpr int t = decltype(it)::value;
+      const int i = 4 * t + sub;
+      const T u = (i == I1) ? T(1) : ((i >= c + 2) ? a[t][c] : T(0));
+      xr[t] = fma_(-dot, u, xr[t]);
+    });
+  });
+}
+
+template <typename T, int R4>
+__global__ __launch_bounds__(256) void lmi_quad_bwd_kernel(
+    const T* __restrict__ image, const T* __restrict__ wrow, int r, int n, int k, int m, int identity, int lmi_seg,
+    int64_t elems, const T* __restrict__ v, int64_t B, int64_t ldv, const T* __restrict__ kappa,
+    const int32_t* __restrict__ active, const T* __restrict__ gy, int64_t ldg, T* __restrict__ gv, int64_t ldgv) {
+  constexpr int R = 4 * R4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* img = reinterpret_cast<T*>(smem_raw);
+  const T* Wf = img;                                      // [n][R][R]
+  const T* Nmat = Wf + (size_t)n * R * R + (size_t)m * n; // [k][n] (absent when identity)
+  T* vt = img + elems;                                    // [64][n + 1]
+  const int LDV = n + 1, LDG = k + 1;
+  T* tt = vt + 64 * LDV;                                  // [64][n + 1]  t = NA_E' g
+  T* ut = tt + 64 * LDV;                                  // [64][n + 1]  grad kappa
+  T* gt = ut + 64 * LDV;                                  // [64][k + 1]  grad_y
+
+  const int tid = threadIdx.x;
+  const int sl = tid >> 2, sub = tid & 3;
+  const int64_t b0 = (int64_t)blockIdx.x * 64;
+  const int nb = (int)((B - b0) < 64 ? (B - b0) : 64);
+  for (int64_t i = tid; i < elems; i += 256) img[i] = image[i];
+  for (int idx = tid; idx < 64 * n; idx += 256) {
+    const int bl = idx / n, j = idx - bl * n;
+    vt[bl * LDV + j] = bl < nb ? v[(b0 + bl) * ldv + j] : T(0);
+    ut[bl * LDV + j] = T(0);
+  }
+  for (int idx = tid; idx < 64 * k; idx += 256) {
+    const int bl = idx / k, j = idx - bl * k;
+    gt[bl * LDG + j] = bl < nb ? gy[(b0 + bl) * ldg + j] : T(0);
+  }
+  __syncthreads();
+  const T* vs = vt + sl * LDV;
+  const T* gs = gt + sl * LDG;
+  const bool live = sl < nb;
+
+  for (int a = sub; a < n; a += 4) {
+    T acc = T(0);
+    if (identity) {
+      acc = gs[a];
+    } else {
+      for (int i = 0; i < k; ++i) acc = fma_(Nmat[i * n + a], gs[i], acc);
+    }
+    tt[sl * LDV + a] = acc;
+  }
+  __syncthreads();
+  const T* ts = tt + sl * LDV;
+  T tv = T(0);
+  for (int a = 0; a < n; ++a) tv = fma_(ts[a], vs[a], tv);
+
+  const T kap = live ? kappa[b0 + sl] : T(0);
+  const int aseg = live ? active[2 * (b0 + sl)] : -1;
+  const int arow = live ? active[2 * (b0 + sl) + 1] : 0;
+  const bool clipped = live && kap > T(1) && aseg >= 0;
+  const T sc = T(1) / fmax(T(1), kap);
+
+  if (clipped && aseg == lmi_seg) {  // the same for the four lanes of a quad
+    T a[R4][R];
+#pragma unroll
+    for (int t = 0; t < R4; ++t)
+#pragma unroll
+      for (int j = 0; j < R; ++j) a[t][j] = (4 * t + sub == j && j >= r) ? T(-1e18) : T(0);
+    for (int aa = 0; aa < n; ++aa) {
+      const T va = vs[aa];
+      const T* wa = Wf + (size_t)aa * R * R + sub * R;
+#pragma unroll
+      for (int t = 0; t < R4; ++t)
+#pragma unroll
+        for (int j = 0; j < R; ++j) a[t][j] = fma_(wa[4 * t * R + j], va, a[t][j]);
+    }
+    T xr[R4];
+    top_eigenvector_quad<T, R4>(a, kap, xr, sub);
+    T xf[R];
+    sfor<0, R>([&](auto ij) {
+      constexpr int j = decltype(ij)::value;
+      xf[j] = qb<(j & 3)>(xr[j >> 2]);
+    });
+    for (int bb = 0; bb < n; ++bb) {  // grad kappa_b = x' G_b x, this lane's rows first
+      const T* wb = Wf + (size_t)bb * R * R + sub * R;
+      T part = T(0);
+#pragma unroll
+      for (int t = 0; t < R4; ++t) {
+        T rowdot = T(0);
+#pragma unroll
+        for (int j = 0; j < R; ++j) rowdot = fma_(wb[4 * t * R + j], xf[j], rowdot);
+        part = fma_(xr[t], rowdot, part);
+      }
+      part = qsum(part);
+      if (sub == 0) ut[sl * LDV + bb] = part;
+    }
+  } else if (clipped) {              // a linear row
+    for (int bb = sub; bb < n; bb += 4) ut[sl * LDV + bb] = wrow[(size_t)arow * n + bb];
+  }
+  __syncthreads();
+  if (live) {
+    const T coef = clipped ? sc * sc * tv : T(0);
+    for (int bb = sub; bb < n; bb += 4) gv[(b0 + sl) * ldgv + bb] = fma_(sc, ts[bb], -coef * ut[sl * LDV + bb]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------------------------
 
@@ -368,17 +563,22 @@ int lmi_quad_build_t(const RayenPack* p, LmiQuadImage** out, int64_t* bytes) {
   for (int i = 0; i < k; ++i) host[off + i] = (T)p->y0[i];
   if (ids.empty()) ids.assign(2, 0);
   img->elems = (int64_t)host.size();
+  std::vector<T> wr((size_t)(p->n_rows > 0 ? p->n_rows : 1) * n, T(0));
+  for (size_t i = 0; i < (size_t)p->n_rows * n; ++i) wr[i] = (T)p->W[i];
   const bool ok = hipMalloc(&img->data, host.size() * sizeof(T)) == hipSuccess &&
                   hipMemcpy(img->data, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMalloc(&img->wrow, wr.size() * sizeof(T)) == hipSuccess &&
+                  hipMemcpy(img->wrow, wr.data(), wr.size() * sizeof(T), hipMemcpyHostToDevice) == hipSuccess &&
                   hipMalloc(&img->lin_id, ids.size() * sizeof(int32_t)) == hipSuccess &&
                   hipMemcpy(img->lin_id, ids.data(), ids.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess;
   if (!ok) {
     if (img->data) (void)hipFree(img->data);
+    if (img->wrow) (void)hipFree(img->wrow);
     if (img->lin_id) (void)hipFree(img->lin_id);
     delete img;
     return RAYEN_E_ALLOC;
   }
-  img->bytes = (int64_t)(host.size() * sizeof(T) + ids.size() * sizeof(int32_t));
+  img->bytes = (int64_t)((host.size() + wr.size()) * sizeof(T) + ids.size() * sizeof(int32_t));
   *bytes = img->bytes;
   *out = img;
   return RAYEN_OK;
@@ -411,6 +611,53 @@ int lmi_quad_forward_t(const RayenPack* p, const LmiQuadImage* img, const T* v, 
     case 24: return launch_quad<T, 6>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
     case 32:
       if constexpr (sizeof(T) == 4) return launch_quad<T, 8>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+      return RAYEN_E_UNSUPPORTED;
+    default: return RAYEN_E_UNSUPPORTED;
+  }
+}
+
+template <typename T>
+size_t quad_bwd_lds_bytes(const RayenPack* p, int R, int m) {
+  const size_t elems = (size_t)p->n * R * R + (size_t)m * p->n + (p->out_identity ? 0 : (size_t)p->k * p->n) + p->k;
+  return sizeof(T) * (elems + 64 * (size_t)(3 * (p->n + 1) + p->k + 1));
+}
+
+template <typename T, int R4>
+int launch_quad_bwd(const RayenPack* p, const LmiQuadImage* img, const T* v, int64_t B, int64_t ldv, const T* kappa,
+                    const int32_t* active, const T* gy, int64_t ldg, T* gv, int64_t ldgv, hipStream_t stream) {
+  const size_t lds = quad_bwd_lds_bytes<T>(p, img->R, img->m);
+  if (lds > 128 * 1024) return RAYEN_E_UNSUPPORTED;
+  auto kern = lmi_quad_bwd_kernel<T, R4>;
+  if (lds > 48 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) !=
+          hipSuccess)
+    return RAYEN_E_LAUNCH;
+  const int64_t grid = (B + 63) / 64;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, static_cast<const T*>(img->data),
+                     static_cast<const T*>(img->wrow), img->r, img->n, img->k, img->m, img->identity, img->lmi_seg,
+                     img->elems, v, B, ldv, kappa, active, gy, ldg, gv, ldgv);
+  return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
+}
+
+// fp64 keeps a quarter of the matrix, the reflectors and the tridiagonal solve in registers only up to 16 x 16
+template <typename T>
+bool lmi_quad_bwd_serves(const RayenPack* p, const LmiQuadImage* img) {
+  if (sizeof(T) == 8 && img->R > 24) return false;
+  return quad_bwd_lds_bytes<T>(p, img->R, img->m) <= 128 * 1024;
+}
+
+template <typename T>
+int lmi_quad_backward_t(const RayenPack* p, const LmiQuadImage* img, const T* v, int64_t B, int64_t ldv,
+                        const T* kappa, const int32_t* active, const T* gy, int64_t ldg, T* gv, int64_t ldgv,
+                        hipStream_t stream) {
+  if (B == 0) return RAYEN_OK;
+  switch (img->R) {
+    case 8: return launch_quad_bwd<T, 2>(p, img, v, B, ldv, kappa, active, gy, ldg, gv, ldgv, stream);
+    case 16: return launch_quad_bwd<T, 4>(p, img, v, B, ldv, kappa, active, gy, ldg, gv, ldgv, stream);
+    case 20: return launch_quad_bwd<T, 5>(p, img, v, B, ldv, kappa, active, gy, ldg, gv, ldgv, stream);
+    case 24: return launch_quad_bwd<T, 6>(p, img, v, B, ldv, kappa, active, gy, ldg, gv, ldgv, stream);
+    case 32:
+      if constexpr (sizeof(T) == 4) return launch_quad_bwd<T, 8>(p, img, v, B, ldv, kappa, active, gy, ldg, gv, ldgv, stream);
       return RAYEN_E_UNSUPPORTED;
     default: return RAYEN_E_UNSUPPORTED;
   }

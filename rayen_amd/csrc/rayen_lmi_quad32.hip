@@ -15,8 +15,16 @@ int lmi_quad_forward_f32(const RayenPack* p, const LmiQuadImage* img, const floa
 void lmi_quad_free(LmiQuadImage* img) {
   if (img == nullptr) return;
   if (img->data) (void)hipFree(img->data);
+  if (img->wrow) (void)hipFree(img->wrow);
   if (img->lin_id) (void)hipFree(img->lin_id);
   delete img;
+}
+
+bool lmi_quad_bwd_serves_f32(const RayenPack* p, const LmiQuadImage* img) { return lq::lmi_quad_bwd_serves<float>(p, img); }
+int lmi_quad_backward_f32(const RayenPack* p, const LmiQuadImage* img, const float* v, int64_t B, int64_t ldv,
+                          const float* kappa, const int32_t* active, const float* grad_y, int64_t ldg, float* grad_v,
+                          int64_t ldgv, hipStream_t stream) {
+  return lq::lmi_quad_backward_t<float>(p, img, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, stream);
 }
 
 }  // namespace rayen

@@ -13,4 +13,11 @@ int lmi_quad_forward_f64(const RayenPack* p, const LmiQuadImage* img, const doub
   return lq::lmi_quad_forward_t<double>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
 }
 
+bool lmi_quad_bwd_serves_f64(const RayenPack* p, const LmiQuadImage* img) { return lq::lmi_quad_bwd_serves<double>(p, img); }
+int lmi_quad_backward_f64(const RayenPack* p, const LmiQuadImage* img, const double* v, int64_t B, int64_t ldv,
+                          const double* kappa, const int32_t* active, const double* grad_y, int64_t ldg, double* grad_v,
+                          int64_t ldgv, hipStream_t stream) {
+  return lq::lmi_quad_backward_t<double>(p, img, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, stream);
+}
+
 }  // namespace rayen

@@ -211,6 +211,70 @@ def test_matrix_core_backward_matches_lane_backward(name, old_head, dtype):
     assert float(err.median()) <= tol / 10
 
 
+@pytest.mark.parametrize("name", ["r3_lin", "r7", "r12_lin_eq", "r16", "r24_lin", "r30_eq", "c4"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_quad_lmi_backward_matches_lane_backward_and_oracle(name, dtype):
+    """The four-lanes-per-sample LMI backward (eigenvector by inverse iteration on the tridiagonal form) against
+    the lane-per-sample Jacobi backward and against autograd through the fp64 oracle's eigvalsh."""
+    import importlib.util, os
+    from rayen_amd import ops
+    from rayen_amd._lib import RayenError
+    spec = importlib.util.spec_from_file_location("_parity", os.path.join(os.path.dirname(__file__), "test_gpu_parity.py"))
+    parity = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(parity)
+    raw = workloads.make_raw("c4", seed=33) if name == "c4" else parity._lmi_cases()[name]
+    cs = workloads.build_constraints(raw)
+    r = cs.lmic.all_F[0].shape[0]
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        layer = ConstraintModule(cs, create_map=False).cuda()
+    finally:
+        torch.set_default_dtype(prev)
+    dp, _ = layer.device_pack(torch.device("cuda", 0))
+    B = 777
+    gen = torch.Generator().manual_seed(19)
+    v = torch.empty(B, cs.n).uniform_(-2.0, 2.0, generator=gen)
+    v[:20] *= 1e-3
+    v[20:22] = 0.0
+    g = torch.empty(B, cs.k).uniform_(-1, 1, generator=gen)
+    vd, gd = v.to(dtype).cuda(), g.to(dtype).cuda()
+    try:
+        _, kappa, active = ops.project_raw(vd, dp, want_active=True)
+    except RayenError:
+        assert dtype == torch.float64 and r > 24               # no fp64 forward at all for this size
+        return
+    try:
+        got = ops.backward_raw(vd, kappa, active, gd, dp).cpu().double()
+    except RayenError:
+        assert dtype == torch.float64 and r > 20               # neither the quad nor the lane kernel fits
+        return
+    assert torch.isfinite(got).all()
+
+    buf = oracle.precompute(csd_from_cs(cs), torch.float64)
+    xr = v.double().unsqueeze(2).requires_grad_(True)
+    y = oracle.forward(buf, xr)
+    (y[:, :, 0] * g.double()).sum().backward()
+    want = xr.grad[:, :, 0]
+    # v = 0: eigvalsh of the zero matrix has no autograd derivative worth comparing; the layer is the identity
+    # map around 0, so its gradient there is NA_E' g
+    want[20:22] = g[20:22].double() @ torch.from_numpy(np.asarray(cs.NA_E, dtype=np.float64))
+    scale = want.abs().amax(1).clamp_min(1e-12)
+    err = (got - want).abs().amax(1) / scale
+    tol = 5e-3 if dtype == torch.float32 else 1e-6
+    assert (err <= tol).double().mean() >= (0.99 if dtype == torch.float32 else 0.999), torch.sort(err).values[-5:]
+    assert float(err.median()) <= tol / 10
+    assert float(err[:22].max()) <= (1e-5 if dtype == torch.float32 else 1e-12)
+
+    try:
+        lane = ops.backward_raw(vd, kappa, active, gd, dp, force_generic=True).cpu().double()
+    except RayenError:                                          # the lane-per-sample kernel stops at ~21 x 21 (fp64)
+        assert r > 20
+        return
+    err = (got - lane).abs().amax(1) / lane.abs().amax(1).clamp_min(1e-12)
+    assert (err <= tol).double().mean() >= (0.99 if dtype == torch.float32 else 0.999), torch.sort(err).values[-5:]
+
+
 @pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("RAYEN_FUZZ_SEEDS", "100")) // 3)))
 def test_random_sets_gradients_match_oracle_autograd(seed):
     """fp64 gradients of random constraint sets (whatever backward kernel serves them) against autograd through
