@@ -31,7 +31,7 @@ for name in sys.argv[1:] or ["c2", "c3", "c5"]:
     cs = workloads.build_constraints(workloads.make_raw(name, seed=0))
     layer = ConstraintModule(cs, create_map=False).cuda()
     dp, _ = layer.device_pack(torch.device("cuda", 0))
-    B = 262144
+    B = int(os.environ.get("BWD_B", "262144"))
     v = torch.empty(B, cs.n, device="cuda").uniform_(-1, 1)
     g = torch.empty(B, cs.k, device="cuda").uniform_(-1, 1)
     _, kappa, active = ops.project_raw(v, dp, want_active=True)
@@ -39,6 +39,6 @@ for name in sys.argv[1:] or ["c2", "c3", "c5"]:
            "fwd_track_ms": time_call(lambda: ops.project_raw(v, dp, want_active=True)),
            "bwd_ms": time_call(lambda: ops.backward_raw(v, kappa, active, g, dp)),
            "dtype": str(DTYPE)}
-    if DTYPE == torch.float32:
+    if DTYPE == torch.float32 or os.environ.get("BWD_GENERIC"):
         row["bwd_generic_ms"] = time_call(lambda: ops.backward_raw(v, kappa, active, g, dp, force_generic=True))
     print(json.dumps(row))

@@ -223,6 +223,45 @@ def test_quad_lmi_backward_matches_lane_backward_and_oracle(name, dtype):
     parity = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(parity)
     raw = workloads.make_raw("c4", seed=33) if name == "c4" else parity._lmi_cases()[name]
+    _check_lmi_backward(raw, dtype)
+
+
+def _random_lmi_set(seed):
+    """[linear rows] + [equalities] + one LMI around a random interior point: what the quad kernels serve."""
+    rng = np.random.default_rng(5000 + seed)
+    k = int(rng.integers(2, 13))
+    r = int(rng.choice([2, 3, 5, 8, 9, 13, 16, 17, 20, 23, 24, 27, 32]))
+    raw = workloads._empty(k)
+    y0 = rng.uniform(-1, 1, size=(k, 1))
+    raw["y0"] = y0
+    n_eq = int(rng.integers(0, min(3, k - 1) + 1)) if rng.random() < 0.4 else 0
+    if n_eq:
+        raw["A2"] = rng.uniform(-1, 1, size=(n_eq, k))
+        raw["b2"] = raw["A2"] @ y0
+    m = int(rng.choice([0, 0, 5, 40]))
+    if m:
+        raw["A1"] = rng.uniform(-1, 1, size=(m, k))
+        raw["b1"] = raw["A1"] @ y0 + rng.uniform(0.1, 1.0, size=(m, 1))
+    F = []
+    for _ in range(k):
+        T = rng.uniform(-1, 1, size=(r, r))
+        F.append((T + T.T) / 2)
+    T = rng.uniform(-1, 1, size=(r, r))
+    H = T @ T.T + 0.5 * np.eye(r)
+    F.append(H - sum(y0[i, 0] * F[i] for i in range(k)))
+    raw["F"] = F
+    return raw
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("RAYEN_FUZZ_SEEDS", "100")) // 4)))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_random_lmi_sets_backward(seed, dtype):
+    _check_lmi_backward(_random_lmi_set(seed), dtype)
+
+
+def _check_lmi_backward(raw, dtype):
+    from rayen_amd import ops
+    from rayen_amd._lib import RayenError
     cs = workloads.build_constraints(raw)
     r = cs.lmic.all_F[0].shape[0]
     prev = torch.get_default_dtype()
@@ -240,7 +279,7 @@ def test_quad_lmi_backward_matches_lane_backward_and_oracle(name, dtype):
     g = torch.empty(B, cs.k).uniform_(-1, 1, generator=gen)
     vd, gd = v.to(dtype).cuda(), g.to(dtype).cuda()
     try:
-        _, kappa, active = ops.project_raw(vd, dp, want_active=True)
+        y_dev, kappa, active = ops.project_raw(vd, dp, want_active=True)
     except RayenError:
         assert dtype == torch.float64 and r > 24               # no fp64 forward at all for this size
         return
@@ -255,6 +294,8 @@ def test_quad_lmi_backward_matches_lane_backward_and_oracle(name, dtype):
     xr = v.double().unsqueeze(2).requires_grad_(True)
     y = oracle.forward(buf, xr)
     (y[:, :, 0] * g.double()).sum().backward()
+    y_err = (y_dev.cpu().double() - y.detach()[:, :, 0]).abs().amax(1) / y.detach()[:, :, 0].abs().amax(1).clamp_min(1e-30)
+    assert float(y_err.max()) <= (3e-5 if dtype == torch.float32 else 1e-9)
     want = xr.grad[:, :, 0]
     # v = 0: eigvalsh of the zero matrix has no autograd derivative worth comparing; the layer is the identity
     # map around 0, so its gradient there is NA_E' g
