@@ -216,6 +216,56 @@ def test_zero_tiny_and_huge_directions():
     assert oracle.max_violation(raw, y) <= VIOLATION_TOL
 
 
+@pytest.mark.parametrize("name,dtype", [("c3", torch.float32), ("c2", torch.float32), ("c4", torch.float32),
+                                        ("c5", torch.float32), ("c3", torch.float64), ("c5", torch.float64)])
+def test_batches_beyond_2_31_elements(name, dtype):
+    """Maximum sizes: direction / output / gradient arrays with more than 2^31 elements (64-bit row offsets in
+    every kernel family).  Slices straddling the 2^31-element mark and the ragged tail must come out exactly as
+    when those rows are projected on their own (the kernels are row-independent and deterministic)."""
+    from rayen_amd import ops
+    raw = workloads.make_raw(name, seed=2)
+    cs, layer = _layer(raw, dtype)
+    dp, _ = layer.device_pack(torch.device("cuda", 0))
+    width = min(cs.n, cs.k)
+    B = (1 << 31) // width + 1500 + 37
+    free, _ = torch.cuda.mem_get_info()
+    need = (4 if dtype == torch.float32 else 8) * B * (2 * cs.n + 3 * cs.k) + (2 << 30)
+    if free < need:
+        pytest.skip(f"needs {need >> 30} GiB of HBM")
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    v = torch.empty(B, cs.n, device="cuda", dtype=dtype).uniform_(-1.5, 1.5, generator=gen)
+    mark = (1 << 31) // width
+    windows = [(0, 700), (mark - 650, mark + 650), (B - 1037, B)]
+    y, kappa, active = ops.project_raw(v, dp, want_active=True)
+    assert y.shape == (B, cs.k) and min(y.numel(), v.numel()) > (1 << 31)
+    # config 4: the big batch runs lane-per-sample, a window of 700 rows four lanes per sample -- two
+    # algorithms for lambda_max, equal to fp32 accuracy but not bit for bit
+    exact = name != "c4"
+
+    def same(a, b):
+        return torch.equal(a, b) if exact else torch.allclose(a, b, rtol=2e-5, atol=1e-6)
+
+    for lo, hi in windows:
+        y_w, kappa_w, active_w = ops.project_raw(v[lo:hi].clone(), dp, want_active=True)
+        assert same(y[lo:hi], y_w), (name, lo, hi)
+        assert same(kappa[lo:hi], kappa_w) and torch.equal(active[lo:hi], active_w)
+    y_plain, _, _ = ops.project_raw(v, dp, want_active=False)
+    for lo, hi in windows:
+        # the untracked instance may round differently from the tracked one, but not depend on the batch
+        y_w, _, _ = ops.project_raw(v[lo:hi].clone(), dp, want_active=False)
+        assert same(y_plain[lo:hi], y_w), (name, lo, hi)
+    del y_plain
+    assert bool(torch.isfinite(y[::4097]).all())
+    g = torch.empty(B, cs.k, device="cuda", dtype=dtype).uniform_(-1, 1, generator=gen)
+    grad = ops.backward_raw(v, kappa, active, g, dp)
+    for lo, hi in windows:
+        grad_w = ops.backward_raw(v[lo:hi].clone(), kappa[lo:hi].clone(), active[lo:hi].clone(), g[lo:hi].clone(), dp)
+        assert torch.equal(grad[lo:hi], grad_w), (name, lo, hi)
+    tail = y[B - 1037:].cpu().numpy().astype(np.float64)
+    # config 5: unnormalised residuals with |P| ~ 1e2 and fp32 equality rows (see the c5 parity test)
+    assert oracle.max_violation(raw, tail) <= ((VIOLATION_TOL if name != "c5" else 5e-5) if dtype == torch.float32 else 1e-11)
+
+
 def test_nan_input_raises_like_the_reference():
     raw = workloads.make_raw("c2", seed=4)
     cs, layer = _layer(raw)
