@@ -70,6 +70,20 @@ int ensure_mfma(const RayenPack* p) {
   return RAYEN_OK;
 }
 
+int ensure_split(const RayenPack* p) {
+  std::lock_guard<std::mutex> lock(p->mu);
+  if (p->sp32_tried) return RAYEN_OK;
+  p->sp32_tried = true;
+  if (!mfma_split_eligible(p)) return RAYEN_OK;
+  int64_t bytes = 0;
+  SplitImage* img = nullptr;
+  const int rc = mfma_split_build(p, &img, &bytes);
+  if (rc != RAYEN_OK) return rc;
+  p->sp32 = img;
+  p->device_bytes += bytes;
+  return RAYEN_OK;
+}
+
 int ensure_mfma64(const RayenPack* p) {
   std::lock_guard<std::mutex> lock(p->mu);
   if (p->m64_tried) return RAYEN_OK;
@@ -273,7 +287,7 @@ int rayen_pack_create(const RayenPackDesc* desc, RayenPack** out) {
   p->out_identity = desc->out_identity ? 1 : 0;
   {
     const char* env = std::getenv("RAYEN_SPLIT_BF16");
-    p->split_bf16 = (env != nullptr && env[0] == '1') ? 1 : 0;
+    p->split_bf16 = (env != nullptr && env[0] >= '0' && env[0] <= '2') ? env[0] - '0' : 0;
   }
   p->W.assign(desc->W, desc->W + (size_t)desc->n_rows * desc->n);
   p->y0.assign(desc->y0, desc->y0 + desc->k);
@@ -301,6 +315,7 @@ void rayen_pack_destroy(RayenPack* p) {
   if (p->mb64) mfma64_bwd_free(p->mb64);
   if (p->mbg32) mfma_bwdg_free(p->mbg32);
   if (p->mbg64) mfma64_bwdg_free(p->mbg64);
+  if (p->sp32) mfma_split_free(p->sp32);
   if (p->q32) lmi_quad_free(p->q32);
   if (p->q64) lmi_quad_free(p->q64);
   if (switched) (void)hipSetDevice(prev);
@@ -340,6 +355,13 @@ static int project_f32(const RayenPack* p, const float* v, int64_t B, int64_t ld
     return RAYEN_E_BAD_ARG;
   int rc = check_device(p);
   if (rc) return rc;
+  if (p->split_bf16 == 2 && y != nullptr && !old_mode) {
+    rc = ensure_split(p);
+    if (rc) return rc;
+    if (p->sp32 != nullptr)
+      return mfma_split_forward(p, p->sp32, v, B, ldv, y, ldy, kappa, active, nan_flag,
+                                static_cast<hipStream_t>(stream));
+  }
   rc = ensure_mfma(p);
   if (rc) return rc;
   if (p->m32 != nullptr && y != nullptr)

@@ -51,6 +51,7 @@ struct Mfma64BwdImage;  // rayen_mfma_bwd64.hip
 struct MfmaBwdgImage;   // rayen_mfma_bwdg.hip
 struct Mfma64BwdgImage; // rayen_mfma_bwdg64.hip
 struct LmiQuadImage;    // rayen_lmi_quad.h
+struct SplitImage;      // rayen_mfma_split.hip
 
 }  // namespace rayen
 
@@ -81,6 +82,8 @@ struct RayenPack {
   mutable rayen::LmiQuadImage* q32 = nullptr;
   mutable rayen::LmiQuadImage* q64 = nullptr;
   mutable bool q32_tried = false, q64_tried = false;
+  mutable rayen::SplitImage* sp32 = nullptr;
+  mutable bool sp32_tried = false;
   mutable int64_t device_bytes = 0;
 };
 
@@ -109,6 +112,14 @@ void mfma_free(MfmaImage* img);
 int mfma_forward(const RayenPack* p, const MfmaImage* img, const float* v, int64_t B, int64_t ldv,
                  float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
                  int old_mode, hipStream_t stream);
+
+// fp32 results on split bf16 operands (rayen_mfma_split.hip)
+bool mfma_split_eligible(const RayenPack* p);
+int mfma_split_build(const RayenPack* p, SplitImage** out, int64_t* bytes);
+void mfma_split_free(SplitImage* img);
+int mfma_split_forward(const RayenPack* p, const SplitImage* img, const float* v, int64_t B, int64_t ldv,
+                       float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
+                       hipStream_t stream);
 
 // fp32 MFMA path with the mapper v = Wm x + b fused in front (rayen_mfma_mapped.hip)
 bool mfma_mapper_fusable(const RayenPack* p, const MfmaImage* img, int in_dim);

@@ -1,0 +1,434 @@
+// Split-operand forward: the fp32 tile walk of rayen_mfma_kernel.h on v_mfma_f32_32x32x16_bf16.
+//
+// Every fp32 operand is split EXACTLY into three bf16 pieces x = x1 + x2 + x3 (8 significant bits each;
+// bf16 has fp32's exponent range, so no scaling is involved) and a product is rebuilt from the six piece
+// products of order <= 2^-16 (x1y1, x1y2, x2y1, x1y3, x2y2, x3y1), each exact in the fp32 accumulator.  The
+// dropped terms are <= 2^-24 relative, below the rounding error of an fp32 FMA chain: fp32-grade results at
+// 6/16 of the fp32 MFMA time.
+//
+// Shape of the kernel: the fp32 kernel's (persistent, barrier-free, two waves per SIMD, 64 samples per wave).
+// What differs:
+//   * A operands: three bf16 images of W in the fragment order of the bf16 instruction, streamed from L2 into a
+//     ROLLING register buffer -- the three chunks of a K-step are re-loaded for the next tile right after the
+//     step's MFMAs were issued, so every load has most of a tile (> 1000 cycles) to land;
+//   * the direction lives in registers only as bf16 pieces (B operands).  No epilogue may need it in fp32,
+//     so symmetric forms are laid out through their factors (||U v||^2, rayen_tiles.h: allow_sym = false) -- which
+//     is also the better conditioned evaluation --, and the NA_E = I write-out rebuilds v = v1 + v2 + v3 (exact).
+#include "rayen_mfma_kernel.h"
+
+#include <cstring>
+#include <vector>
+
+namespace rayen {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct SplitImage {
+  void* Wb = nullptr;      // [n_tiles][NS][3][64] x 8 bf16
+  MItem* items = nullptr;
+  MPack* packs = nullptr;
+  float* y0 = nullptr;
+  int n_items = 0;
+  int nkk = 0;
+  int identity = 0;
+  int n_simd = 1024;
+  int64_t bytes = 0;
+};
+
+template <int NKK, bool TRACK, bool STAGED>
+__global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fwd_kernel(
+    const bf16x8* __restrict__ Wb, const MItem* __restrict__ items, int n_items,
+    const MPack* __restrict__ packs, const float* __restrict__ y0, int identity, int k, int n,
+    const float* __restrict__ v, int64_t B, int64_t ldv, int vec_in, float* __restrict__ y, int64_t ldy,
+    int vec_out, float* __restrict__ kappa_out, int32_t* __restrict__ active_out,
+    int32_t* __restrict__ nan_flag) {
+  constexpr int NT = 2, NS = NKK * 2, NCH = NS * 3, KK = NKK * 16;
+  __shared__ float aux_lds[kMfmaWaves][NT][32][32];
+  __shared__ __attribute__((aligned(16))) float y0_lds[NKK * 32];
+  constexpr int LSTR = NKK * 32 + 4;
+  __shared__ __attribute__((aligned(16))) float line_lds[kMfmaWaves][32][LSTR];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int col = lane & 31;
+  const int hi = lane >> 5;
+  const int64_t n_groups = (B + NT * 32 - 1) / (NT * 32);
+  const int64_t wave_id = (int64_t)blockIdx.x * kMfmaWaves + wave;
+  const int64_t wave_stride = (int64_t)gridDim.x * kMfmaWaves;
+  bool bad = false;
+  for (int i = threadIdx.x; i < NKK * 32; i += kMfmaWaves * 64) y0_lds[i] = y0[i];
+  __syncthreads();  // the only workgroup barrier
+  float (*patch)[LSTR] = line_lds[wave];
+
+  // ---- A operands: a rolling register buffer filled by hand-placed loads.  hipcc treats loads from the
+  // (read-only) image as freely movable and gathers them at the end of a tile, right in front of their uses;
+  // as asm statements they stay where the latency is covered.  The compiler does not see the data arrive, so:
+  //   * `wait_step` (s_waitcnt) takes the three chunks as read-write operands -- the MFMAs depend on it;
+  //   * asm loads are in flight only inside the tile loop (vmcnt(0) before any code that may spill or copy).
+  u32x4 abuf[NCH];
+  const unsigned lane_off = lane * 16;
+  auto load_step = [&](const char* tile_base, const int sp) {
+    const char* sb = tile_base + sp * 3072;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(abuf[3 * sp + 0]) : "v"(lane_off), "s"(sb));
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "+v"(abuf[3 * sp + 1]) : "v"(lane_off), "s"(sb));
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "+v"(abuf[3 * sp + 2]) : "v"(lane_off), "s"(sb));
+  };
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) abuf[c] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int sp = 0; sp < NS; ++sp) load_step(reinterpret_cast<const char*>(Wb), sp);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  for (int64_t grp = wave_id; grp < n_groups; grp += wave_stride) {
+  const int64_t s_base = grp * (NT * 32);
+
+  bool live[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) live[t] = (s_base + t * 32 + col) < B;
+  // vb[t][piece][k-step] = 8 bf16 = the B operand of one MFMA; element i = column 16 sp + 8 (i >> 2) + 4 hi + (i & 3)
+  bf16x8 vb[NT][3][NS];
+  {
+    float vr[NT][KK];
+    load_rows<NT, NKK, LSTR, true>(vr, v, ldv, n, vec_in, s_base, B, live, patch, lane);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q = 0; q < NKK * 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int i = (q & 1) * 4 + c;
+          const float x = vr[t][4 * q + c];
+          const __bf16 p1 = (__bf16)x;
+          const float r1 = x - (float)p1;
+          const __bf16 p2 = (__bf16)r1;
+          const float r2 = r1 - (float)p2;
+          vb[t][0][q >> 1][i] = p1;
+          vb[t][1][q >> 1][i] = p2;
+          vb[t][2][q >> 1][i] = (__bf16)r2;
+        }
+  }
+
+  float kap[NT], part[NT], scale[NT];
+  int aseg[NT], arow[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { kap[t] = 0.f; part[t] = 0.f; scale[t] = 1.f; aseg[t] = -1; arow[t] = 0; }
+
+  auto finish_kappa = [&]() {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float other = xhalf(kap[t]);
+      if (TRACK) {
+        const int oseg = __shfl_xor(aseg[t], 32), orow = __shfl_xor(arow[t], 32);
+        if (other > kap[t] || (other == kap[t] && hi == 1)) { aseg[t] = oseg; arow[t] = orow; }
+      }
+      kap[t] = fmaxf(kap[t], other);
+      scale[t] = 1.0f / fmaxf(1.0f, kap[t]);
+    }
+  };
+
+  f32x16 acc[NT];
+  for (int it = 0; it < n_items; ++it) {
+    const MItem item = items[it];
+    if (item.type == MI_OUT && (item.flags & MF_FIRST)) finish_kappa();
+    // the tile after this one; the last tile of a group fetches tile 0 for the next group
+    const char* next_tile = reinterpret_cast<const char*>(Wb) + (size_t)(it + 1 == n_items ? 0 : it + 1) * (NCH * 1024);
+    // ---- the tile's MFMAs; each K-step's chunks are re-loaded for the next tile as soon as they were used
+    {
+      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sp = 0; sp < NS; ++sp) {
+        __builtin_amdgcn_sched_barrier(0);
+        // chunks 3 sp .. 3 sp + 2 were loaded NCH - 3 loads ago
+        if constexpr (NCH == 12)
+          asm volatile("s_waitcnt vmcnt(9)" : "+v"(abuf[3 * sp + 0]), "+v"(abuf[3 * sp + 1]), "+v"(abuf[3 * sp + 2]));
+        else
+          asm volatile("s_waitcnt vmcnt(3)" : "+v"(abuf[3 * sp + 0]), "+v"(abuf[3 * sp + 1]), "+v"(abuf[3 * sp + 2]));
+        const bf16x8 a1 = __builtin_bit_cast(bf16x8, abuf[3 * sp + 0]), a2 = __builtin_bit_cast(bf16x8, abuf[3 * sp + 1]),
+                     a3 = __builtin_bit_cast(bf16x8, abuf[3 * sp + 2]);
+        // smallest products first; the first MFMA of a chain takes the constant 0 as C
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, vb[t][0][sp], sp == 0 ? zero : acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, vb[t][1][sp], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, vb[t][2][sp], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, vb[t][0][sp], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, vb[t][1][sp], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, vb[t][0][sp], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_step(next_tile, sp);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (item.type == MI_LIN) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (TRACK) {
+#pragma unroll
+          for (int g = 0; g < 16; ++g)
+            if (acc[t][g] > kap[t]) {
+              kap[t] = acc[t][g];
+              aseg[t] = item.seg;
+              arow[t] = item.row0 + (g & 3) + 8 * (g >> 2) + 4 * hi;
+            }
+        } else {
+#pragma unroll
+          for (int g = 0; g < 16; ++g) kap[t] = fmaxf(kap[t], acc[t][g]);
+        }
+      }
+    } else if (item.type == MI_AUX) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; ++g)
+          aux_lds[wave][t][(g & 3) + 8 * (g >> 2) + 4 * hi][col] = acc[t][g];
+      __builtin_amdgcn_wave_barrier();
+    } else if (STAGED && item.type == MI_OUT) {
+      // rows of NA_E: through this wave's aux patch (XOR-swizzled), out as row-coalesced stores
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        float* stage = &aux_lds[wave][t][0][0];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int r = (g & 3) + 8 * (g >> 2) + 4 * hi;
+          const float o = fmaf(acc[t][g], scale[t], y0[item.row0 + r]);  // y0 is padded to a tile multiple
+          bad |= live[t] && (item.row0 + r < k) && (o != o);
+          stage[col * 32 + (r ^ col)] = o;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int orow = item.row0 + col;
+        float* ybase = y + (s_base + t * 32 + hi) * ldy + orow;
+#pragma unroll 4
+        for (int j = 0; j < 16; ++j) {
+          const int sm = 2 * j + hi;
+          const float o = stage[sm * 32 + (col ^ sm)];
+          if (s_base + t * 32 + sm < B && orow < k) ybase[(int64_t)(2 * j) * ldy] = o;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    } else if (item.type == MI_PACK) {
+      const MPack pk = packs[item.aux];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int slot = hi ? pk.aux[a][1] : pk.aux[a][0];
+        const int sid = hi ? pk.seg[a][1] : pk.seg[a][0];
+        const bool pair = (item.row0 >> a) & 1;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          float qs = acc[t][4 * a] * acc[t][4 * a];
+#pragma unroll
+          for (int c = 1; c < 4; ++c) qs = fmaf(acc[t][4 * a + c], acc[t][4 * a + c], qs);
+          if (pair) qs += xhalf(qs);
+          const float kc = aux_lds[wave][t][slot & 31][col] + __builtin_amdgcn_sqrtf(qs);
+          if (sid >= 0 && kc > kap[t]) { kap[t] = kc; aseg[t] = sid; arow[t] = 0; }
+        }
+      }
+    } else if (item.type == MI_QFAC || item.type == MI_SOC) {
+      // a running sum of squares over the segment's tiles, closed on its last tile
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        float sum = (item.flags & MF_FIRST) ? 0.f : part[t];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) sum = fmaf(acc[t][g], acc[t][g], sum);
+        part[t] = sum;
+      }
+      if (item.flags & MF_LAST) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float total = part[t] + xhalf(part[t]);
+          const float a0 = aux_lds[wave][t][item.aux][col];
+          float kc;
+          if (item.type != MI_SOC) {
+            kc = a0 + sqrtf(fmaxf(total, 0.f));
+          } else {
+            // a' x^2 + b' x + c' = 0  (rayen/constraint_module.py:392-396, 339-348), a' < 0
+            const float br = aux_lds[wave][t][item.aux + 1][col];
+            const float cp = total - a0 * a0;
+            const float bp = 2.f * br - 2.f * a0 * item.f0;
+            const float disc = bp * bp - 4.f * item.f1 * cp;
+            kc = 0.f;
+            if (disc >= 0.f) {
+              const float root = sqrtf(disc);
+              const float inv2a = 0.5f / item.f1;
+              kc = fmaxf((-bp - root) * inv2a, (-bp + root) * inv2a);
+            }
+          }
+          if (kc > kap[t]) { kap[t] = kc; aseg[t] = item.seg; arow[t] = 0; }
+        }
+      }
+    }
+  }
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next group's first tile has landed
+
+  if (identity) {
+    finish_kappa();
+    // y = y0 + v / max(1, kappa): v rebuilt from its pieces, v1 + v2 + v3 (exact)
+    float vr[NT][KK];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int sp = 0; sp < NS; ++sp) {
+        const u32x4 w1 = __builtin_bit_cast(u32x4, vb[t][0][sp]);
+        const u32x4 w2 = __builtin_bit_cast(u32x4, vb[t][1][sp]);
+        const u32x4 w3 = __builtin_bit_cast(u32x4, vb[t][2][sp]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int sh = (i & 1) ? 0 : 16;
+          const unsigned m = (i & 1) ? 0xFFFF0000u : 0xFFFFFFFFu;
+          const float x1 = __builtin_bit_cast(float, (w1[i >> 1] << sh) & m);
+          const float x2 = __builtin_bit_cast(float, (w2[i >> 1] << sh) & m);
+          const float x3 = __builtin_bit_cast(float, (w3[i >> 1] << sh) & m);
+          // element i of K-step sp = register 4 (2 sp + (i >> 2)) + (i & 3) of the fp32 layout
+          vr[t][4 * (2 * sp + (i >> 2)) + (i & 3)] = (x1 + x2) + x3;
+        }
+      }
+    bad |= store_rows<NT, NKK, LSTR, true>(vr, scale, y0_lds, y, ldy, k, vec_out, s_base, B, live, patch, lane);
+  }
+
+  if (hi == 0) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (!live[t]) continue;
+      const int64_t s = s_base + t * 32 + col;
+      if (kappa_out) kappa_out[s] = kap[t];
+      if (TRACK) { active_out[2 * s] = aseg[t]; active_out[2 * s + 1] = arow[t]; }
+    }
+  }
+  }  // persistent loop over sample groups
+  if (nan_flag && bad) atomicOr(nan_flag, 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------
+bool mfma_split_eligible(const RayenPack* p) {
+  if (p->n > 64) return false;
+  for (const RayenSegment& g : p->segs)
+    if (g.type == RAYEN_SEG_LMI) return false;
+  TileLayout b(p->n);
+  if (layout_tiles(p, b, /*allow_pack=*/true, /*allow_sym=*/false) != RAYEN_OK || b.items.empty()) return false;
+  const int64_t padded = (int64_t)b.items.size() * 32;
+  return b.useful_rows * 2 >= padded && p->n * 2 >= b.n_pad;
+}
+
+void mfma_split_free(SplitImage* img) {
+  if (img == nullptr) return;
+  if (img->Wb) (void)hipFree(img->Wb);
+  if (img->items) (void)hipFree(img->items);
+  if (img->packs) (void)hipFree(img->packs);
+  if (img->y0) (void)hipFree(img->y0);
+  delete img;
+}
+
+int mfma_split_build(const RayenPack* p, SplitImage** out, int64_t* bytes) {
+  TileLayout b(p->n);
+  const int rc = layout_tiles(p, b, /*allow_pack=*/true, /*allow_sym=*/false);
+  if (rc != RAYEN_OK) return rc;
+  const int n_items = (int)b.items.size();
+  const std::vector<float> frag = b.fragments_f32();
+  if (b.packs.empty()) b.packs.push_back(MPack());
+
+  SplitImage* img = new SplitImage();
+  img->nkk = b.n_pad / 32;
+  img->identity = p->out_identity;
+  img->n_items = n_items;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0)
+      img->n_simd = prop.multiProcessorCount * 4;
+  }
+  // three bf16 pieces of every entry, in the fragment order of v_mfma_f32_32x32x16_bf16:
+  // chunk (tile, k-step s, piece) = 64 lanes x 8 elements, element i of lane l = column
+  // 16 s + 8 (i >> 2) + 4 (l >> 5) + (i & 3) of row l & 31 = entry [2 s + (i >> 2)][l][i & 3] of the fp32 image
+  auto rne = [](float x) -> uint16_t {
+    uint32_t u;
+    std::memcpy(&u, &x, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+  };
+  auto widen = [](uint16_t h) -> float {
+    const uint32_t u = (uint32_t)h << 16;
+    float x;
+    std::memcpy(&x, &u, 4);
+    return x;
+  };
+  const int n_tiles = b.n_tiles(), ns = b.nq() / 2;
+  std::vector<uint16_t> wb((size_t)n_tiles * ns * 3 * 64 * 8);
+  for (int t = 0; t < n_tiles; ++t)
+    for (int sp = 0; sp < ns; ++sp)
+      for (int l = 0; l < 64; ++l)
+        for (int i = 0; i < 8; ++i) {
+          const float x = frag[(((size_t)t * b.nq() + 2 * sp + (i >> 2)) * 64 + l) * 4 + (i & 3)];
+          const uint16_t h1 = rne(x);
+          const float r1 = x - widen(h1);
+          const uint16_t h2 = rne(r1);
+          const float r2 = r1 - widen(h2);
+          const uint16_t h3 = rne(r2);
+          const size_t base = (((size_t)t * ns + sp) * 3) * 64 * 8 + (size_t)l * 8 + i;
+          wb[base] = h1;
+          wb[base + 64 * 8] = h2;
+          wb[base + 2 * 64 * 8] = h3;
+        }
+  const int k_tiles = (p->k + 31) / 32;
+  std::vector<float> y0((size_t)k_tiles * 32 + 32, 0.f);
+  for (int i = 0; i < p->k; ++i) y0[i] = (float)p->y0[i];
+  const bool ok =
+      hipMalloc(&img->Wb, wb.size() * 2) == hipSuccess &&
+      hipMemcpy(img->Wb, wb.data(), wb.size() * 2, hipMemcpyHostToDevice) == hipSuccess &&
+      hipMalloc(&img->y0, y0.size() * sizeof(float)) == hipSuccess &&
+      hipMemcpy(img->y0, y0.data(), y0.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
+      hipMalloc(&img->items, b.items.size() * sizeof(MItem)) == hipSuccess &&
+      hipMemcpy(img->items, b.items.data(), b.items.size() * sizeof(MItem), hipMemcpyHostToDevice) == hipSuccess &&
+      hipMalloc(&img->packs, b.packs.size() * sizeof(MPack)) == hipSuccess &&
+      hipMemcpy(img->packs, b.packs.data(), b.packs.size() * sizeof(MPack), hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) { mfma_split_free(img); return RAYEN_E_ALLOC; }
+  img->bytes = (int64_t)(wb.size() * 2 + y0.size() * sizeof(float) + b.items.size() * sizeof(MItem) +
+                         b.packs.size() * sizeof(MPack));
+  *bytes = img->bytes;
+  *out = img;
+  return RAYEN_OK;
+}
+
+template <int NKK>
+static int launch_split(const RayenPack* p, const SplitImage* img, const float* v, int64_t B, int64_t ldv,
+                        float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
+                        hipStream_t stream) {
+  constexpr int per_wave = 64;
+  const int64_t n_groups = (B + per_wave - 1) / per_wave;
+  const int64_t slots = (int64_t)img->n_simd * kMfmaWavesPerSimd;
+  const int64_t rounds = (n_groups + slots - 1) / slots;
+  const int64_t waves = (n_groups + rounds - 1) / rounds;
+  const int64_t grid = (waves + kMfmaWaves - 1) / kMfmaWaves;
+  const int vec_in = (ldv % 4 == 0) && ((reinterpret_cast<uintptr_t>(v) & 15) == 0);
+  const int vec_out = (ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+  auto go = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kMfmaWaves * 64), 0, stream,
+                       static_cast<const bf16x8*>(img->Wb), img->items, img->n_items, img->packs, img->y0,
+                       img->identity, p->k, p->n, v, B, ldv, vec_in, y, ldy, vec_out, kappa, active, nan_flag);
+  };
+  if (img->identity) {
+    if (active != nullptr) go(mfma_split_fwd_kernel<NKK, true, false>);
+    else go(mfma_split_fwd_kernel<NKK, false, false>);
+  } else {
+    if (active != nullptr) go(mfma_split_fwd_kernel<NKK, true, true>);
+    else go(mfma_split_fwd_kernel<NKK, false, true>);
+  }
+  return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
+}
+
+int mfma_split_forward(const RayenPack* p, const SplitImage* img, const float* v, int64_t B, int64_t ldv,
+                       float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
+                       hipStream_t stream) {
+  if (B == 0) return RAYEN_OK;
+  if (img->nkk == 1) return launch_split<1>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+  if (img->nkk == 2) return launch_split<2>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+  return RAYEN_E_UNSUPPORTED;
+}
+
+}  // namespace rayen

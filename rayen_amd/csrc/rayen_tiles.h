@@ -5,6 +5,7 @@
 // order of a particular MFMA instruction, element type) is up to the kernel family.
 #pragma once
 
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -44,6 +45,7 @@ struct TileLayout {
   std::vector<MItem> items;
   std::vector<MPack> packs;
   int64_t useful_rows = 0;
+  std::vector<std::vector<double>> owned;  // factor rows computed here (layouts without symmetric forms)
 
   explicit TileLayout(int n_) : n(n_), n_pad(n_pad_of(n_)) {}
   int nq() const { return n_pad / 8; }
@@ -87,7 +89,32 @@ inline bool is_small_factor(const RayenSegment& g) { return g.type == RAYEN_SEG_
 //   segments are taken in order, in batches whose aux rows (phi | c, b) fit one aux tile; each
 //   batch = [AUX tile] [own tiles of the large segments] [packed tiles of the small factor ones];
 //   the rows of NA_E (if it is not the identity) come last.
-inline int layout_tiles(const RayenPack* p, TileLayout& b, bool allow_pack) {
+// Factor of a positive semi-definite G (n x n, row-major): rows u_j with sum_j u_j u_j' = G, by Cholesky with
+// diagonal pivoting (outer-product form); stops at the numerical rank.
+inline std::vector<std::vector<double>> psd_factor_rows(const double* G, int n) {
+  std::vector<double> A(G, G + (size_t)n * n);
+  std::vector<std::vector<double>> rows;
+  double dmax0 = 0.0;
+  for (int i = 0; i < n; ++i) dmax0 = A[(size_t)i * n + i] > dmax0 ? A[(size_t)i * n + i] : dmax0;
+  for (int step = 0; step < n; ++step) {
+    int piv = 0;
+    for (int i = 1; i < n; ++i)
+      if (A[(size_t)i * n + i] > A[(size_t)piv * n + piv]) piv = i;
+    const double d = A[(size_t)piv * n + piv];
+    if (!(d > 1e-15 * dmax0) || !(d > 0.0)) break;
+    const double inv = 1.0 / std::sqrt(d);
+    std::vector<double> u(n);
+    for (int c = 0; c < n; ++c) u[c] = 0.5 * (A[(size_t)piv * n + c] + A[(size_t)c * n + piv]) * inv;
+    for (int r = 0; r < n; ++r)
+      for (int c = 0; c < n; ++c) A[(size_t)r * n + c] -= u[r] * u[c];
+    rows.push_back(u);
+  }
+  return rows;
+}
+
+// allow_sym = false: every quadratic / cone is laid out through a factor (rows u with ||U v||^2 = v'Gv), so
+// that no epilogue needs the direction itself (the split-operand kernel keeps v only as bf16 pieces).
+inline int layout_tiles(const RayenPack* p, TileLayout& b, bool allow_pack, bool allow_sym = true) {
   const double* W = p->W.data();
   auto wrow = [&](int r) { return W + (size_t)r * p->n; };
   auto blank = [](int type) { MItem it; std::memset(&it, 0, sizeof(it)); it.type = type; return it; };
@@ -119,7 +146,16 @@ inline int layout_tiles(const RayenPack* p, TileLayout& b, bool allow_pack) {
       // an SOC block M (rows x n) is turned into G = M'M when that is cheaper than its own rows
       const int sym_cost = (b.n_pad / 32) * (b.n_pad / 32 + 1) / 2;        // both in 32 x 32 blocks of MFMA work
       const int fac_cost = ((g.nrows + 31) / 32) * (b.n_pad / 32);
-      const bool sym = g.type == RAYEN_SEG_QUAD_SYM || (g.type == RAYEN_SEG_SOC && sym_cost < fac_cost);
+      const bool sym = allow_sym && (g.type == RAYEN_SEG_QUAD_SYM || (g.type == RAYEN_SEG_SOC && sym_cost < fac_cost));
+      const bool refactor = !allow_sym && g.type == RAYEN_SEG_QUAD_SYM;
+      size_t fac0 = 0;
+      int fac_rows = g.nrows;
+      if (refactor) {
+        fac0 = b.owned.size();
+        for (auto& u : psd_factor_rows(wrow(g.row0), p->n)) b.owned.push_back(std::move(u));
+        fac_rows = (int)(b.owned.size() - fac0);
+        if (fac_rows == 0) { b.owned.push_back(std::vector<double>(p->n, 0.0)); fac_rows = 1; }  // G = 0
+      }
       std::vector<double> gram;  // [n][n] for an SOC in symmetric form
       if (sym && g.type == RAYEN_SEG_SOC) {
         gram.assign((size_t)p->n * p->n, 0.0);
@@ -131,8 +167,8 @@ inline int layout_tiles(const RayenPack* p, TileLayout& b, bool allow_pack) {
           }
       }
       auto srow = [&](int r) { return gram.empty() ? wrow(g.row0 + r) : gram.data() + (size_t)r * p->n; };
-      const int srows = sym ? p->n : g.nrows;
-      const int total = sym ? b.n_pad : g.nrows;
+      const int srows = sym ? p->n : fac_rows;
+      const int total = sym ? b.n_pad : fac_rows;
       const int ntiles = (total + 31) / 32;
       for (int t = 0; t < ntiles; ++t) {
         std::vector<const double*> rows;
@@ -145,7 +181,8 @@ inline int layout_tiles(const RayenPack* p, TileLayout& b, bool allow_pack) {
           }
           for (auto& row : folded) rows.push_back(row.data());
         } else {
-          for (int r = 32 * t; r < 32 * t + 32 && r < g.nrows; ++r) rows.push_back(wrow(g.row0 + r));
+          for (int r = 32 * t; r < 32 * t + 32 && r < fac_rows; ++r)
+            rows.push_back(refactor ? b.owned[fac0 + r].data() : wrow(g.row0 + r));
         }
         b.add_tile(rows, p->n);
         MItem it = blank(0);
@@ -157,7 +194,7 @@ inline int layout_tiles(const RayenPack* p, TileLayout& b, bool allow_pack) {
         if (sym) { it.row0 = t; it.qbegin = 4 * t; }
         switch (g.type) {
           case RAYEN_SEG_LIN: it.type = MI_LIN; it.row0 = g.row0 + 32 * t; break;
-          case RAYEN_SEG_QUAD_SYM: it.type = MI_QSYM; break;
+          case RAYEN_SEG_QUAD_SYM: it.type = refactor ? MI_QFAC : MI_QSYM; break;
           case RAYEN_SEG_QUAD_FAC: it.type = MI_QFAC; break;
           case RAYEN_SEG_SOC: it.type = MI_SOC; break;
           default: return RAYEN_E_UNSUPPORTED;
