@@ -287,7 +287,7 @@ int rayen_pack_create(const RayenPackDesc* desc, RayenPack** out) {
   p->out_identity = desc->out_identity ? 1 : 0;
   {
     const char* env = std::getenv("RAYEN_SPLIT_BF16");
-    p->split_bf16 = (env != nullptr && env[0] >= '0' && env[0] <= '2') ? env[0] - '0' : 0;
+    p->split_bf16 = (env != nullptr && env[0] == '0') ? 0 : 1;   // RAYEN_SPLIT_BF16=0: plain fp32 MFMA kernels only
   }
   p->W.assign(desc->W, desc->W + (size_t)desc->n_rows * desc->n);
   p->y0.assign(desc->y0, desc->y0 + desc->k);
@@ -355,7 +355,7 @@ static int project_f32(const RayenPack* p, const float* v, int64_t B, int64_t ld
     return RAYEN_E_BAD_ARG;
   int rc = check_device(p);
   if (rc) return rc;
-  if (p->split_bf16 == 2 && y != nullptr && !old_mode) {
+  if (p->split_bf16 && y != nullptr && !old_mode) {
     rc = ensure_split(p);
     if (rc) return rc;
     if (p->sp32 != nullptr)
@@ -391,6 +391,8 @@ int rayen_ray_project_old_f32(const RayenPack* p, const float* v, int64_t B, int
 
 int rayen_mapper_fusable(const RayenPack* p, int32_t in_dim) {
   if (p == nullptr || check_device(p) != RAYEN_OK || ensure_mfma(p) != RAYEN_OK) return 0;
+  // packs served by the split-operand kernel are faster as GEMM + projection than through the fused fp32 kernel
+  if (p->split_bf16 && ensure_split(p) == RAYEN_OK && p->sp32 != nullptr) return 0;
   return (p->m32 != nullptr && mfma_mapper_fusable(p, p->m32, in_dim)) ? 1 : 0;
 }
 

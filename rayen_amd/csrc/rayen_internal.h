@@ -59,7 +59,7 @@ struct RayenPack {
   int device = -1;
   int k = 0, n = 0, n_rows = 0;
   int out_identity = 0;
-  int split_bf16 = 0;            // fp32 MFMA path on split bf16 operands (see rayen_mfma.hip)
+  int split_bf16 = 1;            // fp32 results from split bf16 operands where eligible (rayen_mfma_split.hip)
   std::vector<double> W;         // host copy [n_rows, n]
   std::vector<double> NA_E;      // host copy [k, n] (identity materialised)
   std::vector<double> y0;        // host copy [k]

@@ -50,7 +50,6 @@ constexpr int kMfmaWavesPerSimd = RAYEN_MFMA_WPS;
 
 struct MfmaImage {
   MPack* packs = nullptr;
-  void* Wb = nullptr;      // split-operand image: [n_tiles][NS][3][64] x 8 bf16 (null unless requested)
   int n_cu = 256;
   f32x4* W = nullptr;      // [n_tiles + 1][NQ][64] float4, fragment order (one spare tile for the prefetch)
   MItem* items = nullptr;

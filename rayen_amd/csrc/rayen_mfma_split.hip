@@ -24,6 +24,15 @@ namespace rayen {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// developer ablations (scripts/ubench/split_variant.sh): wrong results, timing only
+#ifndef RAYEN_SPLIT_ABL
+#define RAYEN_SPLIT_ABL 0
+#endif
+constexpr bool kAblNoEpilogue = (RAYEN_SPLIT_ABL & 1) != 0;
+constexpr bool kAblNoLoads = (RAYEN_SPLIT_ABL & 2) != 0;
+constexpr bool kAblNoMfma = (RAYEN_SPLIT_ABL & 4) != 0;
+constexpr bool kAblNoIo = (RAYEN_SPLIT_ABL & 8) != 0;
+
 struct SplitImage {
   void* Wb = nullptr;      // [n_tiles][NS][3][64] x 8 bf16
   MItem* items = nullptr;
@@ -90,7 +99,14 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fw
   bf16x8 vb[NT][3][NS];
   {
     float vr[NT][KK];
+    if constexpr (kAblNoIo) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < KK; ++i) vr[t][i] = (float)(lane + i + grp);
+    } else {
     load_rows<NT, NKK, LSTR, true>(vr, v, ldv, n, vec_in, s_base, B, live, patch, lane);
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -140,13 +156,18 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fw
       for (int sp = 0; sp < NS; ++sp) {
         __builtin_amdgcn_sched_barrier(0);
         // chunks 3 sp .. 3 sp + 2 were loaded NCH - 3 loads ago
-        if constexpr (NCH == 12)
+        if constexpr (kAblNoLoads) {
+        } else if constexpr (NCH == 12)
           asm volatile("s_waitcnt vmcnt(9)" : "+v"(abuf[3 * sp + 0]), "+v"(abuf[3 * sp + 1]), "+v"(abuf[3 * sp + 2]));
         else
           asm volatile("s_waitcnt vmcnt(3)" : "+v"(abuf[3 * sp + 0]), "+v"(abuf[3 * sp + 1]), "+v"(abuf[3 * sp + 2]));
         const bf16x8 a1 = __builtin_bit_cast(bf16x8, abuf[3 * sp + 0]), a2 = __builtin_bit_cast(bf16x8, abuf[3 * sp + 1]),
                      a3 = __builtin_bit_cast(bf16x8, abuf[3 * sp + 2]);
         // smallest products first; the first MFMA of a chain takes the constant 0 as C
+        if constexpr (kAblNoMfma) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t][sp] = __builtin_bit_cast(float, __builtin_bit_cast(u32x4, a1)[0] ^ __builtin_bit_cast(u32x4, vb[t][0][sp])[0]);
+        } else {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, vb[t][0][sp], sp == 0 ? zero : acc[t], 0, 0, 0);
@@ -160,12 +181,16 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fw
         for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, vb[t][1][sp], acc[t], 0, 0, 0);
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, vb[t][0][sp], acc[t], 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
-        load_step(next_tile, sp);
+        if constexpr (!kAblNoLoads) load_step(next_tile, sp);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (item.type == MI_LIN) {
+    if (kAblNoEpilogue && item.type != MI_AUX && item.type != MI_OUT) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) kap[t] = fmaxf(kap[t], acc[t][0]);
+    } else if (item.type == MI_LIN) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         if (TRACK) {
@@ -243,8 +268,10 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fw
           const float total = part[t] + xhalf(part[t]);
           const float a0 = aux_lds[wave][t][item.aux][col];
           float kc;
+          // (v_sqrt_f32 / v_rcp_f32, 1 ulp: the IEEE-exact forms cost ~10 VALU instructions each, and VALU work
+          // is serial with the MFMA stream)
           if (item.type != MI_SOC) {
-            kc = a0 + sqrtf(fmaxf(total, 0.f));
+            kc = a0 + __builtin_amdgcn_sqrtf(fmaxf(total, 0.f));
           } else {
             // a' x^2 + b' x + c' = 0  (rayen/constraint_module.py:392-396, 339-348), a' < 0
             const float br = aux_lds[wave][t][item.aux + 1][col];
@@ -253,8 +280,8 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fw
             const float disc = bp * bp - 4.f * item.f1 * cp;
             kc = 0.f;
             if (disc >= 0.f) {
-              const float root = sqrtf(disc);
-              const float inv2a = 0.5f / item.f1;
+              const float root = __builtin_amdgcn_sqrtf(disc);
+              const float inv2a = 0.5f * __builtin_amdgcn_rcpf(item.f1);
               kc = fmaxf((-bp - root) * inv2a, (-bp + root) * inv2a);
             }
           }
@@ -288,7 +315,16 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fw
           vr[t][4 * (2 * sp + (i >> 2)) + (i & 3)] = (x1 + x2) + x3;
         }
       }
+    if constexpr (kAblNoIo) {
+      float sum = 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < KK; ++i) sum += vr[t][i] * scale[t];
+      if (sum == 123.456f) y[s_base] = sum;
+    } else {
     bad |= store_rows<NT, NKK, LSTR, true>(vr, scale, y0_lds, y, ldy, k, vec_out, s_base, B, live, patch, lane);
+    }
   }
 
   if (hi == 0) {

@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""Safety check of rayen_mfma_split.hip's hand-placed loads: between an asm `global_load` into a chunk of the
+rolling A buffer and the `s_waitcnt` that covers it the compiler must not touch those registers (copy, spill):
+it does not know the data is still in flight.  Scans the gfx950 ISA of every instance of the kernel and lists
+any instruction inside the tile loops, other than the MFMAs and the loads themselves, that names a chunk register.
+    python scripts/check_split_asm.py        (exit code 1 if something is found)"""
+import os
+import re
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(REPO, "rayen_amd", "csrc", "rayen_mfma_split.hip")
+asm = "/tmp/rayen_mfma_split.s"
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(REPO, "include"),
+                "-I", os.path.join(REPO, "rayen_amd", "csrc"), "-S", "--cuda-device-only", src, "-o", asm],
+               check=True, stderr=subprocess.DEVNULL)
+lines = open(asm).read().split("\n")
+starts = [i for i, l in enumerate(lines) if l.startswith("_ZN5rayen21mfma_split_fwd_kernel") and l.split(";")[0].rstrip().endswith(":")]
+starts.append(len(lines))
+
+
+def regs_of(text):
+    out = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", text):
+        out.update(range(int(a), int(b) + 1))
+    out.update(int(a) for a in re.findall(r"\bv(\d+)\b", text))
+    return out
+
+
+bad_total = 0
+for s, e in zip(starts[:-1], starts[1:]):
+    body = []
+    for l in lines[s:e]:
+        body.append(l)
+        if "s_endpgm" in l:
+            break
+    name = re.search(r"ILi(\d)ELb(\d)ELb(\d)", lines[s]).groups()
+    loads = [i for i, l in enumerate(body) if "global_load_dwordx4" in l and re.search(r", s\[\d+:\d+\]", l)]
+    chunk = set()
+    for i in loads:
+        chunk |= regs_of(body[i].split(",")[0])
+    # in-flight windows: from the first asm load of the loop nest to the vmcnt(0) that closes it
+    first = loads[2 * 3 * int(name[0])]            # skip the initial fill (NCH = 6 NKK loads before the loops)
+    last = max(i for i, l in enumerate(body) if "s_waitcnt vmcnt(0)" in l and i > loads[-1]) if any(
+        "s_waitcnt vmcnt(0)" in l for l in body[loads[-1]:]) else len(body)
+    closing = min(i for i in range(loads[-1], len(body)) if "s_waitcnt vmcnt(0)" in body[i])
+    bad = []
+    for i in range(first, closing):
+        l = body[i].split(";")[0].strip()
+        if not l or l.startswith(".") or "v_mfma" in l or i in loads:
+            continue
+        if regs_of(l) & chunk:
+            bad.append((i, l))
+    print(f"NKK={name[0]} TRACK={name[1]} STAGED={name[2]}: {len(loads)} asm loads, chunk registers {min(chunk)}..{max(chunk)}"
+          f" ({len(chunk)}), suspicious instructions in the loop: {len(bad)}")
+    for i, l in bad[:12]:
+        print("     ", i, l[:110])
+    bad_total += len(bad)
+sys.exit(1 if bad_total else 0)

@@ -42,6 +42,27 @@ def _oracle_y(cs, layer, x):
     return oracle.forward(buf, v.unsqueeze(2)).numpy()[:, :, 0], v
 
 
+@pytest.fixture(autouse=True)
+def _fp32_mfma_kernels_only(monkeypatch, request):
+    """The fused-mapper kernel belongs to the plain fp32 MFMA family; packs served by the split-operand kernel
+    (the default where eligible) run the mapper as a GEMM of its own, which is faster there.  RAYEN_SPLIT_BF16 is
+    read when a pack is created, so this file pins the fp32 family unless a test asks for the default."""
+    if "default_kernels" not in request.keywords:
+        monkeypatch.setenv("RAYEN_SPLIT_BF16", "0")
+
+
+@pytest.mark.default_kernels
+def test_split_served_packs_run_the_mapper_as_its_own_gemm():
+    cs, layer = _module(_sets()["c3"], 64)
+    x = torch.empty(777, 64).uniform_(-2.0, 2.0, generator=torch.Generator().manual_seed(3))
+    dp, _ = layer.device_pack(torch.device("cuda", 0))
+    assert not ops.mapper_fusable(x.cuda(), layer.mapper.weight, layer.mapper.bias, dp)
+    with torch.no_grad():
+        y = layer(x.cuda()).cpu().numpy()[:, :, 0]
+    y_ref, _ = _oracle_y(cs, layer, x)
+    assert np.max(rel_err_rows(y, y_ref)) <= 1e-5
+
+
 @pytest.mark.parametrize("name,input_dim,fusable", [
     ("c2", 8, True), ("c2", 64, True), ("c3", 64, True), ("c3", 20, True), ("c3", 36, True),
     ("c5", 32, True), ("c5", 64, True), ("wide", 48, True),
