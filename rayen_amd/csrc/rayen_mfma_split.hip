@@ -23,6 +23,7 @@ namespace rayen {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // developer ablations (scripts/ubench/split_variant.sh): wrong results, timing only
 #ifndef RAYEN_SPLIT_ABL
@@ -89,7 +90,14 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fw
   for (int sp = 0; sp < NS; ++sp) load_step(reinterpret_cast<const char*>(Wb), sp);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  for (int64_t grp = wave_id; grp < n_groups; grp += wave_stride) {
+#ifndef RAYEN_SPLIT_SYNC
+#define RAYEN_SPLIT_SYNC 0
+#endif
+  const int64_t n_rounds = (n_groups + wave_stride - 1) / wave_stride;
+  for (int64_t round = 0; round < n_rounds; ++round) {
+  if (RAYEN_SPLIT_SYNC) __syncthreads();
+  const int64_t grp = wave_id + round * wave_stride;
+  if (grp >= n_groups) continue;
   const int64_t s_base = grp * (NT * 32);
 
   bool live[NT];
@@ -255,12 +263,16 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fw
       }
     } else if (item.type == MI_QFAC || item.type == MI_SOC) {
       // a running sum of squares over the segment's tiles, closed on its last tile
+      // (packed fp32 FMAs on the accumulators' own register pairs: 8 + 1 instructions per sample tile)
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        float sum = (item.flags & MF_FIRST) ? 0.f : part[t];
+        f32x2 s2 = {(item.flags & MF_FIRST) ? 0.f : part[t], 0.f};
 #pragma unroll
-        for (int g = 0; g < 16; ++g) sum = fmaf(acc[t][g], acc[t][g], sum);
-        part[t] = sum;
+        for (int g = 0; g < 16; g += 2) {
+          const f32x2 a2 = {acc[t][g], acc[t][g + 1]};
+          s2 = __builtin_elementwise_fma(a2, a2, s2);
+        }
+        part[t] = s2[0] + s2[1];
       }
       if (item.flags & MF_LAST) {
 #pragma unroll
