@@ -32,6 +32,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector = FP32 MFMA peak (spec)
+PEAK_BF16_TFLOPS = 2516.8  # dense bf16 MFMA = 16 x the fp32 MFMA rate (same guide; 2495 measured)
 PEAK_FP64_TFLOPS = 78.6    # MI355X datasheet: FP64 vector = FP64 matrix (v_mfma_f64_16x16x4_f64)
 PEAK_HBM_GBS = 8000.0      # HBM3E spec (≈6.3 TB/s achievable)
 
@@ -181,11 +182,18 @@ def main():
         tflops = flops_pp * B / kern_s / 1e12
         gbs = bytes_pp * B / kern_s / 1e9
         ai = flops_pp / bytes_pp
-        peak_tf = PEAK_FP32_TFLOPS if dtype == torch.float32 else PEAK_FP64_TFLOPS
+        info = layer.device_pack(device)[0].info()
+        split = dtype == torch.float32 and info.mfma_f32 == 2
+        # The split-operand kernel rebuilds every fp32 product from six bf16 MFMA products (fp32-grade results),
+        # so its matrix ceiling in ALGORITHMIC fp32 flops is the dense bf16 peak / 6, not the fp32 MFMA peak
+        peak_tf = (PEAK_BF16_TFLOPS / 6.0 if split else PEAK_FP32_TFLOPS) if dtype == torch.float32 else PEAK_FP64_TFLOPS
         ridge = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
         if ai > ridge:
             roof = {"bound": "mfma", "achieved": tflops, "peak": peak_tf, "unit": "TFLOP/s",
                     "frac": tflops / peak_tf, "traffic": None}
+            if split:
+                roof["peak_basis"] = "dense bf16 MFMA peak %.1f / 6 piece products per fp32 product" % PEAK_BF16_TFLOPS
+                roof["frac_of_fp32_mfma_peak"] = tflops / PEAK_FP32_TFLOPS
         else:
             roof = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": gbs / PEAK_HBM_GBS, "traffic": None}
@@ -194,7 +202,8 @@ def main():
         # bench.py itself cannot collect PMC counters, so this is null for workloads never profiled
         if args.config == "c3" and dtype == torch.float32 and B == 262144:
             import glob
-            found = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_c3_mfma_final_rocprofv3.json")))
+            found = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_c3_split_final_rocprofv3.json" if split
+                                                  else "r*_c3_mfma_final_rocprofv3.json")))
             if found:
                 prof = json.load(open(found[-1]))
                 roof["traffic"] = prof.get("derived", {}).get("hbm_bytes_per_launch")
@@ -203,7 +212,6 @@ def main():
         roof.update({"kernel_ms": dev_ms, "algorithmic_flops_per_projection": flops_pp,
                      "algorithmic_bytes_per_projection": bytes_pp, "hbm_GBps": gbs,
                      "hbm_frac": gbs / PEAK_HBM_GBS, "TFLOPs": tflops})
-        info = layer.device_pack(device)[0].info()
         out = {
             "metric": "feasible projections/sec at k=64, 128 lin+4 quad+2 SOC; max violation"
                       if args.config == "c3" else f"feasible projections/sec ({args.config})",
@@ -219,7 +227,7 @@ def main():
                                    f"batch {B} per GPU, v~U(-{rng:g},{rng:g})",
                        "batch_per_gpu": B, "global_batch": world * B,
                        "parallelism": f"batch-sharded x{world}" + (" + all-gather(y)" if gathered is not None else ""),
-                       "kernel": ("mfma_f32" if info.mfma_f32 else "generic") if dtype == torch.float32
+                       "kernel": ({2: "mfma_split_bf16x3 (fp32-grade)", 1: "mfma_f32"}.get(info.mfma_f32, "generic")) if dtype == torch.float32
                        else ("mfma_f64" if info.mfma_f64 else "generic")},
             "max_violation": max_violation,
             "violations_gt_1e-6": int(max_violation > 1e-6),

@@ -92,7 +92,8 @@ typedef struct RayenPackDesc {
 typedef struct RayenPackInfo {
   int32_t k, n, n_rows, n_segments;
   int32_t device;               /* HIP device ordinal the pack lives on */
-  int32_t mfma_f32;             /* 1: the fp32 MFMA path serves this pack */
+  int32_t mfma_f32;             /* fp32 forward: 0 lane-per-sample kernels | 1 fp32 MFMA kernel | 2 split-operand kernel
+                                   (six bf16 MFMA products per fp32 product, fp32-grade results) */
   int32_t generic_block;        /* fp32 generic path: workgroup size with v staged in LDS; 0 = v read from global memory */
   int32_t mfma_f64;             /* 1: the fp64 MFMA path serves this pack */
   int64_t device_bytes;         /* bytes of device memory the pack holds so far */

@@ -330,7 +330,7 @@ int rayen_pack_info(const RayenPack* p, RayenPackInfo* info) {
   info->n_rows = p->n_rows;
   info->n_segments = (int32_t)p->segs.size();
   info->device = p->device;
-  info->mfma_f32 = mfma_eligible(p) ? 1 : 0;
+  info->mfma_f32 = (p->split_bf16 && mfma_split_eligible(p)) ? 2 : (mfma_eligible(p) ? 1 : 0);
   info->mfma_f64 = mfma64_eligible(p) ? 1 : 0;
   int lmi_words = 0;
   for (const RayenSegment& g : p->segs)

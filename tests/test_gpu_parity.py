@@ -119,6 +119,31 @@ def test_wide_shapes_against_oracle(name):
     assert dp.info().mfma_f32 == 1
 
 
+@pytest.mark.parametrize("name", ["c2", "c3", "c5", "rand3", "rand17", "rand40"])
+def test_plain_fp32_mfma_family(name, monkeypatch):
+    """RAYEN_SPLIT_BF16=0 (read when a pack is created) turns the split-operand kernel off: the plain fp32 MFMA
+    kernels, which otherwise serve only n > 64, the RAYEN_old head and the fused mapper, take the pack."""
+    monkeypatch.setenv("RAYEN_SPLIT_BF16", "0")
+    raw = _random_set(1000 + int(name[4:])) if name.startswith("rand") else workloads.make_raw(name, seed=21)
+    cs, layer = _layer(raw, torch.float32)
+    dp, _ = layer.device_pack(torch.device("cuda", 0))
+    assert dp.info().mfma_f32 in (0, 1)
+    gen = torch.Generator().manual_seed(8)
+    x = torch.empty(3001, cs.n, 1).uniform_(-1.5, 1.5, generator=gen)
+    y = layer(x.cuda()).cpu().numpy()[:, :, 0]
+    monkeypatch.delenv("RAYEN_SPLIT_BF16")
+    _, layer_default = _layer(cs, torch.float32)
+    y_default = layer_default(x.cuda()).cpu().numpy()[:, :, 0]
+    # the two families round differently but agree to fp32 accuracy; both are judged against the oracle elsewhere
+    assert np.max(rel_err_rows(y, y_default)) <= 2 * FP32_TOL
+    try:
+        y_ref = _oracle_forward(cs, x, torch.float32)
+    except AssertionError:
+        return
+    if not name.startswith("rand"):
+        assert np.max(rel_err_rows(y, y_ref)) <= FP32_TOL
+
+
 # --------------------------------------------------------------------------- closed-form answers
 def _run(layer, v):
     return layer(torch.tensor(v, dtype=torch.float32).unsqueeze(2).cuda()).cpu().numpy()[:, :, 0].astype(np.float64)
