@@ -22,7 +22,7 @@ for db in ("pmc_sq", "pmc_fetch", "pmc_write"):
     con = sqlite3.connect(f"{base}/{db}/pmc_results.db")
     for r in con.execute("select kernel_name,counter_name,avg(value),count(*) from counters_collection "
                          "group by kernel_name,counter_name"):
-        if r[0].split("(")[0] == dominant:
+        if r[0].split("(")[0].startswith(dominant) or dominant.startswith(r[0].split("(")[0]):
             out["pmc"][r[1]] = {"avg_per_launch": r[2], "launches": r[3]}
 p = out["pmc"]
 avg_us = out["kernel_stats"][0]["avg_us"]
