@@ -234,7 +234,8 @@ def main():
             "roofline": roof,
         }
         if args.mapper:
-            out["config"]["mapper"] = f"nn.Linear({args.mapper}, {cs.n}) " + ("as its own GEMM" if args.no_fuse else "fused into the projection kernel")
+            fused = (not args.no_fuse) and dtype == torch.float32 and layer.device_pack(device)[0].mapper_fusable(args.mapper)
+            out["config"]["mapper"] = f"nn.Linear({args.mapper}, {cs.n}) " + ("fused into the projection kernel" if fused else "as its own GEMM")
         if world == 1 and not args.no_cpu_baseline and not args.mapper:
             out["cpu_baseline"] = cpu_baseline(raw, cs, B, dtype, args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

@@ -1,0 +1,18 @@
+"""The split-operand kernel places its A-operand loads by hand (inline asm) because hipcc would otherwise gather
+them right in front of their uses; the compiler does not see that data arrive.  This test compiles the kernel to
+gfx950 ISA (no GPU needed) and checks, for every instance, that nothing but the MFMAs and the loads themselves
+touches a chunk register while a load into it may be in flight (scripts/check_split_asm.py)."""
+import os
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_no_compiler_access_to_in_flight_chunk_registers():
+    run = subprocess.run([sys.executable, os.path.join(REPO, "scripts", "check_split_asm.py")],
+                         capture_output=True, text=True)
+    assert run.returncode == 0, run.stdout + run.stderr
+    lines = [l for l in run.stdout.splitlines() if l.startswith("NKK=")]
+    assert len(lines) == 8, run.stdout                       # NKK in {1, 2} x TRACK x STAGED
+    assert all(l.rstrip().endswith("suspicious instructions in the loop: 0") for l in lines), run.stdout
