@@ -29,6 +29,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef RAYEN_SPLIT_ABL
 #define RAYEN_SPLIT_ABL 0
 #endif
+// Wave priority: 2 = everything OUTSIDE a tile's MFMA burst (epilogues, group boundary) runs at s_setprio 1, so
+// that a wave gets through its VALU / memory sections ahead of its SIMD partner's MFMA burst and returns to the
+// matrix pipe sooner (+2 % on configs 3 and 5); 1 = the opposite (-1 %); 0 = no priorities.
+#ifndef RAYEN_SPLIT_PRIO
+#define RAYEN_SPLIT_PRIO 2
+#endif
 constexpr bool kAblNoEpilogue = (RAYEN_SPLIT_ABL & 1) != 0;
 constexpr bool kAblNoLoads = (RAYEN_SPLIT_ABL & 2) != 0;
 constexpr bool kAblNoMfma = (RAYEN_SPLIT_ABL & 4) != 0;
@@ -90,12 +96,8 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fw
   for (int sp = 0; sp < NS; ++sp) load_step(reinterpret_cast<const char*>(Wb), sp);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-#ifndef RAYEN_SPLIT_SYNC
-#define RAYEN_SPLIT_SYNC 0
-#endif
   const int64_t n_rounds = (n_groups + wave_stride - 1) / wave_stride;
   for (int64_t round = 0; round < n_rounds; ++round) {
-  if (RAYEN_SPLIT_SYNC) __syncthreads();
   const int64_t grp = wave_id + round * wave_stride;
   if (grp >= n_groups) continue;
   const int64_t s_base = grp * (NT * 32);
@@ -160,6 +162,11 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fw
     // ---- the tile's MFMAs; each K-step's chunks are re-loaded for the next tile as soon as they were used
     {
       const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#if RAYEN_SPLIT_PRIO == 1
+      __builtin_amdgcn_s_setprio(1);
+#elif RAYEN_SPLIT_PRIO == 2
+      __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
       for (int sp = 0; sp < NS; ++sp) {
         __builtin_amdgcn_sched_barrier(0);
@@ -194,6 +201,11 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fw
         if constexpr (!kAblNoLoads) load_step(next_tile, sp);
         __builtin_amdgcn_sched_barrier(0);
       }
+#if RAYEN_SPLIT_PRIO == 1
+      __builtin_amdgcn_s_setprio(0);
+#elif RAYEN_SPLIT_PRIO == 2
+      __builtin_amdgcn_s_setprio(1);
+#endif
     }
     if (kAblNoEpilogue && item.type != MI_AUX && item.type != MI_OUT) {
 #pragma unroll
