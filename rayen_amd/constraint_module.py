@@ -176,8 +176,13 @@ class ConstraintModule(torch.nn.Module):
             raise RuntimeError(
                 "rayen_amd.ConstraintModule runs on an MI355X (HIP) device only; got a "
                 f"{v.device} tensor. Call .to('cuda') on the model and the input.")
-        _, pack_id = self.device_pack(v.device)
+        dp, pack_id = self.device_pack(v.device)
         need_active = torch.is_grad_enabled() and v.requires_grad
+        if not need_active and type(v) is torch.Tensor and not torch.compiler.is_compiling():
+            # plain inference call: straight to the C ABI (the same code the registered op runs; the dispatcher
+            # layers around a custom op cost ~10 us per call, as much as the kernel at small batches)
+            y, kappa, _ = ops.project_raw(v, dp, want_active=False, old_head=old_head)
+            return y, kappa
         y, kappa, _ = torch.ops.rayen_amd.ray_project(v, pack_id, need_active, old_head)
         return y, kappa
 

@@ -53,8 +53,36 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def _stream():
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _stream(index=None):
+    """The caller's current HIP stream (a raw hipStream_t).  ``torch.cuda.current_stream().cuda_stream`` costs
+    several microseconds of Python per call, which is most of a small-batch forward; the private accessor is what
+    it ends in."""
+    if _raw_stream is not None and index is not None:
+        return ctypes.c_void_p(_raw_stream(index))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _on_device:
+    """``with torch.cuda.device(d)`` only when ``d`` is not already the current device."""
+    __slots__ = ("index", "ctx")
+
+    def __init__(self, device):
+        self.index = device.index
+        self.ctx = None
+
+    def __enter__(self):
+        if torch.cuda.current_device() != self.index:
+            self.ctx = torch.cuda.device(self.index)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
 
 
 _FWD = {(torch.float32, False): "rayen_ray_project_f32", (torch.float64, False): "rayen_ray_project_f64",
@@ -82,9 +110,9 @@ def project_raw(v, pack, want_y=True, force_generic=False, want_active=True, old
     active = torch.empty((B, 2), dtype=torch.int32, device=v.device) if want_active else None
     name = _FWD_OLD[v.dtype] if old_head else _FWD[(v.dtype, bool(force_generic))]
     fn = getattr(_lib.load(), name)
-    with torch.cuda.device(v.device):
+    with _on_device(v.device):
         code = fn(pack.handle, _ptr(v), B, v.stride(0) if B else pack.consts.n, _ptr(y), k,
-                  _ptr(kappa), _ptr(active), _ptr(pack.nan_flag), _stream())
+                  _ptr(kappa), _ptr(active), _ptr(pack.nan_flag), _stream(v.device.index))
     _lib.check(code, "rayen_ray_project")
     return y, kappa, active
 
@@ -124,11 +152,11 @@ def backward_raw(v, kappa, active, grad_y, pack, old_head=False, force_generic=F
         if old_head:
             raise RuntimeError("force_generic selects between the two RAYEN backward kernels only")
         name = "rayen_ray_project_bwd_generic_f32" if v.dtype == torch.float32 else "rayen_ray_project_bwd_generic_f64"
-    with torch.cuda.device(v.device):
+    with _on_device(v.device):
         code = getattr(_lib.load(), name)(pack.handle, _ptr(v), B, v.stride(0) if B else pack.consts.n,
                                           _ptr(kappa), _ptr(active), _ptr(grad_y), grad_y.shape[1],
                                           _ptr(grad_v), grad_v.stride(0) if B else pack.consts.n,
-                                          _stream())
+                                          _stream(v.device.index))
     _lib.check(code, "rayen_ray_project_bwd")
     return grad_v
 
@@ -200,11 +228,11 @@ def ray_project_mapped(x: torch.Tensor, weight: torch.Tensor, bias: Optional[tor
     kappa = torch.empty((B,), dtype=x.dtype, device=x.device)
     active = torch.empty((B if need_grad else 0, 2), dtype=torch.int32, device=x.device)
     v = torch.empty((B if need_grad else 0, n), dtype=x.dtype, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on_device(x.device):
         code = _lib.load().rayen_ray_project_mapped_f32(
             pack.handle, _ptr(x), B, x.stride(0) if B else in_dim, in_dim, _ptr(weight), weight.stride(0),
             _ptr(bias), _ptr(v) if need_grad else None, n, _ptr(y), k, _ptr(kappa),
-            _ptr(active) if need_grad else None, _ptr(pack.nan_flag), _stream())
+            _ptr(active) if need_grad else None, _ptr(pack.nan_flag), _stream(x.device.index))
     _lib.check(code, "rayen_ray_project_mapped")
     return y, kappa, active, v
 
