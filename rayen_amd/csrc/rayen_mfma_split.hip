@@ -39,6 +39,9 @@ constexpr bool kAblNoEpilogue = (RAYEN_SPLIT_ABL & 1) != 0;
 constexpr bool kAblNoLoads = (RAYEN_SPLIT_ABL & 2) != 0;
 constexpr bool kAblNoMfma = (RAYEN_SPLIT_ABL & 4) != 0;
 constexpr bool kAblNoIo = (RAYEN_SPLIT_ABL & 8) != 0;
+constexpr bool kAblNoSplit = (RAYEN_SPLIT_ABL & 16) != 0;  // no split / rebuild arithmetic at the group boundary
+constexpr bool kAblNoStore = (RAYEN_SPLIT_ABL & 32) != 0;
+constexpr bool kAblNoLoadRows = (RAYEN_SPLIT_ABL & 64) != 0;
 
 struct SplitImage {
   void* Wb = nullptr;      // [n_tiles][NS][3][64] x 8 bf16
@@ -114,9 +117,30 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fw
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int i = 0; i < KK; ++i) vr[t][i] = (float)(lane + i + grp);
+    } else if constexpr (kAblNoLoadRows) {
+      if (round == 0) load_rows<NT, NKK, LSTR, true>(vr, v, ldv, n, vec_in, s_base, B, live, patch, lane);
+      else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int i = 0; i < KK; ++i) vr[t][i] = (float)(lane + i + grp);
+      }
     } else {
     load_rows<NT, NKK, LSTR, true>(vr, v, ldv, n, vec_in, s_base, B, live, patch, lane);
     }
+    if constexpr (kAblNoSplit) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int sp = 0; sp < NS; ++sp)
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) {
+            u32x4 w;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[i] = __builtin_bit_cast(unsigned, vr[t][(8 * sp + 2 * i + pc) % KK]);
+            vb[t][pc][sp] = __builtin_bit_cast(bf16x8, w);
+          }
+    } else
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -321,6 +345,14 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fw
     finish_kappa();
     // y = y0 + v / max(1, kappa): v rebuilt from its pieces, v1 + v2 + v3 (exact)
     float vr[NT][KK];
+    if constexpr (kAblNoSplit) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int sp = 0; sp < NS; ++sp)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) vr[t][8 * sp + i] = __builtin_bit_cast(float, __builtin_bit_cast(u32x4, vb[t][i % 3][sp])[i >> 1]);
+    } else
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -346,6 +378,14 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fw
 #pragma unroll
         for (int i = 0; i < KK; ++i) sum += vr[t][i] * scale[t];
       if (sum == 123.456f) y[s_base] = sum;
+    } else if constexpr (kAblNoStore) {
+      float sum = 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < KK; ++i) sum += vr[t][i] * scale[t];
+      if (sum == 123.456f || round + 1 == n_rounds)
+        bad |= store_rows<NT, NKK, LSTR, true>(vr, scale, y0_lds, y, ldy, k, vec_out, s_base, B, live, patch, lane);
     } else {
     bad |= store_rows<NT, NKK, LSTR, true>(vr, scale, y0_lds, y, ldy, k, vec_out, s_base, B, live, patch, lane);
     }
