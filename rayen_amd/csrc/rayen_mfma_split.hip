@@ -160,17 +160,17 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fw
   }
 
   float kap[NT], part[NT], scale[NT];
-  int aseg[NT], arow[NT];
+  int acode[NT];  // arg-max bookkeeping in one register: (segment << 20) | row, -1 = none (host: < 2048 segments, < 2^20 rows)
 #pragma unroll
-  for (int t = 0; t < NT; ++t) { kap[t] = 0.f; part[t] = 0.f; scale[t] = 1.f; aseg[t] = -1; arow[t] = 0; }
+  for (int t = 0; t < NT; ++t) { kap[t] = 0.f; part[t] = 0.f; scale[t] = 1.f; acode[t] = -1; }
 
   auto finish_kappa = [&]() {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const float other = xhalf(kap[t]);
       if (TRACK) {
-        const int oseg = __shfl_xor(aseg[t], 32), orow = __shfl_xor(arow[t], 32);
-        if (other > kap[t] || (other == kap[t] && hi == 1)) { aseg[t] = oseg; arow[t] = orow; }
+        const int ocode = __shfl_xor(acode[t], 32);
+        if (other > kap[t] || (other == kap[t] && hi == 1)) acode[t] = ocode;
       }
       kap[t] = fmaxf(kap[t], other);
       scale[t] = 1.0f / fmaxf(1.0f, kap[t]);
@@ -235,6 +235,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fw
 #pragma unroll
       for (int t = 0; t < NT; ++t) kap[t] = fmaxf(kap[t], acc[t][0]);
     } else if (item.type == MI_LIN) {
+      const int lin_code = (item.seg << 20) + item.row0 + 4 * hi;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         if (TRACK) {
@@ -242,8 +243,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fw
           for (int g = 0; g < 16; ++g)
             if (acc[t][g] > kap[t]) {
               kap[t] = acc[t][g];
-              aseg[t] = item.seg;
-              arow[t] = item.row0 + (g & 3) + 8 * (g >> 2) + 4 * hi;
+              acode[t] = lin_code + ((g & 3) + 8 * (g >> 2));
             }
         } else {
 #pragma unroll
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fw
           for (int c = 1; c < 4; ++c) qs = fmaf(acc[t][4 * a + c], acc[t][4 * a + c], qs);
           if (pair) qs += xhalf(qs);
           const float kc = aux_lds[wave][t][slot & 31][col] + __builtin_amdgcn_sqrtf(qs);
-          if (sid >= 0 && kc > kap[t]) { kap[t] = kc; aseg[t] = sid; arow[t] = 0; }
+          if (sid >= 0 && kc > kap[t]) { kap[t] = kc; acode[t] = sid << 20; }
         }
       }
     } else if (item.type == MI_QFAC || item.type == MI_SOC) {
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fw
               kc = fmaxf((-bp - root) * inv2a, (-bp + root) * inv2a);
             }
           }
-          if (kc > kap[t]) { kap[t] = kc; aseg[t] = item.seg; arow[t] = 0; }
+          if (kc > kap[t]) { kap[t] = kc; acode[t] = item.seg << 20; }
         }
       }
     }
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fw
       if (!live[t]) continue;
       const int64_t s = s_base + t * 32 + col;
       if (kappa_out) kappa_out[s] = kap[t];
-      if (TRACK) { active_out[2 * s] = aseg[t]; active_out[2 * s + 1] = arow[t]; }
+      if (TRACK) { active_out[2 * s] = acode[t] >> 20; active_out[2 * s + 1] = acode[t] < 0 ? 0 : (acode[t] & 0xFFFFF); }
     }
   }
   }  // persistent loop over sample groups
@@ -409,6 +409,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fw
 // ---------------------------------------------------------------------------------------------
 bool mfma_split_eligible(const RayenPack* p) {
   if (p->n > 64) return false;
+  if (p->segs.size() >= 2048 || p->n_rows >= (1 << 20)) return false;  // (segment, row) share one register
   for (const RayenSegment& g : p->segs)
     if (g.type == RAYEN_SEG_LMI) return false;
   TileLayout b(p->n);
