@@ -257,6 +257,33 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fw
         for (int g = 0; g < 16; ++g)
           aux_lds[wave][t][(g & 3) + 8 * (g >> 2) + 4 * hi][col] = acc[t][g];
       __builtin_amdgcn_wave_barrier();
+    } else if (STAGED && NKK == 2 && item.type == MI_OUT) {
+      // (n > 32: the staged write-out below does not fit the registers next to 96 B-operand registers -- hipcc
+      // spills ~100 of them at the group boundary --, so the rows leave as 16-byte pieces straight from the
+      // accumulators)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (!live[t]) continue;
+        float* yrow = y + (s_base + t * 32 + col) * ldy;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int r0 = item.row0 + 8 * a + 4 * hi;
+          if (r0 >= k) continue;
+          f32x4 o;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            o[c] = fmaf(acc[t][4 * a + c], scale[t], y0[r0 + c]);  // y0 is padded to a tile multiple
+            bad |= (o[c] != o[c]) && (r0 + c < k);
+          }
+          if (vec_out && r0 + 3 < k) {
+            *reinterpret_cast<f32x4*>(yrow + r0) = o;
+          } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (r0 + c < k) yrow[r0 + c] = o[c];
+          }
+        }
+      }
     } else if (STAGED && item.type == MI_OUT) {
       // rows of NA_E: through this wave's aux patch (XOR-swizzled), out as row-coalesced stores
 #pragma unroll
