@@ -144,6 +144,32 @@ def test_plain_fp32_mfma_family(name, monkeypatch):
         assert np.max(rel_err_rows(y, y_ref)) <= FP32_TOL
 
 
+@pytest.mark.parametrize("name", ["c2", "c3", "c5", "rand5", "rand12", "rand23", "rand31", "rand47"])
+def test_split_operand_kernel_is_fp32_grade(name, monkeypatch):
+    """The default fp32 forward rebuilds every fp32 product from six bf16 MFMA products.  Measured against the fp64
+    kernel on the same inputs, its error must be that of fp32 arithmetic: no worse than the exact-fp32 MFMA kernel's
+    own error (x2 and a 5e-7 floor for sets where both are at the rounding level of the outputs)."""
+    raw = _random_set(1000 + int(name[4:])) if name.startswith("rand") else workloads.make_raw(name, seed=13)
+    cs, layer_split = _layer(raw, torch.float32)
+    if layer_split.device_pack(torch.device("cuda", 0))[0].info().mfma_f32 != 2:
+        pytest.skip("set not served by the split-operand kernel")
+    monkeypatch.setenv("RAYEN_SPLIT_BF16", "0")
+    _, layer_exact = _layer(cs, torch.float32)
+    monkeypatch.delenv("RAYEN_SPLIT_BF16")
+    _, layer_truth = _layer(cs, torch.float64)
+    gen = torch.Generator().manual_seed(15)
+    x = torch.empty(20000, cs.n, 1).uniform_(-1.5, 1.5, generator=gen)
+    x[:64] *= 1e-3
+    y_split = layer_split(x.cuda()).cpu().double().numpy()[:, :, 0]
+    y_exact = layer_exact(x.cuda()).cpu().double().numpy()[:, :, 0]
+    y_truth = layer_truth(x.double().cuda()).cpu().numpy()[:, :, 0]
+    e_split, e_exact = rel_err_rows(y_split, y_truth), rel_err_rows(y_exact, y_truth)
+    assert np.max(e_split) <= max(2.0 * np.max(e_exact), 5e-7), (np.max(e_split), np.max(e_exact))
+    assert np.mean(e_split) <= max(2.0 * np.mean(e_exact), 1e-7), (np.mean(e_split), np.mean(e_exact))
+    # interior samples: y = y0 + NA_E v, the same fp32 sum in both kernels up to the order of the additions
+    assert np.max(rel_err_rows(y_split[:64], y_exact[:64])) <= 3e-7
+
+
 # --------------------------------------------------------------------------- closed-form answers
 def _run(layer, v):
     return layer(torch.tensor(v, dtype=torch.float32).unsqueeze(2).cuda()).cpu().numpy()[:, :, 0].astype(np.float64)
