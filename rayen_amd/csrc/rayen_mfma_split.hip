@@ -32,6 +32,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // Wave priority: 2 = everything OUTSIDE a tile's MFMA burst (epilogues, group boundary) runs at s_setprio 1, so
 // that a wave gets through its VALU / memory sections ahead of its SIMD partner's MFMA burst and returns to the
 // matrix pipe sooner (+2 % on configs 3 and 5); 1 = the opposite (-1 %); 0 = no priorities.
+// 1: the products of a tile go in by size, in three passes over the K-steps (default); 0: step by step
+#ifndef RAYEN_SPLIT_PHASES
+#define RAYEN_SPLIT_PHASES 1
+#endif
 #ifndef RAYEN_SPLIT_PRIO
 #define RAYEN_SPLIT_PRIO 2
 #endif
@@ -191,6 +195,57 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fw
 #elif RAYEN_SPLIT_PRIO == 2
       __builtin_amdgcn_s_setprio(0);
 #endif
+#if RAYEN_SPLIT_PHASES
+      // Three passes over the K-steps, by product size: the 2^-16 products of ALL steps first, then the 2^-8 ones,
+      // the leading products last.  The instruction aligns its 16 products and C to the largest of them and keeps
+      // ~26 bits (scripts/ubench/mfma_bf16_acc.hip): a small product added to an accumulator that already holds
+      // leading products loses its low bits, so the small ones go in while the accumulator is still small.
+      auto load_chunk = [&](const int idx) {
+        const char* sb = next_tile + idx * 1024;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(abuf[idx]) : "v"(lane_off), "s"(sb));
+      };
+#pragma unroll
+      for (int sp = 0; sp < NS; ++sp) {
+        __builtin_amdgcn_sched_barrier(0);
+        // the step's three chunks: the youngest (a1, re-loaded in the last pass of the previous tile) has NS - 1 loads behind it
+        if constexpr (NS == 4)
+          asm volatile("s_waitcnt vmcnt(3)" : "+v"(abuf[3 * sp + 0]), "+v"(abuf[3 * sp + 1]), "+v"(abuf[3 * sp + 2]));
+        else
+          asm volatile("s_waitcnt vmcnt(1)" : "+v"(abuf[3 * sp + 0]), "+v"(abuf[3 * sp + 1]), "+v"(abuf[3 * sp + 2]));
+        const bf16x8 a1 = __builtin_bit_cast(bf16x8, abuf[3 * sp + 0]), a2 = __builtin_bit_cast(bf16x8, abuf[3 * sp + 1]),
+                     a3 = __builtin_bit_cast(bf16x8, abuf[3 * sp + 2]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, vb[t][0][sp], sp == 0 ? zero : acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, vb[t][1][sp], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, vb[t][2][sp], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_chunk(3 * sp + 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int sp = 0; sp < NS; ++sp) {
+        const bf16x8 a1 = __builtin_bit_cast(bf16x8, abuf[3 * sp + 0]), a2 = __builtin_bit_cast(bf16x8, abuf[3 * sp + 1]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, vb[t][0][sp], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, vb[t][1][sp], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_chunk(3 * sp + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int sp = 0; sp < NS; ++sp) {
+        const bf16x8 a1 = __builtin_bit_cast(bf16x8, abuf[3 * sp + 0]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, vb[t][0][sp], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_chunk(3 * sp + 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#else
 #pragma unroll
       for (int sp = 0; sp < NS; ++sp) {
         __builtin_amdgcn_sched_barrier(0);
@@ -225,6 +280,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fw
         if constexpr (!kAblNoLoads) load_step(next_tile, sp);
         __builtin_amdgcn_sched_barrier(0);
       }
+#endif
 #if RAYEN_SPLIT_PRIO == 1
       __builtin_amdgcn_s_setprio(0);
 #elif RAYEN_SPLIT_PRIO == 2
