@@ -1,9 +1,11 @@
 // C-ABI entry points of librayen_hip.so (declared in include/rayen_hip.h).
 #include "rayen_internal.h"
 
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 using namespace rayen;
 
@@ -287,7 +289,9 @@ int rayen_pack_create(const RayenPackDesc* desc, RayenPack** out) {
   p->out_identity = desc->out_identity ? 1 : 0;
   {
     const char* env = std::getenv("RAYEN_SPLIT_BF16");
-    p->split_bf16 = (env != nullptr && env[0] == '0') ? 0 : 1;   // RAYEN_SPLIT_BF16=0: plain fp32 MFMA kernels only
+    // RAYEN_SPLIT_BF16=0: exact-fp32 MFMA kernels only | 1 (default): split-operand kernel where the comparison
+    // of split_selfcheck accepts it | 2: split-operand kernel without that comparison
+    p->split_bf16 = (env != nullptr && (env[0] == '0' || env[0] == '2')) ? env[0] - '0' : 1;
   }
   p->W.assign(desc->W, desc->W + (size_t)desc->n_rows * desc->n);
   p->y0.assign(desc->y0, desc->y0 + desc->k);
@@ -330,7 +334,7 @@ int rayen_pack_info(const RayenPack* p, RayenPackInfo* info) {
   info->n_rows = p->n_rows;
   info->n_segments = (int32_t)p->segs.size();
   info->device = p->device;
-  info->mfma_f32 = (p->split_bf16 && mfma_split_eligible(p)) ? 2 : (mfma_eligible(p) ? 1 : 0);
+  info->mfma_f32 = (p->split_bf16 && p->sp32_state != 2 && mfma_split_eligible(p)) ? 2 : (mfma_eligible(p) ? 1 : 0);
   info->mfma_f64 = mfma64_eligible(p) ? 1 : 0;
   int lmi_words = 0;
   for (const RayenSegment& g : p->segs)
@@ -348,6 +352,59 @@ int rayen_ray_project_generic_f32(const RayenPack* p, const float* v, int64_t B,
   return project_generic<float>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
 }
 
+// The split-operand kernel is fp32-grade on well-conditioned sums; where a constraint set makes the sums cancel
+// heavily its error constant is ~4x that of an fp32 FMA chain.  So every pack is compared ONCE with
+// the exact-fp32 kernel on 512 pseudo-random directions (first forward call outside a stream capture; two small
+// launches on the null stream and one synchronisation): if any output row differs by more than 5e-6 of its size,
+// the pack is ill-conditioned for fp32 and is served by the exact-fp32 family from then on.
+static int split_selfcheck(const RayenPack* p, hipStream_t user_stream) {
+  if (p->split_bf16 == 2) { p->sp32_state = 1; return RAYEN_OK; }  // RAYEN_SPLIT_BF16=2: no comparison
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (user_stream != nullptr && hipStreamIsCapturing(user_stream, &cap) == hipSuccess &&
+      cap != hipStreamCaptureStatusNone)
+    return RAYEN_OK;  // not now: this call runs unchecked, the comparison happens at the next plain call
+  int rc = ensure_mfma(p);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(p->mu);
+  if (p->sp32_state != 0) return RAYEN_OK;
+  if (p->m32 == nullptr) { p->sp32_state = 1; return RAYEN_OK; }  // (the two families share their eligibility rule)
+  constexpr int B0 = 512;
+  const int n = p->n, k = p->k;
+  std::vector<float> hv((size_t)B0 * n), ya((size_t)B0 * k), yb((size_t)B0 * k);
+  uint32_t state = 0x9E3779B9u;
+  for (float& x : hv) {
+    state = state * 1664525u + 1013904223u;
+    x = ((float)(state >> 8) * (1.0f / 8388608.0f) - 1.0f) * 1.5f;  // uniform in (-1.5, 1.5)
+  }
+  float* dv = nullptr;
+  float* dy = nullptr;
+  bool ok = hipMalloc(&dv, hv.size() * sizeof(float)) == hipSuccess &&
+            hipMalloc(&dy, 2 * ya.size() * sizeof(float)) == hipSuccess &&
+            hipMemcpy(dv, hv.data(), hv.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+  if (ok) {
+    rc = mfma_split_forward(p, p->sp32, dv, B0, n, dy, k, nullptr, nullptr, nullptr, nullptr);
+    if (rc == RAYEN_OK)
+      rc = mfma_forward(p, p->m32, dv, B0, n, dy + ya.size(), k, nullptr, nullptr, nullptr, 0, nullptr);
+    ok = rc == RAYEN_OK && hipMemcpy(ya.data(), dy, ya.size() * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess &&
+         hipMemcpy(yb.data(), dy + ya.size(), yb.size() * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess;
+  }
+  if (dv) (void)hipFree(dv);
+  if (dy) (void)hipFree(dy);
+  if (!ok) return rc != RAYEN_OK ? rc : RAYEN_E_ALLOC;
+  double worst = 0.0;
+  for (int b = 0; b < B0; ++b) {
+    double diff = 0.0, size = 1e-30;
+    for (int i = 0; i < k; ++i) {
+      const double a = ya[(size_t)b * k + i], c = yb[(size_t)b * k + i];
+      diff = std::fmax(diff, std::fabs(a - c));
+      size = std::fmax(size, std::fabs(c));
+    }
+    if (!(diff / size <= worst)) worst = diff / size;  // (NaN counts as a difference)
+  }
+  p->sp32_state = (worst <= 5e-6) ? 1 : 2;
+  return RAYEN_OK;
+}
+
 static int project_f32(const RayenPack* p, const float* v, int64_t B, int64_t ldv, float* y, int64_t ldy,
                        float* kappa, int32_t* active, int32_t* nan_flag, void* stream, int old_mode) {
   if (p == nullptr || B < 0 || (B > 0 && v == nullptr) || ldv < p->n + old_mode ||
@@ -358,7 +415,11 @@ static int project_f32(const RayenPack* p, const float* v, int64_t B, int64_t ld
   if (p->split_bf16 && y != nullptr && !old_mode) {
     rc = ensure_split(p);
     if (rc) return rc;
-    if (p->sp32 != nullptr)
+    if (p->sp32 != nullptr && p->sp32_state == 0) {
+      rc = split_selfcheck(p, static_cast<hipStream_t>(stream));
+      if (rc) return rc;
+    }
+    if (p->sp32 != nullptr && p->sp32_state != 2)
       return mfma_split_forward(p, p->sp32, v, B, ldv, y, ldy, kappa, active, nan_flag,
                                 static_cast<hipStream_t>(stream));
   }
@@ -392,7 +453,7 @@ int rayen_ray_project_old_f32(const RayenPack* p, const float* v, int64_t B, int
 int rayen_mapper_fusable(const RayenPack* p, int32_t in_dim) {
   if (p == nullptr || check_device(p) != RAYEN_OK || ensure_mfma(p) != RAYEN_OK) return 0;
   // packs served by the split-operand kernel are faster as GEMM + projection than through the fused fp32 kernel
-  if (p->split_bf16 && ensure_split(p) == RAYEN_OK && p->sp32 != nullptr) return 0;
+  if (p->split_bf16 && ensure_split(p) == RAYEN_OK && p->sp32 != nullptr && p->sp32_state != 2) return 0;
   return (p->m32 != nullptr && mfma_mapper_fusable(p, p->m32, in_dim)) ? 1 : 0;
 }
 

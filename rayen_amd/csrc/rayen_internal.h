@@ -84,6 +84,7 @@ struct RayenPack {
   mutable bool q32_tried = false, q64_tried = false;
   mutable rayen::SplitImage* sp32 = nullptr;
   mutable bool sp32_tried = false;
+  mutable int sp32_state = 0;    // 0: not yet compared with the exact-fp32 kernel on this pack | 1: accepted | 2: rejected
   mutable int64_t device_bytes = 0;
 };
 

@@ -170,6 +170,33 @@ def test_split_operand_kernel_is_fp32_grade(name, monkeypatch):
     assert np.max(rel_err_rows(y_split[:64], y_exact[:64])) <= 3e-7
 
 
+def test_ill_conditioned_pack_is_served_by_the_exact_fp32_kernels(monkeypatch):
+    """Fuzz set 971 (70 dimensions, one dense quadratic with a large gradient at the interior point, 10 equalities):
+    its sums cancel so heavily that the split-operand kernel is 8x less accurate than fp32 arithmetic.  The library
+    compares the two kernel families once per pack on 512 directions and keeps the exact-fp32 one here."""
+    raw = _random_set(1971)
+    cs, layer = _layer(raw, torch.float32)
+    gen = torch.Generator().manual_seed(971)
+    x = torch.empty(31, cs.n, 1).uniform_(-2.0, 2.0, generator=gen)
+    y = layer(x.cuda()).cpu().numpy()[:, :, 0]
+    dp, _ = layer.device_pack(torch.device("cuda", 0))
+    assert dp.info().mfma_f32 == 1
+    y_true = _oracle_forward(cs, x.double(), torch.float64)
+    y_ref = _oracle_forward(cs, x, torch.float32)
+    assert rel_err_rows(y, y_true).max() <= 2.0 * max(rel_err_rows(y_ref, y_true).max(), 1e-6)
+    # RAYEN_SPLIT_BF16=2 skips the comparison: the split-operand kernel runs, and is visibly less accurate here
+    monkeypatch.setenv("RAYEN_SPLIT_BF16", "2")
+    _, forced = _layer(cs, torch.float32)
+    y_forced = forced(x.cuda()).cpu().numpy()[:, :, 0]
+    assert forced.device_pack(torch.device("cuda", 0))[0].info().mfma_f32 == 2
+    assert rel_err_rows(y_forced, y_true).max() <= 1e-4
+    # a well-conditioned pack keeps the split-operand kernel
+    monkeypatch.delenv("RAYEN_SPLIT_BF16")
+    cs3, layer3 = _layer(workloads.make_raw("c3", seed=3), torch.float32)
+    layer3(torch.zeros(4, cs3.n, 1).cuda())
+    assert layer3.device_pack(torch.device("cuda", 0))[0].info().mfma_f32 == 2
+
+
 # --------------------------------------------------------------------------- closed-form answers
 def _run(layer, v):
     return layer(torch.tensor(v, dtype=torch.float32).unsqueeze(2).cuda()).cpu().numpy()[:, :, 0].astype(np.float64)
