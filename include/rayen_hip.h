@@ -118,7 +118,13 @@ int rayen_pack_info(const RayenPack* pack, RayenPackInfo* info);
  *   nan_flag [1]  set to 1 (never cleared) when any written y is NaN; the
  *                 fused replacement of constraint_module.py:531's full-tensor check
  * y may be NULL to compute kappa only (the computeKappa helper, :351).
- * `stream` is a hipStream_t (NULL = the null stream). */
+ * `stream` is a hipStream_t (NULL = the null stream).  Calls are asynchronous
+ * and allocate nothing, with ONE exception per pack and precision: the first
+ * call builds that kernel family's image of the constants (device allocation)
+ * and, in fp32, compares the two fp32 kernel families on 512 directions (one
+ * synchronisation of the null stream; skipped while `stream` is being
+ * captured, and then done by the next plain call).  Warm a pack up with one
+ * call before capturing it into a HIP graph. */
 int rayen_ray_project_f32(const RayenPack* pack, const float* v, int64_t B, int64_t ldv,
                           float* y, int64_t ldy, float* kappa, int32_t* active,
                           int32_t* nan_flag, void* stream);
