@@ -45,7 +45,11 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwd_kern
   // two sample tiles per wave (every A fetch feeds two MFMA chains); grad_y is read twice -- once for
   // g.v, once for the final combination -- instead of occupying n/2 VGPRs per tile during the walk
   constexpr int NT = RAYEN_BWD_NT, NQ = NKK * 4, KK = NKK * 16, NP = NKK * 32, LSTR = NKK * 32 + 4;
-  __shared__ __attribute__((aligned(16))) float line_lds[kMfmaWaves][32][LSTR];
+  // Per-wave LDS region, used in turn by the transposition patch of load_rows / store_rows and, through the walk,
+  // by grad_y parked in lane-private 16-byte slots (it is needed again for the final combination; a second trip
+  // to global memory would be one more exposed round trip at the group boundary).
+  constexpr int WL = (32 * LSTR > NT * KK * 64) ? 32 * LSTR : NT * KK * 64;
+  __shared__ __attribute__((aligned(16))) float wave_lds[kMfmaWaves][WL];
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -54,7 +58,8 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwd_kern
   const int64_t n_groups = (B + NT * 32 - 1) / (NT * 32);
   const int64_t wave_id = (int64_t)blockIdx.x * kMfmaWaves + wave;
   const int64_t wave_stride = (int64_t)gridDim.x * kMfmaWaves;
-  float (*patch)[LSTR] = line_lds[wave];
+  float (*patch)[LSTR] = reinterpret_cast<float (*)[LSTR]>(wave_lds[wave]);
+  f32x4* gpark = reinterpret_cast<f32x4*>(wave_lds[wave]) + lane;  // piece j of sample tile t: gpark[(t * (KK / 4) + j) * 64]
 
   for (int64_t grp = wave_id; grp < n_groups; grp += wave_stride) {
     const int64_t s_base = grp * (NT * 32);
@@ -75,6 +80,12 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwd_kern
         for (int i = 0; i < KK; ++i) dot = fmaf(tr[t][i], vr[t][i], dot);
         tv[t] = dot + xhalf(dot);
       }
+      __builtin_amdgcn_wave_barrier();  // every lane is done reading the patch
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < KK / 4; ++j)
+          gpark[(t * (KK / 4) + j) * 64] = f32x4{tr[t][4 * j], tr[t][4 * j + 1], tr[t][4 * j + 2], tr[t][4 * j + 3]};
     }
     bool any = false;
 #pragma unroll
@@ -226,10 +237,17 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwd_kern
         }
     }
 
-    // grad_v = s g - coef grad kappa (in place in ur), with g read a second time
+    // grad_v = s g - coef grad kappa (in place in ur), with g back from its parking slots
     {
       float tr[NT][KK];
-      load_rows<NT, NKK, LSTR, true>(tr, gy, ldg, n, vec_g, s_base, B, live, patch, lane);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < KK / 4; ++j) {
+          const f32x4 g4 = gpark[(t * (KK / 4) + j) * 64];
+          tr[t][4 * j] = g4[0]; tr[t][4 * j + 1] = g4[1]; tr[t][4 * j + 2] = g4[2]; tr[t][4 * j + 3] = g4[3];
+        }
+      __builtin_amdgcn_wave_barrier();  // the region goes back to the patch (store_rows below)
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         if (!old_mode) {
