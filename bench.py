@@ -236,6 +236,31 @@ def main():
         if args.mapper:
             fused = (not args.no_fuse) and dtype == torch.float32 and layer.device_pack(device)[0].mapper_fusable(args.mapper)
             out["config"]["mapper"] = f"nn.Linear({args.mapper}, {cs.n}) " + ("fused into the projection kernel" if fused else "as its own GEMM")
+        if split and world == 1 and not args.mapper:
+            # the same workload on the exact-fp32 MFMA kernels (RAYEN_SPLIT_BF16=0 is read when a pack is created),
+            # timed the same way, so that one line carries both fp32 families
+            os.environ["RAYEN_SPLIT_BF16"] = "0"
+            try:
+                exact = ConstraintModule(cs, method="RAYEN", create_map=False).to(device)
+                exact.check_nan = False
+                with torch.no_grad():
+                    for _ in range(args.warmup):
+                        exact(x)
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(args.steps):
+                        exact(x)
+                    e1.record()
+                    torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / args.steps
+                tf = flops_pp * B / (ms * 1e-3) / 1e12
+                out["exact_fp32_kernels"] = {"value": B / (ms * 1e-3), "unit": "projections/s", "ms_per_step": ms,
+                                             "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS,
+                                                          "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS},
+                                             "how": "RAYEN_SPLIT_BF16=0, same inputs, same step count"}
+            finally:
+                del os.environ["RAYEN_SPLIT_BF16"]
         if world == 1 and not args.no_cpu_baseline and not args.mapper:
             out["cpu_baseline"] = cpu_baseline(raw, cs, B, dtype, args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
