@@ -122,15 +122,50 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fw
 #pragma unroll
         for (int i = 0; i < KK; ++i) vr[t][i] = (float)(lane + i + grp);
     } else if constexpr (kAblNoLoadRows) {
-      if (round == 0) load_rows<NT, NKK, LSTR, true>(vr, v, ldv, n, vec_in, s_base, B, live, patch, lane);
+      if (round == 0) load_rows<NT, NKK, LSTR, true>(vr, v, ldv, n, vec_in & 1, s_base, B, live, patch, lane);
       else {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
           for (int i = 0; i < KK; ++i) vr[t][i] = (float)(lane + i + grp);
       }
+    } else if (NKK == 1 && (vec_in & 2) && n != NKK * 32) {  // (n > 32: this path would cost the kernel its last registers)
+      // Ragged rows stored back to back (ldv == n, 16-byte aligned base: config-5-like shapes).  A tile's 32 rows
+      // are one contiguous, 16-byte aligned block of 32 n floats: it comes in as whole-line float4 loads, goes
+      // through the patch as a flat array and is read back row-wise (a lane's own row, 4-byte pieces).  The
+      // per-element path below costs a third of the kernel at n = 30.
+      float* flat = &patch[0][0];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int64_t row0 = s_base + 32 * t;
+        const int64_t left = B - row0;
+        const int nfl = (int)(left >= 32 ? 32 : (left > 0 ? left : 0)) * n;  // floats of this tile that exist
+        const float* src = v + row0 * (int64_t)n;
+#pragma unroll
+        for (int jj = 0; jj < NKK * 4; ++jj) {
+          const int i4 = lane + 64 * jj;  // float4 index inside the block
+          if (i4 < 8 * n) {
+            f32x4 x = {0.f, 0.f, 0.f, 0.f};
+            if (4 * i4 + 3 < nfl) {
+              x = *reinterpret_cast<const f32x4*>(src + 4 * i4);
+            } else {
+              if (4 * i4 + 0 < nfl) x[0] = src[4 * i4 + 0];
+              if (4 * i4 + 1 < nfl) x[1] = src[4 * i4 + 1];
+              if (4 * i4 + 2 < nfl) x[2] = src[4 * i4 + 2];
+            }
+            *reinterpret_cast<f32x4*>(flat + 4 * i4) = x;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const float* myrow = flat + col * n + 4 * hi;
+#pragma unroll
+        for (int q = 0; q < NKK * 4; ++q)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) vr[t][4 * q + c] = (8 * q + 4 * hi + c < n) ? myrow[8 * q + c] : 0.f;
+        __builtin_amdgcn_wave_barrier();
+      }
     } else {
-    load_rows<NT, NKK, LSTR, true>(vr, v, ldv, n, vec_in, s_base, B, live, patch, lane);
+    load_rows<NT, NKK, LSTR, true>(vr, v, ldv, n, vec_in & 1, s_base, B, live, patch, lane);
     }
     if constexpr (kAblNoSplit) {
 #pragma unroll
@@ -589,7 +624,9 @@ static int launch_split(const RayenPack* p, const SplitImage* img, const float* 
   const int64_t rounds = (n_groups + slots - 1) / slots;
   const int64_t waves = (n_groups + rounds - 1) / rounds;
   const int64_t grid = (waves + kMfmaWaves - 1) / kMfmaWaves;
-  const int vec_in = (ldv % 4 == 0) && ((reinterpret_cast<uintptr_t>(v) & 15) == 0);
+  // bit 0: rows are 16-byte aligned (float4 pieces of a row) | bit 1: rows are stored back to back and the base is 16-byte aligned
+  const int vec_in = (((ldv % 4 == 0) && ((reinterpret_cast<uintptr_t>(v) & 15) == 0)) ? 1 : 0) |
+                     ((ldv == p->n && (reinterpret_cast<uintptr_t>(v) & 15) == 0) ? 2 : 0);
   const int vec_out = (ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
   auto go = [&](auto kern) {
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kMfmaWaves * 64), 0, stream,
