@@ -33,7 +33,8 @@
  * code; nothing throws across the ABI; no per-call allocation; launches are
  * asynchronous on the caller's stream (no host sync); tensor memory is owned by
  * the caller and must live on the pack's device; a pack is immutable after
- * creation, so it may be shared by threads and streams.
+ * rayen_pack_create returns, so it may be shared by threads and streams and
+ * captured into a HIP graph from its first call.
  */
 #ifndef RAYEN_HIP_H
 #define RAYEN_HIP_H
@@ -44,7 +45,7 @@
 extern "C" {
 #endif
 
-#define RAYEN_ABI_VERSION 1
+#define RAYEN_ABI_VERSION 2
 
 enum {
   RAYEN_OK = 0,
@@ -54,7 +55,17 @@ enum {
   RAYEN_E_ALLOC = -4,         /* device allocation or upload failed in pack_create */
   RAYEN_E_LAUNCH = -5,        /* hipGetLastError() after a launch */
   RAYEN_E_UNSUPPORTED = -6,   /* shape outside what the kernels handle (see rayen_pack_info) */
-  RAYEN_E_DEVICE_MISMATCH = -7 /* pack lives on another device than the current one */
+  RAYEN_E_DEVICE_MISMATCH = -7, /* pack lives on another device than the current one */
+  RAYEN_E_NOT_PREPARED = -8   /* precision / direction excluded by RayenPackDesc.prepare */
+};
+
+/* RayenPackDesc.prepare: the kernel families whose device images rayen_pack_create builds.  0 = everything
+ * (fp32 + fp64, forward + backward).  A call into a family that was left out returns RAYEN_E_NOT_PREPARED. */
+enum {
+  RAYEN_PREPARE_ALL = 0,
+  RAYEN_PREPARE_F32 = 1,
+  RAYEN_PREPARE_F64 = 2,
+  RAYEN_PREPARE_FWD_ONLY = 4
 };
 
 enum {
@@ -87,6 +98,10 @@ typedef struct RayenPackDesc {
   const RayenSegment* segments; /* HOST [n_segments] */
   const double* NA_E;           /* HOST [k, n] row-major; may be NULL when out_identity */
   const double* y0;             /* HOST [k] */
+  int32_t prepare;              /* RAYEN_PREPARE_* bits; 0 = all families */
+  int32_t fp32_mode;            /* fp32 forward, n <= 64, no LMI: 0 = split-operand kernel where the creation-time
+                                   accuracy measurement accepts it (default) | 1 = exact-fp32 MFMA kernels only |
+                                   2 = split-operand kernel without the measurement */
 } RayenPackDesc;
 
 typedef struct RayenPackInfo {
@@ -96,7 +111,11 @@ typedef struct RayenPackInfo {
                                    (six bf16 MFMA products per fp32 product, fp32-grade results) */
   int32_t generic_block;        /* fp32 generic path: workgroup size with v staged in LDS; 0 = v read from global memory */
   int32_t mfma_f64;             /* 1: the fp64 MFMA path serves this pack */
-  int64_t device_bytes;         /* bytes of device memory the pack holds so far */
+  int64_t device_bytes;         /* bytes of device memory the pack holds */
+  int32_t prepared;             /* RAYEN_PREPARE_F32 | RAYEN_PREPARE_F64 | 4 (backward) */
+  int32_t reserved;
+  double fp32_check_split;      /* worst row error (relative to the row's size) of the split-operand kernel against */
+  double fp32_check_exact;      /* fp64 on the creation-time probe directions, and the exact-fp32 kernel's; -1 = not measured */
 } RayenPackInfo;
 
 typedef struct RayenPack RayenPack;
@@ -104,8 +123,11 @@ typedef struct RayenPack RayenPack;
 int rayen_abi_version(void);
 const char* rayen_strerror(int code);
 
-/* Upload the constants to the CURRENT HIP device.  Host arrays are copied; they
- * may be freed after the call returns. */
+/* Upload the constants to the CURRENT HIP device and build EVERY device image the entry points below will
+ * read (all kernel families selected by desc->prepare), including the one-time accuracy measurement that
+ * decides which fp32 forward family serves the pack (RayenPackInfo.mfma_f32).  This is the only call that
+ * allocates device memory or synchronises; it must not run while a stream of this thread is being captured.
+ * Host arrays are copied; they may be freed after the call returns. */
 int rayen_pack_create(const RayenPackDesc* desc, RayenPack** out);
 void rayen_pack_destroy(RayenPack* pack);
 int rayen_pack_info(const RayenPack* pack, RayenPackInfo* info);
@@ -118,13 +140,8 @@ int rayen_pack_info(const RayenPack* pack, RayenPackInfo* info);
  *   nan_flag [1]  set to 1 (never cleared) when any written y is NaN; the
  *                 fused replacement of constraint_module.py:531's full-tensor check
  * y may be NULL to compute kappa only (the computeKappa helper, :351).
- * `stream` is a hipStream_t (NULL = the null stream).  Calls are asynchronous
- * and allocate nothing, with ONE exception per pack and precision: the first
- * call builds that kernel family's image of the constants (device allocation)
- * and, in fp32, compares the two fp32 kernel families on 512 directions (one
- * synchronisation of the null stream; skipped while `stream` is being
- * captured, and then done by the next plain call).  Warm a pack up with one
- * call before capturing it into a HIP graph. */
+ * `stream` is a hipStream_t (NULL = the null stream).  Calls are asynchronous,
+ * allocate nothing and touch no other stream. */
 int rayen_ray_project_f32(const RayenPack* pack, const float* v, int64_t B, int64_t ldv,
                           float* y, int64_t ldy, float* kappa, int32_t* active,
                           int32_t* nan_flag, void* stream);

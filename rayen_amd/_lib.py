@@ -10,9 +10,10 @@ import os
 
 from ._build import LIBRARY
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 SEG_LIN, SEG_QUAD_SYM, SEG_QUAD_FAC, SEG_SOC, SEG_LMI = range(5)
+PREPARE_ALL, PREPARE_F32, PREPARE_F64, PREPARE_FWD_ONLY = 0, 1, 2, 4
 
 # every symbol include/rayen_hip.h declares
 EXPORTS = (
@@ -39,14 +40,17 @@ class RayenPackDesc(ctypes.Structure):
                 ("W", ctypes.POINTER(ctypes.c_double)),
                 ("segments", ctypes.POINTER(RayenSegment)),
                 ("NA_E", ctypes.POINTER(ctypes.c_double)),
-                ("y0", ctypes.POINTER(ctypes.c_double))]
+                ("y0", ctypes.POINTER(ctypes.c_double)),
+                ("prepare", ctypes.c_int32), ("fp32_mode", ctypes.c_int32)]
 
 
 class RayenPackInfo(ctypes.Structure):
     _fields_ = [("k", ctypes.c_int32), ("n", ctypes.c_int32), ("n_rows", ctypes.c_int32),
                 ("n_segments", ctypes.c_int32), ("device", ctypes.c_int32),
                 ("mfma_f32", ctypes.c_int32), ("generic_block", ctypes.c_int32),
-                ("mfma_f64", ctypes.c_int32), ("device_bytes", ctypes.c_int64)]
+                ("mfma_f64", ctypes.c_int32), ("device_bytes", ctypes.c_int64),
+                ("prepared", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("fp32_check_split", ctypes.c_double), ("fp32_check_exact", ctypes.c_double)]
 
 
 class RayenError(RuntimeError):

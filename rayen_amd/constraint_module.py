@@ -142,8 +142,10 @@ class ConstraintModule(torch.nn.Module):
         """Host-side (fp64) row matrix + segment table derived from the buffers."""
         if self._consts is None:
             names = ("D", "NA_E", "z0", "yp", "y0", "all_phi", "all_delta", "all_M", "all_s",
-                     "all_c", "all_d", "all_F", "L")
-            self._consts = _pack.pack_constants({n: getattr(self, n) for n in names if hasattr(self, n)})
+                     "all_c", "all_d", "all_F", "L", "all_P")
+            exact = ([(qc.P, qc.q, qc.r) for qc in self.cs.qcs], self.cs.y0) if self.cs.qcs else None
+            self._consts = _pack.pack_constants({n: getattr(self, n) for n in names if hasattr(self, n)},
+                                                exact_quadratics=exact)
         return self._consts
 
     def device_pack(self, device):

@@ -17,9 +17,10 @@ hot path.  The arithmetic that does not need an optimisation solver (stacking,
 null-space reparametrisation ``y = NA_E z + yp``, ``A_p``/``b_p``, ``z0`` from a
 user ``y0``) follows the reference exactly.  The reference solves its LPs and
 its max-margin interior-point program with cvxpy (ECOS/SCS/Gurobi), which this
-image does not ship; here those steps use ``scipy.optimize`` (HiGHS ``linprog``
-for the LPs, SLSQP for the margin program), so a *solver-chosen* ``z0`` is not
-bit-comparable with the reference's ("parity unpinned").  With an
+image does not ship; here those steps use HiGHS ``linprog`` for the LPs and the
+small conic solver of ``rayen_amd/conic.py`` for the margin program and for
+``project`` / ``getViolation``, so a *solver-chosen* ``z0`` is not bit-comparable
+with the reference's ("parity unpinned").  With an
 explicit ``y0`` no solver runs and the result is pinned by the golden fixtures.
 """
 from __future__ import annotations
@@ -30,7 +31,7 @@ import numpy as np
 import scipy.linalg
 import scipy.optimize
 
-from . import utils
+from . import conic, utils
 
 
 def _cvxpy():
@@ -372,12 +373,40 @@ class ConvexConstraints:
             out.append(np.array([_lambda_min_sym(H)]))
         return np.concatenate(out)
 
+    def _nonlinear_cone_rows(self, prog, Y, y_off, eps_col=None):
+        """Append the quadratic / SOC / LMI constraints at ``y = Y x + y_off`` to ``prog`` (a
+        :class:`conic.ConeProgram`), each tightened by the margin ``x[eps_col]`` when given --
+        the conic form of ``asCvxpy(y, epsilon)`` (constraints.py:104-106, 129-130, 147-155)."""
+        nvar = prog.nvar
+        e = np.zeros(nvar)
+        if eps_col is not None:
+            e[eps_col] = 1.0
+        y_off = y_off.reshape(-1)
+        for qc in self.qcs:
+            q = qc.q.reshape(-1)
+            # 1/2 y'Py <= t,  t = -q'y - r - eps
+            prog.add_quadratic(qc.P, (Y, y_off), (-(q @ Y) - e, -float(q @ y_off) - float(qc.r.item())))
+        for soc in self.socs:
+            cvec = soc.c.reshape(-1)
+            G = np.concatenate((soc.M @ Y, ((cvec @ Y) - e).reshape(1, -1)), axis=0)
+            h = np.concatenate((soc.M @ y_off + soc.s.reshape(-1), [float(cvec @ y_off) + float(soc.d.item())]))
+            prog.add(conic.SOC, G, h)
+        if self.has_lmi_constraints:
+            F = [np.asarray(Fi, dtype=np.float64) for Fi in self.lmic.all_F]
+            r = F[0].shape[0]
+            Fy = np.stack([Fi.reshape(-1) for Fi in F[:-1]], axis=1)          # [r*r, k]
+            G = Fy @ Y - np.outer(np.eye(r).reshape(-1), e)
+            h = Fy @ y_off + F[-1].reshape(-1)
+            prog.add(conic.PSD, G, h, dim=r)
+
     def _find_interior_point(self):
         """max eps s.t. every constraint holds with margin eps, 0<=eps<=0.5 (constraints.py:412-432).
 
-        Linear-only sets are an LP (HiGHS).  With nonlinear families present the
-        margin program is solved with SLSQP from the LP solution (or the origin);
-        the result only has to be strictly interior, not optimal.
+        Linear-only sets are an LP (HiGHS).  With nonlinear families present the same
+        margin program is solved as a conic program (``rayen_amd/conic.py``: quadratics and
+        cones as second-order cones, the LMI as a PSD cone -- no derivative of ``lambda_min``
+        is needed, so structured LMIs with repeated eigenvalues are handled); the result
+        only has to be strictly interior, which is verified on the true residuals.
         """
         n = self.n
         m = self.A_p.shape[0]
@@ -399,33 +428,21 @@ class ConvexConstraints:
             utils.verify(eps_lp > 1e-8)
             return z_start.reshape(n, 1)
 
-        def neg_eps(x):
-            return -x[-1]
-
-        def neg_eps_grad(x):
-            g = np.zeros_like(x)
-            g[-1] = -1.0
-            return g
-
-        cons = [{"type": "ineq", "fun": lambda x: self.margins(x[:n]) - x[-1]}]
-        best = None
-        starts = [z_start, np.zeros(n)]
-        rng = np.random.default_rng(0)
-        starts += [z_start + 0.1 * rng.standard_normal(n) for _ in range(4)]
-        for start in starts:
-            x0 = np.concatenate((start, [0.0]))
-            sol = scipy.optimize.minimize(neg_eps, x0, jac=neg_eps_grad, constraints=cons,
-                                          bounds=bounds, method="SLSQP",
-                                          options={"maxiter": 500, "ftol": 1e-12})
-            z = sol.x[:n]
-            eps = float(np.min(self.margins(z)))
-            if best is None or eps > best[1]:
-                best = (z, eps)
-            if eps > 1e-3:
-                break
-        if best is None or best[1] <= 1e-8:
+        prog = conic.ConeProgram(n + 1)
+        prog.add(conic.NONNEG, -A_ub, self.b_p[:, 0])                       # b_p - A_p z - eps >= 0
+        box = np.zeros((2, n + 1))
+        box[0, -1], box[1, -1] = 1.0, -1.0
+        prog.add(conic.NONNEG, box, [0.0, 0.5])                             # 0 <= eps <= 0.5
+        Y = np.concatenate((self.NA_E, np.zeros((self.k, 1))), axis=1)
+        self._nonlinear_cone_rows(prog, Y, self.yp, eps_col=n)
+        x, info = conic.solve(prog, None, c, x0=np.concatenate((z_start, [0.0])), eps_abs=1e-8, eps_rel=1e-8)
+        z = x[:n]
+        eps = float(np.min(self.margins(z)))
+        if eps <= 1e-8:
+            # the margin program did not deliver a strictly interior point: the set has an empty interior
+            # in the subspace (or no point at all) -- same outcome as constraints.py:224-234 / :428
             raise Exception("The feasible set is empty")
-        return best[0].reshape(n, 1)
+        return z.reshape(n, 1)
 
     # ------------------------------------------------------------------ export
     def getDataAsDict(self):
@@ -511,17 +528,25 @@ class ConvexConstraints:
         return constraints + self.getNonLinearConstraintsCvxpy(y, epsilon)
 
     def project(self, y_to_be_projected):
-        """Euclidean projection onto the set (constraints.py:539-547); needs cvxpy."""
-        cp = _cvxpy()
-        y_var = cp.Variable((self.k, 1))
-        prob = cp.Problem(cp.Minimize(cp.sum_squares(y_var - y_to_be_projected)),
-                          self.getConstraintsCvxpy(y_var))
-        obj_value = prob.solve(verbose=False)
-        if prob.status not in ("optimal", "optimal_inaccurate"):
-            raise Exception(f"Value is not optimal, prob_status={prob.status}")
-        return y_var.value, obj_value
+        """Euclidean projection onto the set (constraints.py:443-447, 539-547): ``(y_projected [k,1],
+        squared distance)``.  The reference solves this program with cvxpy; here it is the same
+        program in conic form on ``rayen_amd/conic.py`` (no cvxpy in this image)."""
+        p = np.asarray(y_to_be_projected, dtype=np.float64).reshape(self.k)
+        k = self.k
+        prog = conic.ConeProgram(k)
+        if self.has_linear_ineq_constraints:
+            prog.add(conic.NONNEG, -self.lc.A1, self.lc.b1[:, 0])
+        if self.has_linear_eq_constraints:
+            prog.add(conic.ZERO, self.lc.A2, -self.lc.b2[:, 0])
+        self._nonlinear_cone_rows(prog, np.eye(k), np.zeros(k))
+        # min ||y - p||^2 = y'y - 2p'y + p'p  ->  P = 2I, c = -2p
+        y, info = conic.solve(prog, 2.0 * np.eye(k), -2.0 * p, x0=p)
+        if info["status"] != "solved" and info["r_prim"] > 1e-6:
+            raise Exception(f"Value is not optimal, prob_status={info['status']}")
+        return y.reshape(k, 1), float(np.sum((y - p) ** 2))
 
     def getViolation(self, y_to_be_projected):
+        """Squared distance of a point to the set (constraints.py:549-559); 0 for feasible points."""
         if y_to_be_projected.ndim == 1:
             y_to_be_projected = np.expand_dims(y_to_be_projected, axis=1)
         _, violation = self.project(y_to_be_projected)

@@ -47,136 +47,64 @@ int check_device(const RayenPack* p) {
   return dev == p->device ? RAYEN_OK : RAYEN_E_DEVICE_MISMATCH;
 }
 
+// Every device image a pack may ever need is built by rayen_pack_create (build_images below), so the entry points
+// only read the pack: no lazy state, no lock, no allocation, nothing on the null stream after creation.
 template <typename T>
-int ensure_generic(const RayenPack* p) {
-  std::lock_guard<std::mutex> lock(p->mu);
+int check_ready(const RayenPack* p, bool backward) {
+  const int rc = check_device(p);
+  if (rc) return rc;
+  const int want = (sizeof(T) == 4 ? RAYEN_PREPARE_F32 : RAYEN_PREPARE_F64) | (backward ? 4 : 0);
+  return (p->prepared & want) == want ? RAYEN_OK : RAYEN_E_NOT_PREPARED;
+}
+
+template <typename T>
+int build_generic(RayenPack* p) {
   GenericImage<T>& img = image_of<T>(p);
-  if (img.built) return RAYEN_OK;
   const int rc = generic_build<T>(p, &img);
   if (rc != RAYEN_OK) { generic_free<T>(&img); return rc; }
   p->device_bytes += img.bytes;
   return RAYEN_OK;
 }
 
-int ensure_mfma(const RayenPack* p) {
-  std::lock_guard<std::mutex> lock(p->mu);
-  if (p->m32_tried) return RAYEN_OK;
-  p->m32_tried = true;
-  if (!mfma_eligible(p)) return RAYEN_OK;
+template <typename Image, typename Build>
+int build_one(RayenPack* p, bool eligible, Image** slot, Build build) {
+  if (!eligible) return RAYEN_OK;
   int64_t bytes = 0;
-  MfmaImage* img = nullptr;
-  const int rc = mfma_build(p, &img, &bytes);
+  Image* img = nullptr;
+  const int rc = build(p, &img, &bytes);
   if (rc != RAYEN_OK) return rc;
-  p->m32 = img;
+  *slot = img;
   p->device_bytes += bytes;
   return RAYEN_OK;
 }
 
-int ensure_split(const RayenPack* p) {
-  std::lock_guard<std::mutex> lock(p->mu);
-  if (p->sp32_tried) return RAYEN_OK;
-  p->sp32_tried = true;
-  if (!mfma_split_eligible(p)) return RAYEN_OK;
-  int64_t bytes = 0;
-  SplitImage* img = nullptr;
-  const int rc = mfma_split_build(p, &img, &bytes);
-  if (rc != RAYEN_OK) return rc;
-  p->sp32 = img;
-  p->device_bytes += bytes;
-  return RAYEN_OK;
-}
-
-int ensure_mfma64(const RayenPack* p) {
-  std::lock_guard<std::mutex> lock(p->mu);
-  if (p->m64_tried) return RAYEN_OK;
-  p->m64_tried = true;
-  if (!mfma64_eligible(p)) return RAYEN_OK;
-  int64_t bytes = 0;
-  Mfma64Image* img = nullptr;
-  const int rc = mfma64_build(p, &img, &bytes);
-  if (rc != RAYEN_OK) return rc;
-  p->m64 = img;
-  p->device_bytes += bytes;
-  return RAYEN_OK;
-}
-
-int ensure_quad32(const RayenPack* p) {
-  std::lock_guard<std::mutex> lock(p->mu);
-  if (p->q32_tried) return RAYEN_OK;
-  p->q32_tried = true;
-  if (!lmi_quad_eligible_f32(p)) return RAYEN_OK;
-  int64_t bytes = 0;
-  const int rc = lmi_quad_build_f32(p, &p->q32, &bytes);
-  if (rc != RAYEN_OK) return rc;
-  p->device_bytes += bytes;
-  return RAYEN_OK;
-}
-
-int ensure_quad64(const RayenPack* p) {
-  std::lock_guard<std::mutex> lock(p->mu);
-  if (p->q64_tried) return RAYEN_OK;
-  p->q64_tried = true;
-  if (!lmi_quad_eligible_f64(p)) return RAYEN_OK;
-  int64_t bytes = 0;
-  const int rc = lmi_quad_build_f64(p, &p->q64, &bytes);
-  if (rc != RAYEN_OK) return rc;
-  p->device_bytes += bytes;
-  return RAYEN_OK;
-}
-
-int ensure_mfma_bwd(const RayenPack* p) {
-  std::lock_guard<std::mutex> lock(p->mu);
-  if (p->mb32_tried) return RAYEN_OK;
-  p->mb32_tried = true;
-  if (!mfma_bwd_eligible(p)) return RAYEN_OK;
-  int64_t bytes = 0;
-  MfmaBwdImage* img = nullptr;
-  const int rc = mfma_bwd_build(p, &img, &bytes);
-  if (rc != RAYEN_OK) return rc;
-  p->mb32 = img;
-  p->device_bytes += bytes;
-  return RAYEN_OK;
-}
-
-int ensure_mfma_bwdg(const RayenPack* p) {
-  std::lock_guard<std::mutex> lock(p->mu);
-  if (p->mbg32_tried) return RAYEN_OK;
-  p->mbg32_tried = true;
-  if (!mfma_bwdg_eligible(p)) return RAYEN_OK;
-  int64_t bytes = 0;
-  MfmaBwdgImage* img = nullptr;
-  const int rc = mfma_bwdg_build(p, &img, &bytes);
-  if (rc != RAYEN_OK) return rc;
-  p->mbg32 = img;
-  p->device_bytes += bytes;
-  return RAYEN_OK;
-}
-
-int ensure_mfma64_bwdg(const RayenPack* p) {
-  std::lock_guard<std::mutex> lock(p->mu);
-  if (p->mbg64_tried) return RAYEN_OK;
-  p->mbg64_tried = true;
-  if (!mfma64_bwdg_eligible(p)) return RAYEN_OK;
-  int64_t bytes = 0;
-  Mfma64BwdgImage* img = nullptr;
-  const int rc = mfma64_bwdg_build(p, &img, &bytes);
-  if (rc != RAYEN_OK) return rc;
-  p->mbg64 = img;
-  p->device_bytes += bytes;
-  return RAYEN_OK;
-}
-
-int ensure_mfma64_bwd(const RayenPack* p) {
-  std::lock_guard<std::mutex> lock(p->mu);
-  if (p->mb64_tried) return RAYEN_OK;
-  p->mb64_tried = true;
-  if (!mfma64_bwd_eligible(p)) return RAYEN_OK;
-  int64_t bytes = 0;
-  Mfma64BwdImage* img = nullptr;
-  const int rc = mfma64_bwd_build(p, &img, &bytes);
-  if (rc != RAYEN_OK) return rc;
-  p->mb64 = img;
-  p->device_bytes += bytes;
+int build_images(RayenPack* p, int prepare) {
+  const bool f32 = prepare == 0 || (prepare & RAYEN_PREPARE_F32);
+  const bool f64 = prepare == 0 || (prepare & RAYEN_PREPARE_F64);
+  const bool bwd = !(prepare & RAYEN_PREPARE_FWD_ONLY);
+  int rc = RAYEN_OK;
+  if (f32) {
+    p->prepared |= RAYEN_PREPARE_F32;
+    if ((rc = build_generic<float>(p))) return rc;
+    if ((rc = build_one(p, mfma_eligible(p), &p->m32, mfma_build))) return rc;
+    if (p->split_bf16 && (rc = build_one(p, mfma_split_eligible(p), &p->sp32, mfma_split_build))) return rc;
+    if ((rc = build_one(p, lmi_quad_eligible_f32(p), &p->q32, lmi_quad_build_f32))) return rc;
+    if (bwd) {
+      if ((rc = build_one(p, mfma_bwd_eligible(p), &p->mb32, mfma_bwd_build))) return rc;
+      if (p->mb32 == nullptr && (rc = build_one(p, mfma_bwdg_eligible(p), &p->mbg32, mfma_bwdg_build))) return rc;
+    }
+  }
+  if (f64) {
+    p->prepared |= RAYEN_PREPARE_F64;
+    if ((rc = build_generic<double>(p))) return rc;
+    if ((rc = build_one(p, mfma64_eligible(p), &p->m64, mfma64_build))) return rc;
+    if ((rc = build_one(p, lmi_quad_eligible_f64(p), &p->q64, lmi_quad_build_f64))) return rc;
+    if (bwd) {
+      if ((rc = build_one(p, mfma64_bwd_eligible(p), &p->mb64, mfma64_bwd_build))) return rc;
+      if (p->mb64 == nullptr && (rc = build_one(p, mfma64_bwdg_eligible(p), &p->mbg64, mfma64_bwdg_build))) return rc;
+    }
+  }
+  if (bwd) p->prepared |= 4;
   return RAYEN_OK;
 }
 
@@ -186,9 +114,7 @@ int project_generic(const RayenPack* p, const T* v, int64_t B, int64_t ldv, T* y
   if (p == nullptr || B < 0 || (B > 0 && v == nullptr) || ldv < p->n + old_mode ||
       (y != nullptr && ldy < p->k))
     return RAYEN_E_BAD_ARG;
-  int rc = check_device(p);
-  if (rc) return rc;
-  rc = ensure_generic<T>(p);
+  int rc = check_ready<T>(p, false);
   if (rc) return rc;
   return generic_forward<T>(p, image_of<T>(p), v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode,
                             static_cast<hipStream_t>(stream));
@@ -201,24 +127,18 @@ int project_bwd(const RayenPack* p, const T* v, int64_t B, int64_t ldv, const T*
   if (p == nullptr || B < 0 || ldv < p->n + old_mode || ldg < p->k || ldgv < p->n + old_mode)
     return RAYEN_E_BAD_ARG;
   if (B > 0 && (!v || !kappa || !active || !grad_y || !grad_v)) return RAYEN_E_BAD_ARG;
-  int rc = check_device(p);
+  int rc = check_ready<T>(p, true);
   if (rc) return rc;
   if constexpr (sizeof(T) == 4) {
     if (!force_generic && !old_mode) {
-      rc = ensure_quad32(p);
-      if (rc) return rc;
       if (p->q32 != nullptr && lmi_quad_bwd_serves_f32(p, p->q32))
         return lmi_quad_backward_f32(p, p->q32, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv,
                                      static_cast<hipStream_t>(stream));
     }
     if (!force_generic) {
-      rc = ensure_mfma_bwd(p);
-      if (rc) return rc;
       if (p->mb32 != nullptr)
         return mfma_backward(p, p->mb32, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode,
                              static_cast<hipStream_t>(stream));
-      rc = ensure_mfma_bwdg(p);
-      if (rc) return rc;
       if (p->mbg32 != nullptr)
         return mfma_bwdg_backward(p, p->mbg32, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode,
                                   static_cast<hipStream_t>(stream));
@@ -226,27 +146,19 @@ int project_bwd(const RayenPack* p, const T* v, int64_t B, int64_t ldv, const T*
   }
   if constexpr (sizeof(T) == 8) {
     if (!force_generic && !old_mode) {
-      rc = ensure_quad64(p);
-      if (rc) return rc;
       if (p->q64 != nullptr && lmi_quad_bwd_serves_f64(p, p->q64))
         return lmi_quad_backward_f64(p, p->q64, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv,
                                      static_cast<hipStream_t>(stream));
     }
     if (!force_generic) {
-      rc = ensure_mfma64_bwd(p);
-      if (rc) return rc;
       if (p->mb64 != nullptr)
         return mfma64_backward(p, p->mb64, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode,
                                static_cast<hipStream_t>(stream));
-      rc = ensure_mfma64_bwdg(p);
-      if (rc) return rc;
       if (p->mbg64 != nullptr)
         return mfma64_bwdg_backward(p, p->mbg64, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode,
                                     static_cast<hipStream_t>(stream));
     }
   }
-  rc = ensure_generic<T>(p);
-  if (rc) return rc;
   return generic_backward<T>(p, image_of<T>(p), v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv,
                              old_mode, static_cast<hipStream_t>(stream));
 }
@@ -267,8 +179,96 @@ const char* rayen_strerror(int code) {
     case RAYEN_E_LAUNCH: return "kernel launch failed";
     case RAYEN_E_UNSUPPORTED: return "shape or operation not supported by the kernels";
     case RAYEN_E_DEVICE_MISMATCH: return "the pack lives on another device than the current one";
+    case RAYEN_E_NOT_PREPARED: return "this precision / direction was excluded by RayenPackDesc.prepare at pack creation";
     default: return "unknown error code";
   }
+}
+
+// The split-operand kernel is fp32-grade on well-conditioned sums; where a constraint set makes the sums cancel
+// heavily its error constant is ~4x that of an fp32 FMA chain.  So every pack it could serve is
+// measured ONCE, inside rayen_pack_create: probe directions (random at two magnitudes, and +-every row of W -- the
+// worst cancellation is along constraint normals) go through the split-operand kernel, the exact-fp32 MFMA kernel
+// and the fp64 lane kernel (the yardstick); the split-operand kernel serves the pack only if its worst row error
+// against fp64 is below 4e-6 of the row's size or within 1.5x of the exact-fp32 kernel's own.  Private stream,
+// buffers freed before pack_create returns.
+static int split_selfcheck(RayenPack* p) {
+  if (p->sp32 == nullptr) return RAYEN_OK;
+  if (p->split_bf16 == 2 || p->m32 == nullptr) { p->sp32_state = 1; return RAYEN_OK; }
+  const int n = p->n, k = p->k;
+  std::vector<float> hv;
+  uint32_t state = 0x9E3779B9u;
+  auto uniform = [&state]() {
+    state = state * 1664525u + 1013904223u;
+    return (float)(state >> 8) * (1.0f / 8388608.0f) - 1.0f;  // (-1, 1)
+  };
+  for (int b = 0; b < 512; ++b) for (int j = 0; j < n; ++j) hv.push_back(1.5f * uniform());
+  for (int b = 0; b < 256; ++b) for (int j = 0; j < n; ++j) hv.push_back(96.0f * uniform());
+  const int rows = p->n_rows, take = rows < 384 ? rows : 384;
+  for (int t = 0; t < take; ++t) {
+    const double* w = &p->W[(size_t)((int64_t)t * rows / take) * n];
+    double big = 0.0;
+    for (int j = 0; j < n; ++j) big = std::fmax(big, std::fabs(w[j]));
+    if (!(big > 0.0) || !std::isfinite(big)) continue;
+    for (int sign = -1; sign <= 1; sign += 2)
+      for (int j = 0; j < n; ++j) hv.push_back((float)(sign * 1.5 * w[j] / big));
+  }
+  const int64_t B0 = (int64_t)(hv.size() / (size_t)n);
+  std::vector<double> hvd(hv.begin(), hv.end());
+  std::vector<float> ys((size_t)B0 * k), ye((size_t)B0 * k);
+  std::vector<double> yt((size_t)B0 * k);
+  // the yardstick needs the fp64 lane image even when the caller asked for fp32 only
+  bool own_g64 = false;
+  int rc = RAYEN_OK;
+  if (!p->g64.built) {
+    rc = generic_build<double>(p, &p->g64);
+    if (rc != RAYEN_OK) { generic_free<double>(&p->g64); return rc; }
+    own_g64 = !(p->prepared & RAYEN_PREPARE_F64);
+    if (!own_g64) p->device_bytes += p->g64.bytes;
+  }
+  hipStream_t st = nullptr;
+  float *dv = nullptr, *dys = nullptr;
+  double *dvd = nullptr, *dyt = nullptr;
+  bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+            hipMalloc(&dv, hv.size() * sizeof(float)) == hipSuccess &&
+            hipMalloc(&dvd, hvd.size() * sizeof(double)) == hipSuccess &&
+            hipMalloc(&dys, 2 * ys.size() * sizeof(float)) == hipSuccess &&
+            hipMalloc(&dyt, yt.size() * sizeof(double)) == hipSuccess &&
+            hipMemcpyAsync(dv, hv.data(), hv.size() * sizeof(float), hipMemcpyHostToDevice, st) == hipSuccess &&
+            hipMemcpyAsync(dvd, hvd.data(), hvd.size() * sizeof(double), hipMemcpyHostToDevice, st) == hipSuccess;
+  if (ok) {
+    rc = mfma_split_forward(p, p->sp32, dv, B0, n, dys, k, nullptr, nullptr, nullptr, st);
+    if (rc == RAYEN_OK) rc = mfma_forward(p, p->m32, dv, B0, n, dys + ys.size(), k, nullptr, nullptr, nullptr, 0, st);
+    if (rc == RAYEN_OK)
+      rc = generic_forward<double>(p, p->g64, dvd, B0, n, dyt, k, nullptr, nullptr, nullptr, 0, st);
+    ok = rc == RAYEN_OK &&
+         hipMemcpyAsync(ys.data(), dys, ys.size() * sizeof(float), hipMemcpyDeviceToHost, st) == hipSuccess &&
+         hipMemcpyAsync(ye.data(), dys + ys.size(), ye.size() * sizeof(float), hipMemcpyDeviceToHost, st) == hipSuccess &&
+         hipMemcpyAsync(yt.data(), dyt, yt.size() * sizeof(double), hipMemcpyDeviceToHost, st) == hipSuccess &&
+         hipStreamSynchronize(st) == hipSuccess;
+  }
+  if (dv) (void)hipFree(dv);
+  if (dvd) (void)hipFree(dvd);
+  if (dys) (void)hipFree(dys);
+  if (dyt) (void)hipFree(dyt);
+  if (st) (void)hipStreamDestroy(st);
+  if (own_g64) generic_free<double>(&p->g64);
+  if (!ok) return rc != RAYEN_OK ? rc : RAYEN_E_ALLOC;
+  double worst_s = 0.0, worst_e = 0.0;
+  for (int64_t b = 0; b < B0; ++b) {
+    double ds = 0.0, de = 0.0, size = 1e-30;
+    for (int i = 0; i < k; ++i) {
+      const double t = yt[(size_t)b * k + i];
+      ds = std::fmax(ds, std::fabs((double)ys[(size_t)b * k + i] - t));
+      de = std::fmax(de, std::fabs((double)ye[(size_t)b * k + i] - t));
+      size = std::fmax(size, std::fabs(t));
+    }
+    if (!(ds / size <= worst_s)) worst_s = ds / size;  // (NaN counts as a difference)
+    if (!(de / size <= worst_e)) worst_e = de / size;
+  }
+  p->check_split = worst_s;
+  p->check_exact = worst_e;
+  p->sp32_state = (worst_s <= 4e-6 || worst_s <= 1.5 * worst_e) ? 1 : 2;
+  return RAYEN_OK;
 }
 
 int rayen_pack_create(const RayenPackDesc* desc, RayenPack** out) {
@@ -277,6 +277,7 @@ int rayen_pack_create(const RayenPackDesc* desc, RayenPack** out) {
   if (desc->abi_version != RAYEN_ABI_VERSION) return RAYEN_E_ABI;
   int rc = check_table(desc);
   if (rc) return rc;
+  if (desc->prepare < 0 || desc->prepare > 7 || desc->fp32_mode < 0 || desc->fp32_mode > 2) return RAYEN_E_BAD_ARG;
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess) return RAYEN_E_NO_DEVICE;
   if (!device_is_gfx950(dev)) return RAYEN_E_NO_DEVICE;
@@ -288,10 +289,11 @@ int rayen_pack_create(const RayenPackDesc* desc, RayenPack** out) {
   p->n_rows = desc->n_rows;
   p->out_identity = desc->out_identity ? 1 : 0;
   {
+    // fp32_mode 0 (default): split-operand kernel where split_selfcheck accepts it | 1: exact-fp32 MFMA kernels only
+    // | 2: split-operand kernel without the comparison.  RAYEN_SPLIT_BF16=0/1/2 (0 = exact only) overrides it.
+    p->split_bf16 = desc->fp32_mode == 1 ? 0 : (desc->fp32_mode == 2 ? 2 : 1);
     const char* env = std::getenv("RAYEN_SPLIT_BF16");
-    // RAYEN_SPLIT_BF16=0: exact-fp32 MFMA kernels only | 1 (default): split-operand kernel where the comparison
-    // of split_selfcheck accepts it | 2: split-operand kernel without that comparison
-    p->split_bf16 = (env != nullptr && (env[0] == '0' || env[0] == '2')) ? env[0] - '0' : 1;
+    if (env != nullptr && env[0] >= '0' && env[0] <= '2') p->split_bf16 = env[0] - '0';
   }
   p->W.assign(desc->W, desc->W + (size_t)desc->n_rows * desc->n);
   p->y0.assign(desc->y0, desc->y0 + desc->k);
@@ -302,6 +304,9 @@ int rayen_pack_create(const RayenPackDesc* desc, RayenPack** out) {
     p->NA_E.assign(desc->NA_E, desc->NA_E + (size_t)desc->k * desc->n);
   }
   p->segs.assign(desc->segments, desc->segments + desc->n_segments);
+  rc = build_images(p, desc->prepare);
+  if (rc == RAYEN_OK) rc = split_selfcheck(p);
+  if (rc != RAYEN_OK) { rayen_pack_destroy(p); return rc; }
   *out = p;
   return RAYEN_OK;
 }
@@ -334,8 +339,11 @@ int rayen_pack_info(const RayenPack* p, RayenPackInfo* info) {
   info->n_rows = p->n_rows;
   info->n_segments = (int32_t)p->segs.size();
   info->device = p->device;
-  info->mfma_f32 = (p->split_bf16 && p->sp32_state != 2 && mfma_split_eligible(p)) ? 2 : (mfma_eligible(p) ? 1 : 0);
+  info->mfma_f32 = (p->sp32 != nullptr && p->sp32_state == 1) ? 2 : (mfma_eligible(p) ? 1 : 0);
   info->mfma_f64 = mfma64_eligible(p) ? 1 : 0;
+  info->prepared = p->prepared;
+  info->fp32_check_split = p->check_split;
+  info->fp32_check_exact = p->check_exact;
   int lmi_words = 0;
   for (const RayenSegment& g : p->segs)
     if (g.type == RAYEN_SEG_LMI && g.nrows + 4 * g.dim > lmi_words) lmi_words = g.nrows + 4 * g.dim;
@@ -352,91 +360,24 @@ int rayen_ray_project_generic_f32(const RayenPack* p, const float* v, int64_t B,
   return project_generic<float>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
 }
 
-// The split-operand kernel is fp32-grade on well-conditioned sums; where a constraint set makes the sums cancel
-// heavily its error constant is ~4x that of an fp32 FMA chain.  So every pack is compared ONCE with
-// the exact-fp32 kernel on 512 pseudo-random directions (first forward call outside a stream capture; two small
-// launches on the null stream and one synchronisation): if any output row differs by more than 5e-6 of its size,
-// the pack is ill-conditioned for fp32 and is served by the exact-fp32 family from then on.
-static int split_selfcheck(const RayenPack* p, hipStream_t user_stream) {
-  if (p->split_bf16 == 2) { p->sp32_state = 1; return RAYEN_OK; }  // RAYEN_SPLIT_BF16=2: no comparison
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (user_stream != nullptr && hipStreamIsCapturing(user_stream, &cap) == hipSuccess &&
-      cap != hipStreamCaptureStatusNone)
-    return RAYEN_OK;  // not now: this call runs unchecked, the comparison happens at the next plain call
-  int rc = ensure_mfma(p);
-  if (rc) return rc;
-  std::lock_guard<std::mutex> lock(p->mu);
-  if (p->sp32_state != 0) return RAYEN_OK;
-  if (p->m32 == nullptr) { p->sp32_state = 1; return RAYEN_OK; }  // (the two families share their eligibility rule)
-  constexpr int B0 = 512;
-  const int n = p->n, k = p->k;
-  std::vector<float> hv((size_t)B0 * n), ya((size_t)B0 * k), yb((size_t)B0 * k);
-  uint32_t state = 0x9E3779B9u;
-  for (float& x : hv) {
-    state = state * 1664525u + 1013904223u;
-    x = ((float)(state >> 8) * (1.0f / 8388608.0f) - 1.0f) * 1.5f;  // uniform in (-1.5, 1.5)
-  }
-  float* dv = nullptr;
-  float* dy = nullptr;
-  bool ok = hipMalloc(&dv, hv.size() * sizeof(float)) == hipSuccess &&
-            hipMalloc(&dy, 2 * ya.size() * sizeof(float)) == hipSuccess &&
-            hipMemcpy(dv, hv.data(), hv.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
-  if (ok) {
-    rc = mfma_split_forward(p, p->sp32, dv, B0, n, dy, k, nullptr, nullptr, nullptr, nullptr);
-    if (rc == RAYEN_OK)
-      rc = mfma_forward(p, p->m32, dv, B0, n, dy + ya.size(), k, nullptr, nullptr, nullptr, 0, nullptr);
-    ok = rc == RAYEN_OK && hipMemcpy(ya.data(), dy, ya.size() * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess &&
-         hipMemcpy(yb.data(), dy + ya.size(), yb.size() * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess;
-  }
-  if (dv) (void)hipFree(dv);
-  if (dy) (void)hipFree(dy);
-  if (!ok) return rc != RAYEN_OK ? rc : RAYEN_E_ALLOC;
-  double worst = 0.0;
-  for (int b = 0; b < B0; ++b) {
-    double diff = 0.0, size = 1e-30;
-    for (int i = 0; i < k; ++i) {
-      const double a = ya[(size_t)b * k + i], c = yb[(size_t)b * k + i];
-      diff = std::fmax(diff, std::fabs(a - c));
-      size = std::fmax(size, std::fabs(c));
-    }
-    if (!(diff / size <= worst)) worst = diff / size;  // (NaN counts as a difference)
-  }
-  p->sp32_state = (worst <= 5e-6) ? 1 : 2;
-  return RAYEN_OK;
-}
-
 static int project_f32(const RayenPack* p, const float* v, int64_t B, int64_t ldv, float* y, int64_t ldy,
                        float* kappa, int32_t* active, int32_t* nan_flag, void* stream, int old_mode) {
   if (p == nullptr || B < 0 || (B > 0 && v == nullptr) || ldv < p->n + old_mode ||
       (y != nullptr && ldy < p->k))
     return RAYEN_E_BAD_ARG;
-  int rc = check_device(p);
+  const int rc = check_ready<float>(p, false);
   if (rc) return rc;
-  if (p->split_bf16 && y != nullptr && !old_mode) {
-    rc = ensure_split(p);
-    if (rc) return rc;
-    if (p->sp32 != nullptr && p->sp32_state == 0) {
-      rc = split_selfcheck(p, static_cast<hipStream_t>(stream));
-      if (rc) return rc;
-    }
-    if (p->sp32 != nullptr && p->sp32_state != 2)
-      return mfma_split_forward(p, p->sp32, v, B, ldv, y, ldy, kappa, active, nan_flag,
-                                static_cast<hipStream_t>(stream));
-  }
-  rc = ensure_mfma(p);
-  if (rc) return rc;
+  if (p->sp32 != nullptr && p->sp32_state == 1 && y != nullptr && !old_mode)
+    return mfma_split_forward(p, p->sp32, v, B, ldv, y, ldy, kappa, active, nan_flag,
+                              static_cast<hipStream_t>(stream));
   if (p->m32 != nullptr && y != nullptr)
     return mfma_forward(p, p->m32, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode,
                         static_cast<hipStream_t>(stream));
   // four lanes per sample pay off while one lane per sample cannot fill the chip (B/64 waves on
   // 1024 SIMDs x 2); beyond that the lane-per-sample kernel has the higher throughput in fp32
-  if (y != nullptr && !old_mode && B <= 65536) {
-    rc = ensure_quad32(p);
-    if (rc) return rc;
-    if (p->q32 != nullptr)
-      return lmi_quad_forward_f32(p, p->q32, v, B, ldv, y, ldy, kappa, active, nan_flag,
-                                  static_cast<hipStream_t>(stream));
-  }
+  if (y != nullptr && !old_mode && B <= 65536 && p->q32 != nullptr)
+    return lmi_quad_forward_f32(p, p->q32, v, B, ldv, y, ldy, kappa, active, nan_flag,
+                                static_cast<hipStream_t>(stream));
   return project_generic<float>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, old_mode);
 }
 
@@ -451,9 +392,9 @@ int rayen_ray_project_old_f32(const RayenPack* p, const float* v, int64_t B, int
 }
 
 int rayen_mapper_fusable(const RayenPack* p, int32_t in_dim) {
-  if (p == nullptr || check_device(p) != RAYEN_OK || ensure_mfma(p) != RAYEN_OK) return 0;
+  if (p == nullptr || check_ready<float>(p, false) != RAYEN_OK) return 0;
   // packs served by the split-operand kernel are faster as GEMM + projection than through the fused fp32 kernel
-  if (p->split_bf16 && ensure_split(p) == RAYEN_OK && p->sp32 != nullptr && p->sp32_state != 2) return 0;
+  if (p->sp32 != nullptr && p->sp32_state == 1) return 0;
   return (p->m32 != nullptr && mfma_mapper_fusable(p, p->m32, in_dim)) ? 1 : 0;
 }
 
@@ -464,9 +405,7 @@ int rayen_ray_project_mapped_f32(const RayenPack* p, const float* x, int64_t B, 
   if (p == nullptr || B < 0 || in_dim <= 0 || ldx < in_dim || ldw < in_dim || Wm == nullptr || y == nullptr ||
       ldy < p->k || (B > 0 && x == nullptr) || (v_out != nullptr && ldvo < p->n))
     return RAYEN_E_BAD_ARG;
-  int rc = check_device(p);
-  if (rc) return rc;
-  rc = ensure_mfma(p);
+  const int rc = check_ready<float>(p, false);
   if (rc) return rc;
   if (p->m32 == nullptr) return RAYEN_E_UNSUPPORTED;
   return mfma_forward_mapped(p, p->m32, x, B, ldx, in_dim, Wm, ldw, bias, v_out, ldvo, y, ldy, kappa,
@@ -484,20 +423,14 @@ static int project_f64(const RayenPack* p, const double* v, int64_t B, int64_t l
   if (p == nullptr || B < 0 || (B > 0 && v == nullptr) || ldv < p->n + old_mode ||
       (y != nullptr && ldy < p->k))
     return RAYEN_E_BAD_ARG;
-  int rc = check_device(p);
-  if (rc) return rc;
-  rc = ensure_mfma64(p);
+  const int rc = check_ready<double>(p, false);
   if (rc) return rc;
   if (p->m64 != nullptr && y != nullptr)
     return mfma64_forward(p, p->m64, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode,
                           static_cast<hipStream_t>(stream));
-  if (y != nullptr && !old_mode) {
-    rc = ensure_quad64(p);
-    if (rc) return rc;
-    if (p->q64 != nullptr)
-      return lmi_quad_forward_f64(p, p->q64, v, B, ldv, y, ldy, kappa, active, nan_flag,
-                                  static_cast<hipStream_t>(stream));
-  }
+  if (y != nullptr && !old_mode && p->q64 != nullptr)
+    return lmi_quad_forward_f64(p, p->q64, v, B, ldv, y, ldy, kappa, active, nan_flag,
+                                static_cast<hipStream_t>(stream));
   return project_generic<double>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, old_mode);
 }
 

@@ -5,7 +5,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include <mutex>
 #include <vector>
 
 #include "rayen_hip.h"
@@ -55,37 +54,32 @@ struct SplitImage;      // rayen_mfma_split.hip
 
 }  // namespace rayen
 
+// Immutable after rayen_pack_create returns (every device image is built there), so it is shared by threads and
+// streams without a lock.
 struct RayenPack {
   int device = -1;
   int k = 0, n = 0, n_rows = 0;
   int out_identity = 0;
-  int split_bf16 = 1;            // fp32 results from split bf16 operands where eligible (rayen_mfma_split.hip)
+  int split_bf16 = 1;            // 0: exact-fp32 MFMA kernels only | 1: split-operand kernel where accepted | 2: unchecked
+  int prepared = 0;              // RAYEN_PREPARE_F32 | RAYEN_PREPARE_F64 | 4 (backward images)
   std::vector<double> W;         // host copy [n_rows, n]
   std::vector<double> NA_E;      // host copy [k, n] (identity materialised)
   std::vector<double> y0;        // host copy [k]
   std::vector<RayenSegment> segs;
-  mutable std::mutex mu;         // guards the lazily built images
   mutable rayen::GenericImage<float> g32;
   mutable rayen::GenericImage<double> g64;
-  mutable rayen::MfmaImage* m32 = nullptr;
-  mutable bool m32_tried = false;
-  mutable rayen::Mfma64Image* m64 = nullptr;
-  mutable bool m64_tried = false;
-  mutable rayen::MfmaBwdImage* mb32 = nullptr;
-  mutable bool mb32_tried = false;
-  mutable rayen::Mfma64BwdImage* mb64 = nullptr;
-  mutable bool mb64_tried = false;
-  mutable rayen::MfmaBwdgImage* mbg32 = nullptr;
-  mutable bool mbg32_tried = false;
-  mutable rayen::Mfma64BwdgImage* mbg64 = nullptr;
-  mutable bool mbg64_tried = false;
-  mutable rayen::LmiQuadImage* q32 = nullptr;
-  mutable rayen::LmiQuadImage* q64 = nullptr;
-  mutable bool q32_tried = false, q64_tried = false;
-  mutable rayen::SplitImage* sp32 = nullptr;
-  mutable bool sp32_tried = false;
-  mutable int sp32_state = 0;    // 0: not yet compared with the exact-fp32 kernel on this pack | 1: accepted | 2: rejected
-  mutable int64_t device_bytes = 0;
+  rayen::MfmaImage* m32 = nullptr;
+  rayen::Mfma64Image* m64 = nullptr;
+  rayen::MfmaBwdImage* mb32 = nullptr;
+  rayen::Mfma64BwdImage* mb64 = nullptr;
+  rayen::MfmaBwdgImage* mbg32 = nullptr;
+  rayen::Mfma64BwdgImage* mbg64 = nullptr;
+  rayen::LmiQuadImage* q32 = nullptr;
+  rayen::LmiQuadImage* q64 = nullptr;
+  rayen::SplitImage* sp32 = nullptr;
+  int sp32_state = 0;            // 1: the split-operand kernel serves this pack | 2: rejected by split_selfcheck
+  double check_split = -1.0, check_exact = -1.0;  // worst row errors against fp64 measured by split_selfcheck
+  int64_t device_bytes = 0;
 };
 
 namespace rayen {

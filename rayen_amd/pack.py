@@ -21,9 +21,13 @@ same tensors the reference reads in its forward), upcast to fp64.
 Row-count reductions that keep the value of every reduction unchanged:
 all-zero ``D`` rows are dropped (``relu`` makes them no-ops); an SOC block ``M NA_E``
 with more rows than columns is replaced by its triangular QR factor (same
-``||M NA_E v||``); a quadratic whose ``G`` has numerical rank ``<= n/2`` is stored as
+``||M NA_E v||``); a quadratic that is EXACTLY low rank (rank ``<= n/2``) is stored as
 the factor ``U`` (rank rows instead of n), which also makes its radicand a sum of
-squares.
+squares.  "Exactly" is decided on the fp64 constraint data the module was built from
+(``exact_quadratics``), at the fp64 noise floor: the eigenvalues of the fp32 *buffer*
+that are dropped are then provably rounding noise of the buffer, never curvature
+(a form like ``diag(1, 1e-6, 1e-6, 1e-6)`` keeps its full rank and the dense layout).
+Without that data only the fp64 noise floor of the buffer itself is dropped.
 """
 from __future__ import annotations
 
@@ -76,9 +80,27 @@ def _buffer_eps(t):
     return np.finfo(np.float32).eps
 
 
-def pack_constants(buffers: dict, low_rank: bool = True) -> PackedConstants:
+def _true_rank(P, q, r, y0, N):
+    """Numerical rank (fp64 noise floor) of ``N' delta N`` for the quadratic ``(P, q, r)`` at ``y0``,
+    with ``delta`` as in rayen/constraint_module.py:99-122 evaluated in fp64."""
+    y0 = y0.reshape(-1, 1)
+    g = P @ y0 + q.reshape(-1, 1)
+    sigma = 2.0 * float((0.5 * y0.T @ P @ y0 + q.reshape(1, -1) @ y0 + r).item())
+    delta = (g @ g.T - sigma * P) / (sigma * sigma)
+    G = N.T @ delta @ N
+    lam = np.linalg.eigvalsh(0.5 * (G + G.T))
+    lam_max = max(float(lam[-1]), 0.0)
+    return int(np.count_nonzero(lam > 64.0 * N.shape[1] * np.finfo(np.float64).eps * lam_max)), lam_max
+
+
+def pack_constants(buffers: dict, low_rank: bool = True, exact_quadratics=None) -> PackedConstants:
     """``buffers``: the module's ``D, NA_E, z0, yp, y0, all_phi, all_delta, all_M, all_s, all_c,
-    all_d, all_F, L`` (torch tensors or arrays; absent/empty families may be missing)."""
+    all_d, all_F, L`` (+ ``all_P`` when ``exact_quadratics`` is given; torch tensors or arrays;
+    absent/empty families may be missing).
+
+    ``exact_quadratics``: ``(list of (P, q, r) in fp64, y0 in fp64)`` -- the constraint data the
+    buffers were rounded from.  It is trusted for a quadratic only if its ``P`` rounds to exactly the
+    module's ``all_P`` buffer (a ``state_dict`` loaded from elsewhere fails that and falls back)."""
     eps = _buffer_eps(buffers["D"])
     D = _f64(buffers["D"])
     N = _f64(buffers["NA_E"])
@@ -103,6 +125,20 @@ def pack_constants(buffers: dict, low_rank: bool = True) -> PackedConstants:
     # ---- convex quadratic (CM:99-122, CM:374)
     phi = _f64(buffers.get("all_phi"))
     delta = _f64(buffers.get("all_delta"))
+    P_buf = buffers.get("all_P")
+
+    def _exact_rank(i):
+        if exact_quadratics is None or P_buf is None:
+            return None
+        triples, y0_exact = exact_quadratics
+        if i >= len(triples):
+            return None
+        P, q, r = (np.asarray(a, dtype=np.float64) for a in triples[i])
+        Pb = P_buf[i].detach().cpu().numpy() if hasattr(P_buf, "detach") else np.asarray(P_buf[i])
+        if Pb.shape != P.shape or not np.array_equal(P.astype(Pb.dtype), Pb):
+            return None
+        return _true_rank(P, q, r, np.asarray(y0_exact, dtype=np.float64), N)[0]
+
     if phi is not None and phi.ndim == 3:
         for i in range(phi.shape[0]):
             aux = add_rows(phi[i].reshape(1, k) @ N)
@@ -110,9 +146,17 @@ def pack_constants(buffers: dict, low_rank: bool = True) -> PackedConstants:
             G = 0.5 * (G + G.T)
             lam, vec = np.linalg.eigh(G)
             lam_max = max(float(lam[-1]), 0.0)
-            big = lam > 16.0 * eps * lam_max
-            rank = int(np.count_nonzero(big))
-            if low_rank and lam_max > 0.0 and rank <= n // 2:
+            rank = n
+            if low_rank and lam_max > 0.0:
+                rank = _exact_rank(i)
+                if rank is None:   # no trusted fp64 data: drop the fp64 noise floor of the buffer only
+                    rank = int(np.count_nonzero(lam > 64.0 * n * np.finfo(np.float64).eps * lam_max))
+                # the eigenvalues kept must stand clear of the buffer's own rounding noise
+                if rank <= n // 2 and not (rank > 0 and lam[n - rank] > 16.0 * eps * lam_max):
+                    rank = n
+            if rank <= n // 2:
+                big = np.zeros(n, dtype=bool)
+                big[n - rank:] = True
                 U = (np.sqrt(lam[big])[:, None]) * vec[:, big].T
                 row0 = add_rows(U)
                 segments.append(Segment(_lib.SEG_QUAD_FAC, row0, rank, aux_row=aux))
@@ -162,7 +206,9 @@ def _as_double_ptr(a):
 class DevicePack:
     """Owner of one ``RayenPack*`` (constants resident on one HIP device)."""
 
-    def __init__(self, consts: PackedConstants, device_index: int):
+    def __init__(self, consts: PackedConstants, device_index: int, prepare: int = 0, fp32_mode: int = 0):
+        """``rayen_pack_create`` builds every device image and measures the fp32 kernel families here, once:
+        calls on the pack never allocate, and it can be captured into a HIP graph from its first call."""
         import torch
         self.consts = consts
         self.device_index = int(device_index)
@@ -175,7 +221,8 @@ class DevicePack:
         y0 = np.ascontiguousarray(consts.y0, dtype=np.float64)
         desc = _lib.RayenPackDesc(_lib.ABI_VERSION, consts.k, consts.n, W.shape[0],
                                   len(consts.segments), int(consts.out_identity),
-                                  _as_double_ptr(W), segs, _as_double_ptr(N), _as_double_ptr(y0))
+                                  _as_double_ptr(W), segs, _as_double_ptr(N), _as_double_ptr(y0),
+                                  int(prepare), int(fp32_mode))
         handle = ctypes.c_void_p()
         with torch.cuda.device(self.device_index):
             _lib.check(lib.rayen_pack_create(ctypes.byref(desc), ctypes.byref(handle)), "rayen_pack_create")
@@ -190,7 +237,7 @@ class DevicePack:
     def mapper_fusable(self, in_dim):
         """True when ``rayen_ray_project_mapped_f32`` serves this pack with an ``in_dim``-wide mapper."""
         import torch
-        cache = self.__dict__.setdefault("_fusable", {})
+        cache = self.__dict__.setdefault("_fusable", {})   # (the answer is fixed at pack creation)
         if in_dim not in cache:
             with torch.cuda.device(self.device_index):
                 cache[in_dim] = bool(_lib.load().rayen_mapper_fusable(self.handle, int(in_dim)))

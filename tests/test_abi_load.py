@@ -28,7 +28,7 @@ def test_library_builds_and_exports_the_header():
 def test_error_strings_and_null_handling():
     lib = _lib.load()
     assert _lib.strerror(0) == "ok"
-    for code in range(-7, 0):
+    for code in range(-8, 0):
         assert "unknown" not in _lib.strerror(code)
     assert "unknown" in _lib.strerror(-99)
     # argument validation happens before any device call
@@ -40,8 +40,8 @@ def test_error_strings_and_null_handling():
 
 def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(_lib.RayenSegment) == 40
-    assert ctypes.sizeof(_lib.RayenPackInfo) == 40
-    assert ctypes.sizeof(_lib.RayenPackDesc) == 24 + 4 * ctypes.sizeof(ctypes.c_void_p)
+    assert ctypes.sizeof(_lib.RayenPackInfo) == 64
+    assert ctypes.sizeof(_lib.RayenPackDesc) == 32 + 4 * ctypes.sizeof(ctypes.c_void_p)
     bad = _lib.RayenPackDesc()
     bad.abi_version = 999
     handle = ctypes.c_void_p()
@@ -70,7 +70,7 @@ int main(void) {{
   desc.abi_version = 999;
   if (rayen_abi_version() != RAYEN_ABI_VERSION) return 2;
   if (rayen_pack_create(&desc, &pack) != RAYEN_E_ABI) return 3;
-  if (sizeof(RayenSegment) != 40 || sizeof(RayenPackInfo) != 40) return 4;
+  if (sizeof(RayenSegment) != 40 || sizeof(RayenPackInfo) != 64 || sizeof(RayenPackDesc) != 64) return 4;
   for (int i = 0; i < n; ++i) if (table[i] == NULL) return 5;
   printf("%d %s\\n", n, rayen_strerror(RAYEN_E_UNSUPPORTED));
   return 0;

@@ -146,3 +146,38 @@ def test_reference_import_names_resolve_to_this_build():
     assert cm.ConstraintModule is rayen_amd.constraint_module.ConstraintModule is CM2
     assert cons.ConvexConstraints is rayen_amd.constraints.ConvexConstraints
     assert rayen.utils.verify is rayen_amd.utils.verify
+
+
+def test_low_rank_factoring_never_drops_curvature():
+    """A quadratic is stored through its factor only when the fp64 constraint data is EXACTLY low rank.
+    P = diag(1, 1e-6, 1e-6, 1e-6): the small eigenvalues are below fp32 resolution relative to the largest but
+    they are curvature -- along e2 the reference's formula gives kappa = 5 at |v| = 5000 (clipping the output to
+    the boundary); a factor that dropped them would return kappa = 0 and an infeasible y = v."""
+    from rayen_amd import constraints
+    P = np.diag([1.0, 1e-6, 1e-6, 1e-6])
+    qc = constraints.ConvexQuadraticConstraint(P, np.zeros((4, 1)), np.array([[-0.5]]))
+    cs = constraints.ConvexConstraints(qcs=[qc], y0=np.zeros((4, 1)))
+    for dtype in (torch.float32, torch.float64):
+        prev = torch.get_default_dtype()
+        torch.set_default_dtype(dtype)
+        try:
+            layer = ConstraintModule(cs, create_map=False)
+        finally:
+            torch.set_default_dtype(prev)
+        consts = layer.packed_constants()
+        assert [s.type for s in consts.segments] == [_lib.SEG_QUAD_SYM]
+        v = np.zeros((1, 4))
+        v[0, 1] = 5000.0
+        y, kappa, _ = evaluate(consts, v)
+        assert abs(kappa[0] - 5.0) < 1e-4
+        assert 0.5 * y[0] @ P @ y[0] - 0.5 <= 1e-6   # (fp32 rounding of the 1e-6 entries)
+    # the fp32 buffers of an exactly rank-3 form carry full-rank rounding noise: still factored, rank + 1 rows
+    raw = workloads.corridor_like(k=20, n_eq=5, m=30, n_quad=3, rank=2, seed=1)
+    cs32, layer32 = _module_from_raw(raw, torch.float32)
+    fac = [s for s in layer32.packed_constants().segments if s.type == _lib.SEG_QUAD_FAC]
+    assert len(fac) == 3 and all(s.nrows == 3 for s in fac)
+    # buffers that do not come from the module's own constraint data (a foreign state_dict) are not trusted
+    layer32.all_P.mul_(1.0 + 2.0 ** -10)
+    layer32._invalidate_packs()
+    kinds = [s.type for s in layer32.packed_constants().segments]
+    assert _lib.SEG_QUAD_FAC not in kinds and kinds.count(_lib.SEG_QUAD_SYM) == 3

@@ -69,3 +69,104 @@ def test_readme_usage_example_builds():
     cs = constraints.ConvexConstraints(lc=lc, qcs=qcs, socs=socs, lmic=constraints.LMIConstraint(F))
     assert (cs.k, cs.n) == (3, 2)
     assert np.min(cs.margins(cs.z0)) > 1e-6
+
+
+def test_structured_lmi_with_repeated_eigenvalue_without_y0():
+    """y0 >= 10 + |y1| written as an LMI whose smallest eigenvalue is repeated at natural start points
+    (F0 = I, F1 = offdiag, F2 = -10 I): a derivative-based search on lambda_min stalls there; the conic
+    form of the margin program (constraints.py:412-432) does not."""
+    F = [np.eye(2), np.array([[0.0, 1.0], [1.0, 0.0]]), -10.0 * np.eye(2)]
+    cs = constraints.ConvexConstraints(lmic=constraints.LMIConstraint(F))
+    assert np.min(cs.margins(cs.z0)) > 1e-6
+    assert cs.y0[0, 0] - 10.0 - abs(cs.y0[1, 0]) > 1e-6
+
+
+def test_random_lmis_and_mixed_sets_without_y0():
+    from rayen_amd import workloads
+    for seed in range(6):
+        raw = workloads.random_lmi(5, 8, seed=seed)
+        cs = _build(raw)
+        assert np.min(cs.margins(cs.z0)) > 1e-6
+    raw = workloads.random_lin_quad_soc(12, 20, 2, 2, seed=3)
+    cs = _build(raw, do_preprocessing_linear=False)
+    assert np.min(cs.margins(cs.z0)) > 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------
+# project / getViolation (constraints.py:539-559) without cvxpy
+# ---------------------------------------------------------------------------------------------------
+
+def test_project_onto_a_ball_box_and_halfspace_closed_forms():
+    # ball of radius 2 about (1, -1, 0.5): 1/2 y'(2I)y - 2c'y + c'c - 4 <= 0
+    c = np.array([[1.0], [-1.0], [0.5]])
+    qc = constraints.ConvexQuadraticConstraint(2.0 * np.eye(3), -2.0 * c, c.T @ c - 4.0)
+    cs = constraints.ConvexConstraints(qcs=[qc], y0=c)
+    p = np.array([[5.0], [2.0], [-3.0]])
+    y, d2 = cs.project(p)
+    want = c + 2.0 * (p - c) / np.linalg.norm(p - c)
+    assert np.allclose(y, want, atol=1e-6)
+    assert abs(d2 - (np.linalg.norm(p - c) - 2.0) ** 2) < 1e-6
+    assert abs(cs.getViolation(p[:, 0]) - d2) < 1e-9
+    assert cs.getViolation(c) < 1e-10                    # feasible points have zero violation
+    # unit cube
+    A1 = np.concatenate((np.eye(3), -np.eye(3)))
+    b1 = np.array([[1.0], [1], [1], [0], [0], [0]])
+    cs = constraints.ConvexConstraints(lc=constraints.LinearConstraint(A1, b1, None, None))
+    p = np.array([[1.5], [-0.25], [0.5]])
+    y, d2 = cs.project(p)
+    assert np.allclose(y, np.clip(p, 0, 1), atol=1e-7) and abs(d2 - (0.25 + 0.0625)) < 1e-7
+    # cube cut by the plane x + y + z = 1 (examples_sets.py ex0): compare with the KKT solution from scipy
+    lc = constraints.LinearConstraint(A1, b1, np.ones((1, 3)), np.ones((1, 1)))
+    cs = constraints.ConvexConstraints(lc=lc)
+    p = np.array([[0.9], [0.8], [-0.4]])
+    y, d2 = cs.project(p)
+    import scipy.optimize
+    ref = scipy.optimize.minimize(lambda t: np.sum((t - p[:, 0]) ** 2), np.full(3, 1 / 3), method="SLSQP",
+                                  constraints=[{"type": "eq", "fun": lambda t: t.sum() - 1},
+                                               {"type": "ineq", "fun": lambda t: b1[:, 0] - A1 @ t}],
+                                  options={"ftol": 1e-14})
+    assert np.allclose(y[:, 0], ref.x, atol=1e-6)
+    assert cs.getMaxViolation(y.T) < 1e-7
+
+
+def test_project_onto_the_soc_and_psd_cones_closed_forms():
+    # ||(y1,y2)|| <= y3
+    M = np.array([[1.0, 0, 0], [0, 1.0, 0]])
+    soc = constraints.SOCConstraint(M, np.zeros((2, 1)), np.array([[0.0], [0.0], [1.0]]), np.zeros((1, 1)))
+    cs = constraints.ConvexConstraints(socs=[soc], y0=np.array([[0.0], [0.0], [1.0]]))
+    p = np.array([[3.0], [4.0], [1.0]])                  # ||x|| = 5 > t = 1 > -5
+    y, d2 = cs.project(p)
+    a = 0.5 * (5.0 + 1.0)
+    assert np.allclose(y[:, 0], [a * 3 / 5, a * 4 / 5, a], atol=1e-6)
+    # [[y1, y2], [y2, y3]] >= 0: projection = eigenvalue clipping in the sqrt2-scaled coordinates
+    F = [np.array([[1.0, 0], [0, 0]]), np.array([[0, 1.0], [1.0, 0]]), np.array([[0, 0], [0, 1.0]]), np.zeros((2, 2))]
+    cs = constraints.ConvexConstraints(lmic=constraints.LMIConstraint(F), y0=np.array([[1.0], [0.0], [1.0]]))
+    p = np.array([[1.0], [2.0], [-1.0]])
+    y, d2 = cs.project(p)
+    # min (y1-p1)^2 + (y2-p2)^2 + (y3-p3)^2 is NOT the Frobenius distance (the off-diagonal counts once), so
+    # check optimality through a fine SLSQP solve on the 2x2 determinant form instead
+    import scipy.optimize
+    ref = scipy.optimize.minimize(lambda t: np.sum((t - p[:, 0]) ** 2), np.array([1.0, 0.0, 1.0]), method="SLSQP",
+                                  constraints=[{"type": "ineq", "fun": lambda t: t[0] * t[2] - t[1] ** 2},
+                                               {"type": "ineq", "fun": lambda t: t[0]},
+                                               {"type": "ineq", "fun": lambda t: t[2]}],
+                                  options={"ftol": 1e-15, "maxiter": 500})
+    assert abs(d2 - ref.fun) < 1e-5, (d2, ref.fun)
+    assert cs.getMaxViolation(y.T) < 1e-6
+
+
+@pytest.mark.parametrize("index", range(15))
+def test_projection_of_example_sets_is_feasible_and_idempotent(index):
+    raw, csd, _ = load_golden(f"example_{index:02d}")
+    cs = _build(raw)
+    rng = np.random.default_rng(index)
+    for _ in range(3):
+        p = rng.uniform(-3, 3, size=(cs.k, 1))
+        y, d2 = cs.project(p)
+        assert cs.getMaxViolation(y.T) < 1e-6
+        assert abs(d2 - float(np.sum((y - p) ** 2))) < 1e-12
+        y2, d22 = cs.project(y)
+        assert d22 < 1e-10 and np.allclose(y2, y, atol=1e-5)
+        # no feasible point is closer: compare with the interior point and random feasible points on the segment
+        assert d2 <= float(np.sum((cs.y0 - p) ** 2)) + 1e-9
+    assert cs.getViolation(cs.y0[:, 0]) < 1e-12
