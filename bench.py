@@ -1,24 +1,32 @@
 #!/usr/bin/env python
 """Throughput of the RAYEN projection on MI355X -- the driver's bench contract.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c1|c2|c3|c4|c5]
 
 A "step" is one pass of the hot path (``ConstraintModule.forward`` with the identity
 mapper = one launch of the fused projection) over one batch of synthetic directions
 that is already resident in HBM.  Default workload: BASELINE.json ``configs[2]``, the
 headline -- k=64, 128 linear + 4 quadratic + 2 SOC constraints, batch 262144 per GPU,
-fp32.  N>1 runs one process per GPU (torchrun, backend nccl = RCCL); the batch
-dimension is sharded with fixed per-GPU work (weak scaling) and no data-path
-collective (samples are independent; ``--gather`` adds the all-gather of ``y`` the
-north_star describes for a caller that wants every output on every rank).
+fp32.  The other configs are selected with ``--config`` (their lines are committed
+under ``profiles/bench/``).
 
-One JSON line on rank 0: metric / value (whole-job projections/s) plus
-``roofline`` (dominant kernel, live HIP-event timing) and ``cpu_baseline`` (the
-PyTorch-CPU oracle, same workload, timed on this box's host cores).
+N>1 runs one process per GPU (torchrun, backend nccl = RCCL).  The batch dimension is
+sharded -- fixed per-GPU work by default (weak scaling), ``--scaling strong`` shards the
+config's own batch (config 5: 2M rows over the ranks) -- and the step is the north_star's:
+every rank projects its rows and ONE all-gather of ``y`` (chunked, asynchronous, issued
+while the next chunk is projected: ``rayen_amd.dist.ShardedStep``) leaves every output on
+every rank.  ``value`` is that step; the same line carries ``no_gather`` (the projection
+alone, what a data-parallel training step needs).  ``--no-gather`` times only the latter.
+
+One JSON line on rank 0: metric / value (whole-job projections/s) plus ``roofline``
+(dominant kernel, live HIP-event timing on the launch stream, PMC traffic from the
+committed rocprofv3 summary of the same command) and ``cpu_baseline`` (the PyTorch-CPU
+oracle, same workload, timed on this box's host cores).
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
 import sys
@@ -35,9 +43,10 @@ PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector = FP32 MFMA peak (
 PEAK_BF16_TFLOPS = 2516.8  # dense bf16 MFMA = 16 x the fp32 MFMA rate (same guide; 2495 measured)
 PEAK_FP64_TFLOPS = 78.6    # MI355X datasheet: FP64 vector = FP64 matrix (v_mfma_f64_16x16x4_f64)
 PEAK_HBM_GBS = 8000.0      # HBM3E spec (≈6.3 TB/s achievable)
+SETTLE_LAUNCHES = 150      # untimed launches before the warm-up: the clocks of a cold device settle after ~100
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -45,7 +54,13 @@ def parse():
     ap.add_argument("--config", default="c3", choices=["c1", "c2", "c3", "c4", "c5"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0 = the BASELINE.json size)")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp64"])
-    ap.add_argument("--gather", action="store_true", help="all-gather y across ranks inside the step")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank projects the config's per-GPU batch | strong: the config's batch is sharded")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: time the projection alone (no all-gather of y)")
+    ap.add_argument("--gather", action="store_true", help=argparse.SUPPRESS)   # (round-1 flag; now the default)
+    ap.add_argument("--chunks", type=int, default=2, help="row blocks per rank whose all-gathers overlap the next block's projection")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the step from a HIP graph (auto: launch-bound batches, B*k < 2^20)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed even for one rank (exercises the multi-GPU code path)")
@@ -53,10 +68,10 @@ def parse():
                     help="put the module's nn.Linear(D, n) mapper in front (create_map=True); 0 = identity mapper")
     ap.add_argument("--no-fuse", action="store_true", help="with --mapper: run the mapper as its own GEMM")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(raw, cs, B, dtype, budget_s):
+def cpu_baseline(raw, cs, B, dtype, budget_s, rng=1.0):
     """Reference op sequence (oracle/rayen_oracle.py) on the host cores, bounded sample of the workload."""
     from oracle import rayen_oracle as oracle
     cores = os.cpu_count() or 1
@@ -66,7 +81,7 @@ def cpu_baseline(raw, cs, B, dtype, budget_s):
     buf = oracle.precompute(csd, dtype)
     gen = torch.Generator().manual_seed(1234)
     Bs = min(B, 32768)
-    x = torch.empty(Bs, cs.n, 1, dtype=dtype).uniform_(-1.0, 1.0, generator=gen)
+    x = torch.empty(Bs, cs.n, 1, dtype=dtype).uniform_(-rng, rng, generator=gen)
 
     def timed(xx):
         t0 = time.perf_counter()
@@ -95,6 +110,80 @@ def cpu_baseline(raw, cs, B, dtype, budget_s):
                       f"(best of thread counts {sorted(rates)})"}
 
 
+def make_step(project_into, sizes, k, dtype, device, gather, chunks, group=None):
+    """The multi-rank step ``bench.py`` times: ``rayen_amd.dist.ShardedStep`` around ``project_into(x_rows,
+    out_rows)`` -- on the GPU the C-ABI projection writing straight into the gather's send buffer; in
+    ``tests/test_dist_gloo.py`` a CPU stand-in, so the code the 8-GPU driver run executes is the code tested."""
+    from rayen_amd.dist import ShardedStep
+    return ShardedStep(project_into, sizes, k, dtype, device, chunks=chunks, gather=gather, group=group)
+
+
+def local_sizes(config_batch, per_gpu_batch, world, scaling):
+    """Rows per rank: ``weak`` = the per-GPU batch on every rank, ``strong`` = the config's batch sharded."""
+    from rayen_amd.dist import shard_sizes
+    if scaling == "strong":
+        return shard_sizes(config_batch, world)
+    return [per_gpu_batch] * world
+
+
+def timed_loop(step, x, steps, warmup, use_dist, graph=False):
+    """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize; returns (wall seconds,
+    device ms per step from HIP events recorded on the launch stream)."""
+    with torch.no_grad():
+        replay = step
+        if graph:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step(x)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                step(x)
+
+            def replay(_x):
+                g.replay()
+        for _ in range(warmup):
+            replay(x)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(steps):
+            replay(x)
+        ev1.record()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    return elapsed, ev0.elapsed_time(ev1) / steps
+
+
+def profiled_traffic(config, dtype_tag, batch, kernel_tag):
+    """HBM bytes per launch of this workload's dominant kernel from the newest committed rocprofv3 PMC summary
+    (``profiles/r*_<config>_*rocprofv3.json``, written by scripts/summarize_profile.py from separate ``--pmc``
+    passes of this same command; FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE).  ``bench.py`` itself cannot
+    collect PMC counters, so a workload that was never profiled reports None."""
+    best = None
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", f"r*_{config}_*rocprofv3.json"))):
+        try:
+            prof = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        line = prof.get("bench_line_under_profiler", {})
+        cfg = line.get("config", {})
+        if line.get("dtype") != dtype_tag or cfg.get("batch_per_gpu") != batch or cfg.get("kernel") != kernel_tag:
+            continue
+        traffic = prof.get("derived", {}).get("hbm_bytes_per_launch")
+        if traffic is not None:
+            best = (traffic, os.path.relpath(path, REPO))
+    return best
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,9 +201,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    from rayen_amd import workloads
+    from rayen_amd import ops, workloads
     from rayen_amd.constraint_module import ConstraintModule
-    from rayen_amd import ops
 
     dtype = torch.float32 if args.dtype == "fp32" else torch.float64
     torch.set_default_dtype(dtype)
@@ -127,49 +215,53 @@ def main():
     else:
         layer = ConstraintModule(cs, method="RAYEN", create_map=False).to(device)
     layer.check_nan = False                      # no host sync inside the timed region
-    B = args.batch or workloads.CONFIGS[args.config][2]
-    if args.config == "c5" and not args.batch:
-        B = B // 8                               # 2M over 8 GPUs -> 262144 per GPU
+    config_batch = workloads.CONFIGS[args.config][2]
+    per_gpu = args.batch or (config_batch // 8 if args.config == "c5" else config_batch)   # c5: 2M = 8 x 262144
+    sizes = local_sizes(args.batch * world if args.batch else config_batch, per_gpu, world, args.scaling)
+    B = sizes[rank]
+    total_rows = sum(sizes)
     rng = workloads.CONFIGS[args.config][3]
     gen = torch.Generator(device=device).manual_seed(1000 + rank)
     x = torch.empty(B, args.mapper or cs.n, 1, device=device, dtype=dtype).uniform_(-rng, rng, generator=gen)
-    gathered = torch.empty(world * B, cs.k, 1, device=device, dtype=dtype) if (args.gather and use_dist) else None
+    dp, _ = layer.device_pack(device)
+    gather = world > 1 and not args.no_gather and not args.mapper
+    graph = args.graph == "on" or (args.graph == "auto" and B * cs.k < (1 << 20) and not gather)
 
-    def step():
-        y = layer(x)
-        if gathered is not None:
-            dist.all_gather_into_tensor(gathered, y)
-        return y
+    def module_step(xx):
+        return layer(xx)
+
+    last = {}
+
+    def project_into(x_rows, out_rows):
+        ops.project_raw(x_rows.reshape(x_rows.shape[0], -1), dp, want_active=False, want_kappa=False, out=out_rows)
+
+    sharded = make_step(project_into, sizes, cs.k, dtype, device, gather=True, chunks=args.chunks) if gather else None
 
     with torch.no_grad():
-        for _ in range(args.warmup):
-            y = step()
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        ev0.record()
-        for _ in range(args.steps):
-            y = step()
-        ev1.record()
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1) / args.steps    # HIP events on the launch stream
+        for _ in range(SETTLE_LAUNCHES):         # clocks settle; not part of W or K
+            module_step(x)
+    # ---- the projection alone (the whole step at N = 1)
+    elapsed_p, dev_ms = timed_loop(module_step, x, args.steps, args.warmup, use_dist, graph=graph)
+    with torch.no_grad():
+        y = module_step(x)
+    # ---- projection + all-gather of y (the north_star's multi-GPU step)
+    elapsed_g = None
+    if gather:
+        elapsed_g, dev_ms_g = timed_loop(sharded, x, args.steps, args.warmup, use_dist)
+        got = sharded.rows_of(rank).reshape(-1, cs.k)[:B]
+        assert torch.equal(got, y[:, :, 0]), "gathered rows differ from the local projection"
+        last["dev_ms_gather"] = dev_ms_g
 
-    t = torch.tensor([elapsed, dev_ms], device=device, dtype=torch.float64)
+    t = torch.tensor([elapsed_p, dev_ms, elapsed_g or 0.0, last.get("dev_ms_gather", 0.0)], device=device,
+                     dtype=torch.float64)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, dev_ms = float(t[0]), float(t[1])
+    elapsed_p, dev_ms, elapsed_g, dev_ms_g = (float(v) for v in t)
+    elapsed = elapsed_g if gather else elapsed_p
 
     # feasibility of what was just computed (fp64 residuals on a slice, outside the timed region)
-    from rayen_amd.constraints import ConvexConstraints  # noqa: F401
     sl = y[: min(B, 65536), :, 0].double().cpu().numpy()
-    max_violation = cs.getMaxViolation(sl)
+    max_violation = cs.getMaxViolation(sl) if B else 0.0
 
     if rank == 0:
         bytes_pp, flops_pp = workloads.algorithmic_work(cs)
@@ -182,8 +274,11 @@ def main():
         tflops = flops_pp * B / kern_s / 1e12
         gbs = bytes_pp * B / kern_s / 1e9
         ai = flops_pp / bytes_pp
-        info = layer.device_pack(device)[0].info()
+        info = dp.info()
         split = dtype == torch.float32 and info.mfma_f32 == 2
+        lmi = cs.has_lmi_constraints
+        kernel_tag = (({2: "mfma_split_bf16x3 (fp32-grade)", 1: "mfma_f32"}.get(info.mfma_f32, "lmi_lanes" if lmi else "generic"))
+                      if dtype == torch.float32 else ("mfma_f64" if info.mfma_f64 else ("lmi_lanes" if lmi else "generic")))
         # The split-operand kernel rebuilds every fp32 product from six bf16 MFMA products (fp32-grade results),
         # so its matrix ceiling in ALGORITHMIC fp32 flops is the dense bf16 peak / 6, not the fp32 MFMA peak
         peak_tf = (PEAK_BF16_TFLOPS / 6.0 if split else PEAK_FP32_TFLOPS) if dtype == torch.float32 else PEAK_FP64_TFLOPS
@@ -194,75 +289,73 @@ def main():
             if split:
                 roof["peak_basis"] = "dense bf16 MFMA peak %.1f / 6 piece products per fp32 product" % PEAK_BF16_TFLOPS
                 roof["frac_of_fp32_mfma_peak"] = tflops / PEAK_FP32_TFLOPS
+            elif lmi:
+                roof["peak_basis"] = ("fp32/fp64 vector ALU peak (numerically the MFMA peak of the dtype): the per-sample "
+                                      "eigen-solve (Householder + Sturm) has no matrix-core form")
         else:
             roof = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": gbs / PEAK_HBM_GBS, "traffic": None}
-        # HBM bytes per launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE x2 per the
-        # gfx950 correction + WRITE_SIZE), committed under profiles/ by scripts/summarize_profile.py;
-        # bench.py itself cannot collect PMC counters, so this is null for workloads never profiled
-        if args.config == "c3" and dtype == torch.float32 and B == 262144:
-            import glob
-            found = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_c3_split_final_rocprofv3.json" if split
-                                                  else "r*_c3_mfma_final_rocprofv3.json")))
-            if found:
-                prof = json.load(open(found[-1]))
-                roof["traffic"] = prof.get("derived", {}).get("hbm_bytes_per_launch")
-                roof["traffic_unit"] = "bytes/launch (algorithmic: %d)" % (bytes_pp * B)
-                roof["traffic_source"] = os.path.relpath(found[-1], REPO)
+        dtype_tag = "f32" if dtype == torch.float32 else "f64"
+        found = None if args.mapper else profiled_traffic(args.config, dtype_tag, B, kernel_tag)
+        if found:
+            roof["traffic"], roof["traffic_source"] = found
+            roof["traffic_unit"] = "bytes/launch (algorithmic: %d)" % (bytes_pp * B)
         roof.update({"kernel_ms": dev_ms, "algorithmic_flops_per_projection": flops_pp,
                      "algorithmic_bytes_per_projection": bytes_pp, "hbm_GBps": gbs,
-                     "hbm_frac": gbs / PEAK_HBM_GBS, "TFLOPs": tflops})
+                     "hbm_frac": gbs / PEAK_HBM_GBS, "TFLOPs": tflops, "hip_graph_replay": bool(graph)})
         out = {
             "metric": "feasible projections/sec at k=64, 128 lin+4 quad+2 SOC; max violation"
                       if args.config == "c3" else f"feasible projections/sec ({args.config})",
-            "value": world * B * args.steps / elapsed,
+            "value": total_rows * args.steps / elapsed,
             "unit": "projections/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if dtype == torch.float32 else "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": dtype_tag, "data": "synthetic",
             "config": {"workload": f"{args.config}: k={cs.k} n={cs.n}, {cs.A_p.shape[0]} linear + "
                                    f"{len(cs.qcs)} quadratic + {len(cs.socs)} SOC"
                                    f"{' + 1 LMI' if cs.has_lmi_constraints else ''}, "
-                                   f"batch {B} per GPU, v~U(-{rng:g},{rng:g})",
-                       "batch_per_gpu": B, "global_batch": world * B,
-                       "parallelism": f"batch-sharded x{world}" + (" + all-gather(y)" if gathered is not None else ""),
-                       "kernel": ({2: "mfma_split_bf16x3 (fp32-grade)", 1: "mfma_f32"}.get(info.mfma_f32, "generic")) if dtype == torch.float32
-                       else ("mfma_f64" if info.mfma_f64 else "generic")},
+                                   f"batch {B} per GPU, v~U(-{rng:g},{rng:g})"
+                                   + (" [random 288-row stand-in with the corridor set's structure: 15 equalities, "
+                                      "72 rank-3 quadratics; the real corridor_dim3.mat is an absent LFS pointer]"
+                                      if args.config == "c5" else ""),
+                       "batch_per_gpu": B, "global_batch": total_rows,
+                       "parallelism": f"batch-sharded x{world}" + (f" + all-gather(y) in {sharded.chunks} chunks" if gather else ""),
+                       "kernel": kernel_tag},
             "max_violation": max_violation,
             "violations_gt_1e-6": int(max_violation > 1e-6),
             "roofline": roof,
         }
+        if world > 1:
+            out["no_gather"] = {"value": total_rows * args.steps / elapsed_p, "unit": "projections/s",
+                                "ms_per_step": elapsed_p / args.steps * 1e3,
+                                "what": "the projection alone on every rank (no collective), same inputs and step count"}
+            if gather:
+                out["gather"] = {"bytes_received_per_rank": (total_rows - B) * cs.k * (4 if dtype == torch.float32 else 8),
+                                 "chunks": sharded.chunks, "device_ms_per_step": dev_ms_g}
         if args.mapper:
-            fused = (not args.no_fuse) and dtype == torch.float32 and layer.device_pack(device)[0].mapper_fusable(args.mapper)
+            fused = (not args.no_fuse) and dtype == torch.float32 and dp.mapper_fusable(args.mapper)
             out["config"]["mapper"] = f"nn.Linear({args.mapper}, {cs.n}) " + ("fused into the projection kernel" if fused else "as its own GEMM")
         if split and world == 1 and not args.mapper:
-            # the same workload on the exact-fp32 MFMA kernels (RAYEN_SPLIT_BF16=0 is read when a pack is created),
+            # the same workload on the exact-fp32 MFMA kernels (fp32_mode 1 / RAYEN_SPLIT_BF16=0 at pack creation),
             # timed the same way, so that one line carries both fp32 families
             os.environ["RAYEN_SPLIT_BF16"] = "0"
             try:
                 exact = ConstraintModule(cs, method="RAYEN", create_map=False).to(device)
                 exact.check_nan = False
-                with torch.no_grad():
-                    for _ in range(args.warmup):
-                        exact(x)
-                    torch.cuda.synchronize()
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    for _ in range(args.steps):
-                        exact(x)
-                    e1.record()
-                    torch.cuda.synchronize()
-                ms = e0.elapsed_time(e1) / args.steps
-                tf = flops_pp * B / (ms * 1e-3) / 1e12
-                out["exact_fp32_kernels"] = {"value": B / (ms * 1e-3), "unit": "projections/s", "ms_per_step": ms,
-                                             "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS,
-                                                          "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS},
-                                             "how": "RAYEN_SPLIT_BF16=0, same inputs, same step count"}
+                exact.device_pack(device)
             finally:
                 del os.environ["RAYEN_SPLIT_BF16"]
+            _, ms = timed_loop(lambda xx: exact(xx), x, args.steps, args.warmup, False, graph=graph)
+            tf = flops_pp * B / (ms * 1e-3) / 1e12
+            out["exact_fp32_kernels"] = {"value": B / (ms * 1e-3), "unit": "projections/s", "ms_per_step": ms,
+                                         "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS,
+                                                      "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS},
+                                         "how": "exact-fp32 MFMA kernels (RAYEN_SPLIT_BF16=0), same inputs, same step count"}
+            out["fp32_family_check"] = {"split_vs_fp64": info.fp32_check_split, "exact_vs_fp64": info.fp32_check_exact,
+                                        "what": "worst row error on the pack-creation probe directions"}
         if world == 1 and not args.no_cpu_baseline and not args.mapper:
-            out["cpu_baseline"] = cpu_baseline(raw, cs, B, dtype, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(raw, cs, B, dtype, args.cpu_seconds, rng)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if use_dist:

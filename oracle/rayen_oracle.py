@@ -96,9 +96,15 @@ def solve_second_order(a, b, c):
     return torch.relu(torch.maximum(sol1, sol2))
 
 
-def compute_kappa(buf: dict, v_bar: torch.Tensor) -> torch.Tensor:
-    """``kappa [B,1,1]`` for directions ``v_bar [B,n,1]`` (CM:351-458)."""
-    kappa = torch.relu(torch.max(buf["D"] @ v_bar, dim=1, keepdim=True).values)  # CM:353
+def compute_kappa(buf: dict, v_bar: torch.Tensor, terms: bool = False) -> torch.Tensor:
+    """``kappa [B,1,1]`` for directions ``v_bar [B,n,1]`` (CM:351-458).
+
+    ``terms=True`` (test helper, not in the reference): return instead every candidate that enters the final
+    maxima -- ``[B, m + Q + S + 2]``: each linear row, each quadratic, each cone, and the two largest LMI
+    eigenvalues -- so that a test can tell samples sitting on a kink of kappa (two candidates tie) apart."""
+    lin = buf["D"] @ v_bar
+    kappa = torch.relu(torch.max(lin, dim=1, keepdim=True).values)  # CM:353
+    lam_top2 = None
 
     n_quad = buf["all_P"].shape[0] if buf["all_P"].ndim == 3 else 0
     n_soc = buf["all_M"].shape[0] if buf["all_M"].ndim == 3 else 0
@@ -125,9 +131,17 @@ def compute_kappa(buf: dict, v_bar: torch.Tensor) -> torch.Tensor:
             S = torch.einsum("ajk,ial->ijk", [buf["all_F"][0:-1], rho])
             sym = buf["L"].T @ (-S) @ buf["L"]
             lam = torch.linalg.eigvalsh(sym).unsqueeze(2)
+            lam_top2 = lam[:, -2:, :] if lam.shape[1] >= 2 else torch.cat((lam, lam), dim=1)
             parts = torch.cat((parts, torch.relu(torch.max(lam, dim=1, keepdim=True).values)), dim=1)
 
+        if terms:
+            cand = [lin, parts[:, :-1] if has_lmi else parts]
+            if has_lmi:
+                cand.append(lam_top2)
+            return torch.cat(cand, dim=1)[:, :, 0]
         kappa = torch.maximum(kappa, torch.max(parts, dim=1, keepdim=True).values)  # CM:452-453
+    if terms:
+        return lin[:, :, 0]
     return kappa
 
 

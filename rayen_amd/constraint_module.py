@@ -183,8 +183,8 @@ class ConstraintModule(torch.nn.Module):
         if not need_active and type(v) is torch.Tensor and not torch.compiler.is_compiling():
             # plain inference call: straight to the C ABI (the same code the registered op runs; the dispatcher
             # layers around a custom op cost ~10 us per call, as much as the kernel at small batches)
-            y, kappa, _ = ops.project_raw(v, dp, want_active=False, old_head=old_head)
-            return y, kappa
+            y, _, _ = ops.project_raw(v, dp, want_active=False, old_head=old_head, want_kappa=False)
+            return y, None
         y, kappa, _ = torch.ops.rayen_amd.ray_project(v, pack_id, need_active, old_head)
         return y, kappa
 

@@ -5,12 +5,26 @@ independent, so the batch dimension shards with NO data-path collective: every
 rank projects its own rows with the same replicated constants (<= a few hundred
 KiB).  A caller that needs every output on every rank (the layout BASELINE.json's
 north_star describes) adds exactly one collective, an all-gather of ``y`` (RCCL
-over xGMI when the backend is ``nccl``); it can be issued in chunks so that the
-gather of chunk c overlaps the projection of chunk c+1.
+over xGMI when the backend is ``nccl``).
 
-``project_fn`` is the per-rank compute (by default the ``ConstraintModule``
-itself).  It is a parameter so that the sharding/gather logic can be exercised
-on CPU with the ``gloo`` backend, where the HIP kernels cannot run.
+:class:`ShardedStep` is that step, and it is what ``bench.py --gpus N`` times:
+
+* the local batch is cut into ``chunks`` row blocks; block ``c`` is projected
+  STRAIGHT INTO its send buffer (``project_into(x_rows, out_rows)``: the HIP kernel
+  writes the gather's input, no staging copy, no zero-fill),
+* ``all_gather_into_tensor`` of block ``c`` is issued asynchronously as soon as its
+  projection is queued -- RCCL runs it on its own stream, after the kernel, while
+  the main stream already projects block ``c + 1``,
+* the result is ONE buffer ``[chunks, world, rows, k]``; ``rows_of(rank)`` is a
+  strided view of it in the rank's original row order (no reorder pass).
+
+Arithmetic that sizes ``chunks`` (MI355X, direct xGMI mesh): a rank receives
+``(world - 1) x B x k x 4`` bytes -- config 3 at 8 ranks: 7 x 64 MiB over 7 links --
+while projecting ``B`` rows takes 0.1 ms; the gather is the longer leg by ~10x, so
+chunking exists to start it early (after 1/chunks of the compute), not to hide it.
+
+``project_into`` is a parameter so that exactly this code runs on CPU with the
+``gloo`` backend in ``tests/test_dist_gloo.py`` (the HIP kernels cannot run there).
 """
 from __future__ import annotations
 
@@ -29,8 +43,70 @@ def shard_sizes(total: int, world: int):
     return [shard_bounds(total, world, r)[1] - shard_bounds(total, world, r)[0] for r in range(world)]
 
 
+class ShardedStep:
+    """One data-parallel step: project this rank's rows, optionally all-gather ``y``.
+
+    ``sizes``: rows held by every rank (``shard_sizes(total, world)`` for a sharded batch, ``[B] * world``
+    for fixed per-rank work).  Buffers are allocated once, here; a step allocates nothing.
+    """
+
+    def __init__(self, project_into, sizes, k, dtype, device, chunks=4, gather=True, group=None):
+        self.project_into = project_into
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if len(sizes) != self.world:
+            raise ValueError(f"sizes has {len(sizes)} entries for {self.world} ranks")
+        self.sizes = [int(s) for s in sizes]
+        self.n_local = self.sizes[self.rank]
+        self.k = int(k)
+        self.gather = bool(gather) and self.world > 1
+        max_rows = max(self.sizes) if self.sizes else 0
+        self.chunks = max(1, min(int(chunks), max_rows)) if self.gather else 1
+        self.rows = -(-max_rows // self.chunks) if max_rows else 0          # rows per chunk (last one ragged)
+        if self.gather:
+            # [chunk][rank][row][k]: chunk c of every rank is one contiguous all-gather output
+            self.out = torch.empty((self.chunks, self.world, self.rows, self.k), dtype=dtype, device=device)
+            self.send = torch.empty((self.chunks, self.rows, self.k), dtype=dtype, device=device)
+        else:
+            self.out = None
+            self.send = torch.empty((1, max(self.n_local, 0), self.k), dtype=dtype, device=device)
+
+    def __call__(self, x_local):
+        """``x_local [n_local, ...]`` -> this rank's ``y [n_local, k]`` (no gather) or the gather buffer."""
+        if x_local.shape[0] != self.n_local:
+            raise ValueError(f"rank {self.rank} holds {self.n_local} rows, got {x_local.shape[0]}")
+        if not self.gather:
+            y = self.send[0]
+            self.project_into(x_local, y)
+            return y
+        works = []
+        for c in range(self.chunks):
+            lo, hi = min(c * self.rows, self.n_local), min((c + 1) * self.rows, self.n_local)
+            send = self.send[c]
+            if hi > lo:
+                self.project_into(x_local[lo:hi], send[: hi - lo])          # rows beyond hi - lo: padding, never read
+            works.append(dist.all_gather_into_tensor(self.out[c].view(self.world * self.rows, self.k), send,
+                                                     group=self.group, async_op=True))
+        for work in works:
+            work.wait()
+        return self.out
+
+    def rows_of(self, rank):
+        """Strided view ``[sizes[rank], k]``-equivalent of rank ``rank``'s rows inside the gather buffer, in their
+        original order: shape ``[chunks, rows, k]`` whose flattened first two axes are the rank's rows (the last
+        chunk carries ``chunks * rows - sizes[rank]`` padding rows at its end)."""
+        return self.out[:, rank]
+
+    def gathered(self):
+        """All rows of all ranks in global order as ONE new tensor ``[sum(sizes), k]`` (a copy; for callers that
+        want the plain layout -- the timed step never does this)."""
+        parts = [self.rows_of(r).reshape(self.chunks * self.rows, self.k)[: self.sizes[r]] for r in range(self.world)]
+        return torch.cat(parts, dim=0)
+
+
 class ShardedProjection:
-    """Data-parallel wrapper around a projection callable ``[b, ...] -> [b, k, 1]``."""
+    """Convenience wrapper around a projection callable ``[b, ...] -> [b, k, 1]`` (the module itself)."""
 
     def __init__(self, project_fn, group=None):
         self.project_fn = project_fn
@@ -48,13 +124,22 @@ class ShardedProjection:
         """This rank's rows only; no communication (the data-parallel training case)."""
         return self.project_fn(x_local)
 
+    def _step(self, x_local, sizes, chunks):
+        def into(x_rows, out_rows):
+            out_rows.copy_(self.project_fn(x_rows).reshape(out_rows.shape))
+        probe = self.project_fn(x_local[:0])
+        k = probe.shape[1]
+        step = ShardedStep(into, sizes, k, probe.dtype, probe.device, chunks=chunks, gather=True, group=self.group)
+        step(x_local)
+        return step.gathered().reshape((-1, k) + tuple(probe.shape[2:]))
+
     def forward_replicated(self, x_full, chunks: int = 1):
         """``x_full`` is replicated on every rank: project this rank's slice, all-gather ``y``.
-
-        Returns the full ``[B, k, 1]`` result on every rank, rows in the original order.
-        """
+        Returns the full ``[B, k, 1]`` result on every rank, rows in the original order."""
+        if self.world == 1:
+            return self.project_fn(x_full)
         lo, hi = shard_bounds(x_full.shape[0], self.world, self.rank)
-        return self.all_gather_rows(self.project_fn, x_full[lo:hi], x_full.shape[0], chunks)
+        return self._step(x_full[lo:hi], shard_sizes(x_full.shape[0], self.world), chunks)
 
     def forward_gather(self, x_local, chunks: int = 1):
         """Every rank holds its own rows (equal counts or not): project them, all-gather ``y``."""
@@ -63,44 +148,4 @@ class ShardedProjection:
         counts = torch.zeros(self.world, dtype=torch.int64, device=x_local.device)
         counts[self.rank] = x_local.shape[0]
         dist.all_reduce(counts, group=self.group)
-        return self.all_gather_rows(self.project_fn, x_local, int(counts.sum().item()), chunks,
-                                    sizes=[int(c) for c in counts.tolist()])
-
-    # ------------------------------------------------------------------
-    def all_gather_rows(self, fn, x_local, total, chunks=1, sizes=None):
-        world = self.world
-        if world == 1:
-            return fn(x_local)
-        sizes = sizes or shard_sizes(total, world)
-        max_rows = max(sizes)
-        n_local = x_local.shape[0]
-        chunks = max(1, min(chunks, max_rows))
-        step = -(-max_rows // chunks)
-        out = None
-        handles = []
-        pieces = []  # (chunk index, per-rank receive buffers)
-        for c in range(chunks):
-            lo, hi = min(c * step, n_local), min((c + 1) * step, n_local)
-            rows = min((c + 1) * step, max_rows) - c * step
-            if rows <= 0:
-                break
-            y_c = fn(x_local[lo:hi])  # may be an empty slice on a rank with a shorter shard
-            if out is None:
-                tail = tuple(y_c.shape[1:])
-                out = torch.empty((total,) + tail, dtype=y_c.dtype, device=y_c.device)
-            send = torch.zeros((rows,) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device)
-            send[: y_c.shape[0]] = y_c
-            recv = [torch.empty_like(send) for _ in range(world)]
-            handles.append(dist.all_gather(recv, send, group=self.group, async_op=True))
-            pieces.append((c, recv))
-        offsets = [0]
-        for s in sizes:
-            offsets.append(offsets[-1] + s)
-        for handle, (c, recv) in zip(handles, pieces):
-            handle.wait()
-            for r in range(world):
-                lo = min(c * step, sizes[r])
-                hi = min((c + 1) * step, sizes[r])
-                if hi > lo:
-                    out[offsets[r] + lo: offsets[r] + hi] = recv[r][: hi - lo]
-        return out
+        return self._step(x_local, [int(c) for c in counts.tolist()], chunks)

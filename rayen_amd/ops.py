@@ -94,10 +94,13 @@ _BWD = {(torch.float32, False): "rayen_ray_project_bwd_f32", (torch.float64, Fal
         (torch.float64, True): "rayen_ray_project_old_bwd_f64"}
 
 
-def project_raw(v, pack, want_y=True, force_generic=False, want_active=True, old_head=False):
-    """Direct call of the C ABI on an existing ``DevicePack``; returns (y|None, kappa, active|None).
+def project_raw(v, pack, want_y=True, force_generic=False, want_active=True, old_head=False, out=None,
+                want_kappa=True):
+    """Direct call of the C ABI on an existing ``DevicePack``; returns (y|None, kappa|None, active|None).
 
-    ``old_head``: the ``RAYEN_old`` step rule; ``v`` then carries ``beta`` in column ``n``."""
+    ``old_head``: the ``RAYEN_old`` step rule; ``v`` then carries ``beta`` in column ``n``.
+    ``out``: a ``[B, >=k]`` tensor (unit column stride) whose first ``k`` columns receive ``y`` -- e.g. this
+    rank's rows of a gather buffer -- instead of a fresh allocation."""
     _check_input(v, pack)
     if old_head and v.shape[1] < pack.consts.n + 1:
         raise RuntimeError(f"rayen_amd: RAYEN_old needs {pack.consts.n + 1} input columns, got {v.shape[1]}")
@@ -105,13 +108,20 @@ def project_raw(v, pack, want_y=True, force_generic=False, want_active=True, old
         v = v.contiguous()
     B = v.shape[0]
     k = pack.consts.k
-    y = torch.empty((B, k), dtype=v.dtype, device=v.device) if want_y else None
-    kappa = torch.empty((B,), dtype=v.dtype, device=v.device)
+    if out is not None:
+        if (out.dim() != 2 or out.shape[0] != B or out.shape[1] < k or out.dtype != v.dtype
+                or out.device != v.device or (B and out.stride(1) != 1)):
+            raise RuntimeError(f"rayen_amd: out must be a [{B}, >={k}] {v.dtype} tensor on {v.device} with unit column stride")
+        y = out
+    else:
+        y = torch.empty((B, k), dtype=v.dtype, device=v.device) if want_y else None
+    kappa = torch.empty((B,), dtype=v.dtype, device=v.device) if want_kappa else None
     active = torch.empty((B, 2), dtype=torch.int32, device=v.device) if want_active else None
     name = _FWD_OLD[v.dtype] if old_head else _FWD[(v.dtype, bool(force_generic))]
     fn = getattr(_lib.load(), name)
     with _on_device(v.device):
-        code = fn(pack.handle, _ptr(v), B, v.stride(0) if B else pack.consts.n, _ptr(y), k,
+        code = fn(pack.handle, _ptr(v), B, v.stride(0) if B else pack.consts.n, _ptr(y),
+                  y.stride(0) if (y is not None and B) else k,
                   _ptr(kappa), _ptr(active), _ptr(pack.nan_flag), _stream(v.device.index))
     _lib.check(code, "rayen_ray_project")
     return y, kappa, active

@@ -18,7 +18,10 @@ try:
 except Exception:
     pass
 dominant = out["kernel_stats"][0]["name"].split("(")[0]
-for db in ("pmc_sq", "pmc_fetch", "pmc_write"):
+import os
+for db in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
+    if not os.path.exists(f"{base}/{db}/pmc_results.db"):
+        continue
     con = sqlite3.connect(f"{base}/{db}/pmc_results.db")
     for r in con.execute("select kernel_name,counter_name,avg(value),count(*) from counters_collection "
                          "group by kernel_name,counter_name"):
@@ -38,6 +41,13 @@ if "GRBM_GUI_ACTIVE" in p:
     if "SQ_VALU_MFMA_BUSY_CYCLES" in p:
         derived["mfma_busy_fraction"] = p["SQ_VALU_MFMA_BUSY_CYCLES"]["avg_per_launch"] / (
             1024 * p["GRBM_GUI_ACTIVE"]["avg_per_launch"] / 8)
+if "SQ_WAVE_CYCLES" in p and "SQ_BUSY_CYCLES" in p and "GRBM_GUI_ACTIVE" in p:
+    # average waves resident per SIMD while the kernel runs (1024 SIMDs; GRBM_GUI_ACTIVE is summed over 8 XCDs)
+    derived["waves_per_simd_avg"] = p["SQ_WAVE_CYCLES"]["avg_per_launch"] / (1024 * p["GRBM_GUI_ACTIVE"]["avg_per_launch"] / 8) / 4
+if "SQ_ACTIVE_INST_VALU" in p and "SQ_WAVE_CYCLES" in p:
+    derived["valu_active_fraction_of_wave_cycles"] = p["SQ_ACTIVE_INST_VALU"]["avg_per_launch"] / p["SQ_WAVE_CYCLES"]["avg_per_launch"]
+if "SQ_LDS_BANK_CONFLICT" in p and "SQ_WAVE_CYCLES" in p:
+    derived["lds_bank_conflict_fraction_of_wave_cycles"] = p["SQ_LDS_BANK_CONFLICT"]["avg_per_launch"] / p["SQ_WAVE_CYCLES"]["avg_per_launch"]
 if "TCC_HIT_sum" in p:
     derived["l2_hit_rate"] = p["TCC_HIT_sum"]["avg_per_launch"] / (
         p["TCC_HIT_sum"]["avg_per_launch"] + p["TCC_MISS_sum"]["avg_per_launch"])

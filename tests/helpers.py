@@ -61,3 +61,31 @@ def rel_err_rows(y, y_ref):
     num = np.max(np.abs(y - y_ref), axis=1)
     den = np.maximum(np.max(np.abs(y_ref), axis=1), 1e-30)
     return num / den
+
+
+def kink_mask(oracle, cs, x, rel_gap, method="RAYEN"):
+    """Samples at which the layer's gradient is legitimately discontinuous, identified on the fp64 oracle:
+
+    * two candidates of the max in ``computeKappa`` tie within ``rel_gap`` of kappa (the arg-max may flip; this
+      includes the two largest LMI eigenvalues, whose eigenvector derivative diverges as they meet),
+    * ``kappa(v)`` within ``rel_gap`` of 1 (the RAYEN head switches between clipped and unclipped), or of 0
+      (relu corner).
+
+    ``x [B, >=n, 1]`` as fed to the layer.  Returns a boolean numpy array ``[B]``."""
+    import torch
+    buf = oracle.precompute(csd_from_cs(cs), torch.float64)
+    n = cs.n
+    v = x[:, 0:n, 0:1].double().cpu()
+    norm = torch.linalg.vector_norm(v, dim=(1, 2)).clamp_min(1e-300)
+    cand = oracle.compute_kappa(buf, v / norm.reshape(-1, 1, 1), terms=True) * norm.reshape(-1, 1)
+    cand = torch.nan_to_num(cand, nan=0.0)
+    top2 = torch.topk(torch.cat((cand, torch.zeros(cand.shape[0], 2, dtype=cand.dtype)), dim=1), 2, dim=1).values
+    kappa = top2[:, 0].clamp_min(0.0)
+    scale = kappa.clamp_min(1e-300)
+    tie = (top2[:, 0] - top2[:, 1]) <= rel_gap * scale
+    tie &= kappa > 0
+    near_zero = (cand.max(dim=1).values.abs() <= rel_gap * norm) & (norm > 0)
+    kink = tie | near_zero
+    if method == "RAYEN":
+        kink |= (kappa - 1.0).abs() <= rel_gap
+    return kink.numpy()

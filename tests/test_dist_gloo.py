@@ -1,7 +1,9 @@
 """World-size-2 test of the batch sharding + all-gather logic on CPU (gloo backend).
 
 The HIP kernels cannot run here, so the per-rank compute is the CPU oracle; what is
-under test is `rayen_amd.dist` (shard bounds, uneven shards, chunked gather, row order).
+under test is `rayen_amd.dist` (shard bounds, uneven shards, chunked gather, row order) and the
+step function `bench.py --gpus N` times (`bench.make_step` / `bench.local_sizes`), driven here with a
+CPU stand-in for the projection so that the code the 8-GPU run executes is the code tested.
 """
 import os
 import socket
@@ -81,3 +83,60 @@ def test_shard_bounds_cover_and_order():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = shard_sizes(total, world)
             assert sum(sizes) == total and max(sizes) - min(sizes) <= 1
+
+
+def _bench_worker(rank, world, port, scaling, chunks, config_batch, per_gpu, result_dir):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        from helpers import csd_from_cs
+        from oracle import rayen_oracle as oracle
+        from rayen_amd import workloads
+
+        torch.set_num_threads(1)
+        cs = workloads.build_constraints(workloads.make_raw("c2", seed=3))
+        buf = oracle.precompute(csd_from_cs(cs), torch.float32)
+        calls = []
+
+        def project_into(x_rows, out_rows):                # stand-in for ops.project_raw(..., out=out_rows)
+            assert out_rows.shape == (x_rows.shape[0], cs.k) and out_rows.stride(1) == 1
+            calls.append(x_rows.shape[0])
+            out_rows.copy_(oracle.forward(buf, x_rows)[:, :, 0])
+
+        sizes = bench.local_sizes(config_batch, per_gpu, world, scaling)
+        assert len(sizes) == world and (sum(sizes) == config_batch if scaling == "strong" else sizes == [per_gpu] * world)
+        # every rank can rebuild every rank's inputs (seed + rank, as bench.py does)
+        xs = [torch.empty(sizes[r], cs.n, 1).uniform_(-1, 1, generator=torch.Generator().manual_seed(1000 + r))
+              for r in range(world)]
+        step = bench.make_step(project_into, sizes, cs.k, torch.float32, torch.device("cpu"), gather=True, chunks=chunks)
+        for _ in range(2):                                  # a step is repeatable: buffers are reused, nothing accumulates
+            out = step(xs[rank])
+        assert out.shape == (step.chunks, world, step.rows, cs.k)
+        assert sum(calls) == 2 * sizes[rank] and max(calls) <= step.rows
+        for r in range(world):
+            want = oracle.forward(buf, xs[r])[:, :, 0]
+            got = step.rows_of(r).reshape(-1, cs.k)[: sizes[r]]
+            assert torch.equal(got, want), f"rank {rank}: rows of rank {r}"
+        assert torch.equal(step.gathered(), torch.cat([oracle.forward(buf, xx)[:, :, 0] for xx in xs]))
+        # the projection-only step (bench's `no_gather` leg) leaves this rank's rows in its local buffer
+        local = bench.make_step(project_into, sizes, cs.k, torch.float32, torch.device("cpu"), gather=False, chunks=chunks)
+        assert torch.equal(local(xs[rank]), oracle.forward(buf, xs[rank])[:, :, 0])
+        np.save(os.path.join(result_dir, f"ok_{rank}.npy"), np.array([1]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scaling,chunks,config_batch,per_gpu", [("weak", 1, 0, 96), ("weak", 4, 0, 101),
+                                                                 ("strong", 2, 203, 0), ("strong", 3, 64, 0)])
+def test_bench_step_function_world2(tmp_path, scaling, chunks, config_batch, per_gpu):
+    """`bench.py`'s multi-rank step (chunked asynchronous all-gather of y straight from the projection's output
+    buffer), weak and strong sharding, ragged chunks and unequal shards, on two gloo ranks."""
+    world = 2
+    port = _free_port()
+    mp.spawn(_bench_worker, args=(world, port, scaling, chunks, config_batch, per_gpu, str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        assert os.path.exists(tmp_path / f"ok_{rank}.npy")

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import csd_from_cs, load_golden
+from helpers import csd_from_cs, load_golden, kink_mask
 from oracle import rayen_oracle as oracle
 from rayen_amd import workloads
 from rayen_amd.constraint_module import ConstraintModule
@@ -23,17 +23,49 @@ def _cases():
     }
 
 
-def _oracle_grad(cs, x, G):
-    buf = oracle.precompute(csd_from_cs(cs), torch.float64)
-    xr = x.double().clone().requires_grad_(True)
-    y = oracle.forward(buf, xr)
-    (y[:, :, 0] * G.double()).sum().backward()
-    return xr.grad[:, :, 0].numpy(), y.detach()[:, :, 0].numpy()
+# Gradient tolerances.  Away from the kinks of kappa (helpers.kink_mask: ties of the arg-max, kappa = 1, kappa = 0,
+# a nearly repeated top LMI eigenvalue -- identified on the fp64 oracle, not budgeted) EVERY sample is held to
+# GRAD_TOL of the fp64 autograd gradient, per-sample inf-norm relative; in fp32 a sample may exceed it only where
+# the reference's own fp32 autograd gradient is off by a quarter of as much (ill-conditioned roots), and then by
+# no more than 4x that.
+GRAD_TOL = {torch.float32: 1e-3, torch.float64: 1e-8}
+KINK_GAP = {torch.float32: 1e-4, torch.float64: 1e-8}
+
+
+def _oracle_grad(cs, x, G, dtype=torch.float64, method="RAYEN"):
+    buf = oracle.precompute(csd_from_cs(cs), dtype)
+    xr = x.to(dtype).clone().requires_grad_(True)
+    y = oracle.forward(buf, xr, method=method)
+    (y[:, :, 0] * G.to(dtype)).sum().backward()
+    return xr.grad[:, :, 0].double().numpy(), y.detach()[:, :, 0].double().numpy()
+
+
+def _row_err(got, want, floor=None):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    scale = np.maximum(np.max(np.abs(want), axis=1), 1e-12 if floor is None else floor)
+    return np.max(np.abs(got - want), axis=1) / scale
+
+
+def _assert_gradient(got, want, cs, x, G, dtype, method="RAYEN", floor=None, what=""):
+    """``got`` against the fp64 truth ``want`` under the rule above."""
+    err = _row_err(got, want, floor)
+    kink = kink_mask(oracle, cs, x, KINK_GAP[dtype], method=method)
+    bound = np.full(err.shape, GRAD_TOL[dtype])
+    if dtype == torch.float32:
+        try:
+            theirs = _row_err(_oracle_grad(cs, x, G, torch.float32, method)[0], want, floor)
+            bound = np.maximum(bound, 4.0 * np.nan_to_num(theirs, nan=0.0))
+        except AssertionError:          # the reference's fp32 discriminant went negative somewhere
+            pass
+    bad = (~kink) & ~(err <= bound)
+    assert not bad.any(), (what, int(bad.sum()), int(kink.sum()), np.flatnonzero(bad)[:5], err[bad][:5], bound[bad][:5])
+    assert kink.mean() <= 0.02, (what, "too many samples classified as kinks", kink.mean())
+    assert np.median(err) <= GRAD_TOL[dtype] / 10
 
 
 @pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4", "c5", "mixed"])
-@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-6), (torch.float32, 5e-3)])
-def test_backward_matches_oracle_autograd(name, dtype, tol):
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_backward_matches_oracle_autograd(name, dtype):
     raw = _cases()[name]
     prev = torch.get_default_dtype()
     torch.set_default_dtype(dtype)
@@ -56,13 +88,7 @@ def test_backward_matches_oracle_autograd(name, dtype, tol):
     want, y_ref = _oracle_grad(cs, x, G)
 
     assert np.all(np.isfinite(got))
-    scale_g = np.maximum(np.max(np.abs(want), axis=1), 1e-12)
-    err = np.max(np.abs(got - want), axis=1) / scale_g
-    # a sample sitting on a kink of kappa (two constraints tie, or kappa == 1) may legitimately
-    # pick the other one-sided derivative in a different precision: allow a handful
-    frac_ok = np.mean(err <= tol)
-    assert frac_ok >= (0.999 if dtype == torch.float64 else 0.99), (frac_ok, np.sort(err)[-5:])
-    assert np.median(err) <= tol / 10
+    _assert_gradient(got, want, cs, x, G, dtype, what=name)
     # interior samples: y = y0 + NA_E v exactly, so grad = NA_E' G
     lift = G[:8].double().numpy() @ cs.NA_E
     assert np.max(np.abs(got[:8] - lift)) <= 1e-5 * max(1.0, np.max(np.abs(lift)))
@@ -91,8 +117,8 @@ def test_training_step_through_a_model():
 
 
 @pytest.mark.parametrize("name", ["c2", "c3", "c4", "mixed"])
-@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-6), (torch.float32, 5e-3)])
-def test_backward_rayen_old_head(name, dtype, tol):
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_backward_rayen_old_head(name, dtype):
     """Gradients w.r.t. the direction AND the step column beta of method='RAYEN_old'."""
     raw = _cases()[name]
     prev = torch.get_default_dtype()
@@ -110,14 +136,9 @@ def test_backward_rayen_old_head(name, dtype, tol):
     (layer(xg)[:, :, 0] * G.cuda()).sum().backward()
     got = xg.grad[:, :, 0].cpu().double().numpy()
 
-    buf = oracle.precompute(csd_from_cs(cs), torch.float64)
-    xr = x.double().clone().requires_grad_(True)
-    (oracle.forward(buf, xr, method="RAYEN_old")[:, :, 0] * G.double()).sum().backward()
-    want = xr.grad[:, :, 0].numpy()
+    want, _ = _oracle_grad(cs, x, G, torch.float64, "RAYEN_old")
     assert np.all(np.isfinite(got))
-    err = np.max(np.abs(got - want), axis=1) / np.maximum(np.max(np.abs(want), axis=1), 1e-12)
-    assert np.mean(err <= tol) >= (0.999 if dtype == torch.float64 else 0.99), np.sort(err)[-5:]
-    assert np.median(err) <= tol / 10
+    _assert_gradient(got, want, cs, x, G, dtype, method="RAYEN_old", what=name)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -204,11 +225,20 @@ def test_matrix_core_backward_matches_lane_backward(name, old_head, dtype):
     else:
         want = ops.backward_raw(v, kappa, active, g, dp, force_generic=True).cpu().double()
     got = got.cpu().double()
-    scale = want.abs().amax(1).clamp_min(1e-12)
-    err = (got - want).abs().amax(1) / scale
-    tol = (5e-3 if old_head else 2e-4) if dtype == torch.float32 else (1e-6 if old_head else 1e-9)
-    assert (err <= tol).double().mean() >= (0.99 if old_head and dtype == torch.float32 else 0.999), torch.sort(err).values[-5:]
-    assert float(err.median()) <= tol / 10
+    method = "RAYEN_old" if old_head else "RAYEN"
+    x3, g_cpu = v.cpu().unsqueeze(2), g.cpu()
+    if old_head:
+        truth = want.numpy()
+    else:
+        # the lane-per-sample backward reads the same (kappa, active) record, so the two kernels take the same branch
+        # at every sample, kinks included: they must agree everywhere to rounding ...
+        err = _row_err(got.numpy(), want.numpy())
+        assert err.max() <= (2e-4 if dtype == torch.float32 else 1e-9), np.sort(err)[-5:]
+        # ... and the matrix-core one is also held to the fp64 autograd truth
+        xz = x3.clone()
+        truth, _ = _oracle_grad(cs, xz, g_cpu, torch.float64, method)
+        truth[40:44] = g_cpu[40:44].double().numpy() @ np.asarray(cs.NA_E)      # v = 0: the identity map around 0
+    _assert_gradient(got.numpy(), truth, cs, x3, g_cpu, dtype, method=method, what=name)
 
 
 @pytest.mark.parametrize("name", ["r3_lin", "r7", "r12_lin_eq", "r16", "r24_lin", "r30_eq", "c4"])
@@ -294,8 +324,16 @@ def _check_lmi_backward(raw, dtype):
     xr = v.double().unsqueeze(2).requires_grad_(True)
     y = oracle.forward(buf, xr)
     (y[:, :, 0] * g.double()).sum().backward()
-    y_err = (y_dev.cpu().double() - y.detach()[:, :, 0]).abs().amax(1) / y.detach()[:, :, 0].abs().amax(1).clamp_min(1e-30)
-    assert float(y_err.max()) <= (3e-5 if dtype == torch.float32 else 1e-9)
+    y_true = y.detach()[:, :, 0]
+    y_err = (y_dev.cpu().double() - y_true).abs().amax(1) / y_true.abs().amax(1).clamp_min(1e-30)
+    if dtype == torch.float32:
+        # forward parity of the LMI kernels: the north_star's 1e-5, or twice what LAPACK's own fp32 eigvalsh (the
+        # reference's arithmetic) leaves against the fp64 truth on the same inputs
+        y32 = oracle.forward(oracle.precompute(csd_from_cs(cs), torch.float32), v.unsqueeze(2))[:, :, 0].double()
+        theirs = float(((y32 - y_true).abs().amax(1) / y_true.abs().amax(1).clamp_min(1e-30)).max())
+        assert float(y_err.max()) <= max(1e-5, 2.0 * theirs), (float(y_err.max()), theirs, r)
+    else:
+        assert float(y_err.max()) <= 1e-9
     want = xr.grad[:, :, 0]
     # v = 0: eigvalsh of the zero matrix has no autograd derivative worth comparing; the layer is the identity
     # map around 0, so its gradient there is NA_E' g
@@ -303,11 +341,8 @@ def _check_lmi_backward(raw, dtype):
     # (a clipped sample of a one-dimensional set has gradient exactly 0 -- y does not move with v --: errors are
     # measured against the incoming gradient's size there, not against rounding noise)
     floor = g.double().abs().amax(1) * (1e-3 if dtype == torch.float32 else 1e-9)
-    scale = torch.maximum(want.abs().amax(1), floor)
-    err = (got - want).abs().amax(1) / scale
-    tol = 5e-3 if dtype == torch.float32 else 1e-6
-    assert (err <= tol).double().mean() >= (0.99 if dtype == torch.float32 else 0.999), torch.sort(err).values[-5:]
-    assert float(err.median()) <= tol / 10
+    _assert_gradient(got.numpy(), want.numpy(), cs, v.unsqueeze(2), g, dtype, floor=floor.numpy(), what=f"lmi r={r}")
+    err = torch.from_numpy(_row_err(got.numpy(), want.numpy(), floor.numpy()))
     assert float(err[:22].max()) <= (1e-5 if dtype == torch.float32 else 1e-12)
 
     try:
@@ -315,8 +350,7 @@ def _check_lmi_backward(raw, dtype):
     except RayenError:                                          # the lane-per-sample kernel stops at ~21 x 21 (fp64)
         assert r > 20
         return
-    err = (got - lane).abs().amax(1) / torch.maximum(lane.abs().amax(1), floor)
-    assert (err <= tol).double().mean() >= (0.99 if dtype == torch.float32 else 0.999), torch.sort(err).values[-5:]
+    _assert_gradient(lane.numpy(), want.numpy(), cs, v.unsqueeze(2), g, dtype, floor=floor.numpy(), what=f"lmi lane r={r}")
 
 
 @pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("RAYEN_FUZZ_SEEDS", "100")) // 3)))
@@ -354,7 +388,4 @@ def test_random_sets_gradients_match_oracle_autograd(seed):
     (layer(xg)[:, :, 0] * G.cuda()).sum().backward()
     got = xg.grad[:, :, 0].cpu()
     assert torch.isfinite(got).all()
-    scale = want.abs().amax(1).clamp_min(1e-12)
-    err = (got - want).abs().amax(1) / scale
-    # a sample on a kink of kappa (two constraints tie) may take the other one-sided derivative
-    assert float((err <= 1e-6).double().mean()) >= 0.98, (seed, method, torch.sort(err).values[-5:])
+    _assert_gradient(got.numpy(), want.numpy(), cs, x, G, torch.float64, method=method, what=f"seed {seed}")

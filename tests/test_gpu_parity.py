@@ -57,7 +57,9 @@ def test_golden(name, tag, dtype, tol):
     kb = layer.computeKappa(v_bar.cuda()).cpu().numpy()[:, 0, 0]
     ref = z["kappa_bar" + tag]
     assert kb.shape == ref.shape
-    assert np.max(np.abs(kb - ref) / np.maximum(1.0, np.abs(ref))) <= 20 * tol
+    # (kappa of a unit direction, relative to max(1, kappa): the same quantity the 1e-5 bar on y measures once the
+    # step is clipped; fp64: the reference's own kappa carries sqrt/eigvalsh rounding ~1e-13 x its magnitude)
+    assert np.max(np.abs(kb - ref) / np.maximum(1.0, np.abs(ref))) <= (2 * tol if tag == "32" else 1e-8)
 
 
 @pytest.mark.parametrize("name", golden_names())
@@ -73,6 +75,33 @@ def test_golden_generic_fp32_kernel(name):
     a = active.cpu().numpy()
     assert np.all((a[:, 0] >= -1) & (a[:, 0] < len(dp.consts.segments)))
     assert np.all((a[:, 0] == -1) == (kappa.cpu().numpy() == 0))
+
+
+def _violation_bound(raw, cs, v, dtype):
+    """The north_star's 1e-6 (absolute, unnormalised residuals), or three times the violation of the reference's
+    own output at this precision on the same directions ``v [b, n]`` (its fp32 output is not bit-exactly
+    feasible either; sets with |P| ~ 1e2 turn one fp32 ulp of y into 1e-5 of residual)."""
+    floor = VIOLATION_TOL if dtype == torch.float32 else 1e-11
+    y_ref = _oracle_forward(cs, v.detach().cpu().reshape(v.shape[0], -1, 1), dtype)
+    return max(floor, 3.0 * oracle.max_violation(raw, y_ref))
+
+
+def _fp32_bound(cs, x, y_true, layer=None, method="RAYEN"):
+    """The fp32 parity bar with its yardsticks, all measured against the fp64 truth ``y_true`` on the same inputs:
+    the north_star's 1e-5, or twice the error of the reference's own fp32 arithmetic (oracle at fp32), or -- for a
+    set whose constants do not survive fp32 rounding -- four times the error that rounding ALONE causes (the packed
+    fp32 constants evaluated in fp64 arithmetic, tests/packed_eval.py)."""
+    bound = FP32_TOL
+    try:
+        y32 = oracle.forward(oracle.precompute(csd_from_cs(cs), torch.float32), x.float(), method=method).numpy()[:, :, 0]
+        bound = max(bound, 2.0 * rel_err_rows(y32, y_true).max())
+    except AssertionError:          # the reference's fp32 discriminant went negative (CM:342)
+        pass
+    if layer is not None and method == "RAYEN":
+        import packed_eval
+        y_const, _, _ = packed_eval.evaluate(layer.packed_constants(), x[:, :cs.n, 0].double().numpy())
+        bound = max(bound, 4.0 * rel_err_rows(y_const, y_true).max())
+    return bound
 
 
 # --------------------------------------------------------------------------- oracle on fresh seeds
@@ -134,25 +163,39 @@ def test_plain_fp32_mfma_family(name, monkeypatch):
     monkeypatch.delenv("RAYEN_SPLIT_BF16")
     _, layer_default = _layer(cs, torch.float32)
     y_default = layer_default(x.cuda()).cpu().numpy()[:, :, 0]
-    # the two families round differently but agree to fp32 accuracy; both are judged against the oracle elsewhere
-    assert np.max(rel_err_rows(y, y_default)) <= 2 * FP32_TOL
-    try:
-        y_ref = _oracle_forward(cs, x, torch.float32)
-    except AssertionError:
-        return
-    if not name.startswith("rand"):
-        assert np.max(rel_err_rows(y, y_ref)) <= FP32_TOL
+    # both families against the fp64 truth, with the reference's own fp32 arithmetic on the same inputs as yardstick
+    y_true = _oracle_forward(cs, x.double(), torch.float64)
+    bound = _fp32_bound(cs, x, y_true, layer)
+    assert rel_err_rows(y, y_true).max() <= bound, (rel_err_rows(y, y_true).max(), bound)
+    assert rel_err_rows(y_default, y_true).max() <= bound, (rel_err_rows(y_default, y_true).max(), bound)
 
 
-@pytest.mark.parametrize("name", ["c2", "c3", "c5", "rand5", "rand12", "rand23", "rand31", "rand47"])
+def _served_random_set(index):
+    """The ``index``-th random set (seeds 1000, 1001, ...) that the split-operand kernel serves."""
+    found = -1
+    for seed in range(1000, 1200):
+        raw = _random_set(seed)
+        if len(raw["F"]) or raw["y0"].shape[0] > 64:
+            continue
+        cs, layer = _layer(raw, torch.float32)
+        if layer.device_pack(torch.device("cuda", 0))[0].info().mfma_f32 == 2:
+            found += 1
+            if found == index:
+                return raw
+    raise AssertionError("fewer random sets served by the split-operand kernel than expected")
+
+
+@pytest.mark.parametrize("name", ["c2", "c3", "c5", "served0", "served1", "served2", "served3", "served4", "served5"])
 def test_split_operand_kernel_is_fp32_grade(name, monkeypatch):
     """The default fp32 forward rebuilds every fp32 product from six bf16 MFMA products.  Measured against the fp64
     kernel on the same inputs, its error must be that of fp32 arithmetic: no worse than the exact-fp32 MFMA kernel's
     own error (x2 and a 5e-7 floor for sets where both are at the rounding level of the outputs)."""
-    raw = _random_set(1000 + int(name[4:])) if name.startswith("rand") else workloads.make_raw(name, seed=13)
+    raw = _served_random_set(int(name[6:])) if name.startswith("served") else workloads.make_raw(name, seed=13)
     cs, layer_split = _layer(raw, torch.float32)
-    if layer_split.device_pack(torch.device("cuda", 0))[0].info().mfma_f32 != 2:
-        pytest.skip("set not served by the split-operand kernel")
+    info = layer_split.device_pack(torch.device("cuda", 0))[0].info()
+    assert info.mfma_f32 == 2
+    # the creation-time measurement that admitted the pack (probe directions incl. +-rows of W, against fp64)
+    assert 0.0 <= info.fp32_check_split <= max(4e-6, 1.5 * info.fp32_check_exact)
     monkeypatch.setenv("RAYEN_SPLIT_BF16", "0")
     _, layer_exact = _layer(cs, torch.float32)
     monkeypatch.delenv("RAYEN_SPLIT_BF16")
@@ -173,14 +216,15 @@ def test_split_operand_kernel_is_fp32_grade(name, monkeypatch):
 def test_ill_conditioned_pack_is_served_by_the_exact_fp32_kernels(monkeypatch):
     """Fuzz set 971 (70 dimensions, one dense quadratic with a large gradient at the interior point, 10 equalities):
     its sums cancel so heavily that the split-operand kernel is 8x less accurate than fp32 arithmetic.  The library
-    compares the two kernel families once per pack on 512 directions and keeps the exact-fp32 one here."""
+    measures both kernel families against fp64 when the pack is created and keeps the exact-fp32 one here."""
     raw = _random_set(1971)
     cs, layer = _layer(raw, torch.float32)
     gen = torch.Generator().manual_seed(971)
     x = torch.empty(31, cs.n, 1).uniform_(-2.0, 2.0, generator=gen)
     y = layer(x.cuda()).cpu().numpy()[:, :, 0]
     dp, _ = layer.device_pack(torch.device("cuda", 0))
-    assert dp.info().mfma_f32 == 1
+    info = dp.info()
+    assert info.mfma_f32 == 1 and info.fp32_check_split > max(4e-6, 1.5 * info.fp32_check_exact)
     y_true = _oracle_forward(cs, x.double(), torch.float64)
     y_ref = _oracle_forward(cs, x, torch.float32)
     assert rel_err_rows(y, y_true).max() <= 2.0 * max(rel_err_rows(y_ref, y_true).max(), 1e-6)
@@ -254,7 +298,7 @@ def test_known_answer_psd_cone():
     lam_min = 0.5 * (v[:, 0] + v[:, 2]) - np.sqrt(0.25 * (v[:, 0] - v[:, 2]) ** 2 + v[:, 1] ** 2)
     kappa = np.maximum(0.0, -lam_min)
     want = y0.T + v / np.maximum(1.0, kappa)[:, None]
-    assert np.max(np.abs(_run(layer, v) - want)) < 2e-5
+    assert np.max(rel_err_rows(_run(layer, v), want)) <= FP32_TOL
 
 
 # --------------------------------------------------------------------------- edge cases
@@ -321,7 +365,10 @@ def test_batches_beyond_2_31_elements(name, dtype):
     exact = name != "c4"
 
     def same(a, b):
-        return torch.equal(a, b) if exact else torch.allclose(a, b, rtol=2e-5, atol=1e-6)
+        if exact:
+            return torch.equal(a, b)
+        a2, b2 = a.reshape(a.shape[0], -1).double().cpu().numpy(), b.reshape(b.shape[0], -1).double().cpu().numpy()
+        return float(np.max(rel_err_rows(a2, b2))) <= FP32_TOL
 
     for lo, hi in windows:
         y_w, kappa_w, active_w = ops.project_raw(v[lo:hi].clone(), dp, want_active=True)
@@ -340,8 +387,7 @@ def test_batches_beyond_2_31_elements(name, dtype):
         grad_w = ops.backward_raw(v[lo:hi].clone(), kappa[lo:hi].clone(), active[lo:hi].clone(), g[lo:hi].clone(), dp)
         assert torch.equal(grad[lo:hi], grad_w), (name, lo, hi)
     tail = y[B - 1037:].cpu().numpy().astype(np.float64)
-    # config 5: unnormalised residuals with |P| ~ 1e2 and fp32 equality rows (see the c5 parity test)
-    assert oracle.max_violation(raw, tail) <= ((VIOLATION_TOL if name != "c5" else 5e-5) if dtype == torch.float32 else 1e-11)
+    assert oracle.max_violation(raw, tail) <= _violation_bound(raw, cs, v[B - 1037:], dtype)
 
 
 def test_nan_input_raises_like_the_reference():
@@ -384,8 +430,9 @@ def test_full_size_properties(name):
     yc = y[:, :, 0].cpu().numpy()
     res = oracle.residuals(raw, yc)
     worst = max(float(np.max(r)) for r in res.values())
-    # residuals are unnormalised: c5's quadratics have |P| ~ 1e2, so allow the fp32 rounding of y there
-    tol_v = VIOLATION_TOL if name != "c5" else 5e-5
+    # (residuals are unnormalised and c5's quadratics have |P| ~ 1e2: the yardstick is the violation of the
+    # reference's own fp32 output on a slice of the same inputs)
+    tol_v = _violation_bound(raw, cs, x[:4096, :, 0], torch.float32)
     assert worst <= tol_v
     assert sum(int(np.count_nonzero(r > tol_v)) for r in res.values()) == 0
     # clipped samples: y(t v) == y(v) for t > 1 (same ray, same boundary point)
@@ -394,7 +441,7 @@ def test_full_size_properties(name):
     assert int(clipped.sum()) > B // 2
     y3 = layer(3.0 * x)[:, :, 0]
     d = (y3 - y[:, :, 0])[clipped].abs().max().item()
-    assert d <= 2e-5 * max(1.0, float(np.max(np.abs(yc))))
+    assert d <= 2 * FP32_TOL * max(1.0, float(np.max(np.abs(yc))))    # (two results, each within the parity bar)
     # interior samples: the map is the affine lift y0 + NA_E v
     small = 1e-3 * x
     lift = layer.gety0()[:, 0][None, :] + small[:, :, 0] @ layer.NA_E.T
@@ -496,7 +543,7 @@ def test_config5_full_two_million_batch():
     assert y.shape == (B, cs.k, 1)
     assert bool(torch.isfinite(y).all())
     sub = y[::64, :, 0].cpu().numpy()                      # residuals of 32768 evenly spaced samples
-    assert oracle.max_violation(raw, sub) <= 5e-5          # unnormalised residuals, |P| ~ 1e2 (see c5 above)
+    assert oracle.max_violation(raw, sub) <= _violation_bound(raw, cs, x[:4096, :, 0], torch.float32)
     # the same rows in a small batch give the same bits (no dependence on the launch geometry)
     y_small = layer(x[:4096])
     assert torch.equal(y_small, y[:4096])
@@ -571,16 +618,23 @@ def test_lmi_with_linear_rows_and_equalities(name, dtype, tol):
         x = torch.empty(B, cs.n, 1, dtype=torch.float32).uniform_(-2.0, 2.0, generator=gen).to(dtype)
         x[: min(B, 2)] *= 1e-3
         y = layer(x.cuda()).cpu().numpy()[:, :, 0]
-        y_ref = _oracle_forward(cs, x, dtype)
-        # lambda_max of a 30 x 30 matrix in fp32: the oracle's eigvalsh and the Sturm bracket agree to ~1e-5 of kappa
-        assert np.max(rel_err_rows(y, y_ref)) <= (tol if dtype == torch.float64 or cs.lmic.all_F[0].shape[0] < 20 else 3e-5)
+        if dtype == torch.float64:
+            assert np.max(rel_err_rows(y, _oracle_forward(cs, x, dtype))) <= tol
+        else:
+            # against the fp64 truth: 1e-5, or twice what LAPACK's fp32 eigvalsh (the reference's arithmetic) leaves
+            y_true = _oracle_forward(cs, x.double(), torch.float64)
+            bound = _fp32_bound(cs, x, y_true)
+            assert rel_err_rows(y, y_true).max() <= bound, (name, B, rel_err_rows(y, y_true).max(), bound)
         dp, _ = layer.device_pack(torch.device("cuda", 0))
         try:
             y_gen, _, _ = ops.project_raw(x[:, :, 0].cuda(), dp, force_generic=True)
         except RayenError:                                      # fp64 beyond ~21 x 21 has no lane-per-sample kernel
             assert dtype == torch.float64 and cs.lmic.all_F[0].shape[0] > 20
             continue
-        assert np.max(rel_err_rows(y, y_gen.cpu().numpy())) <= (1e-5 if dtype == torch.float32 else 1e-9)
+        if dtype == torch.float32:
+            assert rel_err_rows(y_gen.cpu().numpy(), y_true).max() <= bound
+        else:
+            assert np.max(rel_err_rows(y, y_gen.cpu().numpy())) <= 1e-9
 
 
 # --------------------------------------------------------------------------- randomised constraint sets
@@ -679,19 +733,15 @@ def test_random_constraint_sets(seed):
             # CM:342); the kernels give that cone kappa = 0, its exact value: only feasibility can be checked
             assert _relative_violation(raw, y) <= (1e-5 if dtype == torch.float32 else 1e-13), (seed, dtype)
             continue
-        lmi_fp32 = dtype == torch.float32 and len(raw["F"]) > 0
         if dtype == torch.float32:
-            # random sets can be ill-conditioned in fp32 (cancellation in a radicand).  Judge both fp32 results
-            # against the fp64 truth; the yardsticks are the reference's own fp32 arithmetic (which varies with
-            # the host's summation order) and the error that the fp32 ROUNDING OF THE CONSTANTS alone causes
-            # (the packed constants evaluated in fp64 arithmetic, tests/packed_eval.py)
+            # random sets can be ill-conditioned in fp32 (cancellation in a radicand): judged against the fp64
+            # truth under _fp32_bound's yardsticks
             import packed_eval
             y_true = _oracle_forward(cs, x.double(), torch.float64)
-            ours, theirs = rel_err_rows(y, y_true).max(), rel_err_rows(y_ref, y_true).max()
             y_const, _, _ = packed_eval.evaluate(layer.packed_constants(), x[:, :, 0].double().numpy())
-            inherent = rel_err_rows(y_const, y_true).max()
-            bound = max(3e-5 if lmi_fp32 else tol, 4.0 * theirs, 8.0 * inherent)
-            assert ours <= bound, (seed, ours, theirs, inherent)
+            bound = _fp32_bound(cs, x, y_true, layer)
+            ours = rel_err_rows(y, y_true).max()
+            assert ours <= bound, (seed, ours, bound)
         else:
             assert np.max(rel_err_rows(y, y_ref)) <= tol, (seed, dtype)
         # feasibility relative to each constraint's own magnitude (sum of the absolute values of its terms): random
@@ -714,7 +764,8 @@ def test_random_constraint_sets(seed):
         want = ops.backward_raw(v, kappa, active, g, dp, force_generic=True).cpu().double()
         scale = want.abs().amax(1).clamp_min(1e-12)
         err = (got - want).abs().amax(1) / scale
-        assert float((err <= (1e-3 if dtype == torch.float32 else 1e-8)).double().mean()) >= 0.99, (seed, dtype, err.max())
+        # (same (kappa, active) record in, so both kernels take the same branch at every sample: no kink exemption)
+        assert float(err.max()) <= (2e-4 if dtype == torch.float32 else 1e-9), (seed, dtype, err.max())
 
 
 @pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("RAYEN_FUZZ_SEEDS", "100")) // 2)))
@@ -751,15 +802,5 @@ def test_random_modules(seed):
         if dtype == torch.float64:
             assert err <= 1e-8, (seed, method, input_dim, err)
         else:
-            import packed_eval
-            try:
-                y32 = oracle.forward(oracle.precompute(csd_from_cs(cs), torch.float32), q.float().unsqueeze(2),
-                                     method=method).numpy()[:, :, 0]
-                theirs = rel_err_rows(y32, y_true).max()
-            except AssertionError:                                     # (only the fp32 discriminant went negative)
-                theirs = 0.0
-            bound = max(3e-5 if len(raw["F"]) else tol, 4.0 * theirs)
-            if method == "RAYEN":
-                y_const, _, _ = packed_eval.evaluate(layer.packed_constants(), q.double().numpy()[:, :cs.n])
-                bound = max(bound, 8.0 * rel_err_rows(y_const, y_true).max())
-            assert err <= bound, (seed, method, input_dim, err, theirs)
+            bound = _fp32_bound(cs, q.unsqueeze(2), y_true, layer, method=method)
+            assert err <= bound, (seed, method, input_dim, err, bound)
