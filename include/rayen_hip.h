@@ -205,15 +205,28 @@ int rayen_ray_project_old_bwd_f64(const RayenPack* pack, const double* v, int64_
  * mapper = nn.Linear(input_dim, n); :525 applies it before forwardForRAYEN):
  *     v = Wm x + bias,   y = y0 + NA_E v / max(1, kappa(v))
  * in ONE launch; v is kept in registers and reaches memory only when v_out != NULL (the backward
- * needs it).  x [B, ldx] (first in_dim columns read), Wm [n, ldw] row-major (= Linear.weight, rows
- * 16-byte aligned), bias [n] or NULL.  rayen_mapper_fusable() says whether this pack and input width
- * are served (fp32 MFMA path, in_dim a multiple of 4 and <= 64); otherwise the call returns
- * RAYEN_E_UNSUPPORTED and the caller runs its GEMM followed by rayen_ray_project_f32. */
+ * needs it).  x [B, ldx] (first in_dim columns read).  rayen_mapper_fusable() says which form serves
+ * this pack and input width:
+ *   0  none: the caller runs its GEMM followed by rayen_ray_project_f32;
+ *   1  rayen_ray_project_mapped_f32: Wm [n, ldw] row-major (= Linear.weight, rows 16-byte aligned) and
+ *      bias [n] or NULL are read in place (exact-fp32 MFMA family; in_dim a multiple of 4, <= 64);
+ *   2  rayen_ray_project_mapped_image_f32 (packs served by the split-operand kernel; in_dim <= n rounded
+ *      up to 32): Wm and bias are first converted into a caller-owned image of
+ *      rayen_mapper_image_bytes() bytes (16-byte aligned device memory) by rayen_mapper_prepare_f32 -- one
+ *      small asynchronous launch, to be repeated whenever the weights change -- and the projection reads
+ *      that image.  The library keeps no per-mapper state: packs stay immutable. */
 int rayen_mapper_fusable(const RayenPack* pack, int32_t in_dim);
 int rayen_ray_project_mapped_f32(const RayenPack* pack, const float* x, int64_t B, int64_t ldx,
                                  int32_t in_dim, const float* Wm, int64_t ldw, const float* bias,
                                  float* v_out, int64_t ldvo, float* y, int64_t ldy, float* kappa,
                                  int32_t* active, int32_t* nan_flag, void* stream);
+int64_t rayen_mapper_image_bytes(const RayenPack* pack, int32_t in_dim);
+int rayen_mapper_prepare_f32(const RayenPack* pack, const float* Wm, int64_t ldw, int32_t in_dim,
+                             const float* bias, void* image, void* stream);
+int rayen_ray_project_mapped_image_f32(const RayenPack* pack, const float* x, int64_t B, int64_t ldx,
+                                       int32_t in_dim, const void* image, float* v_out, int64_t ldvo,
+                                       float* y, int64_t ldy, float* kappa, int32_t* active,
+                                       int32_t* nan_flag, void* stream);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,8 @@ EXPORTS = (
     "rayen_ray_project_bwd_f64", "rayen_ray_project_old_f32", "rayen_ray_project_old_f64",
     "rayen_ray_project_old_bwd_f32", "rayen_ray_project_old_bwd_f64",
     "rayen_mapper_fusable", "rayen_ray_project_mapped_f32", "rayen_ray_project_bwd_generic_f32",
-    "rayen_ray_project_bwd_generic_f64",
+    "rayen_ray_project_bwd_generic_f64", "rayen_mapper_image_bytes", "rayen_mapper_prepare_f32",
+    "rayen_ray_project_mapped_image_f32",
 )
 
 
@@ -103,6 +104,13 @@ def load():
     lib.rayen_ray_project_mapped_f32.restype = ctypes.c_int
     lib.rayen_ray_project_mapped_f32.argtypes = [p, p, i64, i64, ctypes.c_int32, p, i64, p, p, i64, p, i64,
                                                  p, i32p, i32p, p]
+    lib.rayen_mapper_image_bytes.restype = ctypes.c_int64
+    lib.rayen_mapper_image_bytes.argtypes = [p, ctypes.c_int32]
+    lib.rayen_mapper_prepare_f32.restype = ctypes.c_int
+    lib.rayen_mapper_prepare_f32.argtypes = [p, p, i64, ctypes.c_int32, p, p, p]
+    lib.rayen_ray_project_mapped_image_f32.restype = ctypes.c_int
+    lib.rayen_ray_project_mapped_image_f32.argtypes = [p, p, i64, i64, ctypes.c_int32, p, p, i64, p, i64,
+                                                       p, i32p, i32p, p]
     if lib.rayen_abi_version() != ABI_VERSION:
         raise RuntimeError(f"librayen_hip.so ABI {lib.rayen_abi_version()} != binding ABI {ABI_VERSION}")
     _lib = lib

@@ -46,7 +46,7 @@ __device__ __forceinline__ void sfor(F&& f) {
 }
 
 template <int CTRL>
-__device__ __forceinline__ int dpp_(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true); }
+__device__ __forceinline__ int dpp_(int x) { return __builtin_amdgcn_mov_dpp(x, CTRL, 0xF, 0xF, true); }  // (quad_perm: every lane has a source)
 template <int CTRL>
 __device__ __forceinline__ float dpp_(float x) { return __int_as_float(dpp_<CTRL>(__float_as_int(x))); }
 template <int CTRL>
@@ -76,46 +76,71 @@ __device__ __forceinline__ U qmin(U x) {
 
 template <typename T> struct Lim;
 template <> struct Lim<float> {
-  static constexpr int rounds = 11;  // 9^-11 < 2^-32 (the lane kernels run 32 bisections)
+  static constexpr int rounds = 8;   // 9^-8 < 2^-25 of the Gershgorin bracket: the midpoint is within 1e-8 of its width
   __device__ static float tiny() { return 1.0e-30f; }
-  __device__ static float rcp(float x) { return __builtin_amdgcn_rcpf(x); }  // only the SIGN sequence of q matters
+  __device__ static float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }  // 1 ulp, no denormal fix-up sequence
+  __device__ static float rcp(float x) { return __builtin_amdgcn_rcpf(x); }   // 1 ulp
+  __device__ static int expo(float x) { return __builtin_amdgcn_frexp_expf(x); }
+  __device__ static float scale2(float x, int e) { return __builtin_amdgcn_ldexpf(x, e); }
+  __device__ static unsigned sign_word(float x) { return (unsigned)__float_as_int(x); }
 };
 template <> struct Lim<double> {
-  static constexpr int rounds = 19;  // 9^-19 < 2^-60 (60 bisections)
+  static constexpr int rounds = 19;  // 9^-19 < 2^-60
   __device__ static double tiny() { return 1.0e-290; }
+  __device__ static double sqrt_(double x) { return sqrt(x); }
   __device__ static double rcp(double x) { return 1.0 / x; }
+  __device__ static int expo(double x) { return __builtin_amdgcn_frexp_exp(x); }
+  __device__ static double scale2(double x, int e) { return __builtin_amdgcn_ldexp(x, e); }
+  __device__ static unsigned sign_word(double x) { return (unsigned)__double2hiint(x); }
 };
 
 template <typename T> __device__ __forceinline__ T fma_(T a, T b, T c);
 template <> __device__ __forceinline__ float fma_(float a, float b, float c) { return fmaf(a, b, c); }
 template <> __device__ __forceinline__ double fma_(double a, double b, double c) { return fma(a, b, c); }
 
-// One Householder step on column C of the distributed matrix (a[t][j] = A[4t + sub][j]).
+// Two adjacent matrix columns in one register pair: on gfx950 an fp32 pair is ONE v_pk_fma_f32 / v_pk_mul_f32 /
+// v_pk_add_f32 (the packed forms are what the 157 TFLOP/s fp32 vector peak is quoted on), so the Householder
+// sweep, the formation of S and the Sturm recurrences below issue half the instructions of their scalar forms.
+// (fp64 pairs compile to two scalar instructions; same source.)
+template <typename T> using V2 = T __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ V2<T> splat(T x) { return V2<T>{x, x}; }
+template <typename T> __device__ __forceinline__ V2<T> fma2(V2<T> a, V2<T> b, V2<T> c) {
+  return __builtin_elementwise_fma(a, b, c);
+}
+
+// One Householder step on column C of the distributed matrix: a[t][jj] = (A[4t + sub][2jj], A[4t + sub][2jj + 1]).
 // KEEP (backward): the reflector H_C = I - beta u u', u = (1, hv...) on rows >= C+1, is kept -- hv in the
 // column it has just annihilated (rows >= C+2 of column C, never touched again), beta in e2[C + R]'s place
 // (the caller passes arrays of 2R) -- and e2[C] holds the SIGNED sub-diagonal entry instead of its square.
 template <typename T, int R4, int C, bool KEEP = false>
-__device__ __forceinline__ void hh_step(T (&a)[R4][4 * R4], T (&dd)[4 * R4], T (&e2)[KEEP ? 8 * R4 : 4 * R4],
+__device__ __forceinline__ void hh_step(V2<T> (&a)[R4][2 * R4], T (&dd)[4 * R4], T (&e2)[KEEP ? 8 * R4 : 4 * R4],
                                         const int sub) {
-  constexpr int R = 4 * R4, I1 = C + 1;
+  constexpr int R = 4 * R4, I1 = C + 1, H = R / 2;
   constexpr int T0 = I1 / 4;  // first row group with a live row (rows >= I1)
-  const T x0 = qb<(I1 & 3)>(a[I1 >> 2][C]);
+  constexpr int J0 = I1 / 2;  // first column pair with a live column (columns >= I1)
+  const T x0 = qb<(I1 & 3)>(a[I1 >> 2][C >> 1][C & 1]);
   T sig = T(0);
   sfor<0, R4>([&](auto it) {
     constexpr int t = decltype(it)::value;
     if constexpr (4 * t + 3 >= C + 2) {
-      const T x = a[t][C];
-      const bool on = (4 * t >= C + 2) || (4 * t + sub >= C + 2);
-      sig += on ? x * x : T(0);
+      const T x = a[t][C >> 1][C & 1];
+      if constexpr (4 * t >= C + 2) {
+        sig = fma_(x, x, sig);
+      } else {
+        sig += (4 * t + sub >= C + 2) ? x * x : T(0);
+      }
     }
   });
   sig = qsum(sig);
-  const T mu = sqrt(fma_(x0, x0, sig));
+  const T mu = Lim<T>::sqrt_(fma_(x0, x0, sig));
   const bool act = sig > T(0);
-  const T v0 = (x0 <= T(0)) ? (x0 - mu) : (-sig / (x0 + mu));
-  const T beta = act ? (T(2) * v0 * v0 / (sig + v0 * v0)) : T(0);
-  const T inv_v0 = act ? (T(1) / v0) : T(0);
-  dd[C] = qb<(C & 3)>(a[C >> 2][C]);
+  const T v0 = (x0 <= T(0)) ? (x0 - mu) : (-sig * Lim<T>::rcp(x0 + mu));
+  // KEEP: u = (1, x / v0) with beta = 2 v0^2 / (sig + v0^2) (the stored form the backward reads back);
+  // otherwise u = (v0, x) as it stands in the column, beta = 2 / (sig + v0^2): one reciprocal and no scaling pass
+  const T bden = Lim<T>::rcp(fma_(v0, v0, sig));
+  const T beta = act ? (KEEP ? T(2) * v0 * v0 * bden : T(2) * bden) : T(0);
+  const T inv_v0 = (KEEP && act) ? Lim<T>::rcp(v0) : T(0);
+  dd[C] = qb<(C & 3)>(a[C >> 2][C >> 1][C & 1]);
   if constexpr (KEEP) {
     e2[C] = act ? mu : x0;   // H x = mu e_1 (mu = ||x|| > 0); untouched column when sigma = 0
     e2[R + C] = beta;
@@ -129,94 +154,190 @@ __device__ __forceinline__ void hh_step(T (&a)[R4][4 * R4], T (&dd)[4 * R4], T (
     const int i = 4 * t + sub;
     hv[t] = T(0);
     p[t] = T(0);
-    if constexpr (t >= T0) hv[t] = (i == I1) ? T(1) : ((i >= C + 2) ? a[t][C] * inv_v0 : T(0));
-    if constexpr (KEEP && t >= T0) a[t][C] = (i >= C + 2) ? hv[t] : a[t][C];
+    if constexpr (4 * t >= C + 2) {          // every row of the group lies below the sub-diagonal
+      hv[t] = KEEP ? a[t][C >> 1][C & 1] * inv_v0 : a[t][C >> 1][C & 1];
+      if constexpr (KEEP) a[t][C >> 1][C & 1] = hv[t];
+    } else if constexpr (t >= T0) {          // the group(s) straddling rows C+1, C+2
+      const T top = KEEP ? T(1) : v0;
+      hv[t] = (i == I1) ? top : ((i >= C + 2) ? (KEEP ? a[t][C >> 1][C & 1] * inv_v0 : a[t][C >> 1][C & 1]) : T(0));
+      if constexpr (KEEP) a[t][C >> 1][C & 1] = (i >= C + 2) ? hv[t] : a[t][C >> 1][C & 1];
+    }
+  });
+  // u over the live columns, every lane's copy (zero in the dead half of a straddling pair)
+  V2<T> hb[H];
+  sfor<J0, H>([&](auto ij) {
+    constexpr int jj = decltype(ij)::value;
+    constexpr int j0 = 2 * jj, j1 = 2 * jj + 1;
+    hb[jj][0] = (j0 >= I1) ? qb<(j0 & 3)>(hv[j0 >> 2]) : T(0);
+    hb[jj][1] = qb<(j1 & 3)>(hv[j1 >> 2]);
   });
   // p = beta A u over the live block
-  sfor<I1, R>([&](auto ij) {
-    constexpr int j = decltype(ij)::value;
-    const T hj = qb<(j & 3)>(hv[j >> 2]);
-    sfor<T0, R4>([&](auto it) {
-      constexpr int t = decltype(it)::value;
-      p[t] = fma_(a[t][j], hj, p[t]);
+  sfor<T0, R4>([&](auto it) {
+    constexpr int t = decltype(it)::value;
+    V2<T> acc = splat(T(0));
+    sfor<J0, H>([&](auto ij) {
+      constexpr int jj = decltype(ij)::value;
+      acc = fma2<T>(a[t][jj], hb[jj], acc);
     });
+    p[t] = acc[0] + acc[1];
   });
   T pv = T(0);
   sfor<T0, R4>([&](auto it) {
     constexpr int t = decltype(it)::value;
-    p[t] = (4 * t + sub >= I1) ? p[t] * beta : T(0);
+    if constexpr (4 * t >= I1) p[t] = p[t] * beta;
+    else p[t] = (4 * t + sub >= I1) ? p[t] * beta : T(0);
     pv = fma_(p[t], hv[t], pv);
   });
   pv = qsum(pv);
   const T K = T(0.5) * beta * pv;
   sfor<T0, R4>([&](auto it) {
     constexpr int t = decltype(it)::value;
-    p[t] -= K * hv[t];  // now w
+    p[t] = fma_(-K, hv[t], p[t]);  // now w
   });
   // A -= u w' + w u'
-  sfor<I1, R>([&](auto ij) {
-    constexpr int j = decltype(ij)::value;
-    const T hj = qb<(j & 3)>(hv[j >> 2]);
-    const T wj = qb<(j & 3)>(p[j >> 2]);
-    sfor<T0, R4>([&](auto it) {
-      constexpr int t = decltype(it)::value;
-      a[t][j] -= hv[t] * wj + p[t] * hj;
+  V2<T> wb[H];
+  sfor<J0, H>([&](auto ij) {
+    constexpr int jj = decltype(ij)::value;
+    constexpr int j0 = 2 * jj, j1 = 2 * jj + 1;
+    wb[jj][0] = (j0 >= I1) ? qb<(j0 & 3)>(p[j0 >> 2]) : T(0);
+    wb[jj][1] = qb<(j1 & 3)>(p[j1 >> 2]);
+  });
+  sfor<T0, R4>([&](auto it) {
+    constexpr int t = decltype(it)::value;
+    const V2<T> mh = splat(-hv[t]), mw = splat(-p[t]);
+    sfor<J0, H>([&](auto ij) {
+      constexpr int jj = decltype(ij)::value;
+      a[t][jj] = fma2<T>(mh, wb[jj], a[t][jj]);
+      a[t][jj] = fma2<T>(mw, hb[jj], a[t][jj]);
     });
   });
 }
 
-// lambda_max of the symmetric R x R matrix spread over a quad; every lane returns the same value.
+// lambda_max of the symmetric R x R matrix spread over a quad (true size r; rows beyond it carry the decoupled
+// pad diagonal); every lane returns the same value.
+//
+// Tridiagonal form by the distributed Householder sweep, then MULTI-section on the Sturm count: eight section
+// points per round (lane `sub` takes points 2 sub + 1 and 2 sub + 2 as the two halves of packed registers), the
+// bracket shrinks 9x per round.  The count is taken on the characteristic polynomials of the leading blocks,
+//     p_0 = 1,  p_1 = d_0 - x,  p_{i+1} = (d_i - x) p_i - e_{i-1}^2 p_{i-1},
+// (number of sign changes = number of eigenvalues below x) -- no division: one packed multiply, add and fma per
+// step for both points, the signs shifted into a bit mask.  The matrix is first mapped into [-1, 0] (shift by the
+// Gershgorin top, divide by its radius) so that |d_i - x| <= 1 and e^2 <= 1: the recurrence cannot overflow, and
+// every fourth step both chains are renormalised by the exponent of their larger member against underflow.
 template <typename T, int R4>
-__device__ __forceinline__ T lambda_max_quad(T (&a)[R4][4 * R4], const int sub) {
+__device__ __forceinline__ T lambda_max_quad(V2<T> (&a)[R4][2 * R4], const int r, const int sub) {
   constexpr int R = 4 * R4;
   T dd[R], e2[R];
   sfor<0, R - 2>([&](auto ic) {
     constexpr int c = decltype(ic)::value;
     hh_step<T, R4, c>(a, dd, e2, sub);
   });
-  dd[R - 2] = qb<((R - 2) & 3)>(a[(R - 2) >> 2][R - 2]);
-  dd[R - 1] = qb<((R - 1) & 3)>(a[(R - 1) >> 2][R - 1]);
+  dd[R - 2] = qb<((R - 2) & 3)>(a[(R - 2) >> 2][(R - 2) >> 1][0]);
+  dd[R - 1] = qb<((R - 1) & 3)>(a[(R - 1) >> 2][(R - 1) >> 1][1]);
   {
-    const T e = qb<((R - 1) & 3)>(a[(R - 1) >> 2][R - 2]);
+    const T e = qb<((R - 1) & 3)>(a[(R - 1) >> 2][(R - 2) >> 1][0]);
     e2[R - 2] = e * e;
   }
   e2[R - 1] = T(0);
 
-  // Gershgorin bracket of lambda_max: max diag <= lambda_max <= max(d_i + |e_{i-1}| + |e_i|)
-  T lo = dd[0], hi = dd[0] + sqrt(e2[0]), emax = T(0), eprev = T(0);
+  // Gershgorin bracket of lambda_max over the true rows: max diag <= lambda_max <= max(d_i + |e_{i-1}| + |e_i|)
+  T lo = dd[0], hi = dd[0] + Lim<T>::sqrt_(e2[0]), dmin = dd[0], emax = T(0), eprev = T(0);
 #pragma unroll
   for (int i = 0; i < R; ++i) {
-    const T enext = (i + 1 < R) ? sqrt(e2[i]) : T(0);
-    lo = (i == 0) ? dd[i] : fmax(lo, dd[i]);
-    hi = (i == 0) ? hi : fmax(hi, dd[i] + eprev + enext);
+    const bool real = i < r;                       // (pad rows: diagonal -1e18, couplings exactly 0)
+    const T enext = (i + 1 < R && i + 1 < r) ? Lim<T>::sqrt_(e2[i]) : T(0);
+    if (i > 0) {
+      lo = real ? fmax(lo, dd[i]) : lo;
+      hi = real ? fmax(hi, dd[i] + eprev + enext) : hi;
+      dmin = real ? fmin(dmin, dd[i]) : dmin;
+    }
     emax = fmax(emax, enext);
     eprev = enext;
   }
-  const T pivmin = Lim<T>::tiny() * fmax(T(1), emax * emax);
-  // eight section points per round: lane `sub` takes points 2 sub and 2 sub + 1 (two independent
-  // recurrences in flight per lane)
+  const T rad = fmax(fmax(hi - dmin, emax), Lim<T>::tiny());
+  const T sc = T(1) / rad;
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    dd[i] = (i < r) ? (dd[i] - hi) * sc : T(-4);   // true rows in [-1, 0]; pad rows below everything
+    e2[i] = (i + 1 < r) ? e2[i] * sc * sc : T(0);
+  }
+  T lo_n = (lo - hi) * sc, hi_n = T(0);
   for (int it = 0; it < Lim<T>::rounds; ++it) {
-    const T w = (hi - lo) * T(1.0 / 9.0);
-    const T xa = fma_(w, T(2 * sub + 1), lo), xb = fma_(w, T(2 * sub + 2), lo);
-    T qa = dd[0] - xa, qb_ = dd[0] - xb;
-    int na = qa < T(0), nb = qb_ < T(0);
+    const T w = (hi_n - lo_n) * T(1.0 / 9.0);
+    const V2<T> x = {fma_(w, T(2 * sub + 1), lo_n), fma_(w, T(2 * sub + 2), lo_n)};
+    V2<T> p0 = splat(T(1)), p1 = splat(dd[0]) - x;
+    unsigned ma = Lim<T>::sign_word(p1[0]) >> 31, mb = Lim<T>::sign_word(p1[1]) >> 31;
 #pragma unroll
     for (int i = 1; i < R; ++i) {
-      if (fabs(qa) < pivmin) qa = -pivmin;
-      if (fabs(qb_) < pivmin) qb_ = -pivmin;
-      qa = dd[i] - xa - e2[i - 1] * Lim<T>::rcp(qa);
-      qb_ = dd[i] - xb - e2[i - 1] * Lim<T>::rcp(qb_);
-      na += qa < T(0);
-      nb += qb_ < T(0);
+      const V2<T> t = splat(e2[i - 1]) * p0;
+      const V2<T> pn = fma2<T>(splat(dd[i]) - x, p1, -t);
+      p0 = p1;
+      p1 = pn;
+      ma = __builtin_amdgcn_alignbit(ma, Lim<T>::sign_word(p1[0]), 31);   // (ma << 1) | sign
+      mb = __builtin_amdgcn_alignbit(mb, Lim<T>::sign_word(p1[1]), 31);
+      if ((i & 3) == 0 && i + 1 < R) {
+        const int ea = Lim<T>::expo(fmax(fabs(p0[0]), fabs(p1[0]))), eb = Lim<T>::expo(fmax(fabs(p0[1]), fabs(p1[1])));
+        p0[0] = Lim<T>::scale2(p0[0], -ea);
+        p1[0] = Lim<T>::scale2(p1[0], -ea);
+        p0[1] = Lim<T>::scale2(p0[1], -eb);
+        p1[1] = Lim<T>::scale2(p1[1], -eb);
+      }
     }
-    // all eigenvalues below x  ->  lambda_max < x
-    T lo_c = lo, hi_c = hi;
-    if (na == R) hi_c = fmin(hi_c, xa); else lo_c = fmax(lo_c, xa);
-    if (nb == R) hi_c = fmin(hi_c, xb); else lo_c = fmax(lo_c, xb);
-    lo = qmax(lo_c);
-    hi = fmax(qmin(hi_c), lo);
+    // sign changes along p_0 (> 0) .. p_R = eigenvalues below x; all R of them  ->  lambda_max < x
+    const int na = __builtin_popcount(ma ^ (ma >> 1)), nb = __builtin_popcount(mb ^ (mb >> 1));
+    T lo_c = lo_n, hi_c = hi_n;
+    if (na == R) hi_c = fmin(hi_c, x[0]); else lo_c = fmax(lo_c, x[0]);
+    if (nb == R) hi_c = fmin(hi_c, x[1]); else lo_c = fmax(lo_c, x[1]);
+    lo_n = qmax(lo_c);
+    hi_n = fmax(qmin(hi_c), lo_n);
   }
-  return T(0.5) * (lo + hi);
+  return fma_(T(0.5) * (lo_n + hi_n), rad, hi);
+}
+
+// S = sum_a v_a G_a, this lane's rows, from the LDS image (pad rows/columns decoupled, far below the spectrum)
+template <typename T, int R4>
+__device__ __forceinline__ void form_S(V2<T> (&a)[R4][2 * R4], const T* Wf, const T* vs, const int n, const int r,
+                                       const int sub) {
+  constexpr int R = 4 * R4, H = R / 2;
+#pragma unroll
+  for (int t = 0; t < R4; ++t)
+#pragma unroll
+    for (int jj = 0; jj < H; ++jj) {
+      a[t][jj][0] = (4 * t + sub == 2 * jj && 2 * jj >= r) ? T(-1e18) : T(0);
+      a[t][jj][1] = (4 * t + sub == 2 * jj + 1 && 2 * jj + 1 >= r) ? T(-1e18) : T(0);
+    }
+  for (int aa = 0; aa < n; ++aa) {
+    const V2<T> va = splat(vs[aa]);
+    const V2<T>* wa = reinterpret_cast<const V2<T>*>(Wf + (size_t)aa * R * R + sub * R);
+#pragma unroll
+    for (int t = 0; t < R4; ++t)
+#pragma unroll
+      for (int jj = 0; jj < H; ++jj) a[t][jj] = fma2<T>(wa[(4 * t * R) / 2 + jj], va, a[t][jj]);
+  }
+}
+
+// the constant image into LDS: 16-byte pieces, all of a thread's loads in flight before its first store
+template <typename T>
+__device__ __forceinline__ void fill_image(T* img, const T* image, const int64_t elems, const int tid) {
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  constexpr int PER = 16 / sizeof(T);
+  const int64_t n16 = elems / PER;
+  const v4i* src = reinterpret_cast<const v4i*>(image);
+  v4i* dst = reinterpret_cast<v4i*>(img);
+  for (int64_t base = 0; base < n16; base += 256 * 8) {
+    v4i tmp[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t i = base + tid + 256 * u;
+      if (i < n16) tmp[u] = src[i];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t i = base + tid + 256 * u;
+      if (i < n16) dst[i] = tmp[u];
+    }
+  }
+  for (int64_t i = n16 * PER + tid; i < elems; i += 256) img[i] = image[i];
 }
 
 template <typename T, int R4>
@@ -231,14 +352,14 @@ __global__ __launch_bounds__(256) void lmi_quad_kernel(
   const T* Wlin = Wf + (size_t)n * R * R;                 // [m][n]
   const T* Nmat = Wlin + (size_t)m * n;                   // [k][n] (absent when identity)
   const T* y0 = Nmat + (identity ? 0 : (size_t)k * n);    // [k]
-  T* vt = img + elems;                                    // [64][n + 1]
+  T* vt = img + ((elems + 3) & ~int64_t(3));              // [64][n + 1]
   const int LDV = n + 1;
 
   const int tid = threadIdx.x;
   const int sl = tid >> 2, sub = tid & 3;
   const int64_t b0 = (int64_t)blockIdx.x * 64;
   const int nb = (int)((B - b0) < 64 ? (B - b0) : 64);
-  for (int64_t i = tid; i < elems; i += 256) img[i] = image[i];
+  fill_image<T>(img, image, elems, tid);
   for (int idx = tid; idx < 64 * n; idx += 256) {
     const int bl = idx / n, j = idx - bl * n;
     vt[bl * LDV + j] = bl < nb ? v[(b0 + bl) * ldv + j] : T(0);
@@ -247,20 +368,8 @@ __global__ __launch_bounds__(256) void lmi_quad_kernel(
   const T* vs = vt + sl * LDV;
   const bool live = sl < nb;
 
-  // ---- S = sum_a v_a G_a, this lane's rows (padding rows/columns decoupled, far below the spectrum)
-  T a[R4][R];
-#pragma unroll
-  for (int t = 0; t < R4; ++t)
-#pragma unroll
-    for (int j = 0; j < R; ++j) a[t][j] = (4 * t + sub == j && j >= r) ? T(-1e18) : T(0);
-  for (int aa = 0; aa < n; ++aa) {
-    const T va = vs[aa];
-    const T* wa = Wf + (size_t)aa * R * R + sub * R;
-#pragma unroll
-    for (int t = 0; t < R4; ++t)
-#pragma unroll
-      for (int j = 0; j < R; ++j) a[t][j] = fma_(wa[4 * t * R + j], va, a[t][j]);
-  }
+  V2<T> a[R4][R / 2];
+  form_S<T, R4>(a, Wf, vs, n, r, sub);
 
   // ---- linear rows, split over the quad
   T kap = T(0);
@@ -285,7 +394,7 @@ __global__ __launch_bounds__(256) void lmi_quad_kernel(
     }
   }
 
-  const T lam = lambda_max_quad<T, R4>(a, sub);
+  const T lam = lambda_max_quad<T, R4>(a, r, sub);
   if (lam > kap) { kap = lam; aseg = lmi_seg; arow = 0; }
 
   const T scale = T(1) / fmax(T(1), kap);
@@ -324,16 +433,16 @@ __global__ __launch_bounds__(256) void lmi_quad_kernel(
 // generators straight from the LDS image.
 // ---------------------------------------------------------------------------------------------
 template <typename T, int R4>
-__device__ __forceinline__ void top_eigenvector_quad(T (&a)[R4][4 * R4], const T lam, T (&xr)[R4], const int sub) {
+__device__ __forceinline__ void top_eigenvector_quad(V2<T> (&a)[R4][2 * R4], const T lam, T (&xr)[R4], const int sub) {
   constexpr int R = 4 * R4;
   T dd[R], eb[2 * R];  // eb[0..R): signed sub-diagonal, eb[R..2R): reflector scales
   sfor<0, R - 2>([&](auto ic) {
     constexpr int c = decltype(ic)::value;
     hh_step<T, R4, c, true>(a, dd, eb, sub);
   });
-  dd[R - 2] = qb<((R - 2) & 3)>(a[(R - 2) >> 2][R - 2]);
-  dd[R - 1] = qb<((R - 1) & 3)>(a[(R - 1) >> 2][R - 1]);
-  eb[R - 2] = qb<((R - 1) & 3)>(a[(R - 1) >> 2][R - 2]);
+  dd[R - 2] = qb<((R - 2) & 3)>(a[(R - 2) >> 2][(R - 2) >> 1][0]);
+  dd[R - 1] = qb<((R - 1) & 3)>(a[(R - 1) >> 2][(R - 1) >> 1][1]);
+  eb[R - 2] = qb<((R - 1) & 3)>(a[(R - 1) >> 2][(R - 2) >> 1][0]);
   eb[R - 1] = T(0);
 
   // M = (lam + shift) I - T, tridiagonal and positive definite; padding rows (d = -1e18) are decoupled
@@ -384,14 +493,14 @@ __device__ __forceinline__ void top_eigenvector_quad(T (&a)[R4][4 * R4], const T
     sfor<T0, R4>([&](auto it) {
       constexpr int t = decltype(it)::value;
       const int i = 4 * t + sub;
-      const T u = (i == I1) ? T(1) : ((i >= c + 2) ? a[t][c] : T(0));
+      const T u = (i == I1) ? T(1) : ((i >= c + 2) ? a[t][c >> 1][c & 1] : T(0));
       dot = fma_(u, xr[t], dot);
     });
     dot = qsum(dot) * eb[R + c];
     sfor<T0, R4>([&](auto it) {
       constexpr int t = decltype(it)::value;
       const int i = 4 * t + sub;
-      const T u = (i == I1) ? T(1) : ((i >= c + 2) ? a[t][c] : T(0));
+      const T u = (i == I1) ? T(1) : ((i >= c + 2) ? a[t][c >> 1][c & 1] : T(0));
       xr[t] = fma_(-dot, u, xr[t]);
     });
   });
@@ -407,7 +516,7 @@ __global__ __launch_bounds__(256) void lmi_quad_bwd_kernel(
   T* img = reinterpret_cast<T*>(smem_raw);
   const T* Wf = img;                                      // [n][R][R]
   const T* Nmat = Wf + (size_t)n * R * R + (size_t)m * n; // [k][n] (absent when identity)
-  T* vt = img + elems;                                    // [64][n + 1]
+  T* vt = img + ((elems + 3) & ~int64_t(3));              // [64][n + 1]
   const int LDV = n + 1, LDG = k + 1;
   T* tt = vt + 64 * LDV;                                  // [64][n + 1]  t = NA_E' g
   T* ut = tt + 64 * LDV;                                  // [64][n + 1]  grad kappa
@@ -417,7 +526,7 @@ __global__ __launch_bounds__(256) void lmi_quad_bwd_kernel(
   const int sl = tid >> 2, sub = tid & 3;
   const int64_t b0 = (int64_t)blockIdx.x * 64;
   const int nb = (int)((B - b0) < 64 ? (B - b0) : 64);
-  for (int64_t i = tid; i < elems; i += 256) img[i] = image[i];
+  fill_image<T>(img, image, elems, tid);
   for (int idx = tid; idx < 64 * n; idx += 256) {
     const int bl = idx / n, j = idx - bl * n;
     vt[bl * LDV + j] = bl < nb ? v[(b0 + bl) * ldv + j] : T(0);
@@ -453,19 +562,8 @@ __global__ __launch_bounds__(256) void lmi_quad_bwd_kernel(
   const T sc = T(1) / fmax(T(1), kap);
 
   if (clipped && aseg == lmi_seg) {  // the same for the four lanes of a quad
-    T a[R4][R];
-#pragma unroll
-    for (int t = 0; t < R4; ++t)
-#pragma unroll
-      for (int j = 0; j < R; ++j) a[t][j] = (4 * t + sub == j && j >= r) ? T(-1e18) : T(0);
-    for (int aa = 0; aa < n; ++aa) {
-      const T va = vs[aa];
-      const T* wa = Wf + (size_t)aa * R * R + sub * R;
-#pragma unroll
-      for (int t = 0; t < R4; ++t)
-#pragma unroll
-        for (int j = 0; j < R; ++j) a[t][j] = fma_(wa[4 * t * R + j], va, a[t][j]);
-    }
+    V2<T> a[R4][R / 2];
+    form_S<T, R4>(a, Wf, vs, n, r, sub);
     T xr[R4];
     top_eigenvector_quad<T, R4>(a, kap, xr, sub);
     T xf[R];
@@ -510,7 +608,7 @@ inline int quad_size_class(int r) {  // padded size R (multiple of 4) the kernel
 template <typename T>
 size_t quad_lds_bytes(const RayenPack* p, int R, int m) {
   const size_t elems = (size_t)p->n * R * R + (size_t)m * p->n + (p->out_identity ? 0 : (size_t)p->k * p->n) + p->k;
-  return sizeof(T) * (elems + 64 * (size_t)(p->n + 1));
+  return sizeof(T) * (((elems + 3) & ~size_t(3)) + 64 * (size_t)(p->n + 1));
 }
 
 template <typename T>
@@ -619,7 +717,7 @@ int lmi_quad_forward_t(const RayenPack* p, const LmiQuadImage* img, const T* v, 
 template <typename T>
 size_t quad_bwd_lds_bytes(const RayenPack* p, int R, int m) {
   const size_t elems = (size_t)p->n * R * R + (size_t)m * p->n + (p->out_identity ? 0 : (size_t)p->k * p->n) + p->k;
-  return sizeof(T) * (elems + 64 * (size_t)(3 * (p->n + 1) + p->k + 1));
+  return sizeof(T) * (((elems + 3) & ~size_t(3)) + 64 * (size_t)(3 * (p->n + 1) + p->k + 1));
 }
 
 template <typename T, int R4>

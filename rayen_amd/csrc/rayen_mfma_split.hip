@@ -59,16 +59,37 @@ struct SplitImage {
   int64_t bytes = 0;
 };
 
-template <int NKK, bool TRACK, bool STAGED>
-__global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fwd_kernel(
+// The module's mapper v = Wm x + b (rayen/constraint_module.py:259-263, 525) in front of the walk (NKX > 0
+// instances): Wm as a split-operand fragment image built by mapper_image_kernel below (caller-owned memory, rebuilt
+// when the weights change), x split into bf16 pieces like v, the fp32 result accumulators -- which ARE in B-operand
+// order (rayen_mfma_kernel.h) -- re-split in registers into the walk's B operands.  v reaches memory only when
+// v_out != null (training: the backward's input).
+struct SplitMapper {
+  const bf16x8* img = nullptr;   // [NKK][NSX][3][64] x 8 bf16, then n_pad floats of bias
+  int in_dim = 0;
+  float* v_out = nullptr;
+  int64_t ldvo = 0;
+};
+
+__device__ __forceinline__ void split3(const float x, __bf16& p1, __bf16& p2, __bf16& p3) {
+  p1 = (__bf16)x;
+  const float r1 = x - (float)p1;
+  p2 = (__bf16)r1;
+  const float r2 = r1 - (float)p2;
+  p3 = (__bf16)r2;
+}
+
+template <int NKK, bool TRACK, bool STAGED, int NKX>
+__device__ __forceinline__ void mfma_split_fwd_body(
     const bf16x8* __restrict__ Wb, const MItem* __restrict__ items, int n_items,
     const MPack* __restrict__ packs, const float* __restrict__ y0, int identity, int k, int n,
     const float* __restrict__ v, int64_t B, int64_t ldv, int vec_in, float* __restrict__ y, int64_t ldy,
     int vec_out, float* __restrict__ kappa_out, int32_t* __restrict__ active_out,
-    int32_t* __restrict__ nan_flag) {
+    int32_t* __restrict__ nan_flag, const SplitMapper mp) {
   constexpr int NT = 2, NS = NKK * 2, NCH = NS * 3, KK = NKK * 16;
   __shared__ float aux_lds[kMfmaWaves][NT][32][32];
   __shared__ __attribute__((aligned(16))) float y0_lds[NKK * 32];
+  __shared__ __attribute__((aligned(16))) float bias_lds[NKX > 0 ? NKK * 32 : 4];
   constexpr int LSTR = NKK * 32 + 4;
   __shared__ __attribute__((aligned(16))) float line_lds[kMfmaWaves][32][LSTR];
 
@@ -81,6 +102,10 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fw
   const int64_t wave_stride = (int64_t)gridDim.x * kMfmaWaves;
   bool bad = false;
   for (int i = threadIdx.x; i < NKK * 32; i += kMfmaWaves * 64) y0_lds[i] = y0[i];
+  if constexpr (NKX > 0) {
+    const float* bias = reinterpret_cast<const float*>(mp.img + (size_t)NKK * (NKX * 2) * 3 * 64);
+    for (int i = threadIdx.x; i < NKK * 32; i += kMfmaWaves * 64) bias_lds[i] = bias[i];
+  }
   __syncthreads();  // the only workgroup barrier
   float (*patch)[LSTR] = line_lds[wave];
 
@@ -99,9 +124,19 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fw
   };
 #pragma unroll
   for (int c = 0; c < NCH; ++c) abuf[c] = u32x4{0u, 0u, 0u, 0u};
+  if constexpr (NKX == 0) {
 #pragma unroll
-  for (int sp = 0; sp < NS; ++sp) load_step(reinterpret_cast<const char*>(Wb), sp);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int sp = 0; sp < NS; ++sp) load_step(reinterpret_cast<const char*>(Wb), sp);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  // mapped instances: the rolling buffer is dead while the mapper runs (its registers hold x and the mapper's
+  // accumulators); tile 0 is fetched afresh once the mapper's MFMAs are issued -- the walk's counted waits cover it
+  auto load_step_fresh = [&](const int sp) {
+    const char* sb = reinterpret_cast<const char*>(Wb) + sp * 3072;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(abuf[3 * sp + 0]) : "v"(lane_off), "s"(sb));
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(abuf[3 * sp + 1]) : "v"(lane_off), "s"(sb));
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(abuf[3 * sp + 2]) : "v"(lane_off), "s"(sb));
+  };
 
   const int64_t n_rounds = (n_groups + wave_stride - 1) / wave_stride;
   for (int64_t round = 0; round < n_rounds; ++round) {
@@ -114,7 +149,89 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fw
   for (int t = 0; t < NT; ++t) live[t] = (s_base + t * 32 + col) < B;
   // vb[t][piece][k-step] = 8 bf16 = the B operand of one MFMA; element i = column 16 sp + 8 (i >> 2) + 4 hi + (i & 3)
   bf16x8 vb[NT][3][NS];
-  {
+  if constexpr (NKX > 0) {
+    constexpr int NSX = NKX * 2;
+    float xr[NT][NKX * 16];
+    load_rows<NT, NKX, LSTR, true>(xr, v, ldv, mp.in_dim, vec_in & 1, s_base, B, live, patch, lane);
+    f32x16 macc[NKK][NT];
+#pragma unroll
+    for (int tp = 0; tp < NKK; ++tp)
+#pragma unroll
+      for (int a4 = 0; a4 < 4; ++a4) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(&bias_lds[32 * tp + 8 * a4 + 4 * hi]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) macc[tp][t][4 * a4 + c] = b4[c];
+      }
+    const bf16x8* mimg = mp.img + lane;
+#pragma unroll
+    for (int sx = 0; sx < NSX; ++sx) {
+      bf16x8 xb[NT][3];   // the K-step's pieces of x: element i = column 16 sx + 8 (i >> 2) + 4 hi + (i & 3)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          __bf16 p1, p2, p3;
+          split3(xr[t][8 * sx + i], p1, p2, p3);
+          xb[t][0][i] = p1;
+          xb[t][1][i] = p2;
+          xb[t][2][i] = p3;
+        }
+#pragma unroll
+      for (int tp = 0; tp < NKK; ++tp) {
+        const bf16x8* ch = mimg + (size_t)((tp * NSX + sx) * 3) * 64;
+        const bf16x8 a1 = ch[0], a2 = ch[64], a3 = ch[128];
+        // smallest products first (the accumulator starts at the bias)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) macc[tp][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, xb[t][0], macc[tp][t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) macc[tp][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, xb[t][1], macc[tp][t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) macc[tp][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xb[t][2], macc[tp][t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) macc[tp][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, xb[t][0], macc[tp][t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) macc[tp][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xb[t][1], macc[tp][t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) macc[tp][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xb[t][0], macc[tp][t], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int sp = 0; sp < NS; ++sp) load_step_fresh(sp);
+    __builtin_amdgcn_sched_barrier(0);
+    if (mp.v_out != nullptr) {
+      float vr[NT][KK], one[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        one[t] = 1.f;
+#pragma unroll
+        for (int tp = 0; tp < NKK; ++tp)
+#pragma unroll
+          for (int g = 0; g < 16; ++g) vr[t][16 * tp + g] = macc[tp][t][g];
+      }
+      (void)store_rows<NT, NKK, LSTR, true>(vr, one, nullptr, mp.v_out, mp.ldvo, n,
+                                            (mp.ldvo % 4 == 0) && ((reinterpret_cast<uintptr_t>(mp.v_out) & 15) == 0),
+                                            s_base, B, live, patch, lane);
+    }
+    // result register g = 4 a + c of row tile tp is direction element 32 tp + 8 a + 4 hi + c = element 4 (a & 1) + c
+    // of K-step 2 tp + (a >> 1): split in place into the walk's B operands
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int tp = 0; tp < NKK; ++tp)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            __bf16 p1, p2, p3;
+            split3(macc[tp][t][4 * a + c], p1, p2, p3);
+            vb[t][0][2 * tp + (a >> 1)][4 * (a & 1) + c] = p1;
+            vb[t][1][2 * tp + (a >> 1)][4 * (a & 1) + c] = p2;
+            vb[t][2][2 * tp + (a >> 1)][4 * (a & 1) + c] = p3;
+          }
+  } else {
     float vr[NT][KK];
     if constexpr (kAblNoIo) {
 #pragma unroll
@@ -457,7 +574,23 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fw
     }
   }
 
+  if constexpr (NKX > 0) {
+    // (mapped instances discard the prefetched tile -- the mapper needs its registers -- but the loads are still
+    // in flight here: the chunks stay live up to this wait so that the compiler cannot hand them out before)
+    if constexpr (NCH == 12)
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(abuf[0]), "+v"(abuf[1]), "+v"(abuf[2]), "+v"(abuf[3]), "+v"(abuf[4]), "+v"(abuf[5]), "+v"(abuf[6]),
+                     "+v"(abuf[7]), "+v"(abuf[8]), "+v"(abuf[9]), "+v"(abuf[10]), "+v"(abuf[11])
+                   :
+                   : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(abuf[0]), "+v"(abuf[1]), "+v"(abuf[2]), "+v"(abuf[3]), "+v"(abuf[4]), "+v"(abuf[5])
+                   :
+                   : "memory");
+  } else {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next group's first tile has landed
+  }
 
   if (identity) {
     finish_kappa();
@@ -520,6 +653,61 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fw
   }
   }  // persistent loop over sample groups
   if (nan_flag && bad) atomicOr(nan_flag, 1);
+}
+
+template <int NKK, bool TRACK, bool STAGED>
+__global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_fwd_kernel(
+    const bf16x8* __restrict__ Wb, const MItem* __restrict__ items, int n_items,
+    const MPack* __restrict__ packs, const float* __restrict__ y0, int identity, int k, int n,
+    const float* __restrict__ v, int64_t B, int64_t ldv, int vec_in, float* __restrict__ y, int64_t ldy,
+    int vec_out, float* __restrict__ kappa_out, int32_t* __restrict__ active_out,
+    int32_t* __restrict__ nan_flag) {
+  mfma_split_fwd_body<NKK, TRACK, STAGED, 0>(Wb, items, n_items, packs, y0, identity, k, n, v, B, ldv, vec_in, y, ldy,
+                                             vec_out, kappa_out, active_out, nan_flag, SplitMapper());
+}
+
+// the same walk behind the fused mapper (x in place of v; NKX 32-column blocks of x)
+template <int NKK, bool TRACK, bool STAGED, int NKX>
+__global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_split_map_kernel(
+    const bf16x8* __restrict__ Wb, const MItem* __restrict__ items, int n_items,
+    const MPack* __restrict__ packs, const float* __restrict__ y0, int identity, int k, int n,
+    const float* __restrict__ x, int64_t B, int64_t ldx, int vec_in, float* __restrict__ y, int64_t ldy,
+    int vec_out, float* __restrict__ kappa_out, int32_t* __restrict__ active_out,
+    int32_t* __restrict__ nan_flag, const SplitMapper mp) {
+  mfma_split_fwd_body<NKK, TRACK, STAGED, NKX>(Wb, items, n_items, packs, y0, identity, k, n, x, B, ldx, vec_in, y, ldy,
+                                               vec_out, kappa_out, active_out, nan_flag, mp);
+}
+
+// Wm [n, ldw] (row-major fp32, torch.nn.Linear.weight) -> the split-operand fragment image the mapped kernel reads:
+// chunk (row tile tp, K-step s, piece) = 64 lanes x 8 bf16, element i of lane l = Wm[32 tp + (l & 31)][16 s + 8 (i >> 2)
+// + 4 (l >> 5) + (i & 3)], zero beyond (n, in_dim); then the bias, zero-padded to n_pad floats.
+__global__ void mapper_image_kernel(const float* __restrict__ w, int64_t ldw, const float* __restrict__ bias, int n,
+                                    int in_dim, int nkk, int nsx, bf16x8* __restrict__ img) {
+  const int chunk = blockIdx.x;            // (tp, s)
+  const int tp = chunk / nsx, sx = chunk - tp * nsx;
+  const int l = threadIdx.x;
+  if (l < 64) {
+    const int row = 32 * tp + (l & 31);
+    bf16x8 o1, o2, o3;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int col = 16 * sx + 8 * (i >> 2) + 4 * (l >> 5) + (i & 3);
+      const float x = (row < n && col < in_dim) ? w[(int64_t)row * ldw + col] : 0.f;
+      __bf16 p1, p2, p3;
+      split3(x, p1, p2, p3);
+      o1[i] = p1;
+      o2[i] = p2;
+      o3[i] = p3;
+    }
+    bf16x8* dst = img + (size_t)chunk * 3 * 64 + l;
+    dst[0] = o1;
+    dst[64] = o2;
+    dst[128] = o3;
+  }
+  if (chunk == 0) {
+    float* b = reinterpret_cast<float*>(img + (size_t)nkk * nsx * 3 * 64);
+    for (int i = l; i < nkk * 32; i += blockDim.x) b[i] = (bias != nullptr && i < n) ? bias[i] : 0.f;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -641,6 +829,67 @@ static int launch_split(const RayenPack* p, const SplitImage* img, const float* 
     else go(mfma_split_fwd_kernel<NKK, false, true>);
   }
   return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
+}
+
+// ---- fused mapper: in_dim <= n_pad columns of x (the transposition patch and the register budget are the walk's)
+int64_t mfma_split_mapper_image_bytes(const RayenPack* p, const SplitImage* img, int in_dim) {
+  (void)p;
+  if (img == nullptr || in_dim < 1 || in_dim > img->nkk * 32) return 0;
+  const int nsx = (in_dim + 31) / 32 * 2;
+  return (int64_t)img->nkk * nsx * 3 * 1024 + (int64_t)img->nkk * 32 * sizeof(float);
+}
+
+int mfma_split_mapper_prepare(const RayenPack* p, const SplitImage* img, const float* w, int64_t ldw, int in_dim,
+                              const float* bias, void* image, hipStream_t stream) {
+  if (mfma_split_mapper_image_bytes(p, img, in_dim) == 0) return RAYEN_E_UNSUPPORTED;
+  const int nsx = (in_dim + 31) / 32 * 2;
+  hipLaunchKernelGGL(mapper_image_kernel, dim3((unsigned)(img->nkk * nsx)), dim3(64), 0, stream, w, ldw, bias, p->n,
+                     in_dim, img->nkk, nsx, static_cast<bf16x8*>(image));
+  return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
+}
+
+template <int NKK, int NKX>
+static int launch_split_map(const RayenPack* p, const SplitImage* img, const float* x, int64_t B, int64_t ldx,
+                            const SplitMapper& mp, float* y, int64_t ldy, float* kappa, int32_t* active,
+                            int32_t* nan_flag, hipStream_t stream) {
+  constexpr int per_wave = 64;
+  const int64_t n_groups = (B + per_wave - 1) / per_wave;
+  const int64_t slots = (int64_t)img->n_simd * kMfmaWavesPerSimd;
+  const int64_t rounds = (n_groups + slots - 1) / slots;
+  const int64_t waves = (n_groups + rounds - 1) / rounds;
+  const int64_t grid = (waves + kMfmaWaves - 1) / kMfmaWaves;
+  const int vec_in = ((ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0)) ? 1 : 0;
+  const int vec_out = (ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+  auto go = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kMfmaWaves * 64), 0, stream,
+                       static_cast<const bf16x8*>(img->Wb), img->items, img->n_items, img->packs, img->y0,
+                       img->identity, p->k, p->n, x, B, ldx, vec_in, y, ldy, vec_out, kappa, active, nan_flag, mp);
+  };
+  if (img->identity) {
+    if (active != nullptr) go(mfma_split_map_kernel<NKK, true, false, NKX>);
+    else go(mfma_split_map_kernel<NKK, false, false, NKX>);
+  } else {
+    if (active != nullptr) go(mfma_split_map_kernel<NKK, true, true, NKX>);
+    else go(mfma_split_map_kernel<NKK, false, true, NKX>);
+  }
+  return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
+}
+
+int mfma_split_forward_mapped(const RayenPack* p, const SplitImage* img, const float* x, int64_t B, int64_t ldx,
+                              int in_dim, const void* image, float* v_out, int64_t ldvo, float* y, int64_t ldy,
+                              float* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream) {
+  if (mfma_split_mapper_image_bytes(p, img, in_dim) == 0 || image == nullptr) return RAYEN_E_UNSUPPORTED;
+  if (B == 0) return RAYEN_OK;
+  SplitMapper mp;
+  mp.img = static_cast<const bf16x8*>(image);
+  mp.in_dim = in_dim;
+  mp.v_out = v_out;
+  mp.ldvo = ldvo;
+  const int nkx = (in_dim + 31) / 32;
+  if (img->nkk == 1 && nkx == 1) return launch_split_map<1, 1>(p, img, x, B, ldx, mp, y, ldy, kappa, active, nan_flag, stream);
+  if (img->nkk == 2 && nkx == 1) return launch_split_map<2, 1>(p, img, x, B, ldx, mp, y, ldy, kappa, active, nan_flag, stream);
+  if (img->nkk == 2 && nkx == 2) return launch_split_map<2, 2>(p, img, x, B, ldx, mp, y, ldy, kappa, active, nan_flag, stream);
+  return RAYEN_E_UNSUPPORTED;
 }
 
 int mfma_split_forward(const RayenPack* p, const SplitImage* img, const float* v, int64_t B, int64_t ldv,

@@ -209,13 +209,17 @@ ray_project.register_autograd(_backward, setup_context=_setup_context)
 # ------------------------------------------------------------------------------------------------
 
 def mapper_fusable(x, weight, bias, pack):
-    """Can ``ray_project_mapped`` serve this call?  (fp32, contiguous rows, the pack on the MFMA path and
-    an input width the fused kernel holds in registers.)"""
-    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 2
+    """Can ``ray_project_mapped`` serve this call?  (fp32, contiguous rows, and a fused form for this pack and input
+    width: weights read in place by the exact-fp32 family, or through their split-operand image by the default one.)"""
+    if not (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 2
             and weight.dim() == 2 and weight.shape[0] == pack.consts.n and x.shape[1] == weight.shape[1]
-            and weight.is_contiguous() and weight.data_ptr() % 16 == 0
-            and (bias is None or (bias.dtype == torch.float32 and bias.is_contiguous()))
-            and pack.mapper_fusable(weight.shape[1]))
+            and weight.stride(1) == 1
+            and (bias is None or (bias.dtype == torch.float32 and bias.is_contiguous()))):
+        return False
+    mode = pack.mapper_mode(weight.shape[1])
+    if mode == 1:
+        return weight.is_contiguous() and weight.data_ptr() % 16 == 0
+    return mode == 2
 
 
 @torch.library.custom_op("rayen_amd::ray_project_mapped", mutates_args=())
@@ -239,10 +243,18 @@ def ray_project_mapped(x: torch.Tensor, weight: torch.Tensor, bias: Optional[tor
     active = torch.empty((B if need_grad else 0, 2), dtype=torch.int32, device=x.device)
     v = torch.empty((B if need_grad else 0, n), dtype=x.dtype, device=x.device)
     with _on_device(x.device):
-        code = _lib.load().rayen_ray_project_mapped_f32(
-            pack.handle, _ptr(x), B, x.stride(0) if B else in_dim, in_dim, _ptr(weight), weight.stride(0),
-            _ptr(bias), _ptr(v) if need_grad else None, n, _ptr(y), k, _ptr(kappa),
-            _ptr(active) if need_grad else None, _ptr(pack.nan_flag), _stream(x.device.index))
+        stream = _stream(x.device.index)
+        if pack.mapper_mode(in_dim) == 2:
+            image = pack.mapper_image(weight, bias, stream)
+            code = _lib.load().rayen_ray_project_mapped_image_f32(
+                pack.handle, _ptr(x), B, x.stride(0) if B else in_dim, in_dim, _ptr(image),
+                _ptr(v) if need_grad else None, n, _ptr(y), k, _ptr(kappa),
+                _ptr(active) if need_grad else None, _ptr(pack.nan_flag), stream)
+        else:
+            code = _lib.load().rayen_ray_project_mapped_f32(
+                pack.handle, _ptr(x), B, x.stride(0) if B else in_dim, in_dim, _ptr(weight), weight.stride(0),
+                _ptr(bias), _ptr(v) if need_grad else None, n, _ptr(y), k, _ptr(kappa),
+                _ptr(active) if need_grad else None, _ptr(pack.nan_flag), stream)
     _lib.check(code, "rayen_ray_project_mapped")
     return y, kappa, active, v
 

@@ -234,14 +234,43 @@ class DevicePack:
         _lib.check(_lib.load().rayen_pack_info(self.handle, ctypes.byref(out)), "rayen_pack_info")
         return out
 
-    def mapper_fusable(self, in_dim):
-        """True when ``rayen_ray_project_mapped_f32`` serves this pack with an ``in_dim``-wide mapper."""
+    def mapper_mode(self, in_dim):
+        """``rayen_mapper_fusable``: 0 = no fused form | 1 = weights read in place (exact-fp32 family) |
+        2 = through a split-operand image of the weights (``rayen_mapper_prepare_f32``)."""
         import torch
         cache = self.__dict__.setdefault("_fusable", {})   # (the answer is fixed at pack creation)
         if in_dim not in cache:
             with torch.cuda.device(self.device_index):
-                cache[in_dim] = bool(_lib.load().rayen_mapper_fusable(self.handle, int(in_dim)))
+                cache[in_dim] = int(_lib.load().rayen_mapper_fusable(self.handle, int(in_dim)))
         return cache[in_dim]
+
+    def mapper_fusable(self, in_dim):
+        """True when one of the fused mapper + projection entry points serves an ``in_dim``-wide mapper."""
+        return self.mapper_mode(in_dim) != 0
+
+    def mapper_image(self, weight, bias, stream):
+        """The split-operand image of ``(weight, bias)`` for ``mapper_mode == 2``; cached per pack and rebuilt (one
+        small launch on ``stream``) when either tensor was modified in place or replaced."""
+        import torch
+        key = (weight.data_ptr(), weight._version, tuple(weight.shape), weight.stride(0),
+               None if bias is None else (bias.data_ptr(), bias._version))
+        cached = self.__dict__.get("_mapper_image")
+        # (while a stream is being captured the conversion launch must be part of the graph: replays follow the weights)
+        if cached is not None and cached[0] == key and not torch.cuda.is_current_stream_capturing():
+            return cached[1]
+        lib = _lib.load()
+        in_dim = weight.shape[1]
+        nbytes = int(lib.rayen_mapper_image_bytes(self.handle, int(in_dim)))
+        if nbytes <= 0:
+            raise RuntimeError("rayen_amd: this pack has no image-based fused mapper for this input width")
+        image = cached[1] if (cached is not None and cached[1].numel() == nbytes) else \
+            torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{self.device_index}")
+        with torch.cuda.device(self.device_index):
+            _lib.check(lib.rayen_mapper_prepare_f32(self.handle, ctypes.c_void_p(weight.data_ptr()), weight.stride(0),
+                                                    int(in_dim), None if bias is None else ctypes.c_void_p(bias.data_ptr()),
+                                                    ctypes.c_void_p(image.data_ptr()), stream), "rayen_mapper_prepare_f32")
+        self.__dict__["_mapper_image"] = (key, image)
+        return image
 
     def close(self):
         if getattr(self, "handle", None):

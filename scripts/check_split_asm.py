@@ -16,7 +16,8 @@ subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++
                 "-I", os.path.join(REPO, "rayen_amd", "csrc"), "-S", "--cuda-device-only", src, "-o", asm],
                check=True, stderr=subprocess.DEVNULL)
 lines = open(asm).read().split("\n")
-starts = [i for i, l in enumerate(lines) if l.startswith("_ZN5rayen21mfma_split_fwd_kernel") and l.split(";")[0].rstrip().endswith(":")]
+starts = [i for i, l in enumerate(lines) if (l.startswith("_ZN5rayen21mfma_split_fwd_kernel") or l.startswith("_ZN5rayen21mfma_split_map_kernel"))
+          and l.split(";")[0].rstrip().endswith(":")]
 starts.append(len(lines))
 
 
@@ -36,12 +37,20 @@ for s, e in zip(starts[:-1], starts[1:]):
         if "s_endpgm" in l:
             break
     name = re.search(r"ILi(\d)ELb(\d)ELb(\d)", lines[s]).groups()
-    loads = [i for i, l in enumerate(body) if "global_load_dwordx4" in l and re.search(r", s\[\d+:\d+\]", l)]
+    mapped = "split_map_kernel" in lines[s]
+    nkx = re.search(r"ELb\dELb\dELi(\d)", lines[s]).group(1) if mapped else "0"
+    # the hand-placed loads are the ones written as asm statements (the compiler's own loads of the mapper image or of
+    # the rows are tracked by the compiler and need no check)
+    loads = [i for i, l in enumerate(body) if "global_load_dwordx4" in l and re.search(r", s\[\d+:\d+\]", l)
+             and i > 0 and "ASMSTART" in body[i - 1]]
     chunk = set()
     for i in loads:
         chunk |= regs_of(body[i].split(",")[0])
     # in-flight windows: from the first asm load of the loop nest to the vmcnt(0) that closes it
-    first = loads[2 * 3 * int(name[0])]            # skip the initial fill (NCH = 6 NKK loads before the loops)
+    # plain instances: skip the initial fill before the loops (NCH = 6 NKK loads, closed by a vmcnt(0));
+    # mapped instances: tile 0 is fetched afresh inside the group loop, right after the mapper's MFMAs, and stays
+    # in flight through the re-split of the mapper's accumulators: the window starts at that first load
+    first = loads[0] if mapped else loads[2 * 3 * int(name[0])]
     last = max(i for i, l in enumerate(body) if "s_waitcnt vmcnt(0)" in l and i > loads[-1]) if any(
         "s_waitcnt vmcnt(0)" in l for l in body[loads[-1]:]) else len(body)
     closing = min(i for i in range(loads[-1], len(body)) if "s_waitcnt vmcnt(0)" in body[i])
@@ -52,7 +61,7 @@ for s, e in zip(starts[:-1], starts[1:]):
             continue
         if regs_of(l) & chunk:
             bad.append((i, l))
-    print(f"NKK={name[0]} TRACK={name[1]} STAGED={name[2]}: {len(loads)} asm loads, chunk registers {min(chunk)}..{max(chunk)}"
+    print(f"NKK={name[0]} TRACK={name[1]} STAGED={name[2]} NKX={nkx}: {len(loads)} asm loads, chunk registers {min(chunk)}..{max(chunk)}"
           f" ({len(chunk)}), suspicious instructions in the loop: {len(bad)}")
     for i, l in bad[:12]:
         print("     ", i, l[:110])

@@ -11,7 +11,6 @@ if REPO not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
-    config.addinivalue_line("markers", "default_kernels: (test_gpu_mapper.py) do not pin the plain fp32 MFMA kernel family")
 
 
 @pytest.fixture(scope="session")

@@ -42,41 +42,36 @@ def _oracle_y(cs, layer, x):
     return oracle.forward(buf, v.unsqueeze(2)).numpy()[:, :, 0], v
 
 
-@pytest.fixture(autouse=True)
-def _fp32_mfma_kernels_only(monkeypatch, request):
-    """The fused-mapper kernel belongs to the plain fp32 MFMA family; packs served by the split-operand kernel
-    (the default where eligible) run the mapper as a GEMM of its own, which is faster there.  RAYEN_SPLIT_BF16 is
-    read when a pack is created, so this file pins the fp32 family unless a test asks for the default."""
-    if "default_kernels" not in request.keywords:
+@pytest.fixture(autouse=True, params=["default", "exact"])
+def family(monkeypatch, request):
+    """Every test of this file runs on both fp32 kernel families: the default one (split-operand kernel where the
+    pack is eligible; its fused mapper reads a split-operand image of the weights, in_dim <= n rounded up to 32) and
+    the exact-fp32 MFMA family (RAYEN_SPLIT_BF16=0, read when a pack is created; weights read in place, in_dim a
+    multiple of 4 up to 64)."""
+    if request.param == "exact":
         monkeypatch.setenv("RAYEN_SPLIT_BF16", "0")
+    return request.param
 
 
-@pytest.mark.default_kernels
-def test_split_served_packs_run_the_mapper_as_its_own_gemm():
-    cs, layer = _module(_sets()["c3"], 64)
-    x = torch.empty(777, 64).uniform_(-2.0, 2.0, generator=torch.Generator().manual_seed(3))
-    dp, _ = layer.device_pack(torch.device("cuda", 0))
-    assert not ops.mapper_fusable(x.cuda(), layer.mapper.weight, layer.mapper.bias, dp)
-    with torch.no_grad():
-        y = layer(x.cuda()).cpu().numpy()[:, :, 0]
-    y_ref, _ = _oracle_y(cs, layer, x)
-    assert np.max(rel_err_rows(y, y_ref)) <= 1e-5
-
-
-@pytest.mark.parametrize("name,input_dim,fusable", [
-    ("c2", 8, True), ("c2", 64, True), ("c3", 64, True), ("c3", 20, True), ("c3", 36, True),
-    ("c5", 32, True), ("c5", 64, True), ("wide", 48, True),
-    ("c3", 6, False),        # not a multiple of 4
-    ("c3", 96, False),       # wider than the fused kernel keeps in registers
-    ("c1", 8, False), ("ex13", 8, False),   # packs on the generic path
+@pytest.mark.parametrize("name,input_dim,fusable_exact,fusable_default", [
+    ("c2", 8, True, True), ("c2", 64, True, False),          # n = 16: the default family keeps in_dim <= 32
+    ("c3", 64, True, True), ("c3", 20, True, True), ("c3", 36, True, True),
+    ("c5", 32, True, True), ("c5", 64, True, False),
+    ("wide", 48, True, True),                                 # n = 96: exact-fp32 family in both runs
+    ("c3", 6, False, True),                                   # not a multiple of 4: only the image form takes it
+    ("c3", 96, False, False),                                 # wider than either fused kernel keeps in registers
+    ("c1", 8, False, False), ("ex13", 8, False, False),       # packs on the generic path
 ])
-def test_fused_mapper_matches_oracle_and_two_op_path(name, input_dim, fusable):
+def test_fused_mapper_matches_oracle_and_two_op_path(name, input_dim, fusable_exact, fusable_default, family):
+    fusable = fusable_default if family == "default" else fusable_exact
     cs, layer = _module(_sets()[name], input_dim)
     B = 1000 if name != "c3" else 4133                        # ragged: not a multiple of 64
     gen = torch.Generator().manual_seed(5)
     x = torch.empty(B, input_dim).uniform_(-2.0, 2.0, generator=gen)
     x[:4] *= 1e-4
     dp, _ = layer.device_pack(torch.device("cuda", 0))
+    if family == "default" and name in ("c2", "c3", "c5"):
+        assert dp.info().mfma_f32 == 2                        # the headline kernel, not a fallback
     assert ops.mapper_fusable(x.cuda(), layer.mapper.weight, layer.mapper.bias, dp) == fusable
 
     with torch.no_grad():
@@ -90,6 +85,25 @@ def test_fused_mapper_matches_oracle_and_two_op_path(name, input_dim, fusable):
     assert rel_err_rows(y_two, y_ref).max() < 1e-5
     viol = oracle.max_violation({**_sets()[name]}, y_fused.astype(np.float64))
     assert viol < max(1e-6, 3 * oracle.max_violation({**_sets()[name]}, y_ref.astype(np.float64)))
+
+
+def test_weight_updates_reach_the_fused_kernel():
+    """The default family reads the weights through an image that is rebuilt when they change (in-place update,
+    optimiser step, load_state_dict): results must follow the weights immediately."""
+    cs, layer = _module(_sets()["c3"], 64)
+    x = torch.empty(500, 64).uniform_(-2.0, 2.0, generator=torch.Generator().manual_seed(11))
+    with torch.no_grad():
+        y_a = layer(x.cuda()).clone()
+        layer.mapper.weight.mul_(0.5)
+        layer.mapper.bias.add_(0.25)
+        y_b = layer(x.cuda()).clone()
+    assert not torch.equal(y_a, y_b)
+    y_ref, _ = _oracle_y(cs, layer, x)
+    assert rel_err_rows(y_b.cpu().numpy()[:, :, 0], y_ref).max() < 1e-5
+    other = ConstraintModule(cs, input_dim=64, create_map=True).cuda()
+    other.load_state_dict(layer.state_dict())
+    with torch.no_grad():
+        assert torch.equal(other(x.cuda()), y_b)
 
 
 def test_no_bias_and_strided_input():
@@ -136,6 +150,9 @@ def test_gradients_of_the_fused_layer_match_the_two_op_path(name, input_dim):
     # identical backward kernel on v that differs in the last bits: a sample on a kink of kappa may flip
     bad_rows = (gx1 - gx0).abs().amax(1) > 1e-4 * gx0.abs().amax().clamp_min(1e-12)
     assert bad_rows.float().mean() < 0.01
+    # the weight / bias gradients are sums over the batch: the few kink rows above are all that may differ
+    good = ~bad_rows
+    assert torch.allclose(gx1[good], gx0[good], rtol=0, atol=1e-4 * float(gx0.abs().max()))
     assert torch.allclose(gw1, gw0, rtol=0, atol=2e-2 * float(gw0.abs().max()))
     assert torch.allclose(gb1, gb0, rtol=0, atol=2e-2 * float(gb0.abs().max()))
 
