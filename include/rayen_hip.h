@@ -210,8 +210,8 @@ int rayen_ray_project_old_bwd_f64(const RayenPack* pack, const double* v, int64_
  *   0  none: the caller runs its GEMM followed by rayen_ray_project_f32;
  *   1  rayen_ray_project_mapped_f32: Wm [n, ldw] row-major (= Linear.weight, rows 16-byte aligned) and
  *      bias [n] or NULL are read in place (exact-fp32 MFMA family; in_dim a multiple of 4, <= 64);
- *   2  rayen_ray_project_mapped_image_f32 (packs served by the split-operand kernel; in_dim <= n rounded
- *      up to 32): Wm and bias are first converted into a caller-owned image of
+ *   2  rayen_ray_project_mapped_image_f32 (packs served by the split-operand kernel, no equality
+ *      constraints, in_dim <= n rounded up to 32): Wm and bias are first converted into a caller-owned image of
  *      rayen_mapper_image_bytes() bytes (16-byte aligned device memory) by rayen_mapper_prepare_f32 -- one
  *      small asynchronous launch, to be repeated whenever the weights change -- and the projection reads
  *      that image.  The library keeps no per-mapper state: packs stay immutable. */

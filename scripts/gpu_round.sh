@@ -25,6 +25,13 @@ prof)
   for cfg in c3 c4 c2 c5 c1; do
     timeout 900 scripts/profile_bench.sh ${tag}_$cfg --config $cfg > $out/prof_$cfg.log 2>&1
     timeout 120 python scripts/summarize_profile.py ${tag}_$cfg $out/prof_${cfg}_summary.json "config $cfg, fp32, default kernels" >> $out/prof_$cfg.log 2>&1
+    rm -rf gpurun_out/prof_${tag}_$cfg          # raw rocprofv3 databases: ~20 MB per config, gpurun_out/ is capped at 64 MiB
   done ;;
+mapper)
+  timeout 600 python bench.py --mapper 64 --no-cpu-baseline > $out/bench_c3_mapper64_fused.json 2> $out/bench_c3_mapper64_fused.err
+  timeout 600 python bench.py --mapper 64 --no-fuse --no-cpu-baseline > $out/bench_c3_mapper64_twoop.json 2> $out/bench_c3_mapper64_twoop.err
+  timeout 600 python bench.py --config c5 --mapper 32 --no-cpu-baseline > $out/bench_c5_mapper32_fused.json 2>&1
+  timeout 600 python bench.py --config c5 --mapper 32 --no-fuse --no-cpu-baseline > $out/bench_c5_mapper32_twoop.json 2>&1
+  cat $out/bench_c3_mapper64_fused.json | head -c 400; echo ;;
 esac
 done

@@ -88,4 +88,39 @@ def kink_mask(oracle, cs, x, rel_gap, method="RAYEN"):
     kink = tie | near_zero
     if method == "RAYEN":
         kink |= (kappa - 1.0).abs() <= rel_gap
-    return kink.numpy()
+    kink = kink.numpy()
+    # square-root singularities of the ACTIVE constraint: a ray tangent to a cone (the quadratic a'x^2 + b'x + c' has
+    # a double root: d kappa / d v = -(...) / (2 a' kappa + b') diverges, rayen/constraint_module.py:339-348, 392-396)
+    # or a quadratic whose radicand rho' delta rho vanishes (CM:374).  Identified by the size of the vanishing quantity
+    # relative to its terms, below sqrt(rel_gap) (the gradient error grows like rounding / that ratio).
+    m = buf["D"].shape[0]
+    n_quad = buf["all_P"].shape[0] if buf["all_P"].ndim == 3 else 0
+    n_soc = buf["all_M"].shape[0] if buf["all_M"].ndim == 3 else 0
+    arg = torch.argmax(cand, dim=1).numpy()
+    rho = (buf["NA_E"] @ (v / norm.reshape(-1, 1, 1)))[:, :, 0].numpy()          # unit directions in y space
+    kap_bar = (kappa / norm).numpy()
+    thr = float(np.sqrt(rel_gap))
+    for j in range(n_soc):
+        idx = np.flatnonzero(arg == m + n_quad + j)
+        if idx.size == 0:
+            continue
+        M, s_, c, d = (buf[key][j].numpy() for key in ("all_M", "all_s", "all_c", "all_d"))
+        y0 = buf["y0"].numpy()
+        beta, tau = (M @ y0 + s_)[:, 0], float((c.T @ y0 + d).item())
+        r = rho[idx]
+        cr = r @ c[:, 0]
+        b_p = 2.0 * (r @ M.T) @ beta - 2.0 * cr * tau
+        a_p = float(beta @ beta - tau * tau)
+        den = 2.0 * a_p * kap_bar[idx] + b_p
+        size = np.abs(2.0 * a_p * kap_bar[idx]) + np.abs(b_p) + 1e-300
+        kink[idx[np.abs(den) <= thr * size]] = True
+    for i in range(n_quad):
+        idx = np.flatnonzero(arg == m + i)
+        if idx.size == 0:
+            continue
+        delta = buf["all_delta"][i].numpy()
+        r = rho[idx]
+        rad = np.einsum("bi,ij,bj->b", r, delta, r)
+        size = np.linalg.norm(delta, 2) * np.einsum("bi,bi->b", r, r) + 1e-300
+        kink[idx[rad <= thr * thr * size]] = True
+    return kink

@@ -235,8 +235,12 @@ def test_matrix_core_backward_matches_lane_backward(name, old_head, dtype):
         err = _row_err(got.numpy(), want.numpy())
         assert err.max() <= (2e-4 if dtype == torch.float32 else 1e-9), np.sort(err)[-5:]
         # ... and the matrix-core one is also held to the fp64 autograd truth
-        xz = x3.clone()
-        truth, _ = _oracle_grad(cs, xz, g_cpu, torch.float64, method)
+        try:
+            truth, _ = _oracle_grad(cs, x3.clone(), g_cpu, torch.float64, method)
+        except AssertionError:
+            # the reference op sequence asserts (NaN) when a ray never meets a cone (negative discriminant, CM:342;
+            # the kernels give that cone kappa = 0): no autograd truth for this set, the kernel-vs-kernel check stands
+            return
         truth[40:44] = g_cpu[40:44].double().numpy() @ np.asarray(cs.NA_E)      # v = 0: the identity map around 0
     _assert_gradient(got.numpy(), truth, cs, x3, g_cpu, dtype, method=method, what=name)
 

@@ -45,7 +45,8 @@ def _oracle_y(cs, layer, x):
 @pytest.fixture(autouse=True, params=["default", "exact"])
 def family(monkeypatch, request):
     """Every test of this file runs on both fp32 kernel families: the default one (split-operand kernel where the
-    pack is eligible; its fused mapper reads a split-operand image of the weights, in_dim <= n rounded up to 32) and
+    pack is eligible; its fused mapper reads a split-operand image of the weights, in_dim <= n rounded up to 32, sets
+    without equality constraints) and
     the exact-fp32 MFMA family (RAYEN_SPLIT_BF16=0, read when a pack is created; weights read in place, in_dim a
     multiple of 4 up to 64)."""
     if request.param == "exact":
@@ -56,7 +57,7 @@ def family(monkeypatch, request):
 @pytest.mark.parametrize("name,input_dim,fusable_exact,fusable_default", [
     ("c2", 8, True, True), ("c2", 64, True, False),          # n = 16: the default family keeps in_dim <= 32
     ("c3", 64, True, True), ("c3", 20, True, True), ("c3", 36, True, True),
-    ("c5", 32, True, True), ("c5", 64, True, False),
+    ("c5", 32, True, False), ("c5", 64, True, False),        # equality constraints: image form not offered (NA_E != I)
     ("wide", 48, True, True),                                 # n = 96: exact-fp32 family in both runs
     ("c3", 6, False, True),                                   # not a multiple of 4: only the image form takes it
     ("c3", 96, False, False),                                 # wider than either fused kernel keeps in registers
