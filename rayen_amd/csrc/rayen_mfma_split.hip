@@ -14,16 +14,13 @@
 //   * the direction lives in registers only as bf16 pieces (B operands).  No epilogue may need it in fp32,
 //     so symmetric forms are laid out through their factors (||U v||^2, rayen_tiles.h: allow_sym = false) -- which
 //     is also the better conditioned evaluation --, and the NA_E = I write-out rebuilds v = v1 + v2 + v3 (exact).
-#include "rayen_mfma_kernel.h"
+#include "rayen_split_image.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 namespace rayen {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // developer ablations (scripts/ubench/split_variant.sh): wrong results, timing only
 #ifndef RAYEN_SPLIT_ABL
@@ -46,18 +43,6 @@ constexpr bool kAblNoIo = (RAYEN_SPLIT_ABL & 8) != 0;
 constexpr bool kAblNoSplit = (RAYEN_SPLIT_ABL & 16) != 0;  // no split / rebuild arithmetic at the group boundary
 constexpr bool kAblNoStore = (RAYEN_SPLIT_ABL & 32) != 0;
 constexpr bool kAblNoLoadRows = (RAYEN_SPLIT_ABL & 64) != 0;
-
-struct SplitImage {
-  void* Wb = nullptr;      // [n_tiles][NS][3][64] x 8 bf16
-  MItem* items = nullptr;
-  MPack* packs = nullptr;
-  float* y0 = nullptr;
-  int n_items = 0;
-  int nkk = 0;
-  int identity = 0;
-  int n_simd = 1024;
-  int64_t bytes = 0;
-};
 
 // The module's mapper v = Wm x + b (rayen/constraint_module.py:259-263, 525) in front of the walk (NKX > 0
 // instances): Wm as a split-operand fragment image built by mapper_image_kernel below (caller-owned memory, rebuilt
@@ -746,6 +731,10 @@ int mfma_split_build(const RayenPack* p, SplitImage** out, int64_t* bytes) {
   img->identity = p->out_identity;
   img->n_items = n_items;
   {
+    const char* env = std::getenv("RAYEN_SPLIT_WAVE1");   // 0: two waves per SIMD everywhere (rayen_mfma_split.hip)
+    img->wave1 = (env != nullptr && env[0] == '0') ? 0 : 1;
+  }
+  {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0)
       img->n_simd = prop.multiProcessorCount * 4;
@@ -895,6 +884,10 @@ int mfma_split_forward(const RayenPack* p, const SplitImage* img, const float* v
                        float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
                        hipStream_t stream) {
   if (B == 0) return RAYEN_OK;
+  // one wave per SIMD with the epilogues inside the MFMA stream (rayen_mfma_split4.hip) once the batch fills the
+  // chip that way (64 samples per wave and SIMD); smaller batches and sets with equality constraints stay here
+  if (img->wave1 && mfma_split4_serves(p, img) && B >= (int64_t)img->n_simd * 64)
+    return mfma_split4_forward(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
   if (img->nkk == 1) return launch_split<1>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
   if (img->nkk == 2) return launch_split<2>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
   return RAYEN_E_UNSUPPORTED;
