@@ -22,28 +22,9 @@
 
 namespace rayen {
 
-// developer ablations (scripts/ubench/split_variant.sh): wrong results, timing only
-#ifndef RAYEN_SPLIT_ABL
-#define RAYEN_SPLIT_ABL 0
-#endif
-// Wave priority: 2 = everything OUTSIDE a tile's MFMA burst (epilogues, group boundary) runs at s_setprio 1, so
-// that a wave gets through its VALU / memory sections ahead of its SIMD partner's MFMA burst and returns to the
-// matrix pipe sooner (+2 % on configs 3 and 5); 1 = the opposite (-1 %); 0 = no priorities.
-// 1: the products of a tile go in by size, in three passes over the K-steps (default); 0: step by step
-#ifndef RAYEN_SPLIT_PHASES
-#define RAYEN_SPLIT_PHASES 1
-#endif
-#ifndef RAYEN_SPLIT_PRIO
-#define RAYEN_SPLIT_PRIO 2
-#endif
-constexpr bool kAblNoEpilogue = (RAYEN_SPLIT_ABL & 1) != 0;
-constexpr bool kAblNoLoads = (RAYEN_SPLIT_ABL & 2) != 0;
-constexpr bool kAblNoMfma = (RAYEN_SPLIT_ABL & 4) != 0;
-constexpr bool kAblNoIo = (RAYEN_SPLIT_ABL & 8) != 0;
-constexpr bool kAblNoSplit = (RAYEN_SPLIT_ABL & 16) != 0;  // no split / rebuild arithmetic at the group boundary
-constexpr bool kAblNoStore = (RAYEN_SPLIT_ABL & 32) != 0;
-constexpr bool kAblNoLoadRows = (RAYEN_SPLIT_ABL & 64) != 0;
-
+// Wave priority: everything OUTSIDE a tile's MFMA burst (epilogues, group boundary) runs at s_setprio 1, so that a wave
+// gets through its VALU / memory sections ahead of its SIMD partner's MFMA burst and returns to the matrix pipe sooner
+// (+2 % on configs 3 and 5; the opposite assignment costs 1 %).
 // The module's mapper v = Wm x + b (rayen/constraint_module.py:259-263, 525) in front of the walk (NKX > 0
 // instances): Wm as a split-operand fragment image built by mapper_image_kernel below (caller-owned memory, rebuilt
 // when the weights change), x split into bf16 pieces like v, the fp32 result accumulators -- which ARE in B-operand
@@ -218,20 +199,7 @@ __device__ __forceinline__ void mfma_split_fwd_body(
           }
   } else {
     float vr[NT][KK];
-    if constexpr (kAblNoIo) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int i = 0; i < KK; ++i) vr[t][i] = (float)(lane + i + grp);
-    } else if constexpr (kAblNoLoadRows) {
-      if (round == 0) load_rows<NT, NKK, LSTR, true>(vr, v, ldv, n, vec_in & 1, s_base, B, live, patch, lane);
-      else {
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-          for (int i = 0; i < KK; ++i) vr[t][i] = (float)(lane + i + grp);
-      }
-    } else if (NKK == 1 && (vec_in & 2) && n != NKK * 32) {  // (n > 32: this path would cost the kernel its last registers)
+    if (NKK == 1 && (vec_in & 2) && n != NKK * 32) {  // (n > 32: this path would cost the kernel its last registers)
       // Ragged rows stored back to back (ldv == n, 16-byte aligned base: config-5-like shapes).  A tile's 32 rows
       // are one contiguous, 16-byte aligned block of 32 n floats: it comes in as whole-line float4 loads, goes
       // through the patch as a flat array and is read back row-wise (a lane's own row, 4-byte pieces).  The
@@ -269,19 +237,6 @@ __device__ __forceinline__ void mfma_split_fwd_body(
     } else {
     load_rows<NT, NKK, LSTR, true>(vr, v, ldv, n, vec_in & 1, s_base, B, live, patch, lane);
     }
-    if constexpr (kAblNoSplit) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int sp = 0; sp < NS; ++sp)
-#pragma unroll
-          for (int pc = 0; pc < 3; ++pc) {
-            u32x4 w;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) w[i] = __builtin_bit_cast(unsigned, vr[t][(8 * sp + 2 * i + pc) % KK]);
-            vb[t][pc][sp] = __builtin_bit_cast(bf16x8, w);
-          }
-    } else
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -327,12 +282,7 @@ __device__ __forceinline__ void mfma_split_fwd_body(
     // ---- the tile's MFMAs; each K-step's chunks are re-loaded for the next tile as soon as they were used
     {
       const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#if RAYEN_SPLIT_PRIO == 1
-      __builtin_amdgcn_s_setprio(1);
-#elif RAYEN_SPLIT_PRIO == 2
       __builtin_amdgcn_s_setprio(0);
-#endif
-#if RAYEN_SPLIT_PHASES
       // Three passes over the K-steps, by product size: the 2^-16 products of ALL steps first, then the 2^-8 ones,
       // the leading products last.  The instruction aligns its 16 products and C to the largest of them and keeps
       // ~26 bits (scripts/ubench/mfma_bf16_acc.hip): a small product added to an accumulator that already holds
@@ -382,52 +332,9 @@ __device__ __forceinline__ void mfma_split_fwd_body(
         load_chunk(3 * sp + 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-#else
-#pragma unroll
-      for (int sp = 0; sp < NS; ++sp) {
-        __builtin_amdgcn_sched_barrier(0);
-        // chunks 3 sp .. 3 sp + 2 were loaded NCH - 3 loads ago
-        if constexpr (kAblNoLoads) {
-        } else if constexpr (NCH == 12)
-          asm volatile("s_waitcnt vmcnt(9)" : "+v"(abuf[3 * sp + 0]), "+v"(abuf[3 * sp + 1]), "+v"(abuf[3 * sp + 2]));
-        else
-          asm volatile("s_waitcnt vmcnt(3)" : "+v"(abuf[3 * sp + 0]), "+v"(abuf[3 * sp + 1]), "+v"(abuf[3 * sp + 2]));
-        const bf16x8 a1 = __builtin_bit_cast(bf16x8, abuf[3 * sp + 0]), a2 = __builtin_bit_cast(bf16x8, abuf[3 * sp + 1]),
-                     a3 = __builtin_bit_cast(bf16x8, abuf[3 * sp + 2]);
-        // smallest products first; the first MFMA of a chain takes the constant 0 as C
-        if constexpr (kAblNoMfma) {
-#pragma unroll
-          for (int t = 0; t < NT; ++t) acc[t][sp] = __builtin_bit_cast(float, __builtin_bit_cast(u32x4, a1)[0] ^ __builtin_bit_cast(u32x4, vb[t][0][sp])[0]);
-        } else {
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, vb[t][0][sp], sp == 0 ? zero : acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, vb[t][1][sp], acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, vb[t][2][sp], acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, vb[t][0][sp], acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, vb[t][1][sp], acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, vb[t][0][sp], acc[t], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!kAblNoLoads) load_step(next_tile, sp);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#endif
-#if RAYEN_SPLIT_PRIO == 1
-      __builtin_amdgcn_s_setprio(0);
-#elif RAYEN_SPLIT_PRIO == 2
       __builtin_amdgcn_s_setprio(1);
-#endif
     }
-    if (kAblNoEpilogue && item.type != MI_AUX && item.type != MI_OUT) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) kap[t] = fmaxf(kap[t], acc[t][0]);
-    } else if (item.type == MI_LIN) {
+    if (item.type == MI_LIN) {
       const int lin_code = (item.seg << 20) + item.row0 + 4 * hi;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -581,14 +488,6 @@ __device__ __forceinline__ void mfma_split_fwd_body(
     finish_kappa();
     // y = y0 + v / max(1, kappa): v rebuilt from its pieces, v1 + v2 + v3 (exact)
     float vr[NT][KK];
-    if constexpr (kAblNoSplit) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int sp = 0; sp < NS; ++sp)
-#pragma unroll
-          for (int i = 0; i < 8; ++i) vr[t][8 * sp + i] = __builtin_bit_cast(float, __builtin_bit_cast(u32x4, vb[t][i % 3][sp])[i >> 1]);
-    } else
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -607,24 +506,7 @@ __device__ __forceinline__ void mfma_split_fwd_body(
           vr[t][4 * (2 * sp + (i >> 2)) + (i & 3)] = (x1 + x2) + x3;
         }
       }
-    if constexpr (kAblNoIo) {
-      float sum = 0.f;
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int i = 0; i < KK; ++i) sum += vr[t][i] * scale[t];
-      if (sum == 123.456f) y[s_base] = sum;
-    } else if constexpr (kAblNoStore) {
-      float sum = 0.f;
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int i = 0; i < KK; ++i) sum += vr[t][i] * scale[t];
-      if (sum == 123.456f || round + 1 == n_rounds)
-        bad |= store_rows<NT, NKK, LSTR, true>(vr, scale, y0_lds, y, ldy, k, vec_out, s_base, B, live, patch, lane);
-    } else {
     bad |= store_rows<NT, NKK, LSTR, true>(vr, scale, y0_lds, y, ldy, k, vec_out, s_base, B, live, patch, lane);
-    }
   }
 
   if (hi == 0) {
@@ -730,10 +612,7 @@ int mfma_split_build(const RayenPack* p, SplitImage** out, int64_t* bytes) {
   img->nkk = b.n_pad / 32;
   img->identity = p->out_identity;
   img->n_items = n_items;
-  {
-    const char* env = std::getenv("RAYEN_SPLIT_WAVE1");   // 0: two waves per SIMD everywhere (rayen_mfma_split.hip)
-    img->wave1 = (env != nullptr && env[0] == '0') ? 0 : 1;
-  }
+
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -884,10 +763,6 @@ int mfma_split_forward(const RayenPack* p, const SplitImage* img, const float* v
                        float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
                        hipStream_t stream) {
   if (B == 0) return RAYEN_OK;
-  // one wave per SIMD with the epilogues inside the MFMA stream (rayen_mfma_split4.hip) once the batch fills the
-  // chip that way (64 samples per wave and SIMD); smaller batches and sets with equality constraints stay here
-  if (img->wave1 && mfma_split4_serves(p, img) && B >= (int64_t)img->n_simd * 64)
-    return mfma_split4_forward(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
   if (img->nkk == 1) return launch_split<1>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
   if (img->nkk == 2) return launch_split<2>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
   return RAYEN_E_UNSUPPORTED;

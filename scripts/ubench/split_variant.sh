@@ -1,6 +1,6 @@
 #!/bin/bash
 # Developer helper: rebuild only rayen_mfma_split.hip with extra flags and link it against the objects of the last
-# regular build -> scripts/ubench/variants/librayen_<name>.so     split_variant.sh noepi -DRAYEN_SPLIT_ABL=1
+# regular build -> scripts/ubench/variants/librayen_<name>.so     split_variant.sh nt1 -DSOME_EXPERIMENT=1
 REPO="$(cd "$(dirname "$0")/../.." && pwd)"
 name="$1"; shift
 out="$REPO/scripts/ubench/variants/librayen_$name.so"
