@@ -123,7 +123,7 @@ int project_generic(const RayenPack* p, const T* v, int64_t B, int64_t ldv, T* y
 template <typename T>
 int project_bwd(const RayenPack* p, const T* v, int64_t B, int64_t ldv, const T* kappa,
                 const int32_t* active, const T* grad_y, int64_t ldg, T* grad_v, int64_t ldgv, void* stream,
-                int old_mode = 0, bool force_generic = false) {
+                int old_mode = 0, bool force_generic = false, void* workspace = nullptr, int64_t workspace_bytes = 0) {
   if (p == nullptr || B < 0 || ldv < p->n + old_mode || ldg < p->k || ldgv < p->n + old_mode)
     return RAYEN_E_BAD_ARG;
   if (B > 0 && (!v || !kappa || !active || !grad_y || !grad_v)) return RAYEN_E_BAD_ARG;
@@ -137,8 +137,8 @@ int project_bwd(const RayenPack* p, const T* v, int64_t B, int64_t ldv, const T*
     }
     if (!force_generic) {
       if (p->mb32 != nullptr)
-        return mfma_backward(p, p->mb32, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode,
-                             static_cast<hipStream_t>(stream));
+        return mfma_backward(p, p->mb32, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode, workspace,
+                             workspace_bytes, static_cast<hipStream_t>(stream));
       if (p->mbg32 != nullptr)
         return mfma_bwdg_backward(p, p->mbg32, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode,
                                   static_cast<hipStream_t>(stream));
@@ -475,6 +475,20 @@ int rayen_ray_project_bwd_f32(const RayenPack* p, const float* v, int64_t B, int
                               const float* kappa, const int32_t* active, const float* grad_y,
                               int64_t ldg, float* grad_v, int64_t ldgv, void* stream) {
   return project_bwd<float>(p, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, stream);
+}
+
+int64_t rayen_bwd_workspace_bytes_f32(const RayenPack* p, int64_t B) {
+  if (p == nullptr || B <= 0 || check_ready<float>(p, true) != RAYEN_OK) return 0;
+  if (p->q32 != nullptr && lmi_quad_bwd_serves_f32(p, p->q32)) return 0;
+  return p->mb32 != nullptr ? mfma_bwd_workspace_bytes(p, p->mb32, B) : 0;
+}
+
+int rayen_ray_project_bwd_ws_f32(const RayenPack* p, const float* v, int64_t B, int64_t ldv,
+                                 const float* kappa, const int32_t* active, const float* grad_y,
+                                 int64_t ldg, float* grad_v, int64_t ldgv, void* workspace, int64_t workspace_bytes,
+                                 void* stream) {
+  return project_bwd<float>(p, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, stream, 0, false, workspace,
+                            workspace_bytes);
 }
 
 int rayen_ray_project_bwd_generic_f32(const RayenPack* p, const float* v, int64_t B, int64_t ldv,

@@ -135,9 +135,10 @@ int mfma_forward_mapped(const RayenPack* p, const MfmaImage* img, const float* x
 bool mfma_bwd_eligible(const RayenPack* p);
 int mfma_bwd_build(const RayenPack* p, MfmaBwdImage** out, int64_t* bytes);
 void mfma_bwd_free(MfmaBwdImage* img);
+int64_t mfma_bwd_workspace_bytes(const RayenPack* p, const MfmaBwdImage* img, int64_t B);
 int mfma_backward(const RayenPack* p, const MfmaBwdImage* img, const float* v, int64_t B, int64_t ldv,
                   const float* kappa, const int32_t* active, const float* grad_y, int64_t ldg, float* grad_v,
-                  int64_t ldgv, int old_mode, hipStream_t stream);
+                  int64_t ldgv, int old_mode, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
 // four-lanes-per-sample LMI kernels (rayen_lmi_quad32.hip / rayen_lmi_quad64.hip)
 bool lmi_quad_eligible_f32(const RayenPack* p);

@@ -30,18 +30,206 @@ struct MfmaBwdImage {
   f32x4* S = nullptr;      // [n_items + 1][NQ][64] float4, fragment order, one dense n_pad x n_pad form per segment
   BItem* items = nullptr;
   float* Wrow = nullptr;   // [n_rows][n_pad] row-major copy of W (gathers: linear rows, phi, c, M'beta)
+  int32_t* seg_bucket = nullptr;  // [n_segments]: 1 = linear rows, 2 + d = the d-th dense form (bucketed walk)
   int n_items = 0;
   int nkk = 0;
+  int n_dense = 0;         // dense forms = segments with tiles
+  int n_segs = 0;
   int n_simd = 1024;
   int64_t bytes = 0;
 };
 
-template <int NKK>
+// ---------------------------------------------------------------------------------------------
+// Bucketed walk.  grad kappa belongs to ONE constraint per sample, but a wave of 64 arbitrary samples meets nearly
+// every segment, so the plain kernel evaluates S_s v for EVERY dense form s (config 3: 12 tiles; 0.122 of its
+// 0.173 ms).  With the samples grouped by active segment a wave walks only its own form (2 tiles) -- or nothing,
+// for samples clipped by a linear row or not clipped at all.  Three small launches ahead of the walk, all in a
+// caller-provided workspace (no allocation, no host synchronisation):
+//   1. bucket_count_kernel   bucket of every sample (0 none | 1 linear row | 2 + d dense form d) -> per-block counts; perm := -1
+//   2. bucket_scatter_kernel offsets = running sum of the bucket totals rounded up to 64 (a wave never straddles two
+//                            buckets); perm[offset + position] = sample (the order inside a block's share of a bucket
+//                            is arbitrary, which no result depends on -- samples are independent)
+//   3. the walk, reading and writing rows through perm (whole 4 n-byte rows: the gather costs no bandwidth)
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxBuckets = 30, kBucketBlocks = 256;
+// workspace: int32 header [kBucketBlocks][32] per-block bucket counts | [kWsOffsets .. +32] padded bucket offsets; then perm
+constexpr int kWsOffsets = kBucketBlocks * 32, kWsHeader = kWsOffsets + 64;
+
+__device__ __forceinline__ int bucket_of(const float kap, const int aseg, const int32_t* __restrict__ seg_bucket) {
+  return (aseg < 0 || !(kap > 1.f)) ? 0 : seg_bucket[aseg];
+}
+
+// Block `blk` owns the samples [blk chunk, (blk + 1) chunk).  No global atomics (same-address atomics on a handful of
+// counters cost ~5 ns each and there would be thousands): the counts go to the block's own slots, and the scatter
+// kernel rebuilds every block's starting position inside every bucket from them -- which also makes the permutation
+// deterministic across blocks.
+__global__ __launch_bounds__(256) void bucket_count_kernel(const float* __restrict__ kappa,
+                                                           const int32_t* __restrict__ active, int64_t B, int64_t chunk,
+                                                           const int32_t* __restrict__ seg_bucket, int nb,
+                                                           int32_t* __restrict__ ws) {
+  __shared__ int cnt[32];
+  if (threadIdx.x < 32) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  int32_t* perm = ws + kWsHeader;
+  const int64_t total = B + 64 * (int64_t)nb;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) perm[i] = -1;
+  const int64_t lo = blockIdx.x * chunk, hi = (lo + chunk < B) ? lo + chunk : B;
+  const int lane = threadIdx.x & 63;
+  for (int64_t s0 = lo + (threadIdx.x & ~63); s0 < hi; s0 += 256) {   // wave-uniform trip count
+    const int64_t s = s0 + lane;
+    const int b = s < hi ? bucket_of(kappa[s], active[2 * s], seg_bucket) : -1;
+    for (int i = 0; i < nb; ++i) {    // one LDS atomic per wave and bucket, not per sample
+      const int c = __popcll(__ballot(b == i));
+      if (lane == 0 && c) atomicAdd(&cnt[i], c);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) ws[blockIdx.x * 32 + threadIdx.x] = cnt[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void bucket_scatter_kernel(const float* __restrict__ kappa,
+                                                             const int32_t* __restrict__ active, int64_t B, int64_t chunk,
+                                                             const int32_t* __restrict__ seg_bucket, int nb,
+                                                             int32_t* __restrict__ ws) {
+  __shared__ int table[kBucketBlocks][33];
+  __shared__ int cursor[32];
+  for (int blk = threadIdx.x; blk < (int)gridDim.x; blk += 256)
+    for (int i = 0; i < 32; ++i) table[blk][i] = ws[blk * 32 + i];
+  __syncthreads();
+  if (threadIdx.x < 32) {             // bucket threadIdx.x: samples of the blocks before this one, and of all blocks
+    int before = 0, all = 0;
+    for (int blk = 0; blk < (int)gridDim.x; ++blk) {
+      const int c = table[blk][threadIdx.x];
+      before += blk < (int)blockIdx.x ? c : 0;
+      all += c;
+    }
+    table[0][threadIdx.x] = before;   // (row 0 is dead now: every thread has read it)
+    table[1][threadIdx.x] = all;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int i = 0; i < nb; ++i) {
+      cursor[i] = run + table[0][i];  // this block's first slot in bucket i
+      if (blockIdx.x == 0) ws[kWsOffsets + i] = run;
+      run += (table[1][i] + 63) & ~63;   // buckets start on wave boundaries
+    }
+    if (blockIdx.x == 0) ws[kWsOffsets + nb] = run;
+  }
+  __syncthreads();
+  const int64_t lo = blockIdx.x * chunk, hi = (lo + chunk < B) ? lo + chunk : B;
+  const int lane = threadIdx.x & 63;
+  for (int64_t s0 = lo + (threadIdx.x & ~63); s0 < hi; s0 += 256) {
+    const int64_t s = s0 + lane;
+    const int b = s < hi ? bucket_of(kappa[s], active[2 * s], seg_bucket) : -1;
+    for (int i = 0; i < nb; ++i) {
+      const unsigned long long m = __ballot(b == i);
+      if (m == 0) continue;
+      int first = 0;
+      if (lane == 0) first = atomicAdd(&cursor[i], __popcll(m));
+      first = __shfl(first, 0);
+      if (b == i) ws[kWsHeader + first + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)s;
+    }
+  }
+}
+
+// rows of a [B, ld] matrix chosen by `rowix` (this lane's entry of the group's 64 row numbers, -1 = none) ->
+// B-operand registers, like load_rows: whole rows through the patch when they are full lines, else 16-byte pieces
+template <int NT, int NK, int LSTR>
+__device__ __forceinline__ void load_rows_ix(float (&dst)[NT][NK * 16], const float* __restrict__ src, int64_t ld,
+                                             int width, int vec, const int rowix, float (*patch)[LSTR], int lane) {
+  constexpr int NQ = NK * 4;
+  const int col = lane & 31, hi = lane >> 5;
+  if (vec && width == NK * 32) {
+    f32x4 piece[NT][NQ];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const int idx = lane + 64 * j;
+        const int s = __shfl(rowix, t * 32 + idx / (NK * 8));
+        piece[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (s >= 0) piece[t][j] = *reinterpret_cast<const f32x4*>(src + (int64_t)s * ld + 4 * (idx % (NK * 8)));
+      }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const int idx = lane + 64 * j;
+        *reinterpret_cast<f32x4*>(&patch[idx / (NK * 8)][4 * (idx % (NK * 8))]) = piece[t][j];
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(&patch[col][8 * q + 4 * hi]);
+        dst[t][4 * q + 0] = x[0];
+        dst[t][4 * q + 1] = x[1];
+        dst[t][4 * q + 2] = x[2];
+        dst[t][4 * q + 3] = x[3];
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int s = __shfl(rowix, t * 32 + col);
+      const float* row = src + (int64_t)(s >= 0 ? s : 0) * ld;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int c0 = 8 * q + 4 * hi;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dst[t][4 * q + c] = (s >= 0 && c0 + c < width) ? row[c0 + c] : 0.f;
+      }
+    }
+  }
+}
+
+template <int NT, int NK, int LSTR>
+__device__ __forceinline__ void store_rows_ix(const float (&val)[NT][NK * 16], float* __restrict__ dst, int64_t ld,
+                                              int width, int vec, const int rowix, float (*patch)[LSTR], int lane) {
+  constexpr int NQ = NK * 4;
+  const int col = lane & 31, hi = lane >> 5;
+  if (vec && width == NK * 32) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        *reinterpret_cast<f32x4*>(&patch[col][8 * q + 4 * hi]) =
+            f32x4{val[t][4 * q], val[t][4 * q + 1], val[t][4 * q + 2], val[t][4 * q + 3]};
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const int idx = lane + 64 * j;
+        const int s = __shfl(rowix, t * 32 + idx / (NK * 8));
+        const f32x4 o = *reinterpret_cast<const f32x4*>(&patch[idx / (NK * 8)][4 * (idx % (NK * 8))]);
+        if (s >= 0) *reinterpret_cast<f32x4*>(dst + (int64_t)s * ld + 4 * (idx % (NK * 8))) = o;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int s = __shfl(rowix, t * 32 + col);
+      if (s < 0) continue;
+      float* row = dst + (int64_t)s * ld;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (8 * q + 4 * hi + c < width) row[8 * q + 4 * hi + c] = val[t][4 * q + c];
+    }
+  }
+}
+
+// BUCKET: the samples come through the permutation of the bucketed walk (`ws`): a group of 64 belongs to ONE bucket
+// and walks only that bucket's tiles.
+template <int NKK, bool BUCKET>
 __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwd_kernel(
     const f32x4* __restrict__ Simg, const BItem* __restrict__ items, int n_items,
     const float* __restrict__ Wrow, int n, const float* __restrict__ v, int64_t B, int64_t ldv, int vec_v,
     const float* __restrict__ kappa, const int32_t* __restrict__ active, const float* __restrict__ gy,
-    int64_t ldg, int vec_g, float* __restrict__ gv, int64_t ldgv, int vec_o, int old_mode) {
+    int64_t ldg, int vec_g, float* __restrict__ gv, int64_t ldgv, int vec_o, int old_mode,
+    const int32_t* __restrict__ ws, int nb) {
   // two sample tiles per wave (every A fetch feeds two MFMA chains); grad_y is read twice -- once for
   // g.v, once for the final combination -- instead of occupying n/2 VGPRs per tile during the walk
   constexpr int NT = RAYEN_BWD_NT, NQ = NKK * 4, KK = NKK * 16, NP = NKK * 32, LSTR = NKK * 32 + 4;
@@ -55,7 +243,8 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwd_kern
   const int wave = threadIdx.x >> 6;
   const int col = lane & 31;
   const int hi = lane >> 5;
-  const int64_t n_groups = (B + NT * 32 - 1) / (NT * 32);
+  static_assert(!BUCKET || NT == 2, "a bucketed group is one wave of 64 samples");
+  const int64_t n_groups = BUCKET ? (int64_t)(ws[kWsOffsets + nb] / 64) : (B + NT * 32 - 1) / (NT * 32);
   const int64_t wave_id = (int64_t)blockIdx.x * kMfmaWaves + wave;
   const int64_t wave_stride = (int64_t)gridDim.x * kMfmaWaves;
   float (*patch)[LSTR] = reinterpret_cast<float (*)[LSTR]>(wave_lds[wave]);
@@ -67,12 +256,31 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwd_kern
     float vr[NT][KK], ur[NT][KK];
     float kap[NT], tv[NT], sc[NT], r_nrm[NT], e_beta[NT], part[NT];
     int aseg[NT], arow[NT];
+    int rowix = -1;        // BUCKET: this lane's entry of the group's 64 sample numbers
+    int bucket = -1;       // BUCKET: the group's bucket (wave-uniform)
+    int64_t smp_of[NT];    // the sample a lane's column holds, per tile
+    if constexpr (BUCKET) {
+      rowix = ws[kWsHeader + s_base + lane];
+      for (int i = 0; i < nb; ++i)
+        if (s_base >= ws[kWsOffsets + i]) bucket = i;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) live[t] = (s_base + t * 32 + col) < B;
-    load_rows<NT, NKK, LSTR, true>(vr, v, ldv, n, vec_v, s_base, B, live, patch, lane);
+      for (int t = 0; t < NT; ++t) {
+        smp_of[t] = __shfl(rowix, t * 32 + col);
+        live[t] = smp_of[t] >= 0;
+      }
+      load_rows_ix<NT, NKK, LSTR>(vr, v, ldv, n, vec_v, rowix, patch, lane);
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        smp_of[t] = s_base + t * 32 + col;
+        live[t] = smp_of[t] < B;
+      }
+      load_rows<NT, NKK, LSTR, true>(vr, v, ldv, n, vec_v, s_base, B, live, patch, lane);
+    }
     {
       float tr[NT][KK];
-      load_rows<NT, NKK, LSTR, true>(tr, gy, ldg, n, vec_g, s_base, B, live, patch, lane);
+      if constexpr (BUCKET) load_rows_ix<NT, NKK, LSTR>(tr, gy, ldg, n, vec_g, rowix, patch, lane);
+      else load_rows<NT, NKK, LSTR, true>(tr, gy, ldg, n, vec_g, s_base, B, live, patch, lane);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         float dot = 0.f;
@@ -90,7 +298,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwd_kern
     bool any = false;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const int64_t smp = s_base + t * 32 + col;
+      const int64_t smp = live[t] ? smp_of[t] : 0;
       kap[t] = live[t] ? kappa[smp] : 0.f;
       aseg[t] = live[t] ? active[2 * smp] : -1;
       arow[t] = live[t] ? active[2 * smp + 1] : 0;
@@ -106,7 +314,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwd_kern
         for (int i = 0; i < KK; ++i) nrm2 = fmaf(vr[t][i], vr[t][i], nrm2);
         nrm2 += xhalf(nrm2);
         r_nrm[t] = sqrtf(nrm2);
-        e_beta[t] = live[t] ? __expf(v[smp * ldv + n]) : 0.f;
+        e_beta[t] = live[t] ? __expf(v[smp * ldv + n]) : 0.f;   // (old head: never bucketed)
         clipped[t] = live[t] && aseg[t] >= 0 && r_nrm[t] > 0.f;
         sc[t] = r_nrm[t] > 0.f ? 1.f / (r_nrm[t] * e_beta[t] + kap[t]) : 0.f;
       } else {
@@ -118,8 +326,11 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwd_kern
       for (int i = 0; i < KK; ++i) ur[t][i] = 0.f;
     }
 
+    // bucketed: the tiles of this group's dense form only (bucket 2 + d = items [d NKK, (d + 1) NKK)); buckets 0 / 1 walk nothing
+    const int it_lo = BUCKET ? (bucket >= 2 ? (bucket - 2) * NKK : 0) : 0;
+    const int it_hi = BUCKET ? (bucket >= 2 ? (bucket - 1) * NKK : 0) : n_items;
     if (__ballot(any) != 0) {  // wave-uniform: a wave of interior samples skips the walk
-      const f32x4* wp = Simg + lane;
+      const f32x4* wp = Simg + lane + (size_t)it_lo * (NQ * 64);
       f32x4 buf_a[NQ], buf_b[NQ];
       auto fetch_tile = [&](f32x4 (&buf)[NQ]) {
 #pragma unroll
@@ -212,13 +423,13 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwd_kern
           for (int t = 0; t < NT; ++t) matched[t] |= sel[t];
         }
       };
-      if (n_items > 0) {
+      if (it_hi > it_lo) {
         fetch_tile(buf_a);
-        for (int it = 0; it < n_items; it += 2) {  // n_items is even (padded with a no-op tile)
-          fetch_tile(buf_b);
-          process(items[it], buf_a);
+        for (int it = it_lo; it < it_hi; it += 2) {  // n_items is even (padded with a no-op tile); a bucket's NKK tiles
+          fetch_tile(buf_b);                         // may be odd: the partner is then skipped (its fetch is a harmless
+          process(items[it], buf_a);                 // look-ahead into the next form / the spare tile)
           fetch_tile(buf_a);
-          process(items[it + 1], buf_b);
+          if (it + 1 < it_hi) process(items[it + 1], buf_b);
         }
       }
       // every quadratic / cone is in the item list: what is left is a linear row
@@ -260,14 +471,18 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwd_kern
           const float dir = r_nrm[t] > 0.f ? e_beta[t] / r_nrm[t] : 0.f;
 #pragma unroll
           for (int i = 0; i < KK; ++i) ur[t][i] = fmaf(sc[t], tr[t][i], -coef * fmaf(dir, vr[t][i], ur[t][i]));
-          if (live[t] && hi == 0) gv[(s_base + t * 32 + col) * ldgv + n] = -coef * r_nrm[t] * e_beta[t];
+          if (live[t] && hi == 0) gv[smp_of[t] * ldgv + n] = -coef * r_nrm[t] * e_beta[t];
         }
       }
     }
-    float one[NT];
+    if constexpr (BUCKET) {
+      store_rows_ix<NT, NKK, LSTR>(ur, gv, ldgv, n, vec_o, rowix, patch, lane);
+    } else {
+      float one[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) one[t] = 1.f;
-    (void)store_rows<NT, NKK, LSTR, true>(ur, one, nullptr, gv, ldgv, n, vec_o, s_base, B, live, patch, lane);
+      for (int t = 0; t < NT; ++t) one[t] = 1.f;
+      (void)store_rows<NT, NKK, LSTR, true>(ur, one, nullptr, gv, ldgv, n, vec_o, s_base, B, live, patch, lane);
+    }
   }
 }
 
@@ -292,6 +507,12 @@ int mfma_bwd_build(const RayenPack* p, MfmaBwdImage** out, int64_t* bytes) {
   MfmaBwdImage* img = new MfmaBwdImage();
   img->nkk = nkk;
   img->n_items = n_real;
+  std::vector<int32_t> seg_bucket(p->segs.size() + 1, 0);
+  for (size_t sgi = 0; sgi < p->segs.size(); ++sgi) {
+    if (bwd_quad_like(p->segs[sgi])) seg_bucket[sgi] = 2 + img->n_dense++;
+    else seg_bucket[sgi] = 1;   // linear rows
+  }
+  img->n_segs = (int)p->segs.size();
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -303,9 +524,12 @@ int mfma_bwd_build(const RayenPack* p, MfmaBwdImage** out, int64_t* bytes) {
       hipMalloc(&img->items, items.size() * sizeof(BItem)) == hipSuccess &&
       hipMemcpy(img->items, items.data(), items.size() * sizeof(BItem), hipMemcpyHostToDevice) == hipSuccess &&
       hipMalloc(&img->Wrow, wrow.size() * sizeof(float)) == hipSuccess &&
-      hipMemcpy(img->Wrow, wrow.data(), wrow.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+      hipMemcpy(img->Wrow, wrow.data(), wrow.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
+      hipMalloc(&img->seg_bucket, seg_bucket.size() * sizeof(int32_t)) == hipSuccess &&
+      hipMemcpy(img->seg_bucket, seg_bucket.data(), seg_bucket.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess;
   if (!ok) { mfma_bwd_free(img); return RAYEN_E_ALLOC; }
-  img->bytes = (int64_t)(frag.size() * sizeof(float) + items.size() * sizeof(BItem) + wrow.size() * sizeof(float));
+  img->bytes = (int64_t)(frag.size() * sizeof(float) + items.size() * sizeof(BItem) + wrow.size() * sizeof(float) +
+                         seg_bucket.size() * sizeof(int32_t));
   *bytes = img->bytes;
   *out = img;
   return RAYEN_OK;
@@ -316,32 +540,59 @@ void mfma_bwd_free(MfmaBwdImage* img) {
   if (img->S) (void)hipFree(img->S);
   if (img->items) (void)hipFree(img->items);
   if (img->Wrow) (void)hipFree(img->Wrow);
+  if (img->seg_bucket) (void)hipFree(img->seg_bucket);
   delete img;
+}
+
+// The bucketed walk pays three small launches (~10 us): worth it once the dense forms it skips cost more, i.e. from
+// two forms up and for batches that fill the chip.
+int64_t mfma_bwd_workspace_bytes(const RayenPack* p, const MfmaBwdImage* img, int64_t B) {
+  (void)p;
+  if (img == nullptr || img->n_dense < 2 || img->n_dense + 2 > kMaxBuckets || B < 32768 || B > (int64_t)2000000000) return 0;
+  return (int64_t)sizeof(int32_t) * (kWsHeader + B + 64 * (int64_t)(img->n_dense + 2));
 }
 
 template <int NKK>
 static int launch_bwd(const RayenPack* p, const MfmaBwdImage* img, const float* v, int64_t B, int64_t ldv,
                       const float* kappa, const int32_t* active, const float* gy, int64_t ldg, float* gv,
-                      int64_t ldgv, int old_mode, hipStream_t stream) {
-  const int64_t n_groups = (B + RAYEN_BWD_NT * 32 - 1) / (RAYEN_BWD_NT * 32);
+                      int64_t ldgv, int old_mode, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+  auto aligned = [](const void* ptr, int64_t ld) { return (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(ptr) & 15) == 0); };
   const int64_t slots = (int64_t)img->n_simd * kMfmaWavesPerSimd;
+  const int64_t need = old_mode ? 0 : mfma_bwd_workspace_bytes(p, img, B);
+  if (need > 0 && workspace != nullptr && workspace_bytes >= need) {
+    const int nb = img->n_dense + 2;
+    int32_t* ws = static_cast<int32_t*>(workspace);
+    const int64_t chunk = ((B + kBucketBlocks - 1) / kBucketBlocks + 255) / 256 * 256;
+    const unsigned blocks = (unsigned)((B + chunk - 1) / chunk);
+    hipLaunchKernelGGL(bucket_count_kernel, dim3(blocks), dim3(256), 0, stream, kappa, active, B, chunk, img->seg_bucket, nb, ws);
+    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(blocks), dim3(256), 0, stream, kappa, active, B, chunk, img->seg_bucket, nb, ws);
+    const int64_t max_groups = (B + 63) / 64 + nb;   // (the kernel reads the true count from the workspace)
+    const int64_t rounds = (max_groups + slots - 1) / slots;
+    const int64_t waves = (max_groups + rounds - 1) / rounds;
+    const int64_t grid = (waves + kMfmaWaves - 1) / kMfmaWaves;
+    hipLaunchKernelGGL((mfma_bwd_kernel<NKK, true>), dim3((unsigned)grid), dim3(kMfmaWaves * 64), 0, stream, img->S,
+                       img->items, img->n_items, img->Wrow, p->n, v, B, ldv, aligned(v, ldv) ? 1 : 0, kappa, active,
+                       gy, ldg, aligned(gy, ldg) ? 1 : 0, gv, ldgv, aligned(gv, ldgv) ? 1 : 0, 0, ws, nb);
+    return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
+  }
+  const int64_t n_groups = (B + RAYEN_BWD_NT * 32 - 1) / (RAYEN_BWD_NT * 32);
   const int64_t rounds = (n_groups + slots - 1) / slots;
   const int64_t waves = (n_groups + rounds - 1) / rounds;
   const int64_t grid = (waves + kMfmaWaves - 1) / kMfmaWaves;
-  auto aligned = [](const void* ptr, int64_t ld) { return (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(ptr) & 15) == 0); };
-  hipLaunchKernelGGL((mfma_bwd_kernel<NKK>), dim3((unsigned)grid), dim3(kMfmaWaves * 64), 0, stream, img->S,
+  hipLaunchKernelGGL((mfma_bwd_kernel<NKK, false>), dim3((unsigned)grid), dim3(kMfmaWaves * 64), 0, stream, img->S,
                      img->items, img->n_items, img->Wrow, p->n, v, B, ldv, aligned(v, ldv) ? 1 : 0, kappa, active,
-                     gy, ldg, aligned(gy, ldg) ? 1 : 0, gv, ldgv, aligned(gv, ldgv) ? 1 : 0, old_mode);
+                     gy, ldg, aligned(gy, ldg) ? 1 : 0, gv, ldgv, aligned(gv, ldgv) ? 1 : 0, old_mode,
+                     static_cast<const int32_t*>(nullptr), 0);
   return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
 }
 
 int mfma_backward(const RayenPack* p, const MfmaBwdImage* img, const float* v, int64_t B, int64_t ldv,
                   const float* kappa, const int32_t* active, const float* grad_y, int64_t ldg, float* grad_v,
-                  int64_t ldgv, int old_mode, hipStream_t stream) {
+                  int64_t ldgv, int old_mode, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   if (B == 0) return RAYEN_OK;
   switch (img->nkk) {
-    case 1: return launch_bwd<1>(p, img, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode, stream);
-    case 2: return launch_bwd<2>(p, img, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode, stream);
+    case 1: return launch_bwd<1>(p, img, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode, workspace, workspace_bytes, stream);
+    case 2: return launch_bwd<2>(p, img, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode, workspace, workspace_bytes, stream);
     default: return RAYEN_E_UNSUPPORTED;
   }
 }

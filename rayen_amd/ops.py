@@ -146,9 +146,11 @@ def _(v, pack_id, need_active, old_head=False):
             v.new_empty((B if need_active else 0, 2), dtype=torch.int32))
 
 
-def backward_raw(v, kappa, active, grad_y, pack, old_head=False, force_generic=False):
+def backward_raw(v, kappa, active, grad_y, pack, old_head=False, force_generic=False, bucketed=True):
     """Direct call of the backward entry points; ``force_generic`` pins the lane-per-sample kernel
-    where ``rayen_ray_project_bwd_f32/_f64`` would pick the matrix-core one."""
+    where ``rayen_ray_project_bwd_f32/_f64`` would pick the matrix-core one.  ``bucketed``: hand the library the
+    scratch buffer it asks for (``rayen_bwd_workspace_bytes_f32``) so that it may group the samples by active
+    constraint and walk only that constraint's tiles; ``False`` pins the plain walk (same results)."""
     _check_input(v, pack)
     if v.stride(1) != 1:
         v = v.contiguous()
@@ -163,10 +165,20 @@ def backward_raw(v, kappa, active, grad_y, pack, old_head=False, force_generic=F
             raise RuntimeError("force_generic selects between the two RAYEN backward kernels only")
         name = "rayen_ray_project_bwd_generic_f32" if v.dtype == torch.float32 else "rayen_ray_project_bwd_generic_f64"
     with _on_device(v.device):
-        code = getattr(_lib.load(), name)(pack.handle, _ptr(v), B, v.stride(0) if B else pack.consts.n,
-                                          _ptr(kappa), _ptr(active), _ptr(grad_y), grad_y.shape[1],
-                                          _ptr(grad_v), grad_v.stride(0) if B else pack.consts.n,
-                                          _stream(v.device.index))
+        lib = _lib.load()
+        ws_bytes = 0
+        if bucketed and not old_head and not force_generic and v.dtype == torch.float32 and B:
+            ws_bytes = int(lib.rayen_bwd_workspace_bytes_f32(pack.handle, B))
+        if ws_bytes > 0:
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=v.device)   # (torch's caching allocator: no hipMalloc)
+            code = lib.rayen_ray_project_bwd_ws_f32(pack.handle, _ptr(v), B, v.stride(0), _ptr(kappa), _ptr(active),
+                                                    _ptr(grad_y), grad_y.shape[1], _ptr(grad_v), grad_v.stride(0),
+                                                    _ptr(ws), ws_bytes, _stream(v.device.index))
+        else:
+            code = getattr(lib, name)(pack.handle, _ptr(v), B, v.stride(0) if B else pack.consts.n,
+                                      _ptr(kappa), _ptr(active), _ptr(grad_y), grad_y.shape[1],
+                                      _ptr(grad_v), grad_v.stride(0) if B else pack.consts.n,
+                                      _stream(v.device.index))
     _lib.check(code, "rayen_ray_project_bwd")
     return grad_v
 

@@ -393,3 +393,31 @@ def test_random_sets_gradients_match_oracle_autograd(seed):
     got = xg.grad[:, :, 0].cpu()
     assert torch.isfinite(got).all()
     _assert_gradient(got.numpy(), want.numpy(), cs, x, G, torch.float64, method=method, what=f"seed {seed}")
+
+
+@pytest.mark.parametrize("name,B", [("c3", 70001), ("c2", 40000), ("lowrank", 33000), ("soc_only", 50000)])
+def test_bucketed_backward_equals_the_plain_walk(name, B):
+    """Large fp32 batches of packs with several dense forms are grouped by active constraint first (three small
+    launches in a scratch buffer) and every group walks only its own form: same bits as the walk over every form,
+    whatever mix of buckets (not clipped / linear row / each form) a batch holds."""
+    from rayen_amd import _lib, ops
+    cs = workloads.build_constraints(_bwd_sets()[name])
+    layer = ConstraintModule(cs, create_map=False).cuda()
+    dp, _ = layer.device_pack(torch.device("cuda", 0))
+    assert int(_lib.load().rayen_bwd_workspace_bytes_f32(dp.handle, B)) > 0, "the pack should take the bucketed walk"
+    assert int(_lib.load().rayen_bwd_workspace_bytes_f32(dp.handle, 1000)) == 0      # small batches: plain walk
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    v = torch.empty(B, cs.n, device="cuda").uniform_(-1.5, 1.5, generator=gen)
+    v[: B // 5] *= 0.05                                     # a fifth of the batch stays inside the set (bucket 0)
+    v[B // 5: B // 5 + 3] = 0.0
+    g = torch.empty(B, cs.k, device="cuda").uniform_(-1, 1, generator=gen)
+    _, kappa, active = ops.project_raw(v, dp, want_active=True)
+    assert 0.05 < float((kappa > 1).float().mean()) < 1.0
+    want = ops.backward_raw(v, kappa, active, g, dp, bucketed=False)
+    for _ in range(2):                                      # (the scratch buffer is re-initialised by every call)
+        got = ops.backward_raw(v, kappa, active, g, dp, bucketed=True)
+        assert torch.equal(got, want)
+    # through autograd (the registered op takes the bucketed path by itself)
+    xg = v.clone().unsqueeze(2).requires_grad_(True)
+    (layer(xg)[:, :, 0] * g).sum().backward()
+    assert torch.equal(xg.grad[:, :, 0], want)
