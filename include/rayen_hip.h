@@ -171,11 +171,16 @@ int rayen_ray_project_bwd_f64(const RayenPack* pack, const double* v, int64_t B,
                               const double* grad_y, int64_t ldg,
                               double* grad_v, int64_t ldgv, void* stream);
 /* The same backward with a caller-provided scratch buffer (device memory, 16-byte aligned, contents irrelevant
- * before and after the call): rayen_bwd_workspace_bytes_f32() is what the pack can use for a batch of B (0: nothing).
+ * before and after the call): rayen_bwd_workspace_bytes_f32/_f64() is what the pack can use for a batch of B (0: nothing).
  * With it, packs made of several dense quadratic / cone forms first group the samples by the constraint that set
  * kappa (two small launches in the workspace) and evaluate, per group, only that constraint's form instead of all of
- * them (config 3: 0.17 -> 0.08 ms).  Results are the same as without; workspace = NULL is rayen_ray_project_bwd_f32. */
+ * them (config 3: 0.17 -> 0.09 ms).  Results are the same as without; workspace = NULL is rayen_ray_project_bwd_f32/_f64. */
 int64_t rayen_bwd_workspace_bytes_f32(const RayenPack* pack, int64_t B);
+int64_t rayen_bwd_workspace_bytes_f64(const RayenPack* pack, int64_t B);
+int rayen_ray_project_bwd_ws_f64(const RayenPack* pack, const double* v, int64_t B, int64_t ldv,
+                                 const double* kappa, const int32_t* active,
+                                 const double* grad_y, int64_t ldg,
+                                 double* grad_v, int64_t ldgv, void* workspace, int64_t workspace_bytes, void* stream);
 int rayen_ray_project_bwd_ws_f32(const RayenPack* pack, const float* v, int64_t B, int64_t ldv,
                                  const float* kappa, const int32_t* active,
                                  const float* grad_y, int64_t ldg,

@@ -25,6 +25,7 @@ EXPORTS = (
     "rayen_mapper_fusable", "rayen_ray_project_mapped_f32", "rayen_ray_project_bwd_generic_f32",
     "rayen_ray_project_bwd_generic_f64", "rayen_mapper_image_bytes", "rayen_mapper_prepare_f32",
     "rayen_ray_project_mapped_image_f32", "rayen_bwd_workspace_bytes_f32", "rayen_ray_project_bwd_ws_f32",
+    "rayen_bwd_workspace_bytes_f64", "rayen_ray_project_bwd_ws_f64",
 )
 
 
@@ -104,10 +105,12 @@ def load():
     lib.rayen_ray_project_mapped_f32.restype = ctypes.c_int
     lib.rayen_ray_project_mapped_f32.argtypes = [p, p, i64, i64, ctypes.c_int32, p, i64, p, p, i64, p, i64,
                                                  p, i32p, i32p, p]
-    lib.rayen_bwd_workspace_bytes_f32.restype = ctypes.c_int64
-    lib.rayen_bwd_workspace_bytes_f32.argtypes = [p, i64]
-    lib.rayen_ray_project_bwd_ws_f32.restype = ctypes.c_int
-    lib.rayen_ray_project_bwd_ws_f32.argtypes = [p, p, i64, i64, p, i32p, p, i64, p, i64, p, i64, p]
+    for name in ("rayen_bwd_workspace_bytes_f32", "rayen_bwd_workspace_bytes_f64"):
+        getattr(lib, name).restype = ctypes.c_int64
+        getattr(lib, name).argtypes = [p, i64]
+    for name in ("rayen_ray_project_bwd_ws_f32", "rayen_ray_project_bwd_ws_f64"):
+        getattr(lib, name).restype = ctypes.c_int
+        getattr(lib, name).argtypes = [p, p, i64, i64, p, i32p, p, i64, p, i64, p, i64, p]
     lib.rayen_mapper_image_bytes.restype = ctypes.c_int64
     lib.rayen_mapper_image_bytes.argtypes = [p, ctypes.c_int32]
     lib.rayen_mapper_prepare_f32.restype = ctypes.c_int

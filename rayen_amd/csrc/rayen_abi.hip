@@ -152,8 +152,8 @@ int project_bwd(const RayenPack* p, const T* v, int64_t B, int64_t ldv, const T*
     }
     if (!force_generic) {
       if (p->mb64 != nullptr)
-        return mfma64_backward(p, p->mb64, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode,
-                               static_cast<hipStream_t>(stream));
+        return mfma64_backward(p, p->mb64, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode, workspace,
+                               workspace_bytes, static_cast<hipStream_t>(stream));
       if (p->mbg64 != nullptr)
         return mfma64_bwdg_backward(p, p->mbg64, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode,
                                     static_cast<hipStream_t>(stream));
@@ -481,6 +481,20 @@ int64_t rayen_bwd_workspace_bytes_f32(const RayenPack* p, int64_t B) {
   if (p == nullptr || B <= 0 || check_ready<float>(p, true) != RAYEN_OK) return 0;
   if (p->q32 != nullptr && lmi_quad_bwd_serves_f32(p, p->q32)) return 0;
   return p->mb32 != nullptr ? mfma_bwd_workspace_bytes(p, p->mb32, B) : 0;
+}
+
+int64_t rayen_bwd_workspace_bytes_f64(const RayenPack* p, int64_t B) {
+  if (p == nullptr || B <= 0 || check_ready<double>(p, true) != RAYEN_OK) return 0;
+  if (p->q64 != nullptr && lmi_quad_bwd_serves_f64(p, p->q64)) return 0;
+  return p->mb64 != nullptr ? mfma64_bwd_workspace_bytes(p, p->mb64, B) : 0;
+}
+
+int rayen_ray_project_bwd_ws_f64(const RayenPack* p, const double* v, int64_t B, int64_t ldv,
+                                 const double* kappa, const int32_t* active, const double* grad_y,
+                                 int64_t ldg, double* grad_v, int64_t ldgv, void* workspace, int64_t workspace_bytes,
+                                 void* stream) {
+  return project_bwd<double>(p, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, stream, 0, false, workspace,
+                             workspace_bytes);
 }
 
 int rayen_ray_project_bwd_ws_f32(const RayenPack* p, const float* v, int64_t B, int64_t ldv,

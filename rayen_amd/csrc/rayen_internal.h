@@ -182,9 +182,11 @@ int lmi_quad_backward_f64(const RayenPack* p, const LmiQuadImage* img, const dou
 bool mfma64_bwd_eligible(const RayenPack* p);
 int mfma64_bwd_build(const RayenPack* p, Mfma64BwdImage** out, int64_t* bytes);
 void mfma64_bwd_free(Mfma64BwdImage* img);
+int64_t mfma64_bwd_workspace_bytes(const RayenPack* p, const Mfma64BwdImage* img, int64_t B);
 int mfma64_backward(const RayenPack* p, const Mfma64BwdImage* img, const double* v, int64_t B, int64_t ldv,
                     const double* kappa, const int32_t* active, const double* grad_y, int64_t ldg,
-                    double* grad_v, int64_t ldgv, int old_mode, hipStream_t stream);
+                    double* grad_v, int64_t ldgv, int old_mode, void* workspace, int64_t workspace_bytes,
+                    hipStream_t stream);
 
 // fp64 MFMA path (rayen_mfma_f64.hip)
 bool mfma64_eligible(const RayenPack* p);

@@ -16,6 +16,7 @@
 // gradient of kappa live in registers, n/2 VGPRs per 32 samples each).
 #include "rayen_mfma_kernel.h"
 #include "rayen_bwd_tiles.h"
+#include "rayen_bwd_bucket.h"
 
 #include <cstring>
 #include <vector>
@@ -38,100 +39,6 @@ struct MfmaBwdImage {
   int n_simd = 1024;
   int64_t bytes = 0;
 };
-
-// ---------------------------------------------------------------------------------------------
-// Bucketed walk.  grad kappa belongs to ONE constraint per sample, but a wave of 64 arbitrary samples meets nearly
-// every segment, so the plain kernel evaluates S_s v for EVERY dense form s (config 3: 12 tiles; 0.122 of its
-// 0.173 ms).  With the samples grouped by active segment a wave walks only its own form (2 tiles) -- or nothing,
-// for samples clipped by a linear row or not clipped at all.  Three small launches ahead of the walk, all in a
-// caller-provided workspace (no allocation, no host synchronisation):
-//   1. bucket_count_kernel   bucket of every sample (0 none | 1 linear row | 2 + d dense form d) -> per-block counts; perm := -1
-//   2. bucket_scatter_kernel offsets = running sum of the bucket totals rounded up to 64 (a wave never straddles two
-//                            buckets); perm[offset + position] = sample (the order inside a block's share of a bucket
-//                            is arbitrary, which no result depends on -- samples are independent)
-//   3. the walk, reading and writing rows through perm (whole 4 n-byte rows: the gather costs no bandwidth)
-// ---------------------------------------------------------------------------------------------
-constexpr int kMaxBuckets = 30, kBucketBlocks = 256;
-// workspace: int32 header [kBucketBlocks][32] per-block bucket counts | [kWsOffsets .. +32] padded bucket offsets; then perm
-constexpr int kWsOffsets = kBucketBlocks * 32, kWsHeader = kWsOffsets + 64;
-
-__device__ __forceinline__ int bucket_of(const float kap, const int aseg, const int32_t* __restrict__ seg_bucket) {
-  return (aseg < 0 || !(kap > 1.f)) ? 0 : seg_bucket[aseg];
-}
-
-// Block `blk` owns the samples [blk chunk, (blk + 1) chunk).  No global atomics (same-address atomics on a handful of
-// counters cost ~5 ns each and there would be thousands): the counts go to the block's own slots, and the scatter
-// kernel rebuilds every block's starting position inside every bucket from them -- which also makes the permutation
-// deterministic across blocks.
-__global__ __launch_bounds__(256) void bucket_count_kernel(const float* __restrict__ kappa,
-                                                           const int32_t* __restrict__ active, int64_t B, int64_t chunk,
-                                                           const int32_t* __restrict__ seg_bucket, int nb,
-                                                           int32_t* __restrict__ ws) {
-  __shared__ int cnt[32];
-  if (threadIdx.x < 32) cnt[threadIdx.x] = 0;
-  __syncthreads();
-  int32_t* perm = ws + kWsHeader;
-  const int64_t total = B + 64 * (int64_t)nb;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) perm[i] = -1;
-  const int64_t lo = blockIdx.x * chunk, hi = (lo + chunk < B) ? lo + chunk : B;
-  const int lane = threadIdx.x & 63;
-  for (int64_t s0 = lo + (threadIdx.x & ~63); s0 < hi; s0 += 256) {   // wave-uniform trip count
-    const int64_t s = s0 + lane;
-    const int b = s < hi ? bucket_of(kappa[s], active[2 * s], seg_bucket) : -1;
-    for (int i = 0; i < nb; ++i) {    // one LDS atomic per wave and bucket, not per sample
-      const int c = __popcll(__ballot(b == i));
-      if (lane == 0 && c) atomicAdd(&cnt[i], c);
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < 32) ws[blockIdx.x * 32 + threadIdx.x] = cnt[threadIdx.x];
-}
-
-__global__ __launch_bounds__(256) void bucket_scatter_kernel(const float* __restrict__ kappa,
-                                                             const int32_t* __restrict__ active, int64_t B, int64_t chunk,
-                                                             const int32_t* __restrict__ seg_bucket, int nb,
-                                                             int32_t* __restrict__ ws) {
-  __shared__ int table[kBucketBlocks][33];
-  __shared__ int cursor[32];
-  for (int blk = threadIdx.x; blk < (int)gridDim.x; blk += 256)
-    for (int i = 0; i < 32; ++i) table[blk][i] = ws[blk * 32 + i];
-  __syncthreads();
-  if (threadIdx.x < 32) {             // bucket threadIdx.x: samples of the blocks before this one, and of all blocks
-    int before = 0, all = 0;
-    for (int blk = 0; blk < (int)gridDim.x; ++blk) {
-      const int c = table[blk][threadIdx.x];
-      before += blk < (int)blockIdx.x ? c : 0;
-      all += c;
-    }
-    table[0][threadIdx.x] = before;   // (row 0 is dead now: every thread has read it)
-    table[1][threadIdx.x] = all;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int i = 0; i < nb; ++i) {
-      cursor[i] = run + table[0][i];  // this block's first slot in bucket i
-      if (blockIdx.x == 0) ws[kWsOffsets + i] = run;
-      run += (table[1][i] + 63) & ~63;   // buckets start on wave boundaries
-    }
-    if (blockIdx.x == 0) ws[kWsOffsets + nb] = run;
-  }
-  __syncthreads();
-  const int64_t lo = blockIdx.x * chunk, hi = (lo + chunk < B) ? lo + chunk : B;
-  const int lane = threadIdx.x & 63;
-  for (int64_t s0 = lo + (threadIdx.x & ~63); s0 < hi; s0 += 256) {
-    const int64_t s = s0 + lane;
-    const int b = s < hi ? bucket_of(kappa[s], active[2 * s], seg_bucket) : -1;
-    for (int i = 0; i < nb; ++i) {
-      const unsigned long long m = __ballot(b == i);
-      if (m == 0) continue;
-      int first = 0;
-      if (lane == 0) first = atomicAdd(&cursor[i], __popcll(m));
-      first = __shfl(first, 0);
-      if (b == i) ws[kWsHeader + first + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)s;
-    }
-  }
-}
 
 // rows of a [B, ld] matrix chosen by `rowix` (this lane's entry of the group's 64 row numbers, -1 = none) ->
 // B-operand registers, like load_rows: whole rows through the patch when they are full lines, else 16-byte pieces
@@ -507,11 +414,7 @@ int mfma_bwd_build(const RayenPack* p, MfmaBwdImage** out, int64_t* bytes) {
   MfmaBwdImage* img = new MfmaBwdImage();
   img->nkk = nkk;
   img->n_items = n_real;
-  std::vector<int32_t> seg_bucket(p->segs.size() + 1, 0);
-  for (size_t sgi = 0; sgi < p->segs.size(); ++sgi) {
-    if (bwd_quad_like(p->segs[sgi])) seg_bucket[sgi] = 2 + img->n_dense++;
-    else seg_bucket[sgi] = 1;   // linear rows
-  }
+  const std::vector<int32_t> seg_bucket = bucket_table(p, bwd_quad_like, &img->n_dense);
   img->n_segs = (int)p->segs.size();
   {
     hipDeviceProp_t prop;
@@ -548,8 +451,7 @@ void mfma_bwd_free(MfmaBwdImage* img) {
 // two forms up and for batches that fill the chip.
 int64_t mfma_bwd_workspace_bytes(const RayenPack* p, const MfmaBwdImage* img, int64_t B) {
   (void)p;
-  if (img == nullptr || img->n_dense < 2 || img->n_dense + 2 > kMaxBuckets || B < 32768 || B > (int64_t)2000000000) return 0;
-  return (int64_t)sizeof(int32_t) * (kWsHeader + B + 64 * (int64_t)(img->n_dense + 2));
+  return img == nullptr ? 0 : bucket_workspace_bytes(img->n_dense, img->nkk, B);
 }
 
 template <int NKK>
@@ -562,10 +464,7 @@ static int launch_bwd(const RayenPack* p, const MfmaBwdImage* img, const float* 
   if (need > 0 && workspace != nullptr && workspace_bytes >= need) {
     const int nb = img->n_dense + 2;
     int32_t* ws = static_cast<int32_t*>(workspace);
-    const int64_t chunk = ((B + kBucketBlocks - 1) / kBucketBlocks + 255) / 256 * 256;
-    const unsigned blocks = (unsigned)((B + chunk - 1) / chunk);
-    hipLaunchKernelGGL(bucket_count_kernel, dim3(blocks), dim3(256), 0, stream, kappa, active, B, chunk, img->seg_bucket, nb, ws);
-    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(blocks), dim3(256), 0, stream, kappa, active, B, chunk, img->seg_bucket, nb, ws);
+    launch_bucket_sort<float>(kappa, active, B, img->seg_bucket, nb, ws, stream);
     const int64_t max_groups = (B + 63) / 64 + nb;   // (the kernel reads the true count from the workspace)
     const int64_t rounds = (max_groups + slots - 1) / slots;
     const int64_t waves = (max_groups + rounds - 1) / rounds;

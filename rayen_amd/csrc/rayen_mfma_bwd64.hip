@@ -7,6 +7,7 @@
 // g.v, once for the final combination) and grad kappa is parked in LDS ([element][lane], written only by
 // the lanes whose segment a tile belongs to), so that the register budget is the forward kernel's.
 #include "rayen_bwd_tiles.h"
+#include "rayen_bwd_bucket.h"
 #include "rayen_internal.h"
 
 namespace rayen {
@@ -18,8 +19,10 @@ struct Mfma64BwdImage {
   f64x2* S = nullptr;      // [tile][step pair][row half][lane] x 2 doubles (rayen_mfma_f64.hip order)
   BItem* items = nullptr;
   double* Wrow = nullptr;  // [n_rows + 2][n_pad] row-major copy of W
+  int32_t* seg_bucket = nullptr;  // [n_segments]: bucket of the bucketed walk (rayen_bwd_bucket.h)
   int n_items = 0;
   int nkk = 0;
+  int n_dense = 0;
   int n_simd = 1024;
   int64_t bytes = 0;
 };
@@ -34,19 +37,21 @@ __device__ __forceinline__ double quad_sum(double x) {
   return x;
 }
 
-template <int NKK>
+// BUCKET: the samples come through the permutation of rayen_bwd_bucket.h; a group of 32 belongs to one bucket and
+// walks only that bucket's tiles (buckets start on multiples of 64).
+template <int NKK, bool BUCKET>
 __global__ __launch_bounds__(kB64Waves * 64, 2) void mfma64_bwd_kernel(
     const f64x2* __restrict__ Simg, const BItem* __restrict__ items, int n_items,
     const double* __restrict__ Wrow, int n, const double* __restrict__ v, int64_t B, int64_t ldv,
     const double* __restrict__ kappa, const int32_t* __restrict__ active, const double* __restrict__ gy,
-    int64_t ldg, double* __restrict__ gv, int64_t ldgv, int old_mode) {
+    int64_t ldg, double* __restrict__ gv, int64_t ldgv, int old_mode, const int32_t* __restrict__ ws, int nb) {
   constexpr int NS = NKK * 8, NP = NKK * 32;
   __shared__ double u_lds[kB64Waves][2][NS][64];  // grad kappa: [wave][column block][element 4 st + q][lane]
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int j = lane & 15;
   const int q = lane >> 4;
-  const int64_t n_groups = (B + 31) / 32;
+  const int64_t n_groups = BUCKET ? (int64_t)(ws[kWsOffsets + nb] / 32) : (B + 31) / 32;
   const int64_t wave_id = (int64_t)blockIdx.x * kB64Waves + wave;
   const int64_t wave_stride = (int64_t)gridDim.x * kB64Waves;
 
@@ -56,10 +61,22 @@ __global__ __launch_bounds__(kB64Waves * 64, 2) void mfma64_bwd_kernel(
     bool live[2], clipped[2], matched[2];
     double kap[2], tv[2], sc[2], r_nrm[2], e_beta[2];
     int aseg[2], arow[2];
+    int64_t smp_of[2];
+    int bucket = -1;
+    if constexpr (BUCKET) {
+      for (int i = 0; i < nb; ++i)
+        if (s_base >= ws[kWsOffsets + i]) bucket = i;
+    }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      const int64_t s = s_base + 16 * c + j;
-      live[c] = s < B;
+      int64_t s = s_base + 16 * c + j;
+      if constexpr (BUCKET) {
+        s = ws[kWsHeader + s];
+        live[c] = s >= 0;
+      } else {
+        live[c] = s < B;
+      }
+      smp_of[c] = s;
       const double* row = v + (live[c] ? s : 0) * ldv;
       const double* grow = gy + (live[c] ? s : 0) * ldg;
       double dot = 0.0, nrm2 = 0.0;
@@ -89,8 +106,10 @@ __global__ __launch_bounds__(kB64Waves * 64, 2) void mfma64_bwd_kernel(
       }
     }
 
-    if (__ballot(clipped[0] || clipped[1]) != 0 && n_items > 0) {  // a wave of interior samples skips the walk
-      const f64x2* wp = Simg + lane;
+    const int it_lo = BUCKET ? (bucket >= 2 ? (bucket - 2) * NKK : 0) : 0;
+    const int it_hi = BUCKET ? (bucket >= 2 ? (bucket - 1) * NKK : 0) : n_items;
+    if (__ballot(clipped[0] || clipped[1]) != 0 && it_hi > it_lo) {  // a wave of interior samples skips the walk
+      const f64x2* wp = Simg + lane + (size_t)it_lo * (NS * 64);
       f64x2 buf_lo[NS / 4][2], buf_hi[NS / 4][2];  // [step pair within the half][row half]
       auto fetch_half = [&](f64x2 (&buf)[NS / 4][2]) {
 #pragma unroll
@@ -104,7 +123,7 @@ __global__ __launch_bounds__(kB64Waves * 64, 2) void mfma64_bwd_kernel(
       fetch_half(buf_hi);
       double part[2] = {0.0, 0.0};
       f64x4 acc[2][2];  // [row half][column block]
-      for (int it = 0; it < n_items; ++it) {
+      for (int it = it_lo; it < it_hi; ++it) {
         const BItem item = items[it];
         if (item.type == BI_NOP) {
           fetch_half(buf_lo);
@@ -212,7 +231,7 @@ __global__ __launch_bounds__(kB64Waves * 64, 2) void mfma64_bwd_kernel(
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       if (!live[c]) continue;
-      const int64_t s = s_base + 16 * c + j;
+      const int64_t s = smp_of[c];
       const double* grow = gy + s * ldg;
       double* orow = gv + s * ldgv;
       if (!old_mode) {
@@ -250,6 +269,7 @@ void mfma64_bwd_free(Mfma64BwdImage* img) {
   if (img->S) (void)hipFree(img->S);
   if (img->items) (void)hipFree(img->items);
   if (img->Wrow) (void)hipFree(img->Wrow);
+  if (img->seg_bucket) (void)hipFree(img->seg_bucket);
   delete img;
 }
 
@@ -275,6 +295,7 @@ int mfma64_bwd_build(const RayenPack* p, Mfma64BwdImage** out, int64_t* bytes) {
   Mfma64BwdImage* img = new Mfma64BwdImage();
   img->nkk = np / 32;
   img->n_items = n_real;
+  const std::vector<int32_t> seg_bucket = bucket_table(p, bwd_quad_like, &img->n_dense);
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -286,35 +307,54 @@ int mfma64_bwd_build(const RayenPack* p, Mfma64BwdImage** out, int64_t* bytes) {
       hipMalloc(&img->items, items.size() * sizeof(BItem)) == hipSuccess &&
       hipMemcpy(img->items, items.data(), items.size() * sizeof(BItem), hipMemcpyHostToDevice) == hipSuccess &&
       hipMalloc(&img->Wrow, wrow.size() * sizeof(double)) == hipSuccess &&
-      hipMemcpy(img->Wrow, wrow.data(), wrow.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+      hipMemcpy(img->Wrow, wrow.data(), wrow.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+      hipMalloc(&img->seg_bucket, seg_bucket.size() * sizeof(int32_t)) == hipSuccess &&
+      hipMemcpy(img->seg_bucket, seg_bucket.data(), seg_bucket.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess;
   if (!ok) { mfma64_bwd_free(img); return RAYEN_E_ALLOC; }
-  img->bytes = (int64_t)(frag.size() * sizeof(double) + items.size() * sizeof(BItem) + wrow.size() * sizeof(double));
+  img->bytes = (int64_t)(frag.size() * sizeof(double) + items.size() * sizeof(BItem) + wrow.size() * sizeof(double) +
+                         seg_bucket.size() * sizeof(int32_t));
   *bytes = img->bytes;
   *out = img;
   return RAYEN_OK;
 }
 
+int64_t mfma64_bwd_workspace_bytes(const RayenPack* p, const Mfma64BwdImage* img, int64_t B) {
+  (void)p;
+  return img == nullptr ? 0 : bucket_workspace_bytes(img->n_dense, img->nkk, B);
+}
+
 template <int NKK>
 static int launch_bwd64(const RayenPack* p, const Mfma64BwdImage* img, const double* v, int64_t B, int64_t ldv,
                         const double* kappa, const int32_t* active, const double* gy, int64_t ldg, double* gv,
-                        int64_t ldgv, int old_mode, hipStream_t stream) {
-  const int64_t n_groups = (B + 31) / 32;
+                        int64_t ldgv, int old_mode, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   const int64_t slots = (int64_t)img->n_simd * 2;
+  const int64_t need = old_mode ? 0 : mfma64_bwd_workspace_bytes(p, img, B);
+  const bool bucketed = need > 0 && workspace != nullptr && workspace_bytes >= need;
+  const int nb = img->n_dense + 2;
+  int32_t* ws = static_cast<int32_t*>(workspace);
+  if (bucketed) launch_bucket_sort<double>(kappa, active, B, img->seg_bucket, nb, ws, stream);
+  const int64_t n_groups = bucketed ? (B + 31) / 32 + 2 * nb : (B + 31) / 32;   // (bucketed: the kernel reads the true count)
   const int64_t rounds = (n_groups + slots - 1) / slots;
   const int64_t waves = (n_groups + rounds - 1) / rounds;
   const int64_t grid = (waves + kB64Waves - 1) / kB64Waves;
-  hipLaunchKernelGGL((mfma64_bwd_kernel<NKK>), dim3((unsigned)grid), dim3(kB64Waves * 64), 0, stream, img->S,
-                     img->items, img->n_items, img->Wrow, p->n, v, B, ldv, kappa, active, gy, ldg, gv, ldgv,
-                     old_mode);
+  if (bucketed)
+    hipLaunchKernelGGL((mfma64_bwd_kernel<NKK, true>), dim3((unsigned)grid), dim3(kB64Waves * 64), 0, stream, img->S,
+                       img->items, img->n_items, img->Wrow, p->n, v, B, ldv, kappa, active, gy, ldg, gv, ldgv, 0,
+                       static_cast<const int32_t*>(ws), nb);
+  else
+    hipLaunchKernelGGL((mfma64_bwd_kernel<NKK, false>), dim3((unsigned)grid), dim3(kB64Waves * 64), 0, stream, img->S,
+                       img->items, img->n_items, img->Wrow, p->n, v, B, ldv, kappa, active, gy, ldg, gv, ldgv,
+                       old_mode, static_cast<const int32_t*>(nullptr), 0);
   return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
 }
 
 int mfma64_backward(const RayenPack* p, const Mfma64BwdImage* img, const double* v, int64_t B, int64_t ldv,
                     const double* kappa, const int32_t* active, const double* grad_y, int64_t ldg,
-                    double* grad_v, int64_t ldgv, int old_mode, hipStream_t stream) {
+                    double* grad_v, int64_t ldgv, int old_mode, void* workspace, int64_t workspace_bytes,
+                    hipStream_t stream) {
   if (B == 0) return RAYEN_OK;
-  if (img->nkk == 1) return launch_bwd64<1>(p, img, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode, stream);
-  if (img->nkk == 2) return launch_bwd64<2>(p, img, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode, stream);
+  if (img->nkk == 1) return launch_bwd64<1>(p, img, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode, workspace, workspace_bytes, stream);
+  if (img->nkk == 2) return launch_bwd64<2>(p, img, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode, workspace, workspace_bytes, stream);
   return RAYEN_E_UNSUPPORTED;
 }
 

@@ -167,13 +167,14 @@ def backward_raw(v, kappa, active, grad_y, pack, old_head=False, force_generic=F
     with _on_device(v.device):
         lib = _lib.load()
         ws_bytes = 0
-        if bucketed and not old_head and not force_generic and v.dtype == torch.float32 and B:
-            ws_bytes = int(lib.rayen_bwd_workspace_bytes_f32(pack.handle, B))
+        tag = "f32" if v.dtype == torch.float32 else "f64"
+        if bucketed and not old_head and not force_generic and B:
+            ws_bytes = int(getattr(lib, "rayen_bwd_workspace_bytes_" + tag)(pack.handle, B))
         if ws_bytes > 0:
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=v.device)   # (torch's caching allocator: no hipMalloc)
-            code = lib.rayen_ray_project_bwd_ws_f32(pack.handle, _ptr(v), B, v.stride(0), _ptr(kappa), _ptr(active),
-                                                    _ptr(grad_y), grad_y.shape[1], _ptr(grad_v), grad_v.stride(0),
-                                                    _ptr(ws), ws_bytes, _stream(v.device.index))
+            code = getattr(lib, "rayen_ray_project_bwd_ws_" + tag)(pack.handle, _ptr(v), B, v.stride(0), _ptr(kappa), _ptr(active),
+                                                                   _ptr(grad_y), grad_y.shape[1], _ptr(grad_v), grad_v.stride(0),
+                                                                   _ptr(ws), ws_bytes, _stream(v.device.index))
         else:
             code = getattr(lib, name)(pack.handle, _ptr(v), B, v.stride(0) if B else pack.consts.n,
                                       _ptr(kappa), _ptr(active), _ptr(grad_y), grad_y.shape[1],

@@ -395,24 +395,33 @@ def test_random_sets_gradients_match_oracle_autograd(seed):
     _assert_gradient(got.numpy(), want.numpy(), cs, x, G, torch.float64, method=method, what=f"seed {seed}")
 
 
-@pytest.mark.parametrize("name,B", [("c3", 70001), ("c2", 40000), ("lowrank", 33000), ("soc_only", 50000)])
-def test_bucketed_backward_equals_the_plain_walk(name, B):
-    """Large fp32 batches of packs with several dense forms are grouped by active constraint first (three small
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("name,B", [("c3", 70001), ("eq_free_2quad", 40000), ("lowrank", 33000), ("soc_quad", 50000)])
+def test_bucketed_backward_equals_the_plain_walk(name, B, dtype):
+    """Large batches of packs with several dense forms are grouped by active constraint first (three small
     launches in a scratch buffer) and every group walks only its own form: same bits as the walk over every form,
     whatever mix of buckets (not clipped / linear row / each form) a batch holds."""
     from rayen_amd import _lib, ops
-    cs = workloads.build_constraints(_bwd_sets()[name])
-    layer = ConstraintModule(cs, create_map=False).cuda()
+    extra = {"eq_free_2quad": workloads.random_lin_quad_soc(k=64, m=128, n_quad=2, n_soc=0, seed=66),   # 2 forms x 2 tiles
+             "soc_quad": workloads.random_lin_quad_soc(k=40, m=20, n_quad=1, n_soc=2, seed=67)}
+    cs = workloads.build_constraints(extra[name] if name in extra else _bwd_sets()[name])
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        layer = ConstraintModule(cs, create_map=False).cuda()
+    finally:
+        torch.set_default_dtype(prev)
     dp, _ = layer.device_pack(torch.device("cuda", 0))
-    assert int(_lib.load().rayen_bwd_workspace_bytes_f32(dp.handle, B)) > 0, "the pack should take the bucketed walk"
-    assert int(_lib.load().rayen_bwd_workspace_bytes_f32(dp.handle, 1000)) == 0      # small batches: plain walk
+    query = getattr(_lib.load(), "rayen_bwd_workspace_bytes_" + ("f32" if dtype == torch.float32 else "f64"))
+    assert int(query(dp.handle, B)) > 0, "the pack should take the bucketed walk"
+    assert int(query(dp.handle, 1000)) == 0                 # small batches: plain walk
     gen = torch.Generator(device="cuda").manual_seed(5)
-    v = torch.empty(B, cs.n, device="cuda").uniform_(-1.5, 1.5, generator=gen)
+    v = torch.empty(B, cs.n, device="cuda", dtype=dtype).uniform_(-1.5, 1.5, generator=gen)
     v[: B // 5] *= 0.05                                     # a fifth of the batch stays inside the set (bucket 0)
     v[B // 5: B // 5 + 3] = 0.0
-    g = torch.empty(B, cs.k, device="cuda").uniform_(-1, 1, generator=gen)
+    g = torch.empty(B, cs.k, device="cuda", dtype=dtype).uniform_(-1, 1, generator=gen)
     _, kappa, active = ops.project_raw(v, dp, want_active=True)
-    assert 0.05 < float((kappa > 1).float().mean()) < 1.0
+    assert 0.05 < float((kappa > 1).double().mean()) < 1.0
     want = ops.backward_raw(v, kappa, active, g, dp, bucketed=False)
     for _ in range(2):                                      # (the scratch buffer is re-initialised by every call)
         got = ops.backward_raw(v, kappa, active, g, dp, bucketed=True)
