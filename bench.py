@@ -58,7 +58,8 @@ def parse(argv=None):
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank projects the config's per-GPU batch | strong: the config's batch is sharded")
     ap.add_argument("--no-gather", action="store_true", help="N>1: time the projection alone (no all-gather of y)")
-    ap.add_argument("--gather", action="store_true", help=argparse.SUPPRESS)   # (round-1 flag; now the default)
+    ap.add_argument("--gather", action="store_true",
+                    help="with --force-dist on one GPU: run the all-gather step anyway (one-rank RCCL group)")
     ap.add_argument("--chunks", type=int, default=2, help="row blocks per rank whose all-gathers overlap the next block's projection")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the step from a HIP graph (auto: launch-bound batches, B*k < 2^20)")
@@ -121,12 +122,13 @@ def cpu_baseline(raw, cs, B, dtype, budget_s, rng=1.0):
                       f"(best of thread counts {sorted(rates)})"}
 
 
-def make_step(project_into, sizes, k, dtype, device, gather, chunks, group=None):
+def make_step(project_into, sizes, k, dtype, device, gather, chunks, group=None, gather_alone=False):
     """The multi-rank step ``bench.py`` times: ``rayen_amd.dist.ShardedStep`` around ``project_into(x_rows,
     out_rows)`` -- on the GPU the C-ABI projection writing straight into the gather's send buffer; in
     ``tests/test_dist_gloo.py`` a CPU stand-in, so the code the 8-GPU driver run executes is the code tested."""
     from rayen_amd.dist import ShardedStep
-    return ShardedStep(project_into, sizes, k, dtype, device, chunks=chunks, gather=gather, group=group)
+    return ShardedStep(project_into, sizes, k, dtype, device, chunks=chunks, gather=gather, group=group,
+                       gather_alone=gather_alone)
 
 
 def local_sizes(config_batch, per_gpu_batch, world, scaling):
@@ -254,7 +256,7 @@ def main():
     gen = torch.Generator(device=device).manual_seed(1000 + rank)
     x = torch.empty(B, args.mapper or cs.n, 1, device=device, dtype=dtype).uniform_(-rng, rng, generator=gen)
     dp, _ = layer.device_pack(device)
-    gather = world > 1 and not args.no_gather and not args.mapper
+    gather = (world > 1 or (args.gather and use_dist)) and not args.no_gather and not args.mapper
     graph = args.graph == "on" or (args.graph == "auto" and B * cs.k < (1 << 20) and not gather)
 
     def module_step(xx):
@@ -265,7 +267,8 @@ def main():
     def project_into(x_rows, out_rows):
         ops.project_raw(x_rows.reshape(x_rows.shape[0], -1), dp, want_active=False, want_kappa=False, out=out_rows)
 
-    sharded = make_step(project_into, sizes, cs.k, dtype, device, gather=True, chunks=args.chunks) if gather else None
+    sharded = make_step(project_into, sizes, cs.k, dtype, device, gather=True, chunks=args.chunks,
+                        gather_alone=True) if gather else None
 
     _note(f"{args.config} {args.dtype} B={B} per GPU, world {world}, graph={graph}, gather={gather}")
     with torch.no_grad():
@@ -361,7 +364,7 @@ def main():
             "violations_gt_1e-6": int(max_violation > 1e-6),
             "roofline": roof,
         }
-        if world > 1:
+        if world > 1 or gather:
             out["no_gather"] = {"value": total_rows * args.steps / elapsed_p, "unit": "projections/s",
                                 "ms_per_step": elapsed_p / args.steps * 1e3,
                                 "what": "the projection alone on every rank (no collective), same inputs and step count"}

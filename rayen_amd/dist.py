@@ -50,7 +50,7 @@ class ShardedStep:
     for fixed per-rank work).  Buffers are allocated once, here; a step allocates nothing.
     """
 
-    def __init__(self, project_into, sizes, k, dtype, device, chunks=4, gather=True, group=None):
+    def __init__(self, project_into, sizes, k, dtype, device, chunks=4, gather=True, group=None, gather_alone=False):
         self.project_into = project_into
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -60,7 +60,8 @@ class ShardedStep:
         self.sizes = [int(s) for s in sizes]
         self.n_local = self.sizes[self.rank]
         self.k = int(k)
-        self.gather = bool(gather) and self.world > 1
+        # (gather_alone: issue the collective even in a one-rank group -- exercises the RCCL path on a single GPU)
+        self.gather = bool(gather) and (self.world > 1 or (gather_alone and dist.is_initialized()))
         max_rows = max(self.sizes) if self.sizes else 0
         self.chunks = max(1, min(int(chunks), max_rows)) if self.gather else 1
         self.rows = -(-max_rows // self.chunks) if max_rows else 0          # rows per chunk (last one ragged)
