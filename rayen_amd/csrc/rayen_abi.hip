@@ -140,8 +140,8 @@ int project_bwd(const RayenPack* p, const T* v, int64_t B, int64_t ldv, const T*
         return mfma_backward(p, p->mb32, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode, workspace,
                              workspace_bytes, static_cast<hipStream_t>(stream));
       if (p->mbg32 != nullptr)
-        return mfma_bwdg_backward(p, p->mbg32, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode,
-                                  static_cast<hipStream_t>(stream));
+        return mfma_bwdg_backward(p, p->mbg32, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode, workspace,
+                                  workspace_bytes, static_cast<hipStream_t>(stream));
     }
   }
   if constexpr (sizeof(T) == 8) {
@@ -480,7 +480,8 @@ int rayen_ray_project_bwd_f32(const RayenPack* p, const float* v, int64_t B, int
 int64_t rayen_bwd_workspace_bytes_f32(const RayenPack* p, int64_t B) {
   if (p == nullptr || B <= 0 || check_ready<float>(p, true) != RAYEN_OK) return 0;
   if (p->q32 != nullptr && lmi_quad_bwd_serves_f32(p, p->q32)) return 0;
-  return p->mb32 != nullptr ? mfma_bwd_workspace_bytes(p, p->mb32, B) : 0;
+  if (p->mb32 != nullptr) return mfma_bwd_workspace_bytes(p, p->mb32, B);
+  return p->mbg32 != nullptr ? mfma_bwdg_workspace_bytes(p, p->mbg32, B) : 0;
 }
 
 int64_t rayen_bwd_workspace_bytes_f64(const RayenPack* p, int64_t B) {

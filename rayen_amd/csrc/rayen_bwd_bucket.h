@@ -3,6 +3,7 @@
 #pragma once
 
 #include "rayen_internal.h"
+#include "rayen_mfma_kernel.h"
 
 namespace rayen {
 
@@ -103,12 +104,105 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(const T* __restrict
   }
 }
 
+// rows of a [B, ld] matrix chosen by `rowix` (this lane's entry of the group's 64 row numbers, -1 = none) ->
+// B-operand registers, like load_rows: whole rows through the patch when they are full lines, else 16-byte pieces
+template <int NT, int NK, int LSTR>
+__device__ __forceinline__ void load_rows_ix(float (&dst)[NT][NK * 16], const float* __restrict__ src, int64_t ld,
+                                             int width, int vec, const int rowix, float (*patch)[LSTR], int lane) {
+  constexpr int NQ = NK * 4;
+  const int col = lane & 31, hi = lane >> 5;
+  if (vec && width == NK * 32) {
+    f32x4 piece[NT][NQ];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const int idx = lane + 64 * j;
+        const int s = __shfl(rowix, t * 32 + idx / (NK * 8));
+        piece[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (s >= 0) piece[t][j] = *reinterpret_cast<const f32x4*>(src + (int64_t)s * ld + 4 * (idx % (NK * 8)));
+      }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const int idx = lane + 64 * j;
+        *reinterpret_cast<f32x4*>(&patch[idx / (NK * 8)][4 * (idx % (NK * 8))]) = piece[t][j];
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(&patch[col][8 * q + 4 * hi]);
+        dst[t][4 * q + 0] = x[0];
+        dst[t][4 * q + 1] = x[1];
+        dst[t][4 * q + 2] = x[2];
+        dst[t][4 * q + 3] = x[3];
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int s = __shfl(rowix, t * 32 + col);
+      const float* row = src + (int64_t)(s >= 0 ? s : 0) * ld;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int c0 = 8 * q + 4 * hi;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dst[t][4 * q + c] = (s >= 0 && c0 + c < width) ? row[c0 + c] : 0.f;
+      }
+    }
+  }
+}
+
+template <int NT, int NK, int LSTR>
+__device__ __forceinline__ void store_rows_ix(const float (&val)[NT][NK * 16], float* __restrict__ dst, int64_t ld,
+                                              int width, int vec, const int rowix, float (*patch)[LSTR], int lane) {
+  constexpr int NQ = NK * 4;
+  const int col = lane & 31, hi = lane >> 5;
+  if (vec && width == NK * 32) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        *reinterpret_cast<f32x4*>(&patch[col][8 * q + 4 * hi]) =
+            f32x4{val[t][4 * q], val[t][4 * q + 1], val[t][4 * q + 2], val[t][4 * q + 3]};
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const int idx = lane + 64 * j;
+        const int s = __shfl(rowix, t * 32 + idx / (NK * 8));
+        const f32x4 o = *reinterpret_cast<const f32x4*>(&patch[idx / (NK * 8)][4 * (idx % (NK * 8))]);
+        if (s >= 0) *reinterpret_cast<f32x4*>(dst + (int64_t)s * ld + 4 * (idx % (NK * 8))) = o;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int s = __shfl(rowix, t * 32 + col);
+      if (s < 0) continue;
+      float* row = dst + (int64_t)s * ld;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (8 * q + 4 * hi + c < width) row[8 * q + 4 * hi + c] = val[t][4 * q + c];
+    }
+  }
+}
+
 // bytes of workspace the bucketed walk of a pack with `n_dense` dense forms of `nkk` tiles each wants for a batch of
 // B (0: plain walk).  The grouping costs two small launches (~10 us): it pays from four tiles of walk up (measured:
 // 2 forms x 2 tiles 0.095 -> 0.080 ms, 6 x 2 0.173 -> 0.093 ms; 2 x 1 loses) and for batches that fill the chip.
 inline int64_t bucket_workspace_bytes(int n_dense, int nkk, int64_t B) {
   if (n_dense < 2 || n_dense * nkk < 4 || n_dense + 2 > kMaxBuckets || B < 32768 || B > (int64_t)2000000000) return 0;
   return (int64_t)sizeof(int32_t) * (kWsHeader + B + 64 * (int64_t)(n_dense + 2));
+}
+// the same for a walk made of `n_groups` item groups (dense forms and packed tile pairs) with `n_tiles` tiles in all
+inline int64_t bucket_workspace_bytes_groups(int n_groups, int n_tiles, int64_t B) {
+  if (n_groups < 2 || n_tiles < 4 || n_groups + 2 > kMaxBuckets || B < 32768 || B > (int64_t)2000000000) return 0;
+  return (int64_t)sizeof(int32_t) * (kWsHeader + B + 64 * (int64_t)(n_groups + 2));
 }
 
 // seg -> bucket table of a pack: 1 = linear rows, 2 + d = the d-th segment with a dense form

@@ -112,7 +112,13 @@ struct BPack {
 // empty) and `seg_aux` ([n_segments + 1]: W row of phi for factor segments, -1 otherwise); returns the
 // number of items the kernel walks (even).
 inline int layout_bwdg_tiles(const RayenPack* p, TileLayout& b, std::vector<BItem>& items,
-                             std::vector<BPack>& packs, std::vector<int32_t>& seg_aux) {
+                             std::vector<BPack>& packs, std::vector<int32_t>& seg_aux,
+                             std::vector<int32_t>* seg_group = nullptr, std::vector<int32_t>* group_items = nullptr) {
+  // seg_group[s]: index of the item group that serves segment s (-1: none: linear rows) and group_items[2 g], [2 g + 1]:
+  // that group's item range -- a dense form's row tiles, or the PACK1 / PACK2 pair of a packed tile (the bucketed walk)
+  if (seg_group) seg_group->assign(p->segs.size() + 1, -1);
+  if (group_items) group_items->clear();
+  std::vector<size_t> in_pack;
   const int n = p->n, np = n_pad_of(n), nkk = np / 32;
   const double* W = p->W.data();
   seg_aux.assign(p->segs.size() + 1, -1);
@@ -135,6 +141,11 @@ inline int layout_bwdg_tiles(const RayenPack* p, TileLayout& b, std::vector<BIte
           for (int j = 0; j < n; ++j) S[(size_t)i * n + j] += row[i] * row[j];
         }
       }
+    }
+    if (seg_group && group_items) {
+      (*seg_group)[s] = (int32_t)(group_items->size() / 2);
+      group_items->push_back((int32_t)items.size());
+      group_items->push_back((int32_t)items.size() + nkk);
     }
     for (int tp = 0; tp < nkk; ++tp) {
       std::vector<const double*> rows;
@@ -166,6 +177,12 @@ inline int layout_bwdg_tiles(const RayenPack* p, TileLayout& b, std::vector<BIte
     };
     auto flush = [&]() {
       if (used == 0) return;
+      if (seg_group && group_items) {
+        for (size_t sidx : in_pack) (*seg_group)[sidx] = (int32_t)(group_items->size() / 2);
+        group_items->push_back((int32_t)items.size());
+        group_items->push_back((int32_t)items.size() + 2);
+      }
+      in_pack.clear();
       BItem it1 = blank(BI_PACK1);
       it1.aux_row = (int32_t)packs.size();
       items.push_back(it1);
@@ -196,6 +213,7 @@ inline int layout_bwdg_tiles(const RayenPack* p, TileLayout& b, std::vector<BIte
       pk.seg[a][h] = (int32_t)s;
       if (pair) { pk.seg[a][1] = (int32_t)s; pk.pair_bits |= 1 << a; }
       used += pair ? 2 : 1;
+      in_pack.push_back(s);
     }
     flush();
   }

@@ -157,9 +157,11 @@ int lmi_quad_forward_f64(const RayenPack* p, const LmiQuadImage* img, const doub
 bool mfma_bwdg_eligible(const RayenPack* p);
 int mfma_bwdg_build(const RayenPack* p, MfmaBwdgImage** out, int64_t* bytes);
 void mfma_bwdg_free(MfmaBwdgImage* img);
+int64_t mfma_bwdg_workspace_bytes(const RayenPack* p, const MfmaBwdgImage* img, int64_t B);
 int mfma_bwdg_backward(const RayenPack* p, const MfmaBwdgImage* img, const float* v, int64_t B, int64_t ldv,
                        const float* kappa, const int32_t* active, const float* grad_y, int64_t ldg,
-                       float* grad_v, int64_t ldgv, int old_mode, hipStream_t stream);
+                       float* grad_v, int64_t ldgv, int old_mode, void* workspace, int64_t workspace_bytes,
+                       hipStream_t stream);
 
 // its fp64 twin (rayen_mfma_bwdg64.hip)
 bool mfma64_bwdg_eligible(const RayenPack* p);

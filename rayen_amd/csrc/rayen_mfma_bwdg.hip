@@ -16,6 +16,7 @@
 // Only the lane's own segment survives the mask, so u = U_s'(U_s v)/||U_s v||; phi_s is a row gather.
 #include "rayen_bwd_tiles.h"
 #include "rayen_mfma_kernel.h"
+#include "rayen_bwd_bucket.h"
 
 #include <cstring>
 #include <vector>
@@ -29,17 +30,23 @@ struct MfmaBwdgImage {
   BPack* packs = nullptr;
   int32_t* seg_aux = nullptr;  // [n_segments] W row of phi for factor segments, -1 otherwise
   float* Wrow = nullptr;     // [n_rows + 2][n_pad]
+  int32_t* seg_bucket = nullptr;    // [n_segments]: bucket of the bucketed walk (1 linear rows, 2 + g item group g)
+  int32_t* group_items = nullptr;   // [n_groups][2]: item range of every group (a dense form / one packed tile pair)
   int n_items = 0, nkk = 0, nkg = 0, n_simd = 1024;
+  int n_groups = 0, n_group_tiles = 0;
   int64_t bytes = 0;
 };
 
-template <int NKK, int NKG>
+// BUCKET: the samples come through the permutation of rayen_bwd_bucket.h (grouped by the item group that serves their
+// active constraint): a group of NT x 32 walks only that item group's tiles (config 5: one packed tile pair of nine).
+template <int NKK, int NKG, bool BUCKET>
 __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwdg_kernel(
     const f32x4* __restrict__ Simg, const f32x4* __restrict__ NTimg, const BItem* __restrict__ items, int n_items,
     const BPack* __restrict__ packs, const int32_t* __restrict__ seg_aux, const float* __restrict__ Wrow, int n,
     int k, const float* __restrict__ v, int64_t B, int64_t ldv, int vec_v, const float* __restrict__ kappa,
     const int32_t* __restrict__ active, const float* __restrict__ gy, int64_t ldg, int vec_g,
-    float* __restrict__ gv, int64_t ldgv, int vec_o, int old_mode) {
+    float* __restrict__ gv, int64_t ldgv, int vec_o, int old_mode, const int32_t* __restrict__ ws, int nb,
+    const int32_t* __restrict__ group_items) {
   constexpr int NT = NKK == 1 ? 2 : 1;  // two 32-column blocks of v leave registers for one sample tile only
   constexpr int NQ = NKK * 4, KK = NKK * 16, NP = NKK * 32;
   constexpr int NKL = NKG > NKK ? NKG : NKK, LSTR = NKL * 32 + 4;
@@ -50,7 +57,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwdg_ker
   const int wave = threadIdx.x >> 6;
   const int col = lane & 31;
   const int hi = lane >> 5;
-  const int64_t n_groups = (B + NT * 32 - 1) / (NT * 32);
+  const int64_t n_groups = BUCKET ? (int64_t)(ws[kWsOffsets + nb] / (NT * 32)) : (B + NT * 32 - 1) / (NT * 32);
   const int64_t wave_id = (int64_t)blockIdx.x * kMfmaWaves + wave;
   const int64_t wave_stride = (int64_t)gridDim.x * kMfmaWaves;
   float (*patch)[LSTR] = line_lds[wave];
@@ -63,17 +70,36 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwdg_ker
     f32x16 u16[NT][NKK];
     float kap[NT], tv[NT], sc[NT], r_nrm[NT], e_beta[NT], part[NT];
     int aseg[NT], arow[NT];
+    int rowix = -1, bucket = -1;
+    int64_t smp_of[NT];
+    if constexpr (BUCKET) {
+      rowix = lane < NT * 32 ? ws[kWsHeader + s_base + lane] : -1;
+      for (int i = 0; i < nb; ++i)
+        if (s_base >= ws[kWsOffsets + i]) bucket = i;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) live[t] = (s_base + t * 32 + col) < B;
-    load_rows<NT, NKK, LSTR, true>(vr, v, ldv, n, vec_v, s_base, B, live, patch, lane);
+      for (int t = 0; t < NT; ++t) {
+        smp_of[t] = __shfl(rowix, t * 32 + col);
+        live[t] = smp_of[t] >= 0;
+      }
+      load_rows_ix<NT, NKK, LSTR>(vr, v, ldv, n, vec_v, rowix, patch, lane);
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        smp_of[t] = s_base + t * 32 + col;
+        live[t] = smp_of[t] < B;
+      }
+      load_rows<NT, NKK, LSTR, true>(vr, v, ldv, n, vec_v, s_base, B, live, patch, lane);
+    }
 
     // t = NA_E' g (or g itself), in the register layout of v
     auto pull_back = [&](float (&tr)[NT][KK]) {
       if constexpr (NKG == 0) {
-        load_rows<NT, NKK, LSTR, true>(tr, gy, ldg, n, vec_g, s_base, B, live, patch, lane);
+        if constexpr (BUCKET) load_rows_ix<NT, NKK, LSTR>(tr, gy, ldg, n, vec_g, rowix, patch, lane);
+        else load_rows<NT, NKK, LSTR, true>(tr, gy, ldg, n, vec_g, s_base, B, live, patch, lane);
       } else {
         float gr[NT][KG];
-        load_rows<NT, NKG, LSTR, true>(gr, gy, ldg, k, vec_g, s_base, B, live, patch, lane);
+        if constexpr (BUCKET) load_rows_ix<NT, NKG, LSTR>(gr, gy, ldg, k, vec_g, rowix, patch, lane);
+        else load_rows<NT, NKG, LSTR, true>(gr, gy, ldg, k, vec_g, s_base, B, live, patch, lane);
 #pragma unroll
         for (int tp = 0; tp < NKK; ++tp) {
           f32x4 a[NQG];
@@ -109,7 +135,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwdg_ker
     bool any = false;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const int64_t smp = s_base + t * 32 + col;
+      const int64_t smp = live[t] ? smp_of[t] : 0;
       kap[t] = live[t] ? kappa[smp] : 0.f;
       aseg[t] = live[t] ? active[2 * smp] : -1;
       arow[t] = live[t] ? active[2 * smp + 1] : 0;
@@ -136,8 +162,11 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwdg_ker
       for (int tp = 0; tp < NKK; ++tp) u16[t][tp] = zero;
     }
 
-    if (__ballot(any) != 0 && n_items > 0) {  // wave-uniform: a wave of interior samples skips the walk
-      const f32x4* wp = Simg + lane;
+    // bucketed: the items of this group's bucket only (buckets 0 / 1: not clipped / a linear row -- nothing to walk)
+    const int it_lo = BUCKET ? (bucket >= 2 ? group_items[2 * (bucket - 2)] : 0) : 0;
+    const int it_hi = BUCKET ? (bucket >= 2 ? group_items[2 * (bucket - 2) + 1] : 0) : n_items;
+    if (__ballot(any) != 0 && it_hi > it_lo) {  // wave-uniform: a wave of interior samples skips the walk
+      const f32x4* wp = Simg + lane + (size_t)it_lo * (NQ * 64);
       f32x4 buf_a[NQ], buf_b[NQ];
       f32x16 wreg[NT];  // step-1 result of a packed tile, masked and scaled: the B operand of step 2
       auto fetch_tile = [&](f32x4 (&buf)[NQ]) {
@@ -269,11 +298,11 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwdg_ker
         }
       };
       fetch_tile(buf_a);
-      for (int it = 0; it < n_items; it += 2) {  // n_items is even (padded with a no-op tile)
+      for (int it = it_lo; it < it_hi; it += 2) {  // (an odd count: the partner's fetch is a harmless look-ahead)
         fetch_tile(buf_b);
         process(items[it], buf_a);
         fetch_tile(buf_a);
-        process(items[it + 1], buf_b);
+        if (it + 1 < it_hi) process(items[it + 1], buf_b);
       }
     }
     // a packed quadratic still needs its phi; what matched nothing at all is a linear row
@@ -311,14 +340,18 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwdg_ker
 #pragma unroll
           for (int i = 0; i < KK; ++i)
             out[t][i] = fmaf(sc[t], tr[t][i], -coef * fmaf(dir, vr[t][i], u16[t][i / 16][i % 16]));
-          if (live[t] && hi == 0) gv[(s_base + t * 32 + col) * ldgv + n] = -coef * r_nrm[t] * e_beta[t];
+          if (live[t] && hi == 0) gv[smp_of[t] * ldgv + n] = -coef * r_nrm[t] * e_beta[t];
         }
       }
     }
-    float one[NT];
+    if constexpr (BUCKET) {
+      store_rows_ix<NT, NKK, LSTR>(out, gv, ldgv, n, vec_o, rowix, patch, lane);
+    } else {
+      float one[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) one[t] = 1.f;
-    (void)store_rows<NT, NKK, LSTR, true>(out, one, nullptr, gv, ldgv, n, vec_o, s_base, B, live, patch, lane);
+      for (int t = 0; t < NT; ++t) one[t] = 1.f;
+      (void)store_rows<NT, NKK, LSTR, true>(out, one, nullptr, gv, ldgv, n, vec_o, s_base, B, live, patch, lane);
+    }
   }
 }
 
@@ -336,6 +369,8 @@ void mfma_bwdg_free(MfmaBwdgImage* img) {
   if (img->packs) (void)hipFree(img->packs);
   if (img->seg_aux) (void)hipFree(img->seg_aux);
   if (img->Wrow) (void)hipFree(img->Wrow);
+  if (img->seg_bucket) (void)hipFree(img->seg_bucket);
+  if (img->group_items) (void)hipFree(img->group_items);
   delete img;
 }
 
@@ -354,9 +389,16 @@ int mfma_bwdg_build(const RayenPack* p, MfmaBwdgImage** out, int64_t* bytes) {
   std::vector<BItem> items;
   std::vector<BPack> packs;
   std::vector<int32_t> seg_aux;
-  const int n_real = layout_bwdg_tiles(p, b, items, packs, seg_aux);
+  std::vector<int32_t> seg_group, group_items;
+  const int n_real = layout_bwdg_tiles(p, b, items, packs, seg_aux, &seg_group, &group_items);
+  std::vector<int32_t> seg_bucket(p->segs.size() + 1, 1);       // 1 = linear rows
+  for (size_t sgi = 0; sgi < p->segs.size(); ++sgi)
+    if (seg_group[sgi] >= 0) seg_bucket[sgi] = 2 + seg_group[sgi];
+  if (group_items.empty()) group_items.assign(2, 0);
 
   MfmaBwdgImage* img = new MfmaBwdgImage();
+  img->n_groups = (int)(group_items.size() / 2) - (n_real == 0 ? 1 : 0);
+  for (int gi = 0; gi < img->n_groups; ++gi) img->n_group_tiles += group_items[2 * gi + 1] - group_items[2 * gi];
   img->nkk = nkk;
   img->nkg = p->out_identity ? 0 : n_pad_of(k) / 32;
   img->n_items = n_real;
@@ -376,7 +418,8 @@ int mfma_bwdg_build(const RayenPack* p, MfmaBwdgImage** out, int64_t* bytes) {
     img->S = reinterpret_cast<f32x4*>(d);
   }
   ok = ok && upload_vec(wrow, &img->Wrow, &img->bytes) && upload_vec(items, &img->items, &img->bytes) &&
-       upload_vec(packs, &img->packs, &img->bytes) && upload_vec(seg_aux, &img->seg_aux, &img->bytes);
+       upload_vec(packs, &img->packs, &img->bytes) && upload_vec(seg_aux, &img->seg_aux, &img->bytes) &&
+       upload_vec(seg_bucket, &img->seg_bucket, &img->bytes) && upload_vec(group_items, &img->group_items, &img->bytes);
   if (ok && !p->out_identity) {
     // NA_E' : rows = the n subspace coordinates, K = the k ambient coordinates
     TileLayout bn(k);
@@ -399,31 +442,50 @@ int mfma_bwdg_build(const RayenPack* p, MfmaBwdgImage** out, int64_t* bytes) {
   return RAYEN_OK;
 }
 
+int64_t mfma_bwdg_workspace_bytes(const RayenPack* p, const MfmaBwdgImage* img, int64_t B) {
+  (void)p;
+  return img == nullptr ? 0 : bucket_workspace_bytes_groups(img->n_groups, img->n_group_tiles, B);
+}
+
 template <int NKK, int NKG>
 static int launch_bwdg(const RayenPack* p, const MfmaBwdgImage* img, const float* v, int64_t B, int64_t ldv,
                        const float* kappa, const int32_t* active, const float* gy, int64_t ldg, float* gv,
-                       int64_t ldgv, int old_mode, hipStream_t stream) {
+                       int64_t ldgv, int old_mode, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   constexpr int per_wave = NKK == 1 ? 64 : 32;
-  const int64_t n_groups = (B + per_wave - 1) / per_wave;
+  const int64_t need = old_mode ? 0 : mfma_bwdg_workspace_bytes(p, img, B);
+  const bool bucketed = need > 0 && workspace != nullptr && workspace_bytes >= need;
+  const int nb = img->n_groups + 2;
+  int32_t* ws = static_cast<int32_t*>(workspace);
+  if (bucketed) launch_bucket_sort<float>(kappa, active, B, img->seg_bucket, nb, ws, stream);
+  const int64_t n_groups = (B + per_wave - 1) / per_wave + (bucketed ? (64 / per_wave) * nb : 0);
   const int64_t slots = (int64_t)img->n_simd * kMfmaWavesPerSimd;
   const int64_t rounds = (n_groups + slots - 1) / slots;
   const int64_t waves = (n_groups + rounds - 1) / rounds;
   const int64_t grid = (waves + kMfmaWaves - 1) / kMfmaWaves;
   auto aligned = [](const void* ptr, int64_t ld) { return (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(ptr) & 15) == 0); };
-  hipLaunchKernelGGL((mfma_bwdg_kernel<NKK, NKG>), dim3((unsigned)grid), dim3(kMfmaWaves * 64), 0, stream, img->S,
-                     img->NT, img->items, img->n_items, img->packs, img->seg_aux, img->Wrow, p->n, p->k, v, B, ldv,
-                     aligned(v, ldv) ? 1 : 0, kappa, active, gy, ldg, aligned(gy, ldg) ? 1 : 0, gv, ldgv,
-                     aligned(gv, ldgv) ? 1 : 0, old_mode);
+  if (bucketed)
+    hipLaunchKernelGGL((mfma_bwdg_kernel<NKK, NKG, true>), dim3((unsigned)grid), dim3(kMfmaWaves * 64), 0, stream, img->S,
+                       img->NT, img->items, img->n_items, img->packs, img->seg_aux, img->Wrow, p->n, p->k, v, B, ldv,
+                       aligned(v, ldv) ? 1 : 0, kappa, active, gy, ldg, aligned(gy, ldg) ? 1 : 0, gv, ldgv,
+                       aligned(gv, ldgv) ? 1 : 0, 0, static_cast<const int32_t*>(ws), nb, img->group_items);
+  else
+    hipLaunchKernelGGL((mfma_bwdg_kernel<NKK, NKG, false>), dim3((unsigned)grid), dim3(kMfmaWaves * 64), 0, stream, img->S,
+                       img->NT, img->items, img->n_items, img->packs, img->seg_aux, img->Wrow, p->n, p->k, v, B, ldv,
+                       aligned(v, ldv) ? 1 : 0, kappa, active, gy, ldg, aligned(gy, ldg) ? 1 : 0, gv, ldgv,
+                       aligned(gv, ldgv) ? 1 : 0, old_mode, static_cast<const int32_t*>(nullptr), 0,
+                       static_cast<const int32_t*>(nullptr));
   return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
 }
 
 int mfma_bwdg_backward(const RayenPack* p, const MfmaBwdgImage* img, const float* v, int64_t B, int64_t ldv,
                        const float* kappa, const int32_t* active, const float* grad_y, int64_t ldg,
-                       float* grad_v, int64_t ldgv, int old_mode, hipStream_t stream) {
+                       float* grad_v, int64_t ldgv, int old_mode, void* workspace, int64_t workspace_bytes,
+                       hipStream_t stream) {
   if (B == 0) return RAYEN_OK;
 #define RAYEN_BWDG_CASE(A, G) \
   if (img->nkk == A && img->nkg == G) \
-    return launch_bwdg<A, G>(p, img, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode, stream);
+    return launch_bwdg<A, G>(p, img, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode, workspace, \
+                             workspace_bytes, stream);
   RAYEN_BWDG_CASE(1, 0)
   RAYEN_BWDG_CASE(1, 1)
   RAYEN_BWDG_CASE(1, 2)

@@ -395,8 +395,14 @@ def test_random_sets_gradients_match_oracle_autograd(seed):
     _assert_gradient(got.numpy(), want.numpy(), cs, x, G, torch.float64, method=method, what=f"seed {seed}")
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
-@pytest.mark.parametrize("name,B", [("c3", 70001), ("eq_free_2quad", 40000), ("lowrank", 33000), ("soc_quad", 50000)])
+@pytest.mark.parametrize("name,B,dtype", [
+    ("c3", 70001, torch.float32), ("eq_free_2quad", 40000, torch.float32), ("lowrank", 33000, torch.float32),
+    ("soc_quad", 50000, torch.float32),
+    ("c3", 70001, torch.float64), ("eq_free_2quad", 40000, torch.float64), ("lowrank", 33000, torch.float64),
+    ("soc_quad", 50000, torch.float64),
+    # the general fp32 backward (equality constraints / packed low-rank quadratics): buckets = packed tile pairs + dense forms
+    ("c5", 66000, torch.float32), ("eq_packed_n50", 40000, torch.float32), ("many_packed", 50000, torch.float32),
+    ("packed_identity", 33333, torch.float32), ("eq_dense", 45000, torch.float32)])
 def test_bucketed_backward_equals_the_plain_walk(name, B, dtype):
     """Large batches of packs with several dense forms are grouped by active constraint first (three small
     launches in a scratch buffer) and every group walks only its own form: same bits as the walk over every form,
