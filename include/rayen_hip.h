@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define RAYEN_ABI_VERSION 2
+#define RAYEN_ABI_VERSION 3
 
 enum {
   RAYEN_OK = 0,
@@ -99,23 +99,27 @@ typedef struct RayenPackDesc {
   const double* NA_E;           /* HOST [k, n] row-major; may be NULL when out_identity */
   const double* y0;             /* HOST [k] */
   int32_t prepare;              /* RAYEN_PREPARE_* bits; 0 = all families */
-  int32_t fp32_mode;            /* fp32 forward, n <= 64, no LMI: 0 = split-operand kernel where the creation-time
-                                   accuracy measurement accepts it (default) | 1 = exact-fp32 MFMA kernels only |
-                                   2 = split-operand kernel without the measurement */
+  int32_t fp32_mode;            /* which family serves the fp32 forward of a set without LMI, n <= 64.  0 (default): the
+                                   fastest one the creation-time accuracy measurement accepts -- f16-pair kernel, then
+                                   bf16-triple kernel, then the exact-fp32 MFMA kernels | 1 = exact-fp32 MFMA kernels only |
+                                   2 = bf16-triple kernel without the measurement | 3 = f16-pair kernel without the
+                                   measurement | 4 = as 0 but never the f16-pair kernel */
 } RayenPackDesc;
 
 typedef struct RayenPackInfo {
   int32_t k, n, n_rows, n_segments;
   int32_t device;               /* HIP device ordinal the pack lives on */
-  int32_t mfma_f32;             /* fp32 forward: 0 lane-per-sample kernels | 1 fp32 MFMA kernel | 2 split-operand kernel
-                                   (six bf16 MFMA products per fp32 product, fp32-grade results) */
+  int32_t mfma_f32;             /* fp32 forward: 0 lane-per-sample kernels | 1 fp32 MFMA kernel | 2 bf16-triple kernel (six
+                                   bf16 MFMA products per fp32 product) | 3 f16-pair kernel (three f16 MFMA products per
+                                   fp32 product, operands carried to 22 bits); 2 and 3 are fp32-grade on the probes */
   int32_t generic_block;        /* fp32 generic path: workgroup size with v staged in LDS; 0 = v read from global memory */
   int32_t mfma_f64;             /* 1: the fp64 MFMA path serves this pack */
   int64_t device_bytes;         /* bytes of device memory the pack holds */
   int32_t prepared;             /* RAYEN_PREPARE_F32 | RAYEN_PREPARE_F64 | 4 (backward) */
   int32_t reserved;
-  double fp32_check_split;      /* worst row error (relative to the row's size) of the split-operand kernel against */
-  double fp32_check_exact;      /* fp64 on the creation-time probe directions, and the exact-fp32 kernel's; -1 = not measured */
+  double fp32_check_split;      /* worst row error (relative to the row's size) against fp64 on the creation-time probe */
+  double fp32_check_exact;      /* directions: bf16-triple kernel, exact-fp32 kernel, */
+  double fp32_check_pair;       /* f16-pair kernel; -1 = not measured */
 } RayenPackInfo;
 
 typedef struct RayenPack RayenPack;

@@ -51,6 +51,7 @@ struct MfmaBwdgImage;   // rayen_mfma_bwdg.hip
 struct Mfma64BwdgImage; // rayen_mfma_bwdg64.hip
 struct LmiQuadImage;    // rayen_lmi_quad.h
 struct SplitImage;      // rayen_mfma_split.hip
+struct PairImage;       // rayen_mfma_pair.hip
 
 }  // namespace rayen
 
@@ -60,7 +61,7 @@ struct RayenPack {
   int device = -1;
   int k = 0, n = 0, n_rows = 0;
   int out_identity = 0;
-  int split_bf16 = 1;            // 0: exact-fp32 MFMA kernels only | 1: split-operand kernel where accepted | 2: unchecked
+  int fp32_mode = 0;             // RayenPackDesc.fp32_mode (after the environment override)
   int prepared = 0;              // RAYEN_PREPARE_F32 | RAYEN_PREPARE_F64 | 4 (backward images)
   std::vector<double> W;         // host copy [n_rows, n]
   std::vector<double> NA_E;      // host copy [k, n] (identity materialised)
@@ -77,8 +78,10 @@ struct RayenPack {
   rayen::LmiQuadImage* q32 = nullptr;
   rayen::LmiQuadImage* q64 = nullptr;
   rayen::SplitImage* sp32 = nullptr;
-  int sp32_state = 0;            // 1: the split-operand kernel serves this pack | 2: rejected by split_selfcheck
-  double check_split = -1.0, check_exact = -1.0;  // worst row errors against fp64 measured by split_selfcheck
+  int sp32_state = 0;            // 1: the bf16-triple kernel may serve this pack | 2: rejected by fp32_selfcheck
+  rayen::PairImage* pr32 = nullptr;
+  int pr32_state = 0;            // the same for the f16-pair kernel (which is preferred when both are accepted)
+  double check_split = -1.0, check_exact = -1.0, check_pair = -1.0;  // worst row errors against fp64 (fp32_selfcheck)
   int64_t device_bytes = 0;
 };
 
@@ -116,7 +119,14 @@ int mfma_split_forward(const RayenPack* p, const SplitImage* img, const float* v
                        float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
                        hipStream_t stream);
 
-// the same kernel behind the module's mapper v = Wm x + b; Wm as a caller-owned split-operand image
+// fp32 results on pairs of f16 operands (rayen_mfma_pair.hip); eligibility is mfma_split_eligible's
+int mfma_pair_build(const RayenPack* p, PairImage** out, int64_t* bytes);
+void mfma_pair_free(PairImage* img);
+int mfma_pair_forward(const RayenPack* p, const PairImage* img, const float* v, int64_t B, int64_t ldv,
+                      float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
+                      hipStream_t stream);
+
+// the bf16-triple kernel behind the module's mapper v = Wm x + b; Wm as a caller-owned split-operand image
 int64_t mfma_split_mapper_image_bytes(const RayenPack* p, const SplitImage* img, int in_dim);
 int mfma_split_mapper_prepare(const RayenPack* p, const SplitImage* img, const float* w, int64_t ldw, int in_dim,
                               const float* bias, void* image, hipStream_t stream);

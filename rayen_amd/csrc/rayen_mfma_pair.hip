@@ -1,0 +1,489 @@
+// Paired-half forward: the tile walk of rayen_mfma_split.hip on v_mfma_f32_32x32x16_f16 with TWO f16 pieces per
+// operand -- three piece products per fp32 product instead of six.
+//
+// An f16 significand has 11 bits, so x = x1 + x2 carries 22 of the 24 bits of an fp32 number: the operands are
+// REPRESENTED to 2^-23 relative (half an ulp of the second piece), and a product is rebuilt from x1y1, x1y2, x2y1
+// (the dropped x2y2 is <= 2^-22 of it).  Unlike rounding in an fp32 FMA chain these errors do not accumulate along K:
+// measured on configs 2, 3 and 5 the row results T = W v are CLOSER to fp64 than those of an fp32 FMA chain
+// (DESIGN.md 4.0b).  f16 has a narrow exponent range, so both operands are scaled by powers of two (exact):
+//   * W by one global factor gW that puts its largest entry into [2^13, 2^14) (entries down to 2^-17 of the largest
+//     keep the full 22 bits; smaller ones are good to 2^-39 of the largest),
+//   * every sample's direction by its own factor sv (largest component into [2^13, 2^14)).
+// Every candidate of kappa is homogeneous of degree 1 in v and in the rows of W (rayen/constraint_module.py:351-458),
+// so the whole walk runs on the scaled numbers and kappa is unscaled once per sample; only the closed form of a
+// second-order cone, which mixes in constants of the set, is evaluated in natural units.
+// Whether a pack is served by this kernel is measured at pack creation (rayen_abi.hip::fp32_selfcheck), like the
+// bf16 triple kernel: against the fp64 lane kernel, next to the exact-fp32 MFMA kernel.
+//
+// Everything else -- persistent barrier-free waves, two per SIMD, 64 samples per wave, the rolling A buffer with
+// hand-placed loads and counted waits, the epilogues -- is the design of rayen_mfma_split.hip; see there.
+#include "rayen_split_image.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace rayen {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <int NKK, bool TRACK, bool STAGED>
+__global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_fwd_kernel(
+    const f16x8* __restrict__ Wh, const MItem* __restrict__ items, int n_items,
+    const MPack* __restrict__ packs, const float* __restrict__ y0, int identity, int k, int n,
+    const float* __restrict__ v, int64_t B, int64_t ldv, int vec_in, float* __restrict__ y, int64_t ldy,
+    int vec_out, float* __restrict__ kappa_out, int32_t* __restrict__ active_out,
+    int32_t* __restrict__ nan_flag, const float w_scale, const float w_inv) {
+  constexpr int NT = 2, NS = NKK * 2, NCH = NS * 2, KK = NKK * 16;
+  __shared__ float aux_lds[kMfmaWaves][NT][32][32];
+  __shared__ __attribute__((aligned(16))) float y0_lds[NKK * 32];
+  constexpr int LSTR = NKK * 32 + 4;
+  __shared__ __attribute__((aligned(16))) float line_lds[kMfmaWaves][32][LSTR];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int col = lane & 31;
+  const int hi = lane >> 5;
+  const int64_t n_groups = (B + NT * 32 - 1) / (NT * 32);
+  const int64_t wave_id = (int64_t)blockIdx.x * kMfmaWaves + wave;
+  const int64_t wave_stride = (int64_t)gridDim.x * kMfmaWaves;
+  bool bad = false;
+  for (int i = threadIdx.x; i < NKK * 32; i += kMfmaWaves * 64) y0_lds[i] = y0[i];
+  __syncthreads();  // the only workgroup barrier
+  float (*patch)[LSTR] = line_lds[wave];
+
+  // ---- A operands: the rolling register buffer of rayen_mfma_split.hip, two chunks (a1, a2) per K-step
+  u32x4 abuf[NCH];
+  const unsigned lane_off = lane * 16;
+  auto load_step_fresh = [&](const int sp) {
+    const char* sb = reinterpret_cast<const char*>(Wh) + sp * 2048;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(abuf[2 * sp + 0]) : "v"(lane_off), "s"(sb));
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(abuf[2 * sp + 1]) : "v"(lane_off), "s"(sb));
+  };
+  // tile 0 for the first group; no wait: the group's row loads queue behind these and loads return in order
+#pragma unroll
+  for (int sp = 0; sp < NS; ++sp) load_step_fresh(sp);
+
+  const int64_t n_rounds = (n_groups + wave_stride - 1) / wave_stride;
+  for (int64_t round = 0; round < n_rounds; ++round) {
+  const int64_t grp = wave_id + round * wave_stride;
+  if (grp >= n_groups) continue;
+  const int64_t s_base = grp * (NT * 32);
+
+  bool live[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) live[t] = (s_base + t * 32 + col) < B;
+  // vb[t][piece][k-step] = 8 f16 = the B operand of one MFMA; element i = column 16 sp + 8 (i >> 2) + 4 hi + (i & 3)
+  f16x8 vb[NT][2][NS];
+  float v_scl[NT], v_inv[NT];  // sv and 1 / sv (powers of two; applied one after the other with gW, never multiplied
+                               // together: sv spans 2^-114 .. 2^126)
+  {
+    float vr[NT][KK];
+    if (NKK == 1 && (vec_in & 2) && n != NKK * 32) {
+      // ragged rows stored back to back (config-5-like shapes): whole-line float4 loads of the tile's contiguous
+      // block, through the patch as a flat array (rayen_mfma_split.hip)
+      float* flat = &patch[0][0];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int64_t row0 = s_base + 32 * t;
+        const int64_t left = B - row0;
+        const int nfl = (int)(left >= 32 ? 32 : (left > 0 ? left : 0)) * n;
+        const float* src = v + row0 * (int64_t)n;
+#pragma unroll
+        for (int jj = 0; jj < NKK * 4; ++jj) {
+          const int i4 = lane + 64 * jj;
+          if (i4 < 8 * n) {
+            f32x4 x = {0.f, 0.f, 0.f, 0.f};
+            if (4 * i4 + 3 < nfl) {
+              x = *reinterpret_cast<const f32x4*>(src + 4 * i4);
+            } else {
+              if (4 * i4 + 0 < nfl) x[0] = src[4 * i4 + 0];
+              if (4 * i4 + 1 < nfl) x[1] = src[4 * i4 + 1];
+              if (4 * i4 + 2 < nfl) x[2] = src[4 * i4 + 2];
+            }
+            *reinterpret_cast<f32x4*>(flat + 4 * i4) = x;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const float* myrow = flat + col * n + 4 * hi;
+#pragma unroll
+        for (int q = 0; q < NKK * 4; ++q)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) vr[t][4 * q + c] = (8 * q + 4 * hi + c < n) ? myrow[8 * q + c] : 0.f;
+        __builtin_amdgcn_wave_barrier();
+      }
+    } else {
+      load_rows<NT, NKK, LSTR, true>(vr, v, ldv, n, vec_in & 1, s_base, B, live, patch, lane);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      // sv = 2^(13 - floor(log2 max|v|)): exponent arithmetic only.  (Biased exponent clamped to [14, 254]: a row
+      // below 2^-113 keeps sv finite and loses relative precision where kappa << 1 decides nothing; inf / NaN rows
+      // stay inf / NaN.)
+      float m = 0.f;
+#pragma unroll
+      for (int i = 0; i < KK; ++i) m = fmaxf(m, __builtin_fabsf(vr[t][i]));
+      m = fmaxf(m, xhalf(m));
+      unsigned e = __builtin_bit_cast(unsigned, m) >> 23;
+      e = e < 14u ? 14u : (e > 254u ? 254u : e);
+      const float sv = __builtin_bit_cast(float, (267u - e) << 23);
+      v_inv[t] = __builtin_bit_cast(float, (e - 13u) << 23);
+      v_scl[t] = sv;
+#pragma unroll
+      for (int q = 0; q < NKK * 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int i = (q & 1) * 4 + c;
+          const float x = vr[t][4 * q + c] * sv;
+          const _Float16 p1 = (_Float16)x;
+          const float r1 = x - (float)p1;
+          vb[t][0][q >> 1][i] = p1;
+          vb[t][1][q >> 1][i] = (_Float16)r1;
+        }
+    }
+  }
+
+  // kap, part, the aux patch and the accumulators live in the SCALED domain (gW sv times the natural value)
+  float kap[NT], part[NT], scale[NT], knat[NT];
+  int acode[NT];  // arg-max bookkeeping in one register: (segment << 20) | row, -1 = none
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { kap[t] = 0.f; part[t] = 0.f; scale[t] = 1.f; knat[t] = 0.f; acode[t] = -1; }
+
+  auto finish_kappa = [&]() {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float other = xhalf(kap[t]);
+      if (TRACK) {
+        const int ocode = __shfl_xor(acode[t], 32);
+        if (other > kap[t] || (other == kap[t] && hi == 1)) acode[t] = ocode;
+      }
+      kap[t] = fmaxf(kap[t], other);
+      knat[t] = (kap[t] * w_inv) * v_inv[t];
+      // what multiplies the scaled numbers on the way out: the accumulators of NA_E rows carry gW sv, the rebuilt
+      // direction of the NA_E = I write-out only sv
+      const float out = v_inv[t] * (1.0f / fmaxf(1.0f, knat[t]));
+      scale[t] = identity ? out : out * w_inv;
+    }
+  };
+
+  f32x16 acc[NT];
+  for (int it = 0; it < n_items; ++it) {
+    const MItem item = items[it];
+    if (item.type == MI_OUT && (item.flags & MF_FIRST)) finish_kappa();
+    // the tile after this one; the last tile of a group fetches tile 0 for the next group
+    const char* next_tile = reinterpret_cast<const char*>(Wh) + (size_t)(it + 1 == n_items ? 0 : it + 1) * (NCH * 1024);
+    {
+      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      __builtin_amdgcn_s_setprio(0);
+      // Two passes over the K-steps, by product size: the 2^-11 cross products of ALL steps first, the leading
+      // products last (the instruction aligns its products and C to the largest and keeps ~26 bits: small products go
+      // in while the accumulator is still small, scripts/ubench/mfma_bf16_acc.hip)
+      auto load_chunk = [&](const int idx) {
+        const char* sb = next_tile + idx * 1024;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(abuf[idx]) : "v"(lane_off), "s"(sb));
+      };
+#pragma unroll
+      for (int sp = 0; sp < NS; ++sp) {
+        __builtin_amdgcn_sched_barrier(0);
+        // the step's two chunks: the younger (a1, re-loaded in the second pass of the previous tile) has NS - 1 loads behind it
+        if constexpr (NS == 4)
+          asm volatile("s_waitcnt vmcnt(3)" : "+v"(abuf[2 * sp + 0]), "+v"(abuf[2 * sp + 1]));
+        else
+          asm volatile("s_waitcnt vmcnt(1)" : "+v"(abuf[2 * sp + 0]), "+v"(abuf[2 * sp + 1]));
+        const f16x8 a1 = __builtin_bit_cast(f16x8, abuf[2 * sp + 0]), a2 = __builtin_bit_cast(f16x8, abuf[2 * sp + 1]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, vb[t][0][sp], sp == 0 ? zero : acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, vb[t][1][sp], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_chunk(2 * sp + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int sp = 0; sp < NS; ++sp) {
+        const f16x8 a1 = __builtin_bit_cast(f16x8, abuf[2 * sp + 0]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, vb[t][0][sp], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_chunk(2 * sp + 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_s_setprio(1);
+    }
+    if (item.type == MI_LIN) {
+      const int lin_code = (item.seg << 20) + item.row0 + 4 * hi;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (TRACK) {
+#pragma unroll
+          for (int g = 0; g < 16; ++g)
+            if (acc[t][g] > kap[t]) {
+              kap[t] = acc[t][g];
+              acode[t] = lin_code + ((g & 3) + 8 * (g >> 2));
+            }
+        } else {
+#pragma unroll
+          for (int g = 0; g < 16; ++g) kap[t] = fmaxf(kap[t], acc[t][g]);
+        }
+      }
+    } else if (item.type == MI_AUX) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; ++g)
+          aux_lds[wave][t][(g & 3) + 8 * (g >> 2) + 4 * hi][col] = acc[t][g];
+      __builtin_amdgcn_wave_barrier();
+    } else if (STAGED && NKK == 2 && item.type == MI_OUT) {
+      // n > 32: rows of NA_E leave as 16-byte pieces straight from the accumulators (rayen_mfma_split.hip)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (!live[t]) continue;
+        float* yrow = y + (s_base + t * 32 + col) * ldy;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int r0 = item.row0 + 8 * a + 4 * hi;
+          if (r0 >= k) continue;
+          f32x4 o;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            o[c] = fmaf(acc[t][4 * a + c], scale[t], y0[r0 + c]);  // y0 is padded to a tile multiple
+            bad |= (o[c] != o[c]) && (r0 + c < k);
+          }
+          if (vec_out && r0 + 3 < k) {
+            *reinterpret_cast<f32x4*>(yrow + r0) = o;
+          } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (r0 + c < k) yrow[r0 + c] = o[c];
+          }
+        }
+      }
+    } else if (STAGED && item.type == MI_OUT) {
+      // rows of NA_E: through this wave's aux patch (XOR-swizzled), out as row-coalesced stores
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        float* stage = &aux_lds[wave][t][0][0];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int r = (g & 3) + 8 * (g >> 2) + 4 * hi;
+          const float o = fmaf(acc[t][g], scale[t], y0[item.row0 + r]);  // y0 is padded to a tile multiple
+          bad |= live[t] && (item.row0 + r < k) && (o != o);
+          stage[col * 32 + (r ^ col)] = o;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int orow = item.row0 + col;
+        float* ybase = y + (s_base + t * 32 + hi) * ldy + orow;
+#pragma unroll 4
+        for (int j = 0; j < 16; ++j) {
+          const int sm = 2 * j + hi;
+          const float o = stage[sm * 32 + (col ^ sm)];
+          if (s_base + t * 32 + sm < B && orow < k) ybase[(int64_t)(2 * j) * ldy] = o;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    } else if (item.type == MI_PACK) {
+      const MPack pk = packs[item.aux];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int slot = hi ? pk.aux[a][1] : pk.aux[a][0];
+        const int sid = hi ? pk.seg[a][1] : pk.seg[a][0];
+        const bool pair = (item.row0 >> a) & 1;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          float qs = acc[t][4 * a] * acc[t][4 * a];
+#pragma unroll
+          for (int c = 1; c < 4; ++c) qs = fmaf(acc[t][4 * a + c], acc[t][4 * a + c], qs);
+          if (pair) qs += xhalf(qs);
+          const float kc = aux_lds[wave][t][slot & 31][col] + __builtin_amdgcn_sqrtf(qs);
+          if (sid >= 0 && kc > kap[t]) { kap[t] = kc; acode[t] = sid << 20; }
+        }
+      }
+    } else if (item.type == MI_QFAC || item.type == MI_SOC) {
+      // a running sum of squares over the segment's tiles, closed on its last tile
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        f32x2 s2 = {(item.flags & MF_FIRST) ? 0.f : part[t], 0.f};
+#pragma unroll
+        for (int g = 0; g < 16; g += 2) {
+          const f32x2 a2 = {acc[t][g], acc[t][g + 1]};
+          s2 = __builtin_elementwise_fma(a2, a2, s2);
+        }
+        part[t] = s2[0] + s2[1];
+      }
+      if (item.flags & MF_LAST) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float total = part[t] + xhalf(part[t]);
+          const float a0 = aux_lds[wave][t][item.aux][col];
+          float kc;
+          if (item.type != MI_SOC) {
+            kc = a0 + __builtin_amdgcn_sqrtf(fmaxf(total, 0.f));
+          } else {
+            // a' x^2 + b' x + c' = 0  (rayen/constraint_module.py:392-396, 339-348), a' < 0: the coefficients mix in
+            // the set's constants f0 = tau, f1 = a' -- natural units here, the root goes back to the scaled domain
+            const float vi = v_inv[t];
+            const float cr = (a0 * w_inv) * vi;
+            const float br = (aux_lds[wave][t][item.aux + 1][col] * w_inv) * vi;
+            const float rt = (__builtin_amdgcn_sqrtf(total) * w_inv) * vi;
+            const float cp = rt * rt - cr * cr;
+            const float bp = 2.f * br - 2.f * cr * item.f0;
+            const float disc = bp * bp - 4.f * item.f1 * cp;
+            kc = 0.f;
+            if (disc >= 0.f) {
+              const float root = __builtin_amdgcn_sqrtf(disc);
+              const float inv2a = 0.5f * __builtin_amdgcn_rcpf(item.f1);
+              kc = (fmaxf((-bp - root) * inv2a, (-bp + root) * inv2a) * v_scl[t]) * w_scale;
+            }
+          }
+          if (kc > kap[t]) { kap[t] = kc; acode[t] = item.seg << 20; }
+        }
+      }
+    }
+  }
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next group's first tile has landed
+
+  if (identity) {
+    finish_kappa();
+    // y = y0 + v / max(1, kappa): v rebuilt from its pieces (22 bits of it; scaled by sv, undone by `scale`)
+    float vr[NT][KK];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int sp = 0; sp < NS; ++sp)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          // element i of K-step sp = register 4 (2 sp + (i >> 2)) + (i & 3) of the fp32 layout
+          vr[t][4 * (2 * sp + (i >> 2)) + (i & 3)] = (float)vb[t][0][sp][i] + (float)vb[t][1][sp][i];
+    bad |= store_rows<NT, NKK, LSTR, true>(vr, scale, y0_lds, y, ldy, k, vec_out, s_base, B, live, patch, lane);
+  }
+
+  if (hi == 0) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (!live[t]) continue;
+      const int64_t s = s_base + t * 32 + col;
+      if (kappa_out) kappa_out[s] = knat[t];
+      if (TRACK) { active_out[2 * s] = acode[t] >> 20; active_out[2 * s + 1] = acode[t] < 0 ? 0 : (acode[t] & 0xFFFFF); }
+    }
+  }
+  }  // persistent loop over sample groups
+  if (nan_flag && bad) atomicOr(nan_flag, 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------
+void mfma_pair_free(PairImage* img) {
+  if (img == nullptr) return;
+  if (img->Wh) (void)hipFree(img->Wh);
+  if (img->items) (void)hipFree(img->items);
+  if (img->packs) (void)hipFree(img->packs);
+  if (img->y0) (void)hipFree(img->y0);
+  delete img;
+}
+
+int mfma_pair_build(const RayenPack* p, PairImage** out, int64_t* bytes) {
+  TileLayout b(p->n);
+  const int rc = layout_tiles(p, b, /*allow_pack=*/true, /*allow_sym=*/false);
+  if (rc != RAYEN_OK) return rc;
+  const std::vector<float> frag = b.fragments_f32();
+  if (b.packs.empty()) b.packs.push_back(MPack());
+
+  PairImage* img = new PairImage();
+  img->nkk = b.n_pad / 32;
+  img->identity = p->out_identity;
+  img->n_items = (int)b.items.size();
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0)
+      img->n_simd = prop.multiProcessorCount * 4;
+  }
+  // gW: the largest entry of the image into [2^13, 2^14)
+  float big = 0.f;
+  for (const float x : frag)
+    if (std::isfinite(x)) big = std::fmax(big, std::fabs(x));
+  int ex = 0;
+  if (big > 0.f) (void)std::frexp(big, &ex);   // big = f 2^ex, f in [0.5, 1)
+  int shift = big > 0.f ? 14 - ex : 0;
+  shift = shift > 100 ? 100 : (shift < -100 ? -100 : shift);   // (beyond: f16 overflow -> the self-check rejects the pack)
+  img->w_scale = std::ldexp(1.0f, shift);
+  img->w_inv = std::ldexp(1.0f, -shift);
+  // two f16 pieces of every scaled entry, in the fragment order of v_mfma_f32_32x32x16_f16 (the bf16 instruction's):
+  // chunk (tile, k-step s, piece) = 64 lanes x 8 elements, element i of lane l = column
+  // 16 s + 8 (i >> 2) + 4 (l >> 5) + (i & 3) of row l & 31 = entry [2 s + (i >> 2)][l][i & 3] of the fp32 image
+  const int n_tiles = b.n_tiles(), ns = b.nq() / 2;
+  std::vector<_Float16> wh((size_t)n_tiles * ns * 2 * 64 * 8);
+  for (int t = 0; t < n_tiles; ++t)
+    for (int sp = 0; sp < ns; ++sp)
+      for (int l = 0; l < 64; ++l)
+        for (int i = 0; i < 8; ++i) {
+          const float x = frag[(((size_t)t * b.nq() + 2 * sp + (i >> 2)) * 64 + l) * 4 + (i & 3)] * img->w_scale;
+          const _Float16 h1 = (_Float16)x;                    // round to nearest even
+          const _Float16 h2 = (_Float16)(x - (float)h1);      // (exact difference)
+          const size_t base = (((size_t)t * ns + sp) * 2) * 64 * 8 + (size_t)l * 8 + i;
+          wh[base] = h1;
+          wh[base + 64 * 8] = h2;
+        }
+  const int k_tiles = (p->k + 31) / 32;
+  std::vector<float> y0((size_t)k_tiles * 32 + 32, 0.f);
+  for (int i = 0; i < p->k; ++i) y0[i] = (float)p->y0[i];
+  const bool ok =
+      hipMalloc(&img->Wh, wh.size() * 2) == hipSuccess &&
+      hipMemcpy(img->Wh, wh.data(), wh.size() * 2, hipMemcpyHostToDevice) == hipSuccess &&
+      hipMalloc(&img->y0, y0.size() * sizeof(float)) == hipSuccess &&
+      hipMemcpy(img->y0, y0.data(), y0.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
+      hipMalloc(&img->items, b.items.size() * sizeof(MItem)) == hipSuccess &&
+      hipMemcpy(img->items, b.items.data(), b.items.size() * sizeof(MItem), hipMemcpyHostToDevice) == hipSuccess &&
+      hipMalloc(&img->packs, b.packs.size() * sizeof(MPack)) == hipSuccess &&
+      hipMemcpy(img->packs, b.packs.data(), b.packs.size() * sizeof(MPack), hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) { mfma_pair_free(img); return RAYEN_E_ALLOC; }
+  img->bytes = (int64_t)(wh.size() * 2 + y0.size() * sizeof(float) + b.items.size() * sizeof(MItem) +
+                         b.packs.size() * sizeof(MPack));
+  *bytes = img->bytes;
+  *out = img;
+  return RAYEN_OK;
+}
+
+template <int NKK>
+static int launch_pair(const RayenPack* p, const PairImage* img, const float* v, int64_t B, int64_t ldv,
+                       float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
+                       hipStream_t stream) {
+  constexpr int per_wave = 64;
+  const int64_t n_groups = (B + per_wave - 1) / per_wave;
+  const int64_t slots = (int64_t)img->n_simd * kMfmaWavesPerSimd;
+  const int64_t rounds = (n_groups + slots - 1) / slots;
+  const int64_t waves = (n_groups + rounds - 1) / rounds;
+  const int64_t grid = (waves + kMfmaWaves - 1) / kMfmaWaves;
+  // bit 0: rows are 16-byte aligned | bit 1: rows are stored back to back and the base is 16-byte aligned
+  const int vec_in = (((ldv % 4 == 0) && ((reinterpret_cast<uintptr_t>(v) & 15) == 0)) ? 1 : 0) |
+                     ((ldv == p->n && (reinterpret_cast<uintptr_t>(v) & 15) == 0) ? 2 : 0);
+  const int vec_out = (ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+  auto go = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kMfmaWaves * 64), 0, stream,
+                       static_cast<const f16x8*>(img->Wh), img->items, img->n_items, img->packs, img->y0,
+                       img->identity, p->k, p->n, v, B, ldv, vec_in, y, ldy, vec_out, kappa, active, nan_flag,
+                       img->w_scale, img->w_inv);
+  };
+  if (img->identity) {
+    if (active != nullptr) go(mfma_pair_fwd_kernel<NKK, true, false>);
+    else go(mfma_pair_fwd_kernel<NKK, false, false>);
+  } else {
+    if (active != nullptr) go(mfma_pair_fwd_kernel<NKK, true, true>);
+    else go(mfma_pair_fwd_kernel<NKK, false, true>);
+  }
+  return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
+}
+
+int mfma_pair_forward(const RayenPack* p, const PairImage* img, const float* v, int64_t B, int64_t ldv,
+                      float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
+                      hipStream_t stream) {
+  if (B == 0) return RAYEN_OK;
+  if (img->nkk == 1) return launch_pair<1>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+  if (img->nkk == 2) return launch_pair<2>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+  return RAYEN_E_UNSUPPORTED;
+}
+
+}  // namespace rayen

@@ -88,13 +88,6 @@ __device__ __forceinline__ void mfma_split_fwd_body(
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "+v"(abuf[3 * sp + 1]) : "v"(lane_off), "s"(sb));
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "+v"(abuf[3 * sp + 2]) : "v"(lane_off), "s"(sb));
   };
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) abuf[c] = u32x4{0u, 0u, 0u, 0u};
-  if constexpr (NKX == 0) {
-#pragma unroll
-    for (int sp = 0; sp < NS; ++sp) load_step(reinterpret_cast<const char*>(Wb), sp);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
   // mapped instances: the rolling buffer is dead while the mapper runs (its registers hold x and the mapper's
   // accumulators); tile 0 is fetched afresh once the mapper's MFMAs are issued -- the walk's counted waits cover it
   auto load_step_fresh = [&](const int sp) {
@@ -103,6 +96,13 @@ __device__ __forceinline__ void mfma_split_fwd_body(
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(abuf[3 * sp + 1]) : "v"(lane_off), "s"(sb));
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(abuf[3 * sp + 2]) : "v"(lane_off), "s"(sb));
   };
+  if constexpr (NKX == 0) {
+    // tile 0 for the first group.  No wait here: the group's row loads are issued behind these and waited for by
+    // the compiler's own counts -- loads return in order, so the tile has landed by then -- and the two round
+    // trips overlap.  (Output-only operands: no initialisation of the buffer that could race with the loads.)
+#pragma unroll
+    for (int sp = 0; sp < NS; ++sp) load_step_fresh(sp);
+  }
 
   const int64_t n_rounds = (n_groups + wave_stride - 1) / wave_stride;
   for (int64_t round = 0; round < n_rounds; ++round) {

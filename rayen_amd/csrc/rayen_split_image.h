@@ -22,4 +22,18 @@ struct SplitImage {
   int64_t bytes = 0;
 };
 
+// rayen_mfma_pair.hip: two f16 pieces of every entry of gW W (gW a power of two), same fragment order
+struct PairImage {
+  void* Wh = nullptr;      // [n_tiles][NS][2][64] x 8 f16
+  MItem* items = nullptr;
+  MPack* packs = nullptr;
+  float* y0 = nullptr;
+  int n_items = 0;
+  int nkk = 0;
+  int identity = 0;
+  int n_simd = 1024;
+  float w_scale = 1.f, w_inv = 1.f;
+  int64_t bytes = 0;
+};
+
 }  // namespace rayen

@@ -47,10 +47,10 @@ for s, e in zip(starts[:-1], starts[1:]):
     for i in loads:
         chunk |= regs_of(body[i].split(",")[0])
     # in-flight windows: from the first asm load of the loop nest to the vmcnt(0) that closes it
-    # plain instances: skip the initial fill before the loops (NCH = 6 NKK loads, closed by a vmcnt(0));
-    # mapped instances: tile 0 is fetched afresh inside the group loop, right after the mapper's MFMAs, and stays
-    # in flight through the re-split of the mapper's accumulators: the window starts at that first load
-    first = loads[0] if mapped else loads[2 * 3 * int(name[0])]
+    # the window starts at the very first hand-placed load: the initial fill of the plain instances stays in flight
+    # through the first group's row loads, the fresh fetch of the mapped instances through the re-split of the
+    # mapper's accumulators
+    first = loads[0]
     last = max(i for i, l in enumerate(body) if "s_waitcnt vmcnt(0)" in l and i > loads[-1]) if any(
         "s_waitcnt vmcnt(0)" in l for l in body[loads[-1]:]) else len(body)
     closing = min(i for i in range(loads[-1], len(body)) if "s_waitcnt vmcnt(0)" in body[i])

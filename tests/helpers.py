@@ -84,8 +84,22 @@ def kink_mask(oracle, cs, x, rel_gap, method="RAYEN"):
     scale = kappa.clamp_min(1e-300)
     tie = (top2[:, 0] - top2[:, 1]) <= rel_gap * scale
     tie &= kappa > 0
-    near_zero = (cand.max(dim=1).values.abs() <= rel_gap * norm) & (norm > 0)
+    # relu corner: the largest candidate sits next to zero.  A candidate that IS zero has no gradient and is no
+    # corner: the placeholder row 0z <= 1 of a set without linear constraints (rayen/constraints.py:386-388), or a
+    # quadratic / cone root the reference has already clamped with relu (an unbounded direction, CM:348)
+    cmax = cand.max(dim=1).values
+    near_zero = (cmax.abs() <= rel_gap * norm) & (cmax != 0) & (norm > 0)
     kink = tie | near_zero
+    if buf["all_F"].ndim == 3:
+        # eigenvector sensitivity: an error dS in the pencil matrix turns the top eigenvector by ~|dS| / (lam1 - lam2)
+        # and |dS| scales with the SPECTRAL RADIUS, not with kappa = lam1 -- a gap that is small against the radius
+        # is a kink for the gradient even when it is not small against kappa
+        rho_v = buf["NA_E"] @ (v / norm.reshape(-1, 1, 1))
+        S = torch.einsum("ajk,ial->ijk", [buf["all_F"][0:-1], rho_v])
+        lam = torch.linalg.eigvalsh(buf["L"].T @ (-S) @ buf["L"]) * norm.reshape(-1, 1)
+        if lam.shape[1] >= 2:
+            lmi_on_top = (lam[:, -1] >= cand.max(dim=1).values * (1.0 - rel_gap)) & (kappa > 0)
+            kink |= lmi_on_top & ((lam[:, -1] - lam[:, -2]) <= 10.0 * rel_gap * lam.abs().amax(dim=1))
     if method == "RAYEN":
         kink |= (kappa - 1.0).abs() <= rel_gap
     kink = kink.numpy()
