@@ -64,6 +64,8 @@ def parse(argv=None):
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the step from a HIP graph (auto: launch-bound batches, B*k < 2^20)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-families", action="store_true",
+                    help="skip the comparison runs on the other fp32 kernel families (profiling: one dominant kernel)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed even for one rank (exercises the multi-GPU code path)")
     ap.add_argument("--mapper", type=int, default=0, metavar="D",
@@ -312,19 +314,21 @@ def main():
         gbs = bytes_pp * B / kern_s / 1e9
         ai = flops_pp / bytes_pp
         info = dp.info()
-        split = dtype == torch.float32 and info.mfma_f32 == 2
+        split = dtype == torch.float32 and info.mfma_f32 in (2, 3)
+        pieces = {2: 6.0, 3: 3.0}.get(info.mfma_f32, 1.0)    # piece products per fp32 product
         lmi = cs.has_lmi_constraints
-        kernel_tag = (({2: "mfma_split_bf16x3 (fp32-grade)", 1: "mfma_f32"}.get(info.mfma_f32, "lmi_lanes" if lmi else "generic"))
+        kernel_tag = (({3: "mfma_pair_f16x2 (fp32-grade)", 2: "mfma_split_bf16x3 (fp32-grade)", 1: "mfma_f32"}.get(info.mfma_f32, "lmi_lanes" if lmi else "generic"))
                       if dtype == torch.float32 else ("mfma_f64" if info.mfma_f64 else ("lmi_lanes" if lmi else "generic")))
-        # The split-operand kernel rebuilds every fp32 product from six bf16 MFMA products (fp32-grade results),
-        # so its matrix ceiling in ALGORITHMIC fp32 flops is the dense bf16 peak / 6, not the fp32 MFMA peak
-        peak_tf = (PEAK_BF16_TFLOPS / 6.0 if split else PEAK_FP32_TFLOPS) if dtype == torch.float32 else PEAK_FP64_TFLOPS
+        # The split-operand kernels rebuild every fp32 product from three f16 (pairs) or six bf16 (triples) MFMA products
+        # (fp32-grade results), so their matrix ceiling in ALGORITHMIC fp32 flops is the dense 16-bit peak / 3 or / 6,
+        # not the fp32 MFMA peak
+        peak_tf = (PEAK_BF16_TFLOPS / pieces if split else PEAK_FP32_TFLOPS) if dtype == torch.float32 else PEAK_FP64_TFLOPS
         ridge = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
         if ai > ridge:
             roof = {"bound": "mfma", "achieved": tflops, "peak": peak_tf, "unit": "TFLOP/s",
                     "frac": tflops / peak_tf, "traffic": None}
             if split:
-                roof["peak_basis"] = "dense bf16 MFMA peak %.1f / 6 piece products per fp32 product" % PEAK_BF16_TFLOPS
+                roof["peak_basis"] = "dense f16/bf16 MFMA peak %.1f / %d piece products per fp32 product" % (PEAK_BF16_TFLOPS, pieces)
                 roof["frac_of_fp32_mfma_peak"] = tflops / PEAK_FP32_TFLOPS
             elif lmi:
                 roof["peak_basis"] = ("fp32/fp64 vector ALU peak (numerically the MFMA peak of the dtype): the per-sample "
@@ -374,24 +378,29 @@ def main():
         if args.mapper:
             fused = (not args.no_fuse) and dtype == torch.float32 and dp.mapper_fusable(args.mapper)
             out["config"]["mapper"] = f"nn.Linear({args.mapper}, {cs.n}) " + ("fused into the projection kernel" if fused else "as its own GEMM")
-        if split and world == 1 and not args.mapper:
-            # the same workload on the exact-fp32 MFMA kernels (fp32_mode 1 / RAYEN_SPLIT_BF16=0 at pack creation),
-            # timed the same way, so that one line carries both fp32 families
-            os.environ["RAYEN_SPLIT_BF16"] = "0"
-            try:
-                exact = ConstraintModule(cs, method="RAYEN", create_map=False).to(device)
-                exact.check_nan = False
-                exact.device_pack(device)
-            finally:
-                del os.environ["RAYEN_SPLIT_BF16"]
-            _, ms = timed_loop(lambda xx: exact(xx), x, args.steps, args.warmup, False, graph=graph)
-            tf = flops_pp * B / (ms * 1e-3) / 1e12
-            out["exact_fp32_kernels"] = {"value": B / (ms * 1e-3), "unit": "projections/s", "ms_per_step": ms,
-                                         "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS,
-                                                      "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS},
-                                         "how": "exact-fp32 MFMA kernels (RAYEN_SPLIT_BF16=0), same inputs, same step count"}
-            out["fp32_family_check"] = {"split_vs_fp64": info.fp32_check_split, "exact_vs_fp64": info.fp32_check_exact,
-                                        "what": "worst row error on the pack-creation probe directions"}
+        if split and world == 1 and not args.mapper and not args.no_families:
+            # the same workload on the other fp32 families (RayenPackDesc.fp32_mode / RAYEN_FP32_MODE at pack
+            # creation), timed the same way, so that one line carries all of them
+            others = [("exact_fp32_kernels", "1", PEAK_FP32_TFLOPS, "exact-fp32 MFMA kernels (fp32_mode 1)")]
+            if info.mfma_f32 == 3:
+                others.insert(0, ("bf16_triple_kernel", "4", PEAK_BF16_TFLOPS / 6.0,
+                                  "bf16-triple kernel, six piece products per fp32 product (fp32_mode 4)"))
+            for key, mode, peak, how in others:
+                os.environ["RAYEN_FP32_MODE"] = mode
+                try:
+                    other = ConstraintModule(cs, method="RAYEN", create_map=False).to(device)
+                    other.check_nan = False
+                    other.device_pack(device)
+                finally:
+                    del os.environ["RAYEN_FP32_MODE"]
+                _, ms = timed_loop(lambda xx: other(xx), x, args.steps, args.warmup, False, graph=graph)
+                tf = flops_pp * B / (ms * 1e-3) / 1e12
+                out[key] = {"value": B / (ms * 1e-3), "unit": "projections/s", "ms_per_step": ms,
+                            "roofline": {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak},
+                            "how": how + ", same inputs, same step count"}
+            out["fp32_family_check"] = {"pair_vs_fp64": info.fp32_check_pair, "triple_vs_fp64": info.fp32_check_split,
+                                        "exact_vs_fp64": info.fp32_check_exact,
+                                        "what": "worst row error on the pack-creation probe directions (-1: not measured)"}
         if world == 1 and not args.no_cpu_baseline and not args.mapper:
             out["cpu_baseline"] = cpu_baseline(raw, cs, B, dtype, args.cpu_seconds, rng)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

@@ -10,7 +10,7 @@ import os
 
 from ._build import LIBRARY
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 SEG_LIN, SEG_QUAD_SYM, SEG_QUAD_FAC, SEG_SOC, SEG_LMI = range(5)
 PREPARE_ALL, PREPARE_F32, PREPARE_F64, PREPARE_FWD_ONLY = 0, 1, 2, 4
@@ -52,7 +52,8 @@ class RayenPackInfo(ctypes.Structure):
                 ("mfma_f32", ctypes.c_int32), ("generic_block", ctypes.c_int32),
                 ("mfma_f64", ctypes.c_int32), ("device_bytes", ctypes.c_int64),
                 ("prepared", ctypes.c_int32), ("reserved", ctypes.c_int32),
-                ("fp32_check_split", ctypes.c_double), ("fp32_check_exact", ctypes.c_double)]
+                ("fp32_check_split", ctypes.c_double), ("fp32_check_exact", ctypes.c_double),
+                ("fp32_check_pair", ctypes.c_double)]
 
 
 class RayenError(RuntimeError):

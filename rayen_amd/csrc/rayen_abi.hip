@@ -87,7 +87,12 @@ int build_images(RayenPack* p, int prepare) {
     p->prepared |= RAYEN_PREPARE_F32;
     if ((rc = build_generic<float>(p))) return rc;
     if ((rc = build_one(p, mfma_eligible(p), &p->m32, mfma_build))) return rc;
-    if (p->split_bf16 && (rc = build_one(p, mfma_split_eligible(p), &p->sp32, mfma_split_build))) return rc;
+    {
+      const int mode = p->fp32_mode;
+      const bool split_ok = mode != 1 && mfma_split_eligible(p);
+      if ((rc = build_one(p, split_ok && mode != 3, &p->sp32, mfma_split_build))) return rc;
+      if ((rc = build_one(p, split_ok && (mode == 0 || mode == 3), &p->pr32, mfma_pair_build))) return rc;
+    }
     if ((rc = build_one(p, lmi_quad_eligible_f32(p), &p->q32, lmi_quad_build_f32))) return rc;
     if (bwd) {
       if ((rc = build_one(p, mfma_bwd_eligible(p), &p->mb32, mfma_bwd_build))) return rc;
@@ -184,16 +189,20 @@ const char* rayen_strerror(int code) {
   }
 }
 
-// The split-operand kernel is fp32-grade on well-conditioned sums; where a constraint set makes the sums cancel
-// heavily its error constant is ~4x that of an fp32 FMA chain.  So every pack it could serve is
-// measured ONCE, inside rayen_pack_create: probe directions (random at two magnitudes, and +-every row of W -- the
-// worst cancellation is along constraint normals) go through the split-operand kernel, the exact-fp32 MFMA kernel
-// and the fp64 lane kernel (the yardstick); the split-operand kernel serves the pack only if its worst row error
-// against fp64 is below 4e-6 of the row's size or within 1.5x of the exact-fp32 kernel's own.  Private stream,
-// buffers freed before pack_create returns.
-static int split_selfcheck(RayenPack* p) {
-  if (p->sp32 == nullptr) return RAYEN_OK;
-  if (p->split_bf16 == 2 || p->m32 == nullptr) { p->sp32_state = 1; return RAYEN_OK; }
+// The split-operand kernels (bf16 triples, f16 pairs) are fp32-grade on well-conditioned sums; where a constraint set
+// makes the sums cancel heavily their error constants are larger than an fp32 FMA chain's.  So
+// every pack they could serve is measured ONCE, inside rayen_pack_create: probe directions (random at two
+// magnitudes, and +-every row of W -- the worst cancellation is along constraint normals) go through each of them,
+// the exact-fp32 MFMA kernel and the fp64 lane kernel (the yardstick); a split-operand kernel may serve the pack only
+// if its worst row error against fp64 is below 4e-6 of the row's size or within 1.5x of the exact-fp32 kernel's own.
+// The f16-pair kernel is preferred when both pass.  Private stream, buffers freed before pack_create returns.
+static int fp32_selfcheck(RayenPack* p) {
+  if (p->sp32 == nullptr && p->pr32 == nullptr) return RAYEN_OK;
+  if (p->fp32_mode == 2 || p->fp32_mode == 3 || p->m32 == nullptr) {
+    p->sp32_state = p->sp32 != nullptr ? 1 : 0;
+    p->pr32_state = p->pr32 != nullptr ? 1 : 0;
+    return RAYEN_OK;
+  }
   const int n = p->n, k = p->k;
   std::vector<float> hv;
   uint32_t state = 0x9E3779B9u;
@@ -203,6 +212,10 @@ static int split_selfcheck(RayenPack* p) {
   };
   for (int b = 0; b < 512; ++b) for (int j = 0; j < n; ++j) hv.push_back(1.5f * uniform());
   for (int b = 0; b < 256; ++b) for (int j = 0; j < n; ++j) hv.push_back(96.0f * uniform());
+  // (the f16-pair kernel scales every row by its own power of two: a row with components spread over many binades
+  // is its worst case)
+  for (int b = 0; b < 128; ++b)
+    for (int j = 0; j < n; ++j) hv.push_back(std::ldexp(uniform(), -(int)((state >> 3) % 20u)));
   const int rows = p->n_rows, take = rows < 384 ? rows : 384;
   for (int t = 0; t < take; ++t) {
     const double* w = &p->W[(size_t)((int64_t)t * rows / take) * n];
@@ -213,9 +226,10 @@ static int split_selfcheck(RayenPack* p) {
       for (int j = 0; j < n; ++j) hv.push_back((float)(sign * 1.5 * w[j] / big));
   }
   const int64_t B0 = (int64_t)(hv.size() / (size_t)n);
+  const size_t ny = (size_t)B0 * k;
   std::vector<double> hvd(hv.begin(), hv.end());
-  std::vector<float> ys((size_t)B0 * k), ye((size_t)B0 * k);
-  std::vector<double> yt((size_t)B0 * k);
+  std::vector<float> yf(3 * ny);      // triple | exact | pair
+  std::vector<double> yt(ny);
   // the yardstick needs the fp64 lane image even when the caller asked for fp32 only
   bool own_g64 = false;
   int rc = RAYEN_OK;
@@ -226,48 +240,50 @@ static int split_selfcheck(RayenPack* p) {
     if (!own_g64) p->device_bytes += p->g64.bytes;
   }
   hipStream_t st = nullptr;
-  float *dv = nullptr, *dys = nullptr;
+  float *dv = nullptr, *dyf = nullptr;
   double *dvd = nullptr, *dyt = nullptr;
   bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
             hipMalloc(&dv, hv.size() * sizeof(float)) == hipSuccess &&
             hipMalloc(&dvd, hvd.size() * sizeof(double)) == hipSuccess &&
-            hipMalloc(&dys, 2 * ys.size() * sizeof(float)) == hipSuccess &&
+            hipMalloc(&dyf, yf.size() * sizeof(float)) == hipSuccess &&
             hipMalloc(&dyt, yt.size() * sizeof(double)) == hipSuccess &&
+            hipMemsetAsync(dyf, 0, yf.size() * sizeof(float), st) == hipSuccess &&
             hipMemcpyAsync(dv, hv.data(), hv.size() * sizeof(float), hipMemcpyHostToDevice, st) == hipSuccess &&
             hipMemcpyAsync(dvd, hvd.data(), hvd.size() * sizeof(double), hipMemcpyHostToDevice, st) == hipSuccess;
   if (ok) {
-    rc = mfma_split_forward(p, p->sp32, dv, B0, n, dys, k, nullptr, nullptr, nullptr, st);
-    if (rc == RAYEN_OK) rc = mfma_forward(p, p->m32, dv, B0, n, dys + ys.size(), k, nullptr, nullptr, nullptr, 0, st);
+    if (p->sp32 != nullptr) rc = mfma_split_forward(p, p->sp32, dv, B0, n, dyf, k, nullptr, nullptr, nullptr, st);
+    if (rc == RAYEN_OK) rc = mfma_forward(p, p->m32, dv, B0, n, dyf + ny, k, nullptr, nullptr, nullptr, 0, st);
+    if (rc == RAYEN_OK && p->pr32 != nullptr)
+      rc = mfma_pair_forward(p, p->pr32, dv, B0, n, dyf + 2 * ny, k, nullptr, nullptr, nullptr, st);
     if (rc == RAYEN_OK)
       rc = generic_forward<double>(p, p->g64, dvd, B0, n, dyt, k, nullptr, nullptr, nullptr, 0, st);
     ok = rc == RAYEN_OK &&
-         hipMemcpyAsync(ys.data(), dys, ys.size() * sizeof(float), hipMemcpyDeviceToHost, st) == hipSuccess &&
-         hipMemcpyAsync(ye.data(), dys + ys.size(), ye.size() * sizeof(float), hipMemcpyDeviceToHost, st) == hipSuccess &&
+         hipMemcpyAsync(yf.data(), dyf, yf.size() * sizeof(float), hipMemcpyDeviceToHost, st) == hipSuccess &&
          hipMemcpyAsync(yt.data(), dyt, yt.size() * sizeof(double), hipMemcpyDeviceToHost, st) == hipSuccess &&
          hipStreamSynchronize(st) == hipSuccess;
   }
   if (dv) (void)hipFree(dv);
   if (dvd) (void)hipFree(dvd);
-  if (dys) (void)hipFree(dys);
+  if (dyf) (void)hipFree(dyf);
   if (dyt) (void)hipFree(dyt);
   if (st) (void)hipStreamDestroy(st);
   if (own_g64) generic_free<double>(&p->g64);
   if (!ok) return rc != RAYEN_OK ? rc : RAYEN_E_ALLOC;
-  double worst_s = 0.0, worst_e = 0.0;
+  double worst[3] = {0.0, 0.0, 0.0};
   for (int64_t b = 0; b < B0; ++b) {
-    double ds = 0.0, de = 0.0, size = 1e-30;
+    double d[3] = {0.0, 0.0, 0.0}, size = 1e-30;
     for (int i = 0; i < k; ++i) {
       const double t = yt[(size_t)b * k + i];
-      ds = std::fmax(ds, std::fabs((double)ys[(size_t)b * k + i] - t));
-      de = std::fmax(de, std::fabs((double)ye[(size_t)b * k + i] - t));
+      for (int f = 0; f < 3; ++f) d[f] = std::fmax(d[f], std::fabs((double)yf[f * ny + (size_t)b * k + i] - t));
       size = std::fmax(size, std::fabs(t));
     }
-    if (!(ds / size <= worst_s)) worst_s = ds / size;  // (NaN counts as a difference)
-    if (!(de / size <= worst_e)) worst_e = de / size;
+    for (int f = 0; f < 3; ++f)
+      if (!(d[f] / size <= worst[f])) worst[f] = d[f] / size;  // (NaN counts as a difference)
   }
-  p->check_split = worst_s;
-  p->check_exact = worst_e;
-  p->sp32_state = (worst_s <= 4e-6 || worst_s <= 1.5 * worst_e) ? 1 : 2;
+  p->check_exact = worst[1];
+  auto accept = [&](double w) { return (w <= 4e-6 || w <= 1.5 * worst[1]) ? 1 : 2; };
+  if (p->sp32 != nullptr) { p->check_split = worst[0]; p->sp32_state = accept(worst[0]); }
+  if (p->pr32 != nullptr) { p->check_pair = worst[2]; p->pr32_state = accept(worst[2]); }
   return RAYEN_OK;
 }
 
@@ -277,7 +293,7 @@ int rayen_pack_create(const RayenPackDesc* desc, RayenPack** out) {
   if (desc->abi_version != RAYEN_ABI_VERSION) return RAYEN_E_ABI;
   int rc = check_table(desc);
   if (rc) return rc;
-  if (desc->prepare < 0 || desc->prepare > 7 || desc->fp32_mode < 0 || desc->fp32_mode > 2) return RAYEN_E_BAD_ARG;
+  if (desc->prepare < 0 || desc->prepare > 7 || desc->fp32_mode < 0 || desc->fp32_mode > 4) return RAYEN_E_BAD_ARG;
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess) return RAYEN_E_NO_DEVICE;
   if (!device_is_gfx950(dev)) return RAYEN_E_NO_DEVICE;
@@ -289,11 +305,14 @@ int rayen_pack_create(const RayenPackDesc* desc, RayenPack** out) {
   p->n_rows = desc->n_rows;
   p->out_identity = desc->out_identity ? 1 : 0;
   {
-    // fp32_mode 0 (default): split-operand kernel where split_selfcheck accepts it | 1: exact-fp32 MFMA kernels only
-    // | 2: split-operand kernel without the comparison.  RAYEN_SPLIT_BF16=0/1/2 (0 = exact only) overrides it.
-    p->split_bf16 = desc->fp32_mode == 1 ? 0 : (desc->fp32_mode == 2 ? 2 : 1);
-    const char* env = std::getenv("RAYEN_SPLIT_BF16");
-    if (env != nullptr && env[0] >= '0' && env[0] <= '2') p->split_bf16 = env[0] - '0';
+    // RayenPackDesc.fp32_mode (include/rayen_hip.h); RAYEN_FP32_MODE=0..4 overrides it.  (RAYEN_SPLIT_BF16, the
+    // switch of earlier versions: 0 = exact-fp32 kernels only, 1 = bf16 triples where accepted, 2 = bf16 triples
+    // without the measurement.)
+    p->fp32_mode = desc->fp32_mode;
+    const char* old_env = std::getenv("RAYEN_SPLIT_BF16");
+    if (old_env != nullptr && old_env[0] >= '0' && old_env[0] <= '2') p->fp32_mode = old_env[0] == '0' ? 1 : (old_env[0] == '1' ? 4 : 2);
+    const char* env = std::getenv("RAYEN_FP32_MODE");
+    if (env != nullptr && env[0] >= '0' && env[0] <= '4') p->fp32_mode = env[0] - '0';
   }
   p->W.assign(desc->W, desc->W + (size_t)desc->n_rows * desc->n);
   p->y0.assign(desc->y0, desc->y0 + desc->k);
@@ -305,7 +324,7 @@ int rayen_pack_create(const RayenPackDesc* desc, RayenPack** out) {
   }
   p->segs.assign(desc->segments, desc->segments + desc->n_segments);
   rc = build_images(p, desc->prepare);
-  if (rc == RAYEN_OK) rc = split_selfcheck(p);
+  if (rc == RAYEN_OK) rc = fp32_selfcheck(p);
   if (rc != RAYEN_OK) { rayen_pack_destroy(p); return rc; }
   *out = p;
   return RAYEN_OK;
@@ -325,6 +344,7 @@ void rayen_pack_destroy(RayenPack* p) {
   if (p->mbg32) mfma_bwdg_free(p->mbg32);
   if (p->mbg64) mfma64_bwdg_free(p->mbg64);
   if (p->sp32) mfma_split_free(p->sp32);
+  if (p->pr32) mfma_pair_free(p->pr32);
   if (p->q32) lmi_quad_free(p->q32);
   if (p->q64) lmi_quad_free(p->q64);
   if (switched) (void)hipSetDevice(prev);
@@ -339,11 +359,13 @@ int rayen_pack_info(const RayenPack* p, RayenPackInfo* info) {
   info->n_rows = p->n_rows;
   info->n_segments = (int32_t)p->segs.size();
   info->device = p->device;
-  info->mfma_f32 = (p->sp32 != nullptr && p->sp32_state == 1) ? 2 : (mfma_eligible(p) ? 1 : 0);
+  info->mfma_f32 = (p->pr32 != nullptr && p->pr32_state == 1) ? 3
+                   : (p->sp32 != nullptr && p->sp32_state == 1) ? 2 : (mfma_eligible(p) ? 1 : 0);
   info->mfma_f64 = mfma64_eligible(p) ? 1 : 0;
   info->prepared = p->prepared;
   info->fp32_check_split = p->check_split;
   info->fp32_check_exact = p->check_exact;
+  info->fp32_check_pair = p->check_pair;
   int lmi_words = 0;
   for (const RayenSegment& g : p->segs)
     if (g.type == RAYEN_SEG_LMI && g.nrows + 4 * g.dim > lmi_words) lmi_words = g.nrows + 4 * g.dim;
@@ -367,6 +389,8 @@ static int project_f32(const RayenPack* p, const float* v, int64_t B, int64_t ld
     return RAYEN_E_BAD_ARG;
   const int rc = check_ready<float>(p, false);
   if (rc) return rc;
+  if (p->pr32 != nullptr && p->pr32_state == 1 && y != nullptr && !old_mode)
+    return mfma_pair_forward(p, p->pr32, v, B, ldv, y, ldy, kappa, active, nan_flag, static_cast<hipStream_t>(stream));
   if (p->sp32 != nullptr && p->sp32_state == 1 && y != nullptr && !old_mode)
     return mfma_split_forward(p, p->sp32, v, B, ldv, y, ldy, kappa, active, nan_flag,
                               static_cast<hipStream_t>(stream));

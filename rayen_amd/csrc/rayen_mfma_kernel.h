@@ -89,7 +89,8 @@ __device__ __forceinline__ float xhalf(float x) { return __shfl_xor(x, 32); }
 // Rows of a [B, ld] matrix -> B-operand registers: dst[t][4q + c] = src[sample][8q + 4hi + c].
 // LINES: every global load instruction moves four whole rows (full 128-B lines) and the fragment
 // shape is produced by a trip through the wave's LDS patch (row stride LSTR floats).
-template <int NT, int NK, int LSTR, bool LINES>
+// STREAM: the rows are read once -- non-temporal loads (they do not displace the W image in the caches).
+template <int NT, int NK, int LSTR, bool LINES, bool STREAM = false>
 __device__ __forceinline__ void load_rows(float (&dst)[NT][NK * 16], const float* __restrict__ src, int64_t ld,
                                           int width, int vec, int64_t s_base, int64_t B,
                                           const bool (&live_t)[NT], float (*patch)[LSTR], int lane) {
@@ -105,7 +106,11 @@ __device__ __forceinline__ void load_rows(float (&dst)[NT][NK * 16], const float
         const int idx = lane + 64 * j;
         const int64_t s = s_base + t * 32 + idx / (NK * 8);
         piece[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (s < B) piece[t][j] = *reinterpret_cast<const f32x4*>(src + s * ld + 4 * (idx % (NK * 8)));
+        if (s < B) {
+          const f32x4* from = reinterpret_cast<const f32x4*>(src + s * ld + 4 * (idx % (NK * 8)));
+          if constexpr (STREAM) piece[t][j] = __builtin_nontemporal_load(from);
+          else piece[t][j] = *from;
+        }
       }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -156,7 +161,8 @@ __device__ __forceinline__ void load_rows(float (&dst)[NT][NK * 16], const float
 // The inverse trip: dst[sample][8q + 4hi + c] = off[8q + 4hi + c] + scale[t] * val[t][4q + c] for the
 // first `width` columns (`off` = an LDS vector padded to NK*32, or null).  Returns true when a NaN was
 // written (the fused form of rayen/constraint_module.py:531).
-template <int NT, int NK, int LSTR, bool LINES>
+// STREAM: non-temporal stores (the output is not read again by this kernel).
+template <int NT, int NK, int LSTR, bool LINES, bool STREAM = false>
 __device__ __forceinline__ bool store_rows(const float (&val)[NT][NK * 16], const float (&scale)[NT],
                                            const float* off, float* __restrict__ dst, int64_t ld, int width,
                                            int vec, int64_t s_base, int64_t B, const bool (&live_t)[NT],
@@ -186,7 +192,11 @@ __device__ __forceinline__ bool store_rows(const float (&val)[NT][NK * 16], cons
         const int idx = lane + 64 * j;
         const int64_t s = s_base + t * 32 + idx / (NK * 8);
         const f32x4 o = *reinterpret_cast<const f32x4*>(&patch[idx / (NK * 8)][4 * (idx % (NK * 8))]);
-        if (s < B) *reinterpret_cast<f32x4*>(dst + s * ld + 4 * (idx % (NK * 8))) = o;
+        if (s < B) {
+          f32x4* to = reinterpret_cast<f32x4*>(dst + s * ld + 4 * (idx % (NK * 8)));
+          if constexpr (STREAM) __builtin_nontemporal_store(o, to);
+          else *to = o;
+        }
       }
       __builtin_amdgcn_wave_barrier();
     }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Safety check of rayen_mfma_split.hip's hand-placed loads: between an asm `global_load` into a chunk of the
+"""Safety check of the hand-placed loads of rayen_mfma_split.hip and rayen_mfma_pair.hip: between an asm `global_load` into a chunk of the
 rolling A buffer and the `s_waitcnt` that covers it the compiler must not touch those registers (copy, spill):
 it does not know the data is still in flight.  Scans the gfx950 ISA of every instance of the kernel and lists
 any instruction inside the tile loops, other than the MFMAs and the loads themselves, that names a chunk register.
@@ -10,15 +10,20 @@ import subprocess
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(REPO, "rayen_amd", "csrc", "rayen_mfma_split.hip")
-asm = "/tmp/rayen_mfma_split.s"
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(REPO, "include"),
-                "-I", os.path.join(REPO, "rayen_amd", "csrc"), "-S", "--cuda-device-only", src, "-o", asm],
-               check=True, stderr=subprocess.DEVNULL)
-lines = open(asm).read().split("\n")
-starts = [i for i, l in enumerate(lines) if (l.startswith("_ZN5rayen21mfma_split_fwd_kernel") or l.startswith("_ZN5rayen21mfma_split_map_kernel"))
-          and l.split(";")[0].rstrip().endswith(":")]
-starts.append(len(lines))
+lines, starts = [], []
+for name in ("rayen_mfma_split", "rayen_mfma_pair"):
+    src = os.path.join(REPO, "rayen_amd", "csrc", name + ".hip")
+    asm = f"/tmp/{name}.s"
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(REPO, "include"),
+                    "-I", os.path.join(REPO, "rayen_amd", "csrc"), "-S", "--cuda-device-only", src, "-o", asm],
+                   check=True, stderr=subprocess.DEVNULL)
+    base = len(lines)
+    text = open(asm).read().split("\n")
+    lines += text
+    starts += [base + i for i, l in enumerate(text)
+               if l.startswith(("_ZN5rayen21mfma_split_fwd_kernel", "_ZN5rayen21mfma_split_map_kernel", "_ZN5rayen20mfma_pair_fwd_kernel"))
+               and l.split(";")[0].rstrip().endswith(":")]
+    starts.append(base + len(text))          # (closes the last kernel of this file)
 
 
 def regs_of(text):
@@ -31,6 +36,8 @@ def regs_of(text):
 
 bad_total = 0
 for s, e in zip(starts[:-1], starts[1:]):
+    if not lines[s].startswith("_ZN5rayen"):
+        continue
     body = []
     for l in lines[s:e]:
         body.append(l)
@@ -61,7 +68,8 @@ for s, e in zip(starts[:-1], starts[1:]):
             continue
         if regs_of(l) & chunk:
             bad.append((i, l))
-    print(f"NKK={name[0]} TRACK={name[1]} STAGED={name[2]} NKX={nkx}: {len(loads)} asm loads, chunk registers {min(chunk)}..{max(chunk)}"
+    family = "pair " if "mfma_pair" in lines[s] else ""
+    print(f"{family}NKK={name[0]} TRACK={name[1]} STAGED={name[2]} NKX={nkx}: {len(loads)} asm loads, chunk registers {min(chunk)}..{max(chunk)}"
           f" ({len(chunk)}), suspicious instructions in the loop: {len(bad)}")
     for i, l in bad[:12]:
         print("     ", i, l[:110])

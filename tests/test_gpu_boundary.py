@@ -123,13 +123,18 @@ def test_prepare_mask_and_fp32_mode():
     assert full.info().prepared == 7 and full.info().device_bytes > info.device_bytes
     assert torch.equal(ops.project_raw(v32, full)[0], y)
     exact = _pack.DevicePack(consts, 0, fp32_mode=1)
-    unchecked = _pack.DevicePack(consts, 0, fp32_mode=2)
-    assert (full.info().mfma_f32, exact.info().mfma_f32, unchecked.info().mfma_f32) == (2, 1, 2)
-    assert full.info().fp32_check_split >= 0 and exact.info().fp32_check_split == -1.0
+    triple_unchecked = _pack.DevicePack(consts, 0, fp32_mode=2)
+    pair_unchecked = _pack.DevicePack(consts, 0, fp32_mode=3)
+    no_pair = _pack.DevicePack(consts, 0, fp32_mode=4)
+    packs = (full, exact, triple_unchecked, pair_unchecked, no_pair)
+    assert tuple(dp.info().mfma_f32 for dp in packs) == (3, 1, 2, 3, 2)
+    assert full.info().fp32_check_pair >= 0 and full.info().fp32_check_split >= 0 and full.info().fp32_check_exact >= 0
+    assert exact.info().fp32_check_split == -1.0 and pair_unchecked.info().fp32_check_pair == -1.0
+    assert no_pair.info().fp32_check_pair == -1.0 and no_pair.info().fp32_check_split >= 0
     y_true = ops.project_raw(v64, full)[0]
-    for dp in (full, exact, unchecked):
+    for dp in packs:
         assert np.max(rel_err_rows(ops.project_raw(v32, dp)[0].cpu().numpy(), y_true.cpu().numpy())) <= 1e-5
-    for dp in (only32, full, exact, unchecked):
+    for dp in (only32,) + packs:
         dp.close()
 
 

@@ -47,10 +47,10 @@ def family(monkeypatch, request):
     """Every test of this file runs on both fp32 kernel families: the default one (split-operand kernel where the
     pack is eligible; its fused mapper reads a split-operand image of the weights, in_dim <= n rounded up to 32, sets
     without equality constraints) and
-    the exact-fp32 MFMA family (RAYEN_SPLIT_BF16=0, read when a pack is created; weights read in place, in_dim a
+    the exact-fp32 MFMA family (RAYEN_FP32_MODE=1, read when a pack is created; weights read in place, in_dim a
     multiple of 4 up to 64)."""
     if request.param == "exact":
-        monkeypatch.setenv("RAYEN_SPLIT_BF16", "0")
+        monkeypatch.setenv("RAYEN_FP32_MODE", "1")
     return request.param
 
 
@@ -72,7 +72,7 @@ def test_fused_mapper_matches_oracle_and_two_op_path(name, input_dim, fusable_ex
     x[:4] *= 1e-4
     dp, _ = layer.device_pack(torch.device("cuda", 0))
     if family == "default" and name in ("c2", "c3", "c5"):
-        assert dp.info().mfma_f32 == 2                        # the headline kernel, not a fallback
+        assert dp.info().mfma_f32 == 3                        # the headline kernel, not a fallback
     assert ops.mapper_fusable(x.cuda(), layer.mapper.weight, layer.mapper.bias, dp) == fusable
 
     with torch.no_grad():

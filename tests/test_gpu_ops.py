@@ -32,7 +32,7 @@ def test_opcheck_ray_project(name):
 @pytest.mark.parametrize("family", ["default", "exact"])
 def test_opcheck_ray_project_mapped(monkeypatch, family):
     if family == "exact":
-        monkeypatch.setenv("RAYEN_SPLIT_BF16", "0")   # weights read in place by the exact-fp32 MFMA family
+        monkeypatch.setenv("RAYEN_FP32_MODE", "1")   # weights read in place by the exact-fp32 MFMA family
     cs, layer = _layer("c3", input_dim=32, create_map=True)
     _, pack_id = layer.device_pack(torch.device("cuda", 0))
     x = torch.randn(130, 32, device="cuda", requires_grad=True)

@@ -148,57 +148,89 @@ def test_wide_shapes_against_oracle(name):
     assert dp.info().mfma_f32 == 1
 
 
+FAMILIES = {"exact": ("1", (0, 1)), "triple": ("2", (2,)), "pair": ("3", (3,))}
+
+
+@pytest.mark.parametrize("family", ["exact", "triple", "pair"])
 @pytest.mark.parametrize("name", ["c2", "c3", "c5", "rand3", "rand17", "rand40"])
-def test_plain_fp32_mfma_family(name, monkeypatch):
-    """RAYEN_SPLIT_BF16=0 (read when a pack is created) turns the split-operand kernel off: the plain fp32 MFMA
-    kernels, which otherwise serve only n > 64, the RAYEN_old head and the fused mapper, take the pack."""
-    monkeypatch.setenv("RAYEN_SPLIT_BF16", "0")
+def test_every_fp32_mfma_family(name, family, monkeypatch):
+    """RAYEN_FP32_MODE (read when a pack is created; RayenPackDesc.fp32_mode) pins the family that serves the fp32
+    forward: 1 the exact-fp32 MFMA kernels (which otherwise serve only n > 64, the RAYEN_old head and their fused
+    mapper), 2 the bf16-triple kernel, 3 the f16-pair kernel (the last two without the creation-time measurement).
+    Each against the fp64 truth, with the reference's own fp32 arithmetic on the same inputs as yardstick."""
+    mode, served = FAMILIES[family]
+    monkeypatch.setenv("RAYEN_FP32_MODE", mode)
     raw = _random_set(1000 + int(name[4:])) if name.startswith("rand") else workloads.make_raw(name, seed=21)
     cs, layer = _layer(raw, torch.float32)
     dp, _ = layer.device_pack(torch.device("cuda", 0))
-    assert dp.info().mfma_f32 in (0, 1)
+    if name.startswith("rand") and family != "exact" and dp.info().mfma_f32 not in served:
+        pytest.skip("this random set is not laid out for the split-operand kernels")
+    assert dp.info().mfma_f32 in served
     gen = torch.Generator().manual_seed(8)
     x = torch.empty(3001, cs.n, 1).uniform_(-1.5, 1.5, generator=gen)
+    x[:8] *= 1e-4
+    x[8:16] *= 300.0
+    x[16] = 0.0
     y = layer(x.cuda()).cpu().numpy()[:, :, 0]
-    monkeypatch.delenv("RAYEN_SPLIT_BF16")
+    monkeypatch.delenv("RAYEN_FP32_MODE")
     _, layer_default = _layer(cs, torch.float32)
     y_default = layer_default(x.cuda()).cpu().numpy()[:, :, 0]
-    # both families against the fp64 truth, with the reference's own fp32 arithmetic on the same inputs as yardstick
     y_true = _oracle_forward(cs, x.double(), torch.float64)
     bound = _fp32_bound(cs, x, y_true, layer)
     assert rel_err_rows(y, y_true).max() <= bound, (rel_err_rows(y, y_true).max(), bound)
     assert rel_err_rows(y_default, y_true).max() <= bound, (rel_err_rows(y_default, y_true).max(), bound)
+    # (feasibility next to the reference's own fp32 arithmetic: the equality rows of config 5 leave ~2e-6 in fp32)
+    assert oracle.max_violation(raw, y) <= max(VIOLATION_TOL, 3 * oracle.max_violation(raw, _oracle_forward(cs, x, torch.float32)))
 
 
-def _served_random_set(index):
-    """The ``index``-th random set (seeds 1000, 1001, ...) that the split-operand kernel serves."""
+def test_legacy_family_switch(monkeypatch):
+    """RAYEN_SPLIT_BF16 = 0 / 1 / 2, the switch of ABI v2: exact-fp32 kernels only / bf16 triples where the
+    measurement accepts them (never f16 pairs) / bf16 triples unmeasured."""
+    raw = workloads.make_raw("c3", seed=21)
+    for value, want in (("0", 1), ("1", 2), ("2", 2)):
+        monkeypatch.setenv("RAYEN_SPLIT_BF16", value)
+        _, layer = _layer(raw, torch.float32)
+        assert layer.device_pack(torch.device("cuda", 0))[0].info().mfma_f32 == want
+    monkeypatch.delenv("RAYEN_SPLIT_BF16")
+
+
+def _served_random_set(index, family_code):
+    """The ``index``-th random set (seeds 1000, 1001, ...) that the given split-operand family (2 / 3) serves under the
+    mode in force."""
     found = -1
     for seed in range(1000, 1200):
         raw = _random_set(seed)
         if len(raw["F"]) or raw["y0"].shape[0] > 64:
             continue
         cs, layer = _layer(raw, torch.float32)
-        if layer.device_pack(torch.device("cuda", 0))[0].info().mfma_f32 == 2:
+        if layer.device_pack(torch.device("cuda", 0))[0].info().mfma_f32 == family_code:
             found += 1
             if found == index:
                 return raw
     raise AssertionError("fewer random sets served by the split-operand kernel than expected")
 
 
+@pytest.mark.parametrize("family", ["pair", "triple"])
 @pytest.mark.parametrize("name", ["c2", "c3", "c5", "served0", "served1", "served2", "served3", "served4", "served5"])
-def test_split_operand_kernel_is_fp32_grade(name, monkeypatch):
-    """The default fp32 forward rebuilds every fp32 product from six bf16 MFMA products.  Measured against the fp64
-    kernel on the same inputs, its error must be that of fp32 arithmetic: no worse than the exact-fp32 MFMA kernel's
-    own error (x2 and a 5e-7 floor for sets where both are at the rounding level of the outputs)."""
-    raw = _served_random_set(int(name[6:])) if name.startswith("served") else workloads.make_raw(name, seed=13)
+def test_split_operand_kernels_are_fp32_grade(name, family, monkeypatch):
+    """The default fp32 forward rebuilds every fp32 product from three f16 MFMA products (operands carried as pairs
+    of f16 pieces, 22 bits) or, where the creation-time measurement rejects that (and under fp32_mode 4), from six
+    bf16 products (triples, 24 bits).  Measured against the fp64 kernel on the same inputs, the error of either must be
+    that of fp32 arithmetic: no worse than the exact-fp32 MFMA kernel's own error (x2 and a 5e-7 floor for sets where
+    both are at the rounding level of the outputs)."""
+    code = 3 if family == "pair" else 2
+    if family == "triple":
+        monkeypatch.setenv("RAYEN_FP32_MODE", "4")           # measured, but never the f16 pairs
+    raw = _served_random_set(int(name[6:]), code) if name.startswith("served") else workloads.make_raw(name, seed=13)
     cs, layer_split = _layer(raw, torch.float32)
     info = layer_split.device_pack(torch.device("cuda", 0))[0].info()
-    assert info.mfma_f32 == 2
+    assert info.mfma_f32 == code
     # the creation-time measurement that admitted the pack (probe directions incl. +-rows of W, against fp64)
-    assert 0.0 <= info.fp32_check_split <= max(4e-6, 1.5 * info.fp32_check_exact)
-    monkeypatch.setenv("RAYEN_SPLIT_BF16", "0")
+    measured = info.fp32_check_pair if family == "pair" else info.fp32_check_split
+    assert 0.0 <= measured <= max(4e-6, 1.5 * info.fp32_check_exact)
+    monkeypatch.setenv("RAYEN_FP32_MODE", "1")
     _, layer_exact = _layer(cs, torch.float32)
-    monkeypatch.delenv("RAYEN_SPLIT_BF16")
+    monkeypatch.delenv("RAYEN_FP32_MODE")
     _, layer_truth = _layer(cs, torch.float64)
     gen = torch.Generator().manual_seed(15)
     x = torch.empty(20000, cs.n, 1).uniform_(-1.5, 1.5, generator=gen)
@@ -209,14 +241,15 @@ def test_split_operand_kernel_is_fp32_grade(name, monkeypatch):
     e_split, e_exact = rel_err_rows(y_split, y_truth), rel_err_rows(y_exact, y_truth)
     assert np.max(e_split) <= max(2.0 * np.max(e_exact), 5e-7), (np.max(e_split), np.max(e_exact))
     assert np.mean(e_split) <= max(2.0 * np.mean(e_exact), 1e-7), (np.mean(e_split), np.mean(e_exact))
-    # interior samples: y = y0 + NA_E v, the same fp32 sum in both kernels up to the order of the additions
-    assert np.max(rel_err_rows(y_split[:64], y_exact[:64])) <= 3e-7
+    # interior samples: y = y0 + NA_E v -- the same fp32 sum up to the order of the additions (triples), or with v
+    # rebuilt from its two f16 pieces (22 bits: 2^-23 of the row's largest component)
+    assert np.max(rel_err_rows(y_split[:64], y_exact[:64])) <= (3e-7 if family == "triple" else 6e-7)
 
 
-def test_ill_conditioned_pack_is_served_by_the_exact_fp32_kernels(monkeypatch):
+def test_ill_conditioned_pack_is_measured_at_creation(monkeypatch):
     """Fuzz set 971 (70 dimensions, one dense quadratic with a large gradient at the interior point, 10 equalities):
-    its sums cancel so heavily that the split-operand kernel is 8x less accurate than fp32 arithmetic.  The library
-    measures both kernel families against fp64 when the pack is created and keeps the exact-fp32 one here."""
+    its sums cancel so heavily that the bf16-triple kernel is 8x less accurate than fp32 arithmetic.  The library
+    measures every family against fp64 when the pack is created and keeps one that is fp32-grade here."""
     raw = _random_set(1971)
     cs, layer = _layer(raw, torch.float32)
     gen = torch.Generator().manual_seed(971)
@@ -224,21 +257,25 @@ def test_ill_conditioned_pack_is_served_by_the_exact_fp32_kernels(monkeypatch):
     y = layer(x.cuda()).cpu().numpy()[:, :, 0]
     dp, _ = layer.device_pack(torch.device("cuda", 0))
     info = dp.info()
-    assert info.mfma_f32 == 1 and info.fp32_check_split > max(4e-6, 1.5 * info.fp32_check_exact)
+    assert info.fp32_check_split > max(4e-6, 1.5 * info.fp32_check_exact)          # the triples are turned down
+    if info.mfma_f32 == 3:
+        assert info.fp32_check_pair <= max(4e-6, 1.5 * info.fp32_check_exact)
+    else:
+        assert info.mfma_f32 == 1 and info.fp32_check_pair > max(4e-6, 1.5 * info.fp32_check_exact)
     y_true = _oracle_forward(cs, x.double(), torch.float64)
     y_ref = _oracle_forward(cs, x, torch.float32)
     assert rel_err_rows(y, y_true).max() <= 2.0 * max(rel_err_rows(y_ref, y_true).max(), 1e-6)
-    # RAYEN_SPLIT_BF16=2 skips the comparison: the split-operand kernel runs, and is visibly less accurate here
-    monkeypatch.setenv("RAYEN_SPLIT_BF16", "2")
+    # fp32_mode 2 skips the comparison: the bf16-triple kernel runs, and is visibly less accurate here
+    monkeypatch.setenv("RAYEN_FP32_MODE", "2")
     _, forced = _layer(cs, torch.float32)
     y_forced = forced(x.cuda()).cpu().numpy()[:, :, 0]
     assert forced.device_pack(torch.device("cuda", 0))[0].info().mfma_f32 == 2
     assert rel_err_rows(y_forced, y_true).max() <= 1e-4
-    # a well-conditioned pack keeps the split-operand kernel
-    monkeypatch.delenv("RAYEN_SPLIT_BF16")
+    # a well-conditioned pack is served by the fastest family
+    monkeypatch.delenv("RAYEN_FP32_MODE")
     cs3, layer3 = _layer(workloads.make_raw("c3", seed=3), torch.float32)
     layer3(torch.zeros(4, cs3.n, 1).cuda())
-    assert layer3.device_pack(torch.device("cuda", 0))[0].info().mfma_f32 == 2
+    assert layer3.device_pack(torch.device("cuda", 0))[0].info().mfma_f32 == 3
 
 
 # --------------------------------------------------------------------------- closed-form answers
@@ -478,9 +515,9 @@ def test_hip_graph_capture_replays_the_projection():
 
 
 @pytest.mark.parametrize("name,B", [("c2", 4096), ("c3", 8192), ("c5", 8192)])
-def test_split_bf16_operand_mode(name, B, monkeypatch):
-    """Opt-in MFMA mode on bf16 operand triples (6 partial products, fp32 accumulate): same parity bar."""
-    monkeypatch.setenv("RAYEN_SPLIT_BF16", "1")          # read by rayen_pack_create
+def test_bf16_triple_mode(name, B, monkeypatch):
+    """fp32_mode 4: bf16 operand triples (6 partial products, fp32 accumulate) where measured fit: same parity bar."""
+    monkeypatch.setenv("RAYEN_FP32_MODE", "4")          # read by rayen_pack_create
     raw = workloads.make_raw(name, seed=51)
     cs, layer = _layer(raw)
     gen = torch.Generator().manual_seed(8)
