@@ -506,7 +506,7 @@ __device__ __forceinline__ void mfma_split_fwd_body(
           vr[t][4 * (2 * sp + (i >> 2)) + (i & 3)] = (x1 + x2) + x3;
         }
       }
-    bad |= store_rows<NT, NKK, LSTR, true>(vr, scale, y0_lds, y, ldy, k, vec_out, s_base, B, live, patch, lane);
+    bad |= store_rows<NT, NKK, LSTR, true, true>(vr, scale, y0_lds, y, ldy, k, vec_out, s_base, B, live, patch, lane);  // (non-temporal stores: the rows are not read again)
   }
 
   if (hi == 0) {

@@ -138,3 +138,31 @@ def kink_mask(oracle, cs, x, rel_gap, method="RAYEN"):
         size = np.linalg.norm(delta, 2) * np.einsum("bi,bi->b", r, r) + 1e-300
         kink[idx[rad <= thr * thr * size]] = True
     return kink
+
+
+def lmi_gradient_bound(oracle, cs, x, eps, factor=4.0):
+    """Per-sample yardstick for the gradient of the LMI candidate, ``[B]`` (0 where no LMI or it is not on top).
+
+    d lambda_max / d v_a = u' G_a u with u the top eigenvector of the r x r pencil matrix S(v); an eigen-solver that
+    is backward stable to ||dS|| ~ r eps ||S|| (Householder tridiagonalisation + bisection + inverse iteration, which
+    is what the kernels do, and what LAPACK guarantees) returns u with an error of ||dS|| / (lambda_1 - lambda_2), and
+    the gradient inherits it to first order.  The bound is ``factor * r * eps * ||S|| / (lambda_1 - lambda_2)``."""
+    import torch
+    buf = oracle.precompute(csd_from_cs(cs), torch.float64)
+    B = x.shape[0]
+    if buf["all_F"].ndim != 3:
+        return np.zeros(B)
+    n = cs.n
+    v = x[:, 0:n, 0:1].double().cpu()
+    norm = torch.linalg.vector_norm(v, dim=(1, 2)).clamp_min(1e-300)
+    unit = v / norm.reshape(-1, 1, 1)
+    cand = torch.nan_to_num(oracle.compute_kappa(buf, unit, terms=True), nan=0.0)
+    S = torch.einsum("ajk,ial->ijk", [buf["all_F"][0:-1], buf["NA_E"] @ unit])
+    lam = torch.linalg.eigvalsh(buf["L"].T @ (-S) @ buf["L"])
+    r = lam.shape[1]
+    if r < 2:
+        return np.zeros(B)
+    on_top = lam[:, -1] >= cand.max(dim=1).values * (1.0 - 1e-6)
+    gap = (lam[:, -1] - lam[:, -2]).clamp_min(1e-300)
+    bound = factor * r * eps * lam.abs().amax(dim=1) / gap
+    return torch.where(on_top, bound, torch.zeros_like(bound)).numpy()

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import csd_from_cs, load_golden, kink_mask
+from helpers import lmi_gradient_bound, csd_from_cs, load_golden, kink_mask
 from oracle import rayen_oracle as oracle
 from rayen_amd import workloads
 from rayen_amd.constraint_module import ConstraintModule
@@ -57,6 +57,9 @@ def _assert_gradient(got, want, cs, x, G, dtype, method="RAYEN", floor=None, wha
             bound = np.maximum(bound, 4.0 * np.nan_to_num(theirs, nan=0.0))
         except AssertionError:          # the reference's fp32 discriminant went negative somewhere
             pass
+    # nearly repeated top LMI eigenvalues that are not close enough to be a kink: what a backward-stable eigen-solver
+    # delivers at the working precision (helpers.lmi_gradient_bound)
+    bound = np.maximum(bound, lmi_gradient_bound(oracle, cs, x, 6e-8 if dtype == torch.float32 else 1.1e-16))
     bad = (~kink) & ~(err <= bound)
     assert not bad.any(), (what, int(bad.sum()), int(kink.sum()), np.flatnonzero(bad)[:5], err[bad][:5], bound[bad][:5])
     assert kink.sum() <= max(2, 0.02 * kink.size), (what, "too many samples classified as kinks", kink.mean())
