@@ -185,7 +185,11 @@ def test_every_fp32_mfma_family(name, family, monkeypatch):
     assert rel_err_rows(y, y_true).max() <= bound, (rel_err_rows(y, y_true).max(), bound)
     assert rel_err_rows(y_default, y_true).max() <= bound, (rel_err_rows(y_default, y_true).max(), bound)
     # (feasibility next to the reference's own fp32 arithmetic: the equality rows of config 5 leave ~2e-6 in fp32)
-    assert oracle.max_violation(raw, y) <= max(VIOLATION_TOL, 3 * oracle.max_violation(raw, _oracle_forward(cs, x, torch.float32)))
+    try:
+        y_ref = _oracle_forward(cs, x, torch.float32)
+    except AssertionError:                                   # the reference's fp32 discriminant went negative (CM:342)
+        y_ref = y_true
+    assert oracle.max_violation(raw, y) <= max(VIOLATION_TOL, 3 * oracle.max_violation(raw, y_ref))
 
 
 def test_legacy_family_switch(monkeypatch):
