@@ -417,13 +417,17 @@ int rayen_ray_project_old_f32(const RayenPack* p, const float* v, int64_t B, int
 
 int rayen_mapper_fusable(const RayenPack* p, int32_t in_dim) {
   if (p == nullptr || check_ready<float>(p, false) != RAYEN_OK) return 0;
-  if (p->sp32 != nullptr && p->sp32_state == 1)   // the split-operand kernel serves the pack: its own fused form or none
+  if (p->pr32 != nullptr && p->pr32_state == 1)   // a split-operand kernel serves the pack: its own fused form or none
+    return mfma_pair_mapper_image_bytes(p, p->pr32, in_dim) > 0 ? 2 : 0;
+  if (p->sp32 != nullptr && p->sp32_state == 1)
     return mfma_split_mapper_image_bytes(p, p->sp32, in_dim) > 0 ? 2 : 0;
   return (p->m32 != nullptr && mfma_mapper_fusable(p, p->m32, in_dim)) ? 1 : 0;
 }
 
 int64_t rayen_mapper_image_bytes(const RayenPack* p, int32_t in_dim) {
-  if (p == nullptr || p->sp32 == nullptr || p->sp32_state != 1) return 0;
+  if (p == nullptr) return 0;
+  if (p->pr32 != nullptr && p->pr32_state == 1) return mfma_pair_mapper_image_bytes(p, p->pr32, in_dim);
+  if (p->sp32 == nullptr || p->sp32_state != 1) return 0;
   return mfma_split_mapper_image_bytes(p, p->sp32, in_dim);
 }
 
@@ -432,6 +436,8 @@ int rayen_mapper_prepare_f32(const RayenPack* p, const float* Wm, int64_t ldw, i
   if (p == nullptr || Wm == nullptr || image == nullptr || in_dim <= 0 || ldw < in_dim) return RAYEN_E_BAD_ARG;
   const int rc = check_ready<float>(p, false);
   if (rc) return rc;
+  if (p->pr32 != nullptr && p->pr32_state == 1)
+    return mfma_pair_mapper_prepare(p, p->pr32, Wm, ldw, in_dim, bias, image, static_cast<hipStream_t>(stream));
   if (p->sp32 == nullptr || p->sp32_state != 1) return RAYEN_E_UNSUPPORTED;
   return mfma_split_mapper_prepare(p, p->sp32, Wm, ldw, in_dim, bias, image, static_cast<hipStream_t>(stream));
 }
@@ -444,6 +450,9 @@ int rayen_ray_project_mapped_image_f32(const RayenPack* p, const float* x, int64
     return RAYEN_E_BAD_ARG;
   const int rc = check_ready<float>(p, false);
   if (rc) return rc;
+  if (p->pr32 != nullptr && p->pr32_state == 1)
+    return mfma_pair_forward_mapped(p, p->pr32, x, B, ldx, in_dim, image, v_out, ldvo, y, ldy, kappa, active, nan_flag,
+                                    static_cast<hipStream_t>(stream));
   if (p->sp32 == nullptr || p->sp32_state != 1) return RAYEN_E_UNSUPPORTED;
   return mfma_split_forward_mapped(p, p->sp32, x, B, ldx, in_dim, image, v_out, ldvo, y, ldy, kappa, active, nan_flag,
                                    static_cast<hipStream_t>(stream));

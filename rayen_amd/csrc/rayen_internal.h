@@ -126,6 +126,13 @@ int mfma_pair_forward(const RayenPack* p, const PairImage* img, const float* v, 
                       float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
                       hipStream_t stream);
 
+int64_t mfma_pair_mapper_image_bytes(const RayenPack* p, const PairImage* img, int in_dim);
+int mfma_pair_mapper_prepare(const RayenPack* p, const PairImage* img, const float* w, int64_t ldw, int in_dim,
+                             const float* bias, void* image, hipStream_t stream);
+int mfma_pair_forward_mapped(const RayenPack* p, const PairImage* img, const float* x, int64_t B, int64_t ldx,
+                             int in_dim, const void* image, float* v_out, int64_t ldvo, float* y, int64_t ldy,
+                             float* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream);
+
 // the bf16-triple kernel behind the module's mapper v = Wm x + b; Wm as a caller-owned split-operand image
 int64_t mfma_split_mapper_image_bytes(const RayenPack* p, const SplitImage* img, int in_dim);
 int mfma_split_mapper_prepare(const RayenPack* p, const SplitImage* img, const float* w, int64_t ldw, int in_dim,

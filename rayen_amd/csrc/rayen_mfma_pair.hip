@@ -28,16 +28,38 @@ namespace rayen {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-template <int NKK, bool TRACK, bool STAGED>
-__global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_fwd_kernel(
+// The module's mapper v = Wm x + b (rayen/constraint_module.py:259-263, 525) in front of the walk (NKX > 0 instances),
+// the f16-pair form of rayen_mfma_split.hip's: Wm as an image of f16 pairs of gM Wm (gM a power of two chosen by
+// pair_mapper_image_kernel from the weights' largest entry), x scaled per sample like v, the accumulators start at
+// gM sx b, and the fp32 results -- which ARE in B-operand order -- are re-scaled and re-split in registers into the
+// walk's B operands.  v reaches memory only when v_out != null (training).
+struct PairMapper {
+  const f16x8* img = nullptr;   // [NKK][NSX][2][64] x 8 f16, then n_pad floats of bias, then gM, 1 / gM
+  int in_dim = 0;
+  float* v_out = nullptr;
+  int64_t ldvo = 0;
+};
+
+// 2^13 / 2^floor(log2 m) as a float and its inverse, from the biased exponent of m (clamped to [14, 254])
+__device__ __forceinline__ void pow2_scale(const float m, float& scale, float& inv, int& exp_scale) {
+  unsigned e = __builtin_bit_cast(unsigned, m) >> 23;
+  e = e < 14u ? 14u : (e > 254u ? 254u : e);
+  scale = __builtin_bit_cast(float, (267u - e) << 23);
+  inv = __builtin_bit_cast(float, (e - 13u) << 23);
+  exp_scale = 140 - (int)e;
+}
+
+template <int NKK, bool TRACK, bool STAGED, int NKX>
+__device__ __forceinline__ void mfma_pair_fwd_body(
     const f16x8* __restrict__ Wh, const MItem* __restrict__ items, int n_items,
     const MPack* __restrict__ packs, const float* __restrict__ y0, int identity, int k, int n,
     const float* __restrict__ v, int64_t B, int64_t ldv, int vec_in, float* __restrict__ y, int64_t ldy,
     int vec_out, float* __restrict__ kappa_out, int32_t* __restrict__ active_out,
-    int32_t* __restrict__ nan_flag, const float w_scale, const float w_inv) {
+    int32_t* __restrict__ nan_flag, const float w_scale, const float w_inv, const PairMapper mp) {
   constexpr int NT = 2, NS = NKK * 2, NCH = NS * 2, KK = NKK * 16;
   __shared__ float aux_lds[kMfmaWaves][NT][32][32];
   __shared__ __attribute__((aligned(16))) float y0_lds[NKK * 32];
+  __shared__ __attribute__((aligned(16))) float bias_lds[NKX > 0 ? NKK * 32 : 4];   // gM b, zero-padded
   constexpr int LSTR = NKK * 32 + 4;
   __shared__ __attribute__((aligned(16))) float line_lds[kMfmaWaves][32][LSTR];
 
@@ -50,6 +72,15 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_fwd
   const int64_t wave_stride = (int64_t)gridDim.x * kMfmaWaves;
   bool bad = false;
   for (int i = threadIdx.x; i < NKK * 32; i += kMfmaWaves * 64) y0_lds[i] = y0[i];
+  float gm = 1.f, gm_inv = 1.f;
+  int gm_exp = 0;
+  if constexpr (NKX > 0) {
+    const float* tail = reinterpret_cast<const float*>(mp.img + (size_t)NKK * (NKX * 2) * 2 * 64);
+    gm = tail[NKK * 32];
+    gm_inv = tail[NKK * 32 + 1];
+    gm_exp = (int)((__builtin_bit_cast(unsigned, gm) >> 23) & 255u) - 127;
+    for (int i = threadIdx.x; i < NKK * 32; i += kMfmaWaves * 64) bias_lds[i] = tail[i] * gm;
+  }
   __syncthreads();  // the only workgroup barrier
   float (*patch)[LSTR] = line_lds[wave];
 
@@ -61,9 +92,11 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_fwd
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(abuf[2 * sp + 0]) : "v"(lane_off), "s"(sb));
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(abuf[2 * sp + 1]) : "v"(lane_off), "s"(sb));
   };
-  // tile 0 for the first group; no wait: the group's row loads queue behind these and loads return in order
+  if constexpr (NKX == 0) {
+    // tile 0 for the first group; no wait: the group's row loads queue behind these and loads return in order
 #pragma unroll
-  for (int sp = 0; sp < NS; ++sp) load_step_fresh(sp);
+    for (int sp = 0; sp < NS; ++sp) load_step_fresh(sp);
+  }
 
   const int64_t n_rounds = (n_groups + wave_stride - 1) / wave_stride;
   for (int64_t round = 0; round < n_rounds; ++round) {
@@ -78,7 +111,107 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_fwd
   f16x8 vb[NT][2][NS];
   float v_scl[NT], v_inv[NT];  // sv and 1 / sv (powers of two; applied one after the other with gW, never multiplied
                                // together: sv spans 2^-114 .. 2^126)
-  {
+  if constexpr (NKX > 0) {
+    constexpr int NSX = NKX * 2;
+    float xr[NT][NKX * 16];
+    load_rows<NT, NKX, LSTR, true>(xr, v, ldv, mp.in_dim, vec_in & 1, s_base, B, live, patch, lane);
+    float sx[NT], sx_inv[NT];
+    int sx_exp[NT];
+    f32x16 macc[NKK][NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float m = 0.f;
+#pragma unroll
+      for (int i = 0; i < NKX * 16; ++i) m = fmaxf(m, __builtin_fabsf(xr[t][i]));
+      m = fmaxf(m, xhalf(m));
+      pow2_scale(m, sx[t], sx_inv[t], sx_exp[t]);
+    }
+#pragma unroll
+    for (int tp = 0; tp < NKK; ++tp)
+#pragma unroll
+      for (int a4 = 0; a4 < 4; ++a4) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(&bias_lds[32 * tp + 8 * a4 + 4 * hi]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) macc[tp][t][4 * a4 + c] = b4[c] * sx[t];
+      }
+    const f16x8* mimg = mp.img + lane;
+#pragma unroll
+    for (int sxs = 0; sxs < NSX; ++sxs) {
+      f16x8 xb[NT][2];   // the K-step's pieces of sx x: element i = column 16 sxs + 8 (i >> 2) + 4 hi + (i & 3)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float x = xr[t][8 * sxs + i] * sx[t];
+          const _Float16 p1 = (_Float16)x;
+          xb[t][0][i] = p1;
+          xb[t][1][i] = (_Float16)(x - (float)p1);
+        }
+#pragma unroll
+      for (int tp = 0; tp < NKK; ++tp) {
+        const f16x8* ch = mimg + (size_t)((tp * NSX + sxs) * 2) * 64;
+        const f16x8 a1 = ch[0], a2 = ch[64];
+        // (cross products first; the accumulator starts at the bias)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) macc[tp][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, xb[t][0], macc[tp][t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) macc[tp][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xb[t][1], macc[tp][t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) macc[tp][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xb[t][0], macc[tp][t], 0, 0, 0);
+      }
+    }
+    // the rolling buffer is dead while the mapper runs (its registers hold x and the mapper's accumulators): tile 0
+    // is fetched afresh once the mapper's MFMAs are issued -- the walk's counted waits cover it
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int sp = 0; sp < NS; ++sp) load_step_fresh(sp);
+    __builtin_amdgcn_sched_barrier(0);
+    // macc = gM sx v
+    if (mp.v_out != nullptr) {
+      float vr[NT][KK];
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int tp = 0; tp < NKK; ++tp)
+#pragma unroll
+          for (int g = 0; g < 16; ++g) vr[t][16 * tp + g] = macc[tp][t][g] * gm_inv;
+      (void)store_rows<NT, NKK, LSTR, true>(vr, sx_inv, nullptr, mp.v_out, mp.ldvo, n,
+                                            (mp.ldvo % 4 == 0) && ((reinterpret_cast<uintptr_t>(mp.v_out) & 15) == 0),
+                                            s_base, B, live, patch, lane);
+    }
+    // result register g = 4 a + c of row tile tp is direction element 32 tp + 8 a + 4 hi + c = element 4 (a & 1) + c
+    // of K-step 2 tp + (a >> 1): re-scaled (largest component into [2^13, 2^14)) and split in place
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float m = 0.f;
+#pragma unroll
+      for (int tp = 0; tp < NKK; ++tp)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) m = fmaxf(m, __builtin_fabsf(macc[tp][t][g]));
+      m = fmaxf(m, xhalf(m));
+      float f, f_inv;
+      int f_exp;
+      pow2_scale(m, f, f_inv, f_exp);
+      // sv = f gM sx as a power of two (the exponents are added, the product of the floats could overflow on the way)
+      int sv_exp = f_exp + gm_exp + sx_exp[t];
+      sv_exp = sv_exp > 126 ? 126 : (sv_exp < -126 ? -126 : sv_exp);
+      v_scl[t] = __builtin_bit_cast(float, (unsigned)(127 + sv_exp) << 23);
+      v_inv[t] = __builtin_bit_cast(float, (unsigned)(127 - sv_exp) << 23);
+#pragma unroll
+      for (int tp = 0; tp < NKK; ++tp)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float x = macc[tp][t][4 * a + c] * f;
+            const _Float16 p1 = (_Float16)x;
+            vb[t][0][2 * tp + (a >> 1)][4 * (a & 1) + c] = p1;
+            vb[t][1][2 * tp + (a >> 1)][4 * (a & 1) + c] = (_Float16)(x - (float)p1);
+          }
+    }
+  } else {
     float vr[NT][KK];
     if (NKK == 1 && (vec_in & 2) && n != NKK * 32) {
       // ragged rows stored back to back (config-5-like shapes): whole-line float4 loads of the tile's contiguous
@@ -125,10 +258,9 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_fwd
 #pragma unroll
       for (int i = 0; i < KK; ++i) m = fmaxf(m, __builtin_fabsf(vr[t][i]));
       m = fmaxf(m, xhalf(m));
-      unsigned e = __builtin_bit_cast(unsigned, m) >> 23;
-      e = e < 14u ? 14u : (e > 254u ? 254u : e);
-      const float sv = __builtin_bit_cast(float, (267u - e) << 23);
-      v_inv[t] = __builtin_bit_cast(float, (e - 13u) << 23);
+      float sv;
+      int sv_exp;
+      pow2_scale(m, sv, v_inv[t], sv_exp);
       v_scl[t] = sv;
 #pragma unroll
       for (int q = 0; q < NKK * 4; ++q)
@@ -343,7 +475,19 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_fwd
     }
   }
 
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next group's first tile has landed
+  if constexpr (NKX > 0) {
+    // (mapped instances discard the prefetched tile -- the mapper needs its registers -- but the loads are still in
+    // flight here: the chunks stay live up to this wait so that the compiler cannot hand them out before)
+    if constexpr (NCH == 8)
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(abuf[0]), "+v"(abuf[1]), "+v"(abuf[2]), "+v"(abuf[3]), "+v"(abuf[4]), "+v"(abuf[5]), "+v"(abuf[6]), "+v"(abuf[7])
+                   :
+                   : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(abuf[0]), "+v"(abuf[1]), "+v"(abuf[2]), "+v"(abuf[3]) : : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next group's first tile has landed
+  }
 
   if (identity) {
     finish_kappa();
@@ -373,6 +517,74 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_fwd
   }
   }  // persistent loop over sample groups
   if (nan_flag && bad) atomicOr(nan_flag, 1);
+}
+
+template <int NKK, bool TRACK, bool STAGED>
+__global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_fwd_kernel(
+    const f16x8* __restrict__ Wh, const MItem* __restrict__ items, int n_items,
+    const MPack* __restrict__ packs, const float* __restrict__ y0, int identity, int k, int n,
+    const float* __restrict__ v, int64_t B, int64_t ldv, int vec_in, float* __restrict__ y, int64_t ldy,
+    int vec_out, float* __restrict__ kappa_out, int32_t* __restrict__ active_out,
+    int32_t* __restrict__ nan_flag, const float w_scale, const float w_inv) {
+  mfma_pair_fwd_body<NKK, TRACK, STAGED, 0>(Wh, items, n_items, packs, y0, identity, k, n, v, B, ldv, vec_in, y, ldy,
+                                            vec_out, kappa_out, active_out, nan_flag, w_scale, w_inv, PairMapper());
+}
+
+// the same walk behind the fused mapper (x in place of v; NKX 32-column blocks of x)
+template <int NKK, bool TRACK, int NKX>
+__global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_map_kernel(
+    const f16x8* __restrict__ Wh, const MItem* __restrict__ items, int n_items,
+    const MPack* __restrict__ packs, const float* __restrict__ y0, int identity, int k, int n,
+    const float* __restrict__ x, int64_t B, int64_t ldx, int vec_in, float* __restrict__ y, int64_t ldy,
+    int vec_out, float* __restrict__ kappa_out, int32_t* __restrict__ active_out,
+    int32_t* __restrict__ nan_flag, const float w_scale, const float w_inv, const PairMapper mp) {
+  mfma_pair_fwd_body<NKK, TRACK, false, NKX>(Wh, items, n_items, packs, y0, identity, k, n, x, B, ldx, vec_in, y, ldy,
+                                             vec_out, kappa_out, active_out, nan_flag, w_scale, w_inv, mp);
+}
+
+// Wm [n, ldw] (row-major fp32, torch.nn.Linear.weight) -> the image the mapped kernel reads.  ONE workgroup: the
+// largest |entry| (LDS reduction) fixes gM = the power of two that puts it into [2^13, 2^14); then chunk (row tile
+// tp, K-step s, piece) = 64 lanes x 8 f16, element i of lane l = piece of gM Wm[32 tp + (l & 31)][16 s + 8 (i >> 2) +
+// 4 (l >> 5) + (i & 3)], zero beyond (n, in_dim); then the bias (zero-padded to n_pad floats), gM and 1 / gM.
+__global__ __launch_bounds__(256) void pair_mapper_image_kernel(const float* __restrict__ w, int64_t ldw,
+                                                                const float* __restrict__ bias, int n, int in_dim,
+                                                                int nkk, int nsx, f16x8* __restrict__ img) {
+  __shared__ float red[256];
+  float m = 0.f;
+  for (int i = threadIdx.x; i < n * in_dim; i += 256) {
+    const float x = __builtin_fabsf(w[(int64_t)(i / in_dim) * ldw + (i % in_dim)]);
+    if (x < __builtin_inff()) m = fmaxf(m, x);     // (NaN / inf entries do not set the scale; they propagate)
+  }
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  unsigned e = __builtin_bit_cast(unsigned, red[0]) >> 23;
+  e = red[0] > 0.f ? (e < 67u ? 67u : (e > 200u ? 200u : e)) : 140u;     // |shift| <= 73
+  const float gm = __builtin_bit_cast(float, (267u - e) << 23);
+  const float gm_inv = __builtin_bit_cast(float, (e - 13u) << 23);
+  const int l = threadIdx.x & 63;
+  for (int chunk = threadIdx.x >> 6; chunk < nkk * nsx; chunk += 4) {
+    const int tp = chunk / nsx, sx = chunk - tp * nsx;
+    const int row = 32 * tp + (l & 31);
+    f16x8 o1, o2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int col = 16 * sx + 8 * (i >> 2) + 4 * (l >> 5) + (i & 3);
+      const float x = ((row < n && col < in_dim) ? w[(int64_t)row * ldw + col] : 0.f) * gm;
+      const _Float16 p1 = (_Float16)x;
+      o1[i] = p1;
+      o2[i] = (_Float16)(x - (float)p1);
+    }
+    f16x8* dst = img + (size_t)chunk * 2 * 64 + l;
+    dst[0] = o1;
+    dst[64] = o2;
+  }
+  float* tail = reinterpret_cast<float*>(img + (size_t)nkk * nsx * 2 * 64);
+  for (int i = threadIdx.x; i < nkk * 32; i += 256) tail[i] = (bias != nullptr && i < n) ? bias[i] : 0.f;
+  if (threadIdx.x == 0) { tail[nkk * 32] = gm; tail[nkk * 32 + 1] = gm_inv; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -477,6 +689,64 @@ static int launch_pair(const RayenPack* p, const PairImage* img, const float* v,
     else go(mfma_pair_fwd_kernel<NKK, false, true>);
   }
   return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
+}
+
+// ---- fused mapper: in_dim <= n_pad columns of x.  Sets without equality constraints only (as the bf16-triple form).
+int64_t mfma_pair_mapper_image_bytes(const RayenPack* p, const PairImage* img, int in_dim) {
+  (void)p;
+  if (img == nullptr || !img->identity || in_dim < 1 || in_dim > img->nkk * 32) return 0;
+  const int nsx = (in_dim + 31) / 32 * 2;
+  return (int64_t)img->nkk * nsx * 2 * 1024 + (int64_t)(img->nkk * 32 + 4) * sizeof(float);
+}
+
+int mfma_pair_mapper_prepare(const RayenPack* p, const PairImage* img, const float* w, int64_t ldw, int in_dim,
+                             const float* bias, void* image, hipStream_t stream) {
+  if (mfma_pair_mapper_image_bytes(p, img, in_dim) == 0) return RAYEN_E_UNSUPPORTED;
+  const int nsx = (in_dim + 31) / 32 * 2;
+  hipLaunchKernelGGL(pair_mapper_image_kernel, dim3(1), dim3(256), 0, stream, w, ldw, bias, p->n, in_dim, img->nkk, nsx,
+                     static_cast<f16x8*>(image));
+  return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
+}
+
+template <int NKK, int NKX>
+static int launch_pair_map(const RayenPack* p, const PairImage* img, const float* x, int64_t B, int64_t ldx,
+                           const PairMapper& mp, float* y, int64_t ldy, float* kappa, int32_t* active,
+                           int32_t* nan_flag, hipStream_t stream) {
+  constexpr int per_wave = 64;
+  const int64_t n_groups = (B + per_wave - 1) / per_wave;
+  const int64_t slots = (int64_t)img->n_simd * kMfmaWavesPerSimd;
+  const int64_t rounds = (n_groups + slots - 1) / slots;
+  const int64_t waves = (n_groups + rounds - 1) / rounds;
+  const int64_t grid = (waves + kMfmaWaves - 1) / kMfmaWaves;
+  const int vec_in = ((ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0)) ? 1 : 0;
+  const int vec_out = (ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+  auto go = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kMfmaWaves * 64), 0, stream,
+                       static_cast<const f16x8*>(img->Wh), img->items, img->n_items, img->packs, img->y0,
+                       img->identity, p->k, p->n, x, B, ldx, vec_in, y, ldy, vec_out, kappa, active, nan_flag,
+                       img->w_scale, img->w_inv, mp);
+  };
+  if (!img->identity) return RAYEN_E_UNSUPPORTED;
+  if (active != nullptr) go(mfma_pair_map_kernel<NKK, true, NKX>);
+  else go(mfma_pair_map_kernel<NKK, false, NKX>);
+  return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
+}
+
+int mfma_pair_forward_mapped(const RayenPack* p, const PairImage* img, const float* x, int64_t B, int64_t ldx,
+                             int in_dim, const void* image, float* v_out, int64_t ldvo, float* y, int64_t ldy,
+                             float* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream) {
+  if (mfma_pair_mapper_image_bytes(p, img, in_dim) == 0 || image == nullptr) return RAYEN_E_UNSUPPORTED;
+  if (B == 0) return RAYEN_OK;
+  PairMapper mp;
+  mp.img = static_cast<const f16x8*>(image);
+  mp.in_dim = in_dim;
+  mp.v_out = v_out;
+  mp.ldvo = ldvo;
+  const int nkx = (in_dim + 31) / 32;
+  if (img->nkk == 1 && nkx == 1) return launch_pair_map<1, 1>(p, img, x, B, ldx, mp, y, ldy, kappa, active, nan_flag, stream);
+  if (img->nkk == 2 && nkx == 1) return launch_pair_map<2, 1>(p, img, x, B, ldx, mp, y, ldy, kappa, active, nan_flag, stream);
+  if (img->nkk == 2 && nkx == 2) return launch_pair_map<2, 2>(p, img, x, B, ldx, mp, y, ldy, kappa, active, nan_flag, stream);
+  return RAYEN_E_UNSUPPORTED;
 }
 
 int mfma_pair_forward(const RayenPack* p, const PairImage* img, const float* v, int64_t B, int64_t ldv,

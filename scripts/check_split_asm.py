@@ -21,7 +21,7 @@ for name in ("rayen_mfma_split", "rayen_mfma_pair"):
     text = open(asm).read().split("\n")
     lines += text
     starts += [base + i for i, l in enumerate(text)
-               if l.startswith(("_ZN5rayen21mfma_split_fwd_kernel", "_ZN5rayen21mfma_split_map_kernel", "_ZN5rayen20mfma_pair_fwd_kernel"))
+               if l.startswith(("_ZN5rayen21mfma_split_fwd_kernel", "_ZN5rayen21mfma_split_map_kernel", "_ZN5rayen20mfma_pair_fwd_kernel", "_ZN5rayen20mfma_pair_map_kernel"))
                and l.split(";")[0].rstrip().endswith(":")]
     starts.append(base + len(text))          # (closes the last kernel of this file)
 
@@ -43,9 +43,13 @@ for s, e in zip(starts[:-1], starts[1:]):
         body.append(l)
         if "s_endpgm" in l:
             break
-    name = re.search(r"ILi(\d)ELb(\d)ELb(\d)", lines[s]).groups()
+    found = re.search(r"ILi(\d)ELb(\d)ELb(\d)", lines[s])
+    name = found.groups() if found else ("?", "?", "0")
     mapped = "split_map_kernel" in lines[s]
     nkx = re.search(r"ELb\dELb\dELi(\d)", lines[s]).group(1) if mapped else "0"
+    if "pair_map_kernel" in lines[s]:                    # <NKK, TRACK, NKX>: never staged
+        m3 = re.search(r"ILi(\d)ELb(\d)ELi(\d)", lines[s]).groups()
+        name, nkx = (m3[0], m3[1], "0"), m3[2]
     # the hand-placed loads are the ones written as asm statements (the compiler's own loads of the mapper image or of
     # the rows are tracked by the compiler and need no check)
     loads = [i for i, l in enumerate(body) if "global_load_dwordx4" in l and re.search(r", s\[\d+:\d+\]", l)
