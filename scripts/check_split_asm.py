@@ -15,7 +15,8 @@ for name in ("rayen_mfma_split", "rayen_mfma_pair"):
     src = os.path.join(REPO, "rayen_amd", "csrc", name + ".hip")
     asm = f"/tmp/{name}.s"
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(REPO, "include"),
-                    "-I", os.path.join(REPO, "rayen_amd", "csrc"), "-S", "--cuda-device-only", src, "-o", asm],
+                    "-I", os.path.join(REPO, "rayen_amd", "csrc"), *os.environ.get("RAYEN_CHECK_DEFS", "").split(),
+                    "-S", "--cuda-device-only", src, "-o", asm],
                    check=True, stderr=subprocess.DEVNULL)
     base = len(lines)
     text = open(asm).read().split("\n")

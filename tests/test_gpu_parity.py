@@ -192,6 +192,50 @@ def test_every_fp32_mfma_family(name, family, monkeypatch):
     assert oracle.max_violation(raw, y) <= max(VIOLATION_TOL, 3 * oracle.max_violation(raw, y_ref))
 
 
+@pytest.mark.parametrize("name", ["c2", "c3", "c5"])
+def test_pair_kernel_scales_every_row_on_its_own(name):
+    """The f16-pair kernel moves every direction into f16 range with its own power of two: rows of very different
+    magnitudes in one batch, components spread over many binades inside a row, zero rows, and non-finite rows (which
+    must come out non-finite and raise the NaN flag, never contaminate their neighbours)."""
+    raw = workloads.make_raw(name, seed=77)
+    cs, layer = _layer(raw, torch.float32)
+    dp, _ = layer.device_pack(torch.device("cuda", 0))
+    assert dp.info().mfma_f32 == 3
+    gen = torch.Generator().manual_seed(12)
+    B = 2048
+    x = torch.empty(B, cs.n).uniform_(-1.0, 1.0, generator=gen)
+    mag = 10.0 ** torch.randint(-12, 13, (B, 1), generator=gen).float()            # 1e-12 .. 1e12 per row
+    x = x * mag
+    spread = 2.0 ** (-torch.randint(0, 20, (B // 2, cs.n), generator=gen).float())  # 2^0 .. 2^-19 inside a row
+    x[: B // 2] *= spread
+    x[5] = 0.0
+    y_true = _oracle_forward(cs, x.double().unsqueeze(2), torch.float64)
+    y, kappa, _ = ops.project_raw(x.cuda(), dp)
+    err = rel_err_rows(y.cpu().numpy(), y_true)
+    bound = _fp32_bound(cs, x.unsqueeze(2), y_true, layer)
+    assert err.max() <= bound, (err.max(), bound, int(err.argmax()))
+    assert np.allclose(y[5].cpu().numpy(), cs.y0[:, 0], atol=1e-6)
+    k_true = oracle.compute_kappa(oracle.precompute(csd_from_cs(cs), torch.float64), x.double().unsqueeze(2))[:, 0, 0].numpy()
+    # (kappa against the truth, with what the fp32 rounding of the constants alone does to it as yardstick: config 5)
+    import packed_eval
+    _, k_const, _ = packed_eval.evaluate(layer.packed_constants(), x.double().numpy())
+    size = np.maximum(np.abs(k_true), 1e-30)
+    k_bound = max(1e-5, 4.0 * float(np.max(np.abs(k_const - k_true) / size)))
+    assert np.all(np.abs(kappa.cpu().numpy() - k_true) <= k_bound * size), (k_bound, float(np.max(np.abs(kappa.cpu().numpy() - k_true) / size)))
+    # non-finite rows
+    xb = x.clone()
+    xb[7, 3] = float("nan")
+    xb[9, 0] = float("inf")
+    dp.nan_flag.zero_()
+    yb, _, _ = ops.project_raw(xb.cuda(), dp)
+    yb = yb.cpu().numpy()
+    assert not np.all(np.isfinite(yb[7])) and not np.all(np.isfinite(yb[9])) and int(dp.nan_flag.item()) == 1
+    dp.nan_flag.zero_()
+    keep = np.ones(B, dtype=bool)
+    keep[[7, 9]] = False
+    assert np.array_equal(yb[keep], y.cpu().numpy()[keep])
+
+
 def test_legacy_family_switch(monkeypatch):
     """RAYEN_SPLIT_BF16 = 0 / 1 / 2, the switch of ABI v2: exact-fp32 kernels only / bf16 triples where the
     measurement accepts them (never f16 pairs) / bf16 triples unmeasured."""
