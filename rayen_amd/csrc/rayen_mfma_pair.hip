@@ -360,6 +360,46 @@ __device__ __forceinline__ void mfma_pair_fwd_body(
           for (int g = 0; g < 16; ++g) kap[t] = fmaxf(kap[t], acc[t][g]);
         }
       }
+    } else if (item.type == MI_QFAC || item.type == MI_SOC) {
+      // a running sum of squares over the segment's tiles, closed on its last tile
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        f32x2 s2 = {(item.flags & MF_FIRST) ? 0.f : part[t], 0.f};
+#pragma unroll
+        for (int g = 0; g < 16; g += 2) {
+          const f32x2 a2 = {acc[t][g], acc[t][g + 1]};
+          s2 = __builtin_elementwise_fma(a2, a2, s2);
+        }
+        part[t] = s2[0] + s2[1];
+      }
+      if (item.flags & MF_LAST) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float total = part[t] + xhalf(part[t]);
+          const float a0 = aux_lds[wave][t][item.aux][col];
+          float kc;
+          if (item.type != MI_SOC) {
+            kc = a0 + __builtin_amdgcn_sqrtf(fmaxf(total, 0.f));
+          } else {
+            // a' x^2 + b' x + c' = 0  (rayen/constraint_module.py:392-396, 339-348), a' < 0: the coefficients mix in
+            // the set's constants f0 = tau, f1 = a' -- natural units here, the root goes back to the scaled domain
+            const float vi = v_inv[t];
+            const float cr = (a0 * w_inv) * vi;
+            const float br = (aux_lds[wave][t][item.aux + 1][col] * w_inv) * vi;
+            const float rt = (__builtin_amdgcn_sqrtf(total) * w_inv) * vi;
+            const float cp = rt * rt - cr * cr;
+            const float bp = 2.f * br - 2.f * cr * item.f0;
+            const float disc = bp * bp - 4.f * item.f1 * cp;
+            kc = 0.f;
+            if (disc >= 0.f) {
+              const float root = __builtin_amdgcn_sqrtf(disc);
+              const float inv2a = 0.5f * __builtin_amdgcn_rcpf(item.f1);
+              kc = (fmaxf((-bp - root) * inv2a, (-bp + root) * inv2a) * v_scl[t]) * w_scale;
+            }
+          }
+          if (kc > kap[t]) { kap[t] = kc; acode[t] = item.seg << 20; }
+        }
+      }
     } else if (item.type == MI_AUX) {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -430,46 +470,6 @@ __device__ __forceinline__ void mfma_pair_fwd_body(
           if (pair) qs += xhalf(qs);
           const float kc = aux_lds[wave][t][slot & 31][col] + __builtin_amdgcn_sqrtf(qs);
           if (sid >= 0 && kc > kap[t]) { kap[t] = kc; acode[t] = sid << 20; }
-        }
-      }
-    } else if (item.type == MI_QFAC || item.type == MI_SOC) {
-      // a running sum of squares over the segment's tiles, closed on its last tile
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        f32x2 s2 = {(item.flags & MF_FIRST) ? 0.f : part[t], 0.f};
-#pragma unroll
-        for (int g = 0; g < 16; g += 2) {
-          const f32x2 a2 = {acc[t][g], acc[t][g + 1]};
-          s2 = __builtin_elementwise_fma(a2, a2, s2);
-        }
-        part[t] = s2[0] + s2[1];
-      }
-      if (item.flags & MF_LAST) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const float total = part[t] + xhalf(part[t]);
-          const float a0 = aux_lds[wave][t][item.aux][col];
-          float kc;
-          if (item.type != MI_SOC) {
-            kc = a0 + __builtin_amdgcn_sqrtf(fmaxf(total, 0.f));
-          } else {
-            // a' x^2 + b' x + c' = 0  (rayen/constraint_module.py:392-396, 339-348), a' < 0: the coefficients mix in
-            // the set's constants f0 = tau, f1 = a' -- natural units here, the root goes back to the scaled domain
-            const float vi = v_inv[t];
-            const float cr = (a0 * w_inv) * vi;
-            const float br = (aux_lds[wave][t][item.aux + 1][col] * w_inv) * vi;
-            const float rt = (__builtin_amdgcn_sqrtf(total) * w_inv) * vi;
-            const float cp = rt * rt - cr * cr;
-            const float bp = 2.f * br - 2.f * cr * item.f0;
-            const float disc = bp * bp - 4.f * item.f1 * cp;
-            kc = 0.f;
-            if (disc >= 0.f) {
-              const float root = __builtin_amdgcn_sqrtf(disc);
-              const float inv2a = 0.5f * __builtin_amdgcn_rcpf(item.f1);
-              kc = (fmaxf((-bp - root) * inv2a, (-bp + root) * inv2a) * v_scl[t]) * w_scale;
-            }
-          }
-          if (kc > kap[t]) { kap[t] = kc; acode[t] = item.seg << 20; }
         }
       }
     }

@@ -2,7 +2,7 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-os.environ["RAYEN_HIP_LIBRARY"] = os.path.join(ROOT, "rayen_amd", "csrc", "variants", "librayen_hip_v64.so")
+os.environ["RAYEN_HIP_LIBRARY"] = os.path.join(ROOT, "rayen_amd", "csrc", "variants", "librayen_hip_v320.so")
 os.environ["RAYEN_FP32_MODE"] = "3"
 import torch
 from rayen_amd import ops, workloads

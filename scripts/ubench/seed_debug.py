@@ -30,12 +30,12 @@ for seed in map(int, sys.argv[1:]):
     print(f"  oracle fp32 err {rel_err_rows(y32, y_true).max():.3e}   constants rounding {rel_err_rows(y_const, y_true).max():.3e}")
     if not torch.cuda.is_available():
         continue
-    for mode, tag in ((0, "default"), (1, "exact"), (2, "split")):
+    for mode, tag in ((0, "default"), (1, "exact"), (2, "triple"), (3, "pair")):
         dp = _pack.DevicePack(consts, 0, fp32_mode=mode)
         info = dp.info()
         y = ops.project_raw(x[:, :, 0].cuda().contiguous(), dp)[0].cpu().numpy()
         e = rel_err_rows(y, y_true)
-        print(f"  {tag:8s} family {info.mfma_f32} check split/exact {info.fp32_check_split:.2e}/{info.fp32_check_exact:.2e} "
+        print(f"  {tag:8s} family {info.mfma_f32} check pair/triple/exact {info.fp32_check_pair:.2e}/{info.fp32_check_split:.2e}/{info.fp32_check_exact:.2e} "
               f"err max {e.max():.3e} at {int(e.argmax())}  p99 {np.quantile(e, 0.99):.2e}")
         yg = ops.project_raw(x[:, :, 0].cuda().contiguous(), dp, force_generic=True)[0].cpu().numpy()
         print(f"           lane kernel err {rel_err_rows(yg, y_true).max():.3e}")
