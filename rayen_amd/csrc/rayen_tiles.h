@@ -89,24 +89,66 @@ inline bool is_small_factor(const RayenSegment& g) { return g.type == RAYEN_SEG_
 //   segments are taken in order, in batches whose aux rows (phi | c, b) fit one aux tile; each
 //   batch = [AUX tile] [own tiles of the large segments] [packed tiles of the small factor ones];
 //   the rows of NA_E (if it is not the identity) come last.
-// Factor of a positive semi-definite G (n x n, row-major): rows u_j with sum_j u_j u_j' = G, by Cholesky with
-// diagonal pivoting (outer-product form); stops at the numerical rank.
+// Factor of a positive semi-definite G (n x n, row-major): rows u_j with sum_j u_j u_j' = G.
+// Through the eigen-decomposition (cyclic Jacobi, fp64): u_j = sqrt(lambda_j) q_j' for the eigenvalues above
+// 1e-13 lambda_max.  A module built in fp32 hands over forms that carry the rounding noise of its buffers (eigenvalues
+// of -1e-8 lambda_max where the exact form is rank deficient): the negative part is dropped, everything else is
+// reproduced to fp64 rounding.  (Round 1 used a Cholesky with diagonal pivoting; on such forms it stops at the first
+// non-positive pivot with a residual of 1e-6 |G| -- the reason fuzz set 971 was 2e-5 off on the split-operand kernels.)
 inline std::vector<std::vector<double>> psd_factor_rows(const double* G, int n) {
-  std::vector<double> A(G, G + (size_t)n * n);
+  std::vector<double> A((size_t)n * n), Q((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i) {
+    Q[(size_t)i * n + i] = 1.0;
+    for (int j = 0; j < n; ++j) A[(size_t)i * n + j] = 0.5 * (G[(size_t)i * n + j] + G[(size_t)j * n + i]);
+  }
+  double scale = 0.0;
+  for (const double x : A) scale = std::fabs(x) > scale ? std::fabs(x) : scale;
   std::vector<std::vector<double>> rows;
-  double dmax0 = 0.0;
-  for (int i = 0; i < n; ++i) dmax0 = A[(size_t)i * n + i] > dmax0 ? A[(size_t)i * n + i] : dmax0;
-  for (int step = 0; step < n; ++step) {
-    int piv = 0;
-    for (int i = 1; i < n; ++i)
-      if (A[(size_t)i * n + i] > A[(size_t)piv * n + piv]) piv = i;
-    const double d = A[(size_t)piv * n + piv];
-    if (!(d > 1e-15 * dmax0) || !(d > 0.0)) break;
-    const double inv = 1.0 / std::sqrt(d);
+  if (!(scale > 0.0) || !std::isfinite(scale)) return rows;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0;
+    for (int p = 0; p < n; ++p)
+      for (int q = p + 1; q < n; ++q) off += A[(size_t)p * n + q] * A[(size_t)p * n + q];
+    if (!(std::sqrt(off) > 1e-17 * scale * n)) break;
+    for (int p = 0; p < n; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        const double apq = A[(size_t)p * n + q];
+        if (std::fabs(apq) <= 1e-300) continue;
+        const double theta = (A[(size_t)q * n + q] - A[(size_t)p * n + p]) / (2.0 * apq);
+        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < n; ++k) {   // columns p, q of A
+          const double akp = A[(size_t)k * n + p], akq = A[(size_t)k * n + q];
+          A[(size_t)k * n + p] = c * akp - sn * akq;
+          A[(size_t)k * n + q] = sn * akp + c * akq;
+        }
+        for (int k = 0; k < n; ++k) {   // rows p, q of A
+          const double apk = A[(size_t)p * n + k], aqk = A[(size_t)q * n + k];
+          A[(size_t)p * n + k] = c * apk - sn * aqk;
+          A[(size_t)q * n + k] = sn * apk + c * aqk;
+        }
+        for (int k = 0; k < n; ++k) {   // eigenvectors: columns of Q
+          const double qkp = Q[(size_t)k * n + p], qkq = Q[(size_t)k * n + q];
+          Q[(size_t)k * n + p] = c * qkp - sn * qkq;
+          Q[(size_t)k * n + q] = sn * qkp + c * qkq;
+        }
+      }
+  }
+  double lmax = 0.0;
+  for (int i = 0; i < n; ++i) lmax = A[(size_t)i * n + i] > lmax ? A[(size_t)i * n + i] : lmax;
+  // largest eigenvalues first (the order only decides which rows share a tile)
+  std::vector<int> order(n);
+  for (int i = 0; i < n; ++i) order[i] = i;
+  for (int i = 0; i < n; ++i)
+    for (int j = i + 1; j < n; ++j)
+      if (A[(size_t)order[j] * n + order[j]] > A[(size_t)order[i] * n + order[i]]) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+  for (int idx = 0; idx < n; ++idx) {
+    const int i = order[idx];
+    const double lam = A[(size_t)i * n + i];
+    if (!(lam > 1e-13 * lmax) || !(lam > 0.0)) continue;
+    const double root = std::sqrt(lam);
     std::vector<double> u(n);
-    for (int c = 0; c < n; ++c) u[c] = 0.5 * (A[(size_t)piv * n + c] + A[(size_t)c * n + piv]) * inv;
-    for (int r = 0; r < n; ++r)
-      for (int c = 0; c < n; ++c) A[(size_t)r * n + c] -= u[r] * u[c];
+    for (int c = 0; c < n; ++c) u[c] = root * Q[(size_t)c * n + i];
     rows.push_back(u);
   }
   return rows;
