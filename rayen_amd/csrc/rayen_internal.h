@@ -25,6 +25,8 @@ struct GSeg {
   int32_t dim;     // LMI: r
   int32_t seg;     // index into the caller's segment table (reported in `active`)
   int32_t row0;    // first logical W row (reported for LIN)
+  int32_t frb0;    // QUAD_SYM, forward: row blocks of a factor U (U'U = G, rayen_tiles.h::psd_factor_rows): ||U v||^2
+  int32_t fnrb;    // instead of v'(G v) -- no cancellation between the terms of the form; 0 = none
   double f0, f1;
 };
 
