@@ -478,8 +478,9 @@ int generic_build(const RayenPack* p, GenericImage<T>* img) {
     g.rb0 = rb;
     g.nrb = append_rowblocks(Wg, p->W.data(), sg.row0, sg.nrows, p->n);
     rb += g.nrb;
-    if (sg.type == RAYEN_SEG_QUAD_SYM && sg.nrows == p->n) {
-      // the forward's factor of G (eigen-factor, <= n rows); the backward keeps reading G itself
+    if (sg.type == RAYEN_SEG_QUAD_SYM && sg.nrows == p->n && p->n <= 128) {
+      // the forward's factor of G (eigen-factor, <= n rows; the Jacobi sweeps are O(n^3) on the host: not for the
+      // 800 x 800 forms this path also serves); the backward keeps reading G itself
       const std::vector<std::vector<double>> rows = psd_factor_rows(p->W.data() + (size_t)sg.row0 * p->n, p->n);
       if (!rows.empty()) {
         std::vector<double> flat;
