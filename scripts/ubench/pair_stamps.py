@@ -1,4 +1,5 @@
-"""Phase timestamps of three waves of the f16-pair kernel (variant 64 of scripts/ubench/pair_variants.py)."""
+"""Timestamps of three waves of the f16-pair kernel: build variant 320 (per tile) or 64 (per phase) with
+scripts/ubench/pair_variants.py and point RAYEN_HIP_LIBRARY below at it."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

@@ -1,7 +1,8 @@
 """Build librayen_hip variants that differ in RAYEN_PAIR_VARIANT (the developer copy of the f16-pair kernel with its
 experiment switches, scripts/ubench/experiments/rayen_mfma_pair_variants.hip.txt: 1 streaming y stores everywhere,
 2 / 128 L2 warm-up of the next group's rows, 4 streaming v loads, 8 no A stream (timing only), 16 / 32 asymmetric
-burst priority, 64 phase timestamps over kappa_out) into
+burst priority, 64 phase timestamps over kappa_out, 64 + 256 = 320 per-tile timestamps (tile top / burst issued /
+epilogue done, from tile 5 on); read by scripts/ubench/pair_stamps.py) into
 rayen_amd/csrc/variants/ and, on a GPU, time config 3 / 5 with each.
     python scripts/ubench/pair_variants.py build 1 2 3 ...     (here)
     python scripts/ubench/pair_variants.py run 0 1 2 3 ...       (GPU box; 0 = the product library)"""
