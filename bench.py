@@ -319,6 +319,10 @@ def main():
         lmi = cs.has_lmi_constraints
         kernel_tag = (({3: "mfma_pair_f16x2 (fp32-grade)", 2: "mfma_split_bf16x3 (fp32-grade)", 1: "mfma_f32"}.get(info.mfma_f32, "lmi_lanes" if lmi else "generic"))
                       if dtype == torch.float32 else ("mfma_f64" if info.mfma_f64 else ("lmi_lanes" if lmi else "generic")))
+        from rayen_amd import _lib
+        served_by = _lib.load().rayen_last_forward_kernel()      # which instruction stream the last call ran
+        if served_by == _lib.KERNEL_PAIR_IO:
+            kernel_tag = "mfma_pair_io_f16x2 (fp32-grade; rows of v and y trickled through LDS under the tile walk)"
         # The split-operand kernels rebuild every fp32 product from three f16 (pairs) or six bf16 (triples) MFMA products
         # (fp32-grade results), so their matrix ceiling in ALGORITHMIC fp32 flops is the dense 16-bit peak / 3 or / 6,
         # not the fp32 MFMA peak
@@ -331,6 +335,7 @@ def main():
                 roof["peak_basis"] = "dense f16/bf16 MFMA peak %.1f / %d piece products per fp32 product" % (PEAK_BF16_TFLOPS, pieces)
                 roof["frac_of_fp32_mfma_peak"] = tflops / PEAK_FP32_TFLOPS
             elif lmi:
+                roof["bound"] = "valu"
                 roof["peak_basis"] = ("fp32/fp64 vector ALU peak (numerically the MFMA peak of the dtype): the per-sample "
                                       "eigen-solve (Householder + Sturm) has no matrix-core form")
         else:
@@ -381,6 +386,22 @@ def main():
         if split and world == 1 and not args.mapper and not args.no_families:
             # the same workload on the other fp32 families (RayenPackDesc.fp32_mode / RAYEN_FP32_MODE at pack
             # creation), timed the same way, so that one line carries all of them
+            if served_by == _lib.KERNEL_PAIR_IO:
+                # the same pack on the plain f16-pair kernel (rows loaded / stored at the group boundaries): same values
+                prev = _lib.load().rayen_pair_schedule(0)
+                try:
+                    with torch.no_grad():
+                        for _ in range(SETTLE_LAUNCHES // 3):
+                            module_step(x)
+                    torch.cuda.synchronize()
+                    _, ms = timed_loop(module_step, x, args.steps, args.warmup, False, graph=graph)
+                finally:
+                    _lib.load().rayen_pair_schedule(prev)
+                tf = flops_pp * B / (ms * 1e-3) / 1e12
+                out["pair_kernel_without_trickled_rows"] = {
+                    "value": B / (ms * 1e-3), "unit": "projections/s", "ms_per_step": ms,
+                    "roofline": {"bound": "mfma", "achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": tf / peak_tf},
+                    "how": "rayen_pair_schedule(0): rayen_mfma_pair.hip, same pack, same inputs, same step count"}
             others = [("exact_fp32_kernels", "1", PEAK_FP32_TFLOPS, "exact-fp32 MFMA kernels (fp32_mode 1)")]
             if info.mfma_f32 == 3:
                 others.insert(0, ("bf16_triple_kernel", "4", PEAK_BF16_TFLOPS / 6.0,

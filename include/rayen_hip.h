@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define RAYEN_ABI_VERSION 3
+#define RAYEN_ABI_VERSION 4
 
 enum {
   RAYEN_OK = 0,
@@ -126,6 +126,27 @@ typedef struct RayenPack RayenPack;
 
 int rayen_abi_version(void);
 const char* rayen_strerror(int code);
+
+/* Diagnostics (ABI v4): the kernel family that served the calling thread's most recent forward call
+ * (rayen_ray_project_f32 / _f64 / _old_* / _generic_*); thread-local, no device work.  The reference has one code
+ * path (rayen/constraint_module.py:351-474); here the shape of a call (alignment, batch, leading dimensions) can
+ * select between instruction streams that compute the same values, and tests / benchmarks want to know which. */
+enum {
+  RAYEN_KERNEL_NONE = 0,
+  RAYEN_KERNEL_LANE = 1,      /* lane-per-sample kernels (rayen_generic.hip) */
+  RAYEN_KERNEL_MFMA = 2,      /* exact fp32 / fp64 matrix-core kernels */
+  RAYEN_KERNEL_TRIPLE = 3,    /* bf16 triples */
+  RAYEN_KERNEL_PAIR = 4,      /* f16 pairs */
+  RAYEN_KERNEL_PAIR_IO = 5,   /* f16 pairs, rows of v and y trickled through LDS under the tile walk */
+  RAYEN_KERNEL_LMI_QUAD = 6   /* four lanes per sample (one LMI + linear rows) */
+};
+int rayen_last_forward_kernel(void);
+
+/* Tuning / A-B switch (ABI v4, process-wide): which SCHEDULE of the f16-pair forward serves the calls whose shape
+ * allows it -- 1 (default): rows of v and y trickled through LDS under the tile walk | 0: the plain kernel.  Both
+ * compute the same values bit for bit.  Initial value from the environment variable RAYEN_PAIR_IO.  mode outside 0..1
+ * only queries.  Returns the previous setting. */
+int rayen_pair_schedule(int mode);
 
 /* Upload the constants to the CURRENT HIP device and build EVERY device image the entry points below will
  * read (all kernel families selected by desc->prepare), including the one-time accuracy measurement that

@@ -10,7 +10,7 @@ import os
 
 from ._build import LIBRARY
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 SEG_LIN, SEG_QUAD_SYM, SEG_QUAD_FAC, SEG_SOC, SEG_LMI = range(5)
 PREPARE_ALL, PREPARE_F32, PREPARE_F64, PREPARE_FWD_ONLY = 0, 1, 2, 4
@@ -25,8 +25,10 @@ EXPORTS = (
     "rayen_mapper_fusable", "rayen_ray_project_mapped_f32", "rayen_ray_project_bwd_generic_f32",
     "rayen_ray_project_bwd_generic_f64", "rayen_mapper_image_bytes", "rayen_mapper_prepare_f32",
     "rayen_ray_project_mapped_image_f32", "rayen_bwd_workspace_bytes_f32", "rayen_ray_project_bwd_ws_f32",
-    "rayen_bwd_workspace_bytes_f64", "rayen_ray_project_bwd_ws_f64",
+    "rayen_bwd_workspace_bytes_f64", "rayen_ray_project_bwd_ws_f64", "rayen_last_forward_kernel",
+    "rayen_pair_schedule",
 )
+KERNEL_NONE, KERNEL_LANE, KERNEL_MFMA, KERNEL_TRIPLE, KERNEL_PAIR, KERNEL_PAIR_IO, KERNEL_LMI_QUAD = range(7)
 
 
 class RayenSegment(ctypes.Structure):
@@ -82,6 +84,10 @@ def load():
     p, i64, i32p = ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p
     lib.rayen_abi_version.restype = ctypes.c_int
     lib.rayen_abi_version.argtypes = []
+    lib.rayen_last_forward_kernel.restype = ctypes.c_int
+    lib.rayen_last_forward_kernel.argtypes = []
+    lib.rayen_pair_schedule.restype = ctypes.c_int
+    lib.rayen_pair_schedule.argtypes = [ctypes.c_int]
     lib.rayen_strerror.restype = ctypes.c_char_p
     lib.rayen_strerror.argtypes = [ctypes.c_int]
     lib.rayen_pack_create.restype = ctypes.c_int

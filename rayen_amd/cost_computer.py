@@ -86,8 +86,22 @@ class CostComputer(nn.Module):
         return soft_cost
 
     def getSumObjCostAllSamples(self, y, Pobj, qobj, robj):
+        """``sum_b 0.5 y_b'P y_b + q'y_b + r`` with ONE objective (``P [k,k]``, ``q [k,1]``, ``r [1,1]``) or one per
+        sample, as the reference's ``DataLoader`` hands them over (``P [B,k,k]``, ``q [B,k,1]``, ``r [B,1,1]``;
+        examples/main.py:132-155, ``utils.quadExpression`` rayen/utils.py:228-242)."""
+        if Pobj.ndim == 3 or qobj.ndim == 3 or robj.ndim == 3:
+            B = y.shape[0]
+            yv = y[:, :, 0]
+            P = Pobj.to(y).expand(B, -1, -1) if Pobj.ndim == 3 else Pobj.to(y).unsqueeze(0).expand(B, -1, -1)
+            q = qobj.to(y).reshape(-1, yv.shape[1]).expand(B, -1)
+            r = robj.to(y).reshape(-1).expand(B)
+            tmp = 0.5 * torch.einsum("bi,bij,bj->b", yv, P, yv) + torch.sum(q * yv, dim=1) + r
+            if tmp.shape != (B,):
+                raise RuntimeError(f"objective batch {tuple(Pobj.shape)} does not match {B} samples")
+            return torch.sum(tmp)
         tmp = _quad(y, Pobj, qobj, robj)
-        assert tmp.shape == (y.shape[0], 1)
+        if tmp.shape != (y.shape[0], 1):
+            raise RuntimeError(f"expected one objective, got P {tuple(Pobj.shape)}")
         return torch.sum(tmp)
 
     def getSumSupervisedCostAllSamples(self, y, y_predicted):

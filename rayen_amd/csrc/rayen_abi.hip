@@ -1,6 +1,7 @@
 // C-ABI entry points of librayen_hip.so (declared in include/rayen_hip.h).
 #include "rayen_internal.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -40,6 +41,21 @@ int check_table(const RayenPackDesc* d) {
 template <typename T> GenericImage<T>& image_of(const RayenPack* p);
 template <> GenericImage<float>& image_of<float>(const RayenPack* p) { return p->g32; }
 template <> GenericImage<double>& image_of<double>(const RayenPack* p) { return p->g64; }
+
+// which kernel family served this thread's most recent forward call (rayen_last_forward_kernel)
+thread_local int g_last_forward = RAYEN_KERNEL_NONE;
+
+// Schedules of the f16-pair forward (same arithmetic): 1 (default) = rows of v and y trickled through LDS under the tile
+// walk (rayen_mfma_pair_io.hip) where the call's shape allows it | 0 = rayen_mfma_pair.hip always.  RAYEN_PAIR_IO /
+// rayen_pair_schedule select (A/B runs).
+std::atomic<int>& pair_schedule_cell() {
+  static std::atomic<int> mode([] {
+    const char* e = std::getenv("RAYEN_PAIR_IO");
+    return (e != nullptr && e[0] >= '0' && e[0] <= '1') ? e[0] - '0' : 1;
+  }());
+  return mode;
+}
+int pair_schedule() { return pair_schedule_cell().load(std::memory_order_relaxed); }
 
 int check_device(const RayenPack* p) {
   int dev = -1;
@@ -173,6 +189,13 @@ int project_bwd(const RayenPack* p, const T* v, int64_t B, int64_t ldv, const T*
 extern "C" {
 
 int rayen_abi_version(void) { return RAYEN_ABI_VERSION; }
+
+int rayen_last_forward_kernel(void) { return g_last_forward; }
+
+int rayen_pair_schedule(int mode) {
+  if (mode >= 0 && mode <= 1) return pair_schedule_cell().exchange(mode, std::memory_order_relaxed);
+  return pair_schedule();
+}
 
 const char* rayen_strerror(int code) {
   switch (code) {
@@ -379,6 +402,7 @@ int rayen_pack_info(const RayenPack* p, RayenPackInfo* info) {
 int rayen_ray_project_generic_f32(const RayenPack* p, const float* v, int64_t B, int64_t ldv, float* y,
                                   int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
                                   void* stream) {
+  g_last_forward = RAYEN_KERNEL_LANE;
   return project_generic<float>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
 }
 
@@ -389,19 +413,32 @@ static int project_f32(const RayenPack* p, const float* v, int64_t B, int64_t ld
     return RAYEN_E_BAD_ARG;
   const int rc = check_ready<float>(p, false);
   if (rc) return rc;
-  if (p->pr32 != nullptr && p->pr32_state == 1 && y != nullptr && !old_mode)
+  if (p->pr32 != nullptr && p->pr32_state == 1 && y != nullptr && !old_mode) {
+    if (pair_schedule() >= 1 && mfma_pair_io_serves(p, p->pr32, v, B, ldv, y, ldy)) {
+      g_last_forward = RAYEN_KERNEL_PAIR_IO;
+      return mfma_pair_io_forward(p, p->pr32, v, B, ldv, y, ldy, kappa, active, nan_flag, static_cast<hipStream_t>(stream));
+    }
+    g_last_forward = RAYEN_KERNEL_PAIR;
     return mfma_pair_forward(p, p->pr32, v, B, ldv, y, ldy, kappa, active, nan_flag, static_cast<hipStream_t>(stream));
-  if (p->sp32 != nullptr && p->sp32_state == 1 && y != nullptr && !old_mode)
+  }
+  if (p->sp32 != nullptr && p->sp32_state == 1 && y != nullptr && !old_mode) {
+    g_last_forward = RAYEN_KERNEL_TRIPLE;
     return mfma_split_forward(p, p->sp32, v, B, ldv, y, ldy, kappa, active, nan_flag,
                               static_cast<hipStream_t>(stream));
-  if (p->m32 != nullptr && y != nullptr)
+  }
+  if (p->m32 != nullptr && y != nullptr) {
+    g_last_forward = RAYEN_KERNEL_MFMA;
     return mfma_forward(p, p->m32, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode,
                         static_cast<hipStream_t>(stream));
+  }
   // four lanes per sample pay off while one lane per sample cannot fill the chip (B/64 waves on
   // 1024 SIMDs x 2); beyond that the lane-per-sample kernel has the higher throughput in fp32
-  if (y != nullptr && !old_mode && B <= 65536 && p->q32 != nullptr)
+  if (y != nullptr && !old_mode && B <= 65536 && p->q32 != nullptr) {
+    g_last_forward = RAYEN_KERNEL_LMI_QUAD;
     return lmi_quad_forward_f32(p, p->q32, v, B, ldv, y, ldy, kappa, active, nan_flag,
                                 static_cast<hipStream_t>(stream));
+  }
+  g_last_forward = RAYEN_KERNEL_LANE;
   return project_generic<float>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, old_mode);
 }
 
@@ -475,6 +512,7 @@ int rayen_ray_project_mapped_f32(const RayenPack* p, const float* x, int64_t B, 
 int rayen_ray_project_generic_f64(const RayenPack* p, const double* v, int64_t B, int64_t ldv, double* y,
                                   int64_t ldy, double* kappa, int32_t* active, int32_t* nan_flag,
                                   void* stream) {
+  g_last_forward = RAYEN_KERNEL_LANE;
   return project_generic<double>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
 }
 
@@ -485,12 +523,17 @@ static int project_f64(const RayenPack* p, const double* v, int64_t B, int64_t l
     return RAYEN_E_BAD_ARG;
   const int rc = check_ready<double>(p, false);
   if (rc) return rc;
-  if (p->m64 != nullptr && y != nullptr)
+  if (p->m64 != nullptr && y != nullptr) {
+    g_last_forward = RAYEN_KERNEL_MFMA;
     return mfma64_forward(p, p->m64, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode,
                           static_cast<hipStream_t>(stream));
-  if (y != nullptr && !old_mode && p->q64 != nullptr)
+  }
+  if (y != nullptr && !old_mode && p->q64 != nullptr) {
+    g_last_forward = RAYEN_KERNEL_LMI_QUAD;
     return lmi_quad_forward_f64(p, p->q64, v, B, ldv, y, ldy, kappa, active, nan_flag,
                                 static_cast<hipStream_t>(stream));
+  }
+  g_last_forward = RAYEN_KERNEL_LANE;
   return project_generic<double>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, old_mode);
 }
 

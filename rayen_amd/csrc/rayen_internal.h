@@ -128,6 +128,13 @@ int mfma_pair_forward(const RayenPack* p, const PairImage* img, const float* v, 
                       float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
                       hipStream_t stream);
 
+// the same arithmetic with the rows of v and y trickled through LDS under the tile walk (rayen_mfma_pair_io.hip)
+bool mfma_pair_io_serves(const RayenPack* p, const PairImage* img, const float* v, int64_t B, int64_t ldv,
+                         const float* y, int64_t ldy);
+int mfma_pair_io_forward(const RayenPack* p, const PairImage* img, const float* v, int64_t B, int64_t ldv,
+                         float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
+                         hipStream_t stream);
+
 int64_t mfma_pair_mapper_image_bytes(const RayenPack* p, const PairImage* img, int in_dim);
 int mfma_pair_mapper_prepare(const RayenPack* p, const PairImage* img, const float* w, int64_t ldw, int in_dim,
                              const float* bias, void* image, hipStream_t stream);

@@ -26,8 +26,6 @@
 
 namespace rayen {
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
 // The module's mapper v = Wm x + b (rayen/constraint_module.py:259-263, 525) in front of the walk (NKX > 0 instances),
 // the f16-pair form of rayen_mfma_split.hip's: Wm as an image of f16 pairs of gM Wm (gM a power of two chosen by
 // pair_mapper_image_kernel from the weights' largest entry), x scaled per sample like v, the accumulators start at
@@ -39,15 +37,6 @@ struct PairMapper {
   float* v_out = nullptr;
   int64_t ldvo = 0;
 };
-
-// 2^13 / 2^floor(log2 m) as a float and its inverse, from the biased exponent of m (clamped to [14, 254])
-__device__ __forceinline__ void pow2_scale(const float m, float& scale, float& inv, int& exp_scale) {
-  unsigned e = __builtin_bit_cast(unsigned, m) >> 23;
-  e = e < 14u ? 14u : (e > 254u ? 254u : e);
-  scale = __builtin_bit_cast(float, (267u - e) << 23);
-  inv = __builtin_bit_cast(float, (e - 13u) << 23);
-  exp_scale = 140 - (int)e;
-}
 
 template <int NKK, bool TRACK, bool STAGED, int NKX>
 __device__ __forceinline__ void mfma_pair_fwd_body(
@@ -610,6 +599,7 @@ int mfma_pair_build(const RayenPack* p, PairImage** out, int64_t* bytes) {
   img->nkk = b.n_pad / 32;
   img->identity = p->out_identity;
   img->n_items = (int)b.items.size();
+  for (const RayenSegment& g : p->segs) img->aux_rows += aux_rows_of(g);
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0)

@@ -1,0 +1,520 @@
+// Paired-half forward with the rows of v and y TRICKLED through LDS under the tile walk
+// (rayen/constraint_module.py:468-474, 351-458 in one launch; the arithmetic is rayen_mfma_pair.hip's, bit for bit).
+//
+// What this kernel changes is WHEN the HBM traffic happens.  In rayen_mfma_pair.hip every wave loads its 64 rows, walks
+// the tiles, stores its 64 rows -- and since every wave of the chip does so at the same time, the loads and stores are
+// chip-wide bursts at the HBM roofline with the matrix pipe idle, and the walks run with HBM idle (DESIGN.md 4.0b:
+// 19 k of 52 k cycles per group).  Here a wave owns ONE LDS buffer of 64 rows and, while it walks group g:
+//   * chunk c (1 KiB = 4 rows of 64 floats | 8 rows of 32) of y(g-1), staged in the buffer at the last boundary, is read
+//     back (ds_read_b128) and stored (global_store_dwordx4, whole 128-byte lines) at the end of tile c's MFMA burst,
+//   * and right behind it the same 1 KiB of the buffer is refilled with chunk c of v(g+1) by an LDS-DMA
+//     (global_load_lds_dwordx4: no VGPRs, no instructions at arrival),
+// so that a group's 32 KiB of HBM traffic is spread over the ~33 k cycles of a walk (chip-wide ~4.6 TB/s, continuous)
+// instead of two bursts.  At the group boundary nothing goes to memory: y(g) is rebuilt from the B-operand registers
+// and written into the buffer in place of v(g+1), which has just been read into registers.
+//
+// vmcnt retires in order and counts stores, and the A stream (rolling register buffer, hand-placed loads, counted
+// waits: rayen_mfma_split.hip) shares the counter: the two I/O operations of a tile are issued BEHIND the tile's last
+// A re-load, so the first wait that has to cover them is the first K-step of the tile after the next (a full tile
+// plus an epilogue later, ~2.8 k cycles); the waits of the next tile are counted past them (vmcnt(NS - 1 + 2)).  The
+// count of a wait is an immediate, so EVERY tile issues exactly two vector-memory operations there: where there is
+// nothing to store (a wave's first group) or nothing to fetch (its last), a 4-byte LDS-DMA of a cached word into a
+// scratch slot takes the place (no VGPR destination: nothing the compiler could hand out while it is in flight).
+// The walk therefore has ONE instruction stream whatever the round (three instances of it, one per case, made hipcc
+// spill ~115 VGPRs, and a scratch reload inside the walk is a compiler-counted vmcnt(0): the trickle would drain).
+//
+// LDS image of a group's rows: the buffer holds the rows as 16-byte pieces; block j (1 KiB) = RPB consecutive rows,
+// and inside the block piece p of row r sits in slot s = p ^ x(j, r) of that row (x: see swz()).  LDS-DMA writes
+// lane-linear (lane L -> byte 16 L of the block), so the swizzle is applied to the per-lane SOURCE address; the
+// fragment-shaped reads (lane (col, hi) reads piece 2 q + hi of row col) are then conflict-free ds_read_b128s, and
+// every DMA / store instruction still covers whole 128-byte lines (the XOR permutes pieces inside aligned lines).
+//
+// Served shapes: NA_E = I, n = k = 32 NKK exactly, rows 16-byte aligned, at most 8 aux rows at NKK = 2 (LDS: 8 waves
+// x 16 KiB of rows + the aux patch), n_items >= blocks per group.  Everything else stays on rayen_mfma_pair.hip.
+#include "rayen_split_image.h"
+
+#include <type_traits>
+
+namespace rayen {
+
+namespace {
+
+template <int NKK>
+struct IoGeom {
+  static constexpr int NT = 2;
+  static constexpr int PIECES = NKK * 8;          // 16-byte pieces per row
+  static constexpr int RPB = 64 / PIECES;         // rows per 1-KiB block
+  static constexpr int NBLK = NT * 32 / RPB;      // blocks per group of 64 rows
+  static constexpr int SWB = NKK == 2 ? 64 : 32;  // byte weight of (block & 3) in the piece swizzle
+  static constexpr int BYTES = NT * 32 * NKK * 128;
+  static constexpr int AUXR = NKK == 2 ? 8 : 32;  // aux rows the patch holds
+};
+
+// slot swizzle of row r of block j (see the header): the 16 rows a ds_read_b128 lane group touches get 16 distinct
+// 16-byte bank slots
+template <int NKK>
+__device__ __forceinline__ int swz(const int j, const int r) {
+  if constexpr (NKK == 2) return (4 * (j & 3) + r) & 15;
+  else return 2 * (j & 3) + ((r >> 1) & 1);
+}
+
+__device__ __forceinline__ const char* uniform_ptr(const void* p) {
+  const uint64_t x = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
+  return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+}
+
+// one LDS-DMA: every lane fetches 16 bytes from gbase + voff; lane L lands at LDS byte lds + 16 L
+// (M0 = the LDS base; written in the statement that reads it, restored behind it)
+__device__ __forceinline__ void dma16(const char* gbase, const unsigned voff, const unsigned lds) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(gbase), "s"(lds)
+               : "memory");
+}
+
+// the stand-in: 4 bytes per lane of a cached word into a scratch slot of LDS (keeps the per-tile operation count)
+__device__ __forceinline__ void dma4_dummy(const char* gbase, const unsigned voff, const unsigned lds) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(gbase), "s"(lds)
+               : "memory");
+}
+
+__device__ __forceinline__ void store16_nt(char* gbase, const unsigned voff, const f32x4 x) {
+  asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(voff), "v"(x), "s"(gbase) : "memory");
+}
+
+}  // namespace
+
+template <int NKK, bool TRACK>
+__global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_io_kernel(
+    const f16x8* __restrict__ Wh, const MItem* __restrict__ items, int n_items,
+    const MPack* __restrict__ packs, const float* __restrict__ y0, int k, int n,
+    const float* __restrict__ v, int64_t B, int64_t ldv, float* __restrict__ y, int64_t ldy,
+    float* __restrict__ kappa_out, int32_t* __restrict__ active_out,
+    int32_t* __restrict__ nan_flag, const float w_scale, const float w_inv) {
+  using G = IoGeom<NKK>;
+  constexpr int NT = G::NT, NS = NKK * 2, NCH = NS * 2, KK = NKK * 16, NQ = NKK * 4;
+  constexpr int PIECES = G::PIECES, RPB = G::RPB, NBLK = G::NBLK, SWB = G::SWB, AUXR = G::AUXR;
+  __shared__ float aux_lds[kMfmaWaves][NT][AUXR][32];
+  __shared__ __attribute__((aligned(16))) float y0_lds[NKK * 32];
+  __shared__ __attribute__((aligned(1024))) char io_lds[kMfmaWaves][G::BYTES];
+  __shared__ __attribute__((aligned(256))) char sink_lds[kMfmaWaves][256];   // where the stand-in operations land
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col = lane & 31;
+  const int hi = lane >> 5;
+  const int64_t n_groups = (B + NT * 32 - 1) / (NT * 32);
+  const int64_t wave_id = (int64_t)blockIdx.x * kMfmaWaves + wave;
+  const int64_t wave_stride = (int64_t)gridDim.x * kMfmaWaves;
+  bool bad = false;
+  for (int i = threadIdx.x; i < NKK * 32; i += kMfmaWaves * 64) y0_lds[i] = y0[i];
+  __syncthreads();  // the only workgroup barrier
+  (void)k; (void)n;
+
+  char* const io = io_lds[wave];
+  const unsigned io_addr = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(io));  // LDS byte address
+  const unsigned sink_addr = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(&sink_lds[wave][0]));
+
+  // This lane as the reader / writer of ITS samples' rows (fragment shape): piece 2 q + hi of row 32 t + col sits at
+  // byte base + ((32 q) ^ xh).  Recomputed from the lane number wherever it is needed: as loop invariants hipcc keeps
+  // all sixteen piece addresses live across the walk and spills them (the `asm` makes the lane number opaque).
+  auto row_addr = [&](const int t, unsigned& base, unsigned& xh) {
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    const int row = 32 * t + (l & 31), j = row / RPB, r = row % RPB;
+    base = (unsigned)(j * 1024 + r * PIECES * 16);
+    xh = (unsigned)((swz<NKK>(j, r) ^ (l >> 5)) * 16);
+  };
+  // this lane as a DMA / store lane of block c: row c RPB + io_r, piece (io_s ^ x(c, io_r))
+  const int io_r = lane / PIECES, io_s = lane % PIECES;
+  const unsigned ps16 = (unsigned)((NKK == 2 ? (io_s ^ io_r) : (io_s ^ ((io_r >> 1) & 1))) * 16);
+  const unsigned ldvB = (unsigned)ldv * 4u, ldyB = (unsigned)ldy * 4u;
+  const unsigned lane_rv = (unsigned)io_r * ldvB, lane_ry = (unsigned)io_r * ldyB;
+
+  // ---- A operands: the rolling register buffer of rayen_mfma_split.hip, two chunks (a1, a2) per K-step
+  u32x4 abuf[NCH];
+  const unsigned lane_off = lane * 16;
+#pragma unroll
+  for (int sp = 0; sp < NS; ++sp) {
+    const char* sb = reinterpret_cast<const char*>(Wh) + sp * 2048;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(abuf[2 * sp + 0]) : "v"(lane_off), "s"(sb));
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(abuf[2 * sp + 1]) : "v"(lane_off), "s"(sb));
+  }
+
+  // the whole group in one burst (first group of a wave; a ragged last group): rows beyond B are not requested
+  auto burst_load = [&](const int64_t s_base) {
+    const char* vg = uniform_ptr(v + s_base * ldv);
+#pragma nounroll
+    for (int c = 0; c < NBLK; ++c)
+      if (s_base + c * RPB + io_r < B)
+        dma16(vg, (unsigned)(c * RPB) * ldvB + lane_rv + (ps16 ^ (unsigned)(SWB * (c & 3))), io_addr + c * 1024);
+  };
+  auto burst_store = [&](const int64_t s_base) {
+    char* yg = const_cast<char*>(uniform_ptr(y + s_base * ldy));
+#pragma unroll 4
+    for (int c = 0; c < NBLK; ++c) {
+      const f32x4 o = *reinterpret_cast<const f32x4*>(io + c * 1024 + lane * 16);
+      if (s_base + c * RPB + io_r < B)
+        __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(
+            yg + ((unsigned)(c * RPB) * ldyB + lane_ry + (ps16 ^ (unsigned)(SWB * (c & 3))))));
+    }
+  };
+
+  // vb[t][piece][k-step] = 8 f16 = the B operand of one MFMA; element i = column 16 sp + 8 (i >> 2) + 4 hi + (i & 3)
+  f16x8 vb[NT][2][NS];
+  float v_scl[NT], v_inv[NT];
+  bool live[NT];
+  // rows of sample tile t: LDS -> registers (fp32) ...
+  auto read_rows = [&](float (&vr)[KK], const int t) {
+    unsigned base, xh;
+    row_addr(t, base, xh);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(io + base + ((unsigned)(32 * q) ^ xh));
+      vr[4 * q + 0] = x[0];
+      vr[4 * q + 1] = x[1];
+      vr[4 * q + 2] = x[2];
+      vr[4 * q + 3] = x[3];
+    }
+  };
+  // ... -> scaled f16 pairs.  sv = 2^(13 - floor(log2 max|v|)): exponent arithmetic only (rayen_mfma_pair.hip)
+  auto split_rows = [&](const float (&vr)[KK], const int t) {
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < KK; ++i) m = fmaxf(m, __builtin_fabsf(vr[i]));
+    m = fmaxf(m, xhalf(m));
+    float sv;
+    int sv_exp;
+    pow2_scale(m, sv, v_inv[t], sv_exp);
+    v_scl[t] = sv;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int i = (q & 1) * 4 + c;
+        const float x = vr[4 * q + c] * sv;
+        const _Float16 p1 = (_Float16)x;
+        const float r1 = x - (float)p1;
+        vb[t][0][q >> 1][i] = p1;
+        vb[t][1][q >> 1][i] = (_Float16)r1;
+      }
+  };
+  auto fetch_tile = [&](const int t) {
+    float vr[KK];
+    __builtin_amdgcn_sched_barrier(0);
+    read_rows(vr, t);
+    __builtin_amdgcn_sched_barrier(0);
+    split_rows(vr, t);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // every in-flight vector-memory operation of this wave has retired (the chunks of the A buffer are named: they
+  // are asm-loaded, the compiler must not move them before this point)
+  auto drain = [&]() {
+    if constexpr (NCH == 8)
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(abuf[0]), "+v"(abuf[1]), "+v"(abuf[2]), "+v"(abuf[3]), "+v"(abuf[4]), "+v"(abuf[5]), "+v"(abuf[6]), "+v"(abuf[7])
+                   :
+                   : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(abuf[0]), "+v"(abuf[1]), "+v"(abuf[2]), "+v"(abuf[3]) : : "memory");
+  };
+
+  int64_t grp = wave_id;
+  bool need_fetch = false;   // the buffer holds the rows of group `grp`, still to be split
+  if (grp < n_groups) {
+    burst_load(grp * (NT * 32));
+    drain();
+    need_fetch = true;
+  }
+  bool has_prev = false;
+  int64_t prev_base = 0;
+
+  while (grp < n_groups) {
+    const int64_t s_base = grp * (NT * 32);
+    const int64_t next = grp + wave_stride;
+    const bool has_next = next < n_groups;
+    const bool trickle_ld = has_next && (next + 1) * (NT * 32) <= B;   // whole groups only: every lane takes part
+    const char* vnext = uniform_ptr(v + (has_next ? next : grp) * (NT * 32) * ldv);
+    char* yprev = const_cast<char*>(uniform_ptr(y + prev_base * ldy));
+    if (need_fetch) {   // a wave's first group, or a ragged one (requested in one burst at the last boundary)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        live[t] = (s_base + t * 32 + col) < B;
+        fetch_tile(t);
+      }
+    }
+
+    // kap, part, the aux patch and the accumulators live in the SCALED domain (gW sv times the natural value)
+    float kap[NT], part[NT], scale[NT], knat[NT];
+    int acode[NT];  // arg-max bookkeeping in one register: (segment << 20) | row, -1 = none
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { kap[t] = 0.f; part[t] = 0.f; scale[t] = 1.f; knat[t] = 0.f; acode[t] = -1; }
+
+    {
+      f32x16 acc[NT];
+      for (int it = 0; it < n_items; ++it) {
+        const MItem item = items[it];
+        // the tile after this one; the last tile of a group fetches tile 0 for the next group
+        const char* next_tile = reinterpret_cast<const char*>(Wh) + (size_t)(it + 1 == n_items ? 0 : it + 1) * (NCH * 1024);
+        const bool slot = it < NBLK;
+        f32x4 ytmp = {0.f, 0.f, 0.f, 0.f};
+        if (slot && has_prev) ytmp = *reinterpret_cast<const f32x4*>(io + it * 1024 + lane * 16);
+        {
+          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          __builtin_amdgcn_s_setprio(0);
+          auto load_chunk = [&](const int idx) {
+            const char* sb = next_tile + idx * 1024;
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(abuf[idx]) : "v"(lane_off), "s"(sb));
+          };
+          // Two passes over the K-steps, by product size (rayen_mfma_pair.hip).  The counted waits step over the two
+          // I/O operations the previous tile issued behind its last re-load.  (Tile 0: everything it needs landed
+          // before the boundary's vmcnt(0), the count is irrelevant there.)
+#pragma unroll
+          for (int sp = 0; sp < NS; ++sp) {
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NS == 4)
+              asm volatile("s_waitcnt vmcnt(5)" : "+v"(abuf[2 * sp + 0]), "+v"(abuf[2 * sp + 1]));
+            else
+              asm volatile("s_waitcnt vmcnt(3)" : "+v"(abuf[2 * sp + 0]), "+v"(abuf[2 * sp + 1]));
+            const f16x8 a1 = __builtin_bit_cast(f16x8, abuf[2 * sp + 0]), a2 = __builtin_bit_cast(f16x8, abuf[2 * sp + 1]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, vb[t][0][sp], sp == 0 ? zero : acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, vb[t][1][sp], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_chunk(2 * sp + 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#pragma unroll
+          for (int sp = 0; sp < NS; ++sp) {
+            const f16x8 a1 = __builtin_bit_cast(f16x8, abuf[2 * sp + 0]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, vb[t][0][sp], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_chunk(2 * sp + 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          // ---- the tile's two I/O operations: 1 KiB of y(prev) out, 1 KiB of v(next) in (or their stand-ins)
+          {
+            const unsigned px = ps16 ^ (unsigned)(SWB * (it & 3));
+            if (slot && has_prev) store16_nt(yprev, (unsigned)(it * RPB) * ldyB + lane_ry + px, ytmp);
+            else dma4_dummy(reinterpret_cast<const char*>(Wh), lane_off >> 2, sink_addr);
+            if (slot && trickle_ld) dma16(vnext, (unsigned)(it * RPB) * ldvB + lane_rv + px, io_addr + it * 1024);
+            else dma4_dummy(reinterpret_cast<const char*>(Wh), lane_off >> 2, sink_addr);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_setprio(1);
+        }
+        if (item.type == MI_LIN) {
+          const int lin_code = (item.seg << 20) + item.row0 + 4 * hi;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            if (TRACK) {
+#pragma unroll
+              for (int g = 0; g < 16; ++g)
+                if (acc[t][g] > kap[t]) {
+                  kap[t] = acc[t][g];
+                  acode[t] = lin_code + ((g & 3) + 8 * (g >> 2));
+                }
+            } else {
+#pragma unroll
+              for (int g = 0; g < 16; ++g) kap[t] = fmaxf(kap[t], acc[t][g]);
+            }
+          }
+        } else if (item.type == MI_QFAC || item.type == MI_SOC) {
+          // a running sum of squares over the segment's tiles, closed on its last tile
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            f32x2 s2 = {(item.flags & MF_FIRST) ? 0.f : part[t], 0.f};
+#pragma unroll
+            for (int g = 0; g < 16; g += 2) {
+              const f32x2 a2 = {acc[t][g], acc[t][g + 1]};
+              s2 = __builtin_elementwise_fma(a2, a2, s2);
+            }
+            part[t] = s2[0] + s2[1];
+          }
+          if (item.flags & MF_LAST) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              const float total = part[t] + xhalf(part[t]);
+              const float a0 = aux_lds[wave][t][item.aux][col];
+              float kc;
+              if (item.type != MI_SOC) {
+                kc = a0 + __builtin_amdgcn_sqrtf(fmaxf(total, 0.f));
+              } else {
+                // a' x^2 + b' x + c' = 0  (rayen/constraint_module.py:392-396, 339-348), a' < 0: natural units here
+                // (the coefficients mix in the set's constants f0 = tau, f1 = a'), the root goes back to the scaled domain
+                const float vi = v_inv[t];
+                const float cr = (a0 * w_inv) * vi;
+                const float br = (aux_lds[wave][t][item.aux + 1][col] * w_inv) * vi;
+                const float rt = (__builtin_amdgcn_sqrtf(total) * w_inv) * vi;
+                const float cp = rt * rt - cr * cr;
+                const float bp = 2.f * br - 2.f * cr * item.f0;
+                const float disc = bp * bp - 4.f * item.f1 * cp;
+                kc = 0.f;
+                if (disc >= 0.f) {
+                  const float root = __builtin_amdgcn_sqrtf(disc);
+                  const float inv2a = 0.5f * __builtin_amdgcn_rcpf(item.f1);
+                  kc = (fmaxf((-bp - root) * inv2a, (-bp + root) * inv2a) * v_scl[t]) * w_scale;
+                }
+              }
+              if (kc > kap[t]) { kap[t] = kc; acode[t] = item.seg << 20; }
+            }
+          }
+        } else if (item.type == MI_AUX) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < (AUXR == 8 ? 4 : 16); ++g)
+              aux_lds[wave][t][(g & 3) + 8 * (g >> 2) + 4 * hi][col] = acc[t][g];
+          __builtin_amdgcn_wave_barrier();
+        } else if (item.type == MI_PACK) {
+          const MPack pk = packs[item.aux];
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            const int slot = hi ? pk.aux[a][1] : pk.aux[a][0];
+            const int sid = hi ? pk.seg[a][1] : pk.seg[a][0];
+            const bool pair = (item.row0 >> a) & 1;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              float qs = acc[t][4 * a] * acc[t][4 * a];
+#pragma unroll
+              for (int c = 1; c < 4; ++c) qs = fmaf(acc[t][4 * a + c], acc[t][4 * a + c], qs);
+              if (pair) qs += xhalf(qs);
+              const float kc = aux_lds[wave][t][slot & (AUXR - 1)][col] + __builtin_amdgcn_sqrtf(qs);
+              if (sid >= 0 && kc > kap[t]) { kap[t] = kc; acode[t] = sid << 20; }
+            }
+          }
+        }
+      }
+    }
+    // every row of v(next) has landed, y(prev) is out, the next group's first tile is in the A buffer
+    drain();
+
+    // ---- kappa is final
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float other = xhalf(kap[t]);
+      if (TRACK) {
+        const int ocode = __shfl_xor(acode[t], 32);
+        if (other > kap[t] || (other == kap[t] && hi == 1)) acode[t] = ocode;
+      }
+      kap[t] = fmaxf(kap[t], other);
+      knat[t] = (kap[t] * w_inv) * v_inv[t];
+      scale[t] = v_inv[t] * (1.0f / fmaxf(1.0f, knat[t]));   // (the rebuilt direction carries sv only)
+    }
+    if (hi == 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (!live[t]) continue;
+        const int64_t s = s_base + t * 32 + col;
+        if (kappa_out) kappa_out[s] = knat[t];
+        if (TRACK) { active_out[2 * s] = acode[t] >> 20; active_out[2 * s + 1] = acode[t] < 0 ? 0 : (acode[t] & 0xFFFFF); }
+      }
+    }
+
+    // y = y0 + v / max(1, kappa): v rebuilt from its pieces (22 bits of it; scaled by sv, undone by `scale`), written
+    // into the buffer in place of the row it came from
+    auto stage_tile = [&](const int t) {
+      unsigned base, xh;
+      row_addr(t, base, xh);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const f32x4 o4 = *reinterpret_cast<const f32x4*>(&y0_lds[8 * q + 4 * hi]);
+        f32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int i = (q & 1) * 4 + c;
+          const float val = (float)vb[t][0][q >> 1][i] + (float)vb[t][1][q >> 1][i];
+          o[c] = fmaf(val, scale[t], o4[c]);
+          bad |= live[t] && (o[c] != o[c]);
+        }
+        *reinterpret_cast<f32x4*>(io + base + ((unsigned)(32 * q) ^ xh)) = o;
+      }
+    };
+
+    // The buffer holds v(next) when its rows were trickled in: per sample tile, read the next rows, write this
+    // group's y over them, split.  (ONE copy of the staging code for both cases: written once per arm, hipcc hoists the
+    // arms' common arithmetic -- all 64 outputs of a lane -- in front of the branch and spills it.)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float vr[KK];
+      __builtin_amdgcn_sched_barrier(0);
+      if (trickle_ld) read_rows(vr, t);
+      __builtin_amdgcn_sched_barrier(0);
+      stage_tile(t);
+      __builtin_amdgcn_sched_barrier(0);
+      if (trickle_ld) {
+        split_rows(vr, t);
+        live[t] = true;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    has_prev = trickle_ld;
+    prev_base = s_base;
+    need_fetch = false;
+    if (!trickle_ld) {
+      burst_store(s_base);
+      if (has_next) {   // a ragged last group: requested only now, in one burst
+        burst_load(next * (NT * 32));
+        drain();
+        need_fetch = true;
+      }
+    }
+    grp = next;
+  }  // persistent loop over sample groups
+  if (nan_flag && bad) atomicOr(nan_flag, 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------
+bool mfma_pair_io_serves(const RayenPack* p, const PairImage* img, const float* v, int64_t B, int64_t ldv,
+                         const float* y, int64_t ldy) {
+  if (img == nullptr || !img->identity || img->nkk < 1 || img->nkk > 2) return false;
+  if (p->n != img->nkk * 32 || p->k != p->n) return false;
+  if (img->nkk == 2 && img->aux_rows > IoGeom<2>::AUXR) return false;
+  if (img->n_items < (img->nkk == 2 ? IoGeom<2>::NBLK : IoGeom<1>::NBLK)) return false;
+  if (B < 64) return false;
+  if ((ldv % 4) != 0 || (ldy % 4) != 0 || ldv > (1 << 22) || ldy > (1 << 22)) return false;
+  if ((reinterpret_cast<uintptr_t>(v) & 15) != 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0) return false;
+  return true;
+}
+
+template <int NKK>
+static int launch_pair_io(const RayenPack* p, const PairImage* img, const float* v, int64_t B, int64_t ldv,
+                          float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
+                          hipStream_t stream) {
+  constexpr int per_wave = 64;
+  const int64_t n_groups = (B + per_wave - 1) / per_wave;
+  const int64_t slots = (int64_t)img->n_simd * kMfmaWavesPerSimd;
+  const int64_t rounds = (n_groups + slots - 1) / slots;
+  const int64_t waves = (n_groups + rounds - 1) / rounds;
+  const int64_t grid = (waves + kMfmaWaves - 1) / kMfmaWaves;
+  auto go = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kMfmaWaves * 64), 0, stream,
+                       static_cast<const f16x8*>(img->Wh), img->items, img->n_items, img->packs, img->y0,
+                       p->k, p->n, v, B, ldv, y, ldy, kappa, active, nan_flag, img->w_scale, img->w_inv);
+  };
+  if (active != nullptr) go(mfma_pair_io_kernel<NKK, true>);
+  else go(mfma_pair_io_kernel<NKK, false>);
+  return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
+}
+
+int mfma_pair_io_forward(const RayenPack* p, const PairImage* img, const float* v, int64_t B, int64_t ldv,
+                         float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
+                         hipStream_t stream) {
+  if (B == 0) return RAYEN_OK;
+  if (!mfma_pair_io_serves(p, img, v, B, ldv, y, ldy)) return RAYEN_E_UNSUPPORTED;
+  if (img->nkk == 1) return launch_pair_io<1>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+  return launch_pair_io<2>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+}
+
+}  // namespace rayen

@@ -9,6 +9,16 @@ namespace rayen {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// 2^13 / 2^floor(log2 m) as a float and its inverse, from the biased exponent of m (clamped to [14, 254])
+__device__ __forceinline__ void pow2_scale(const float m, float& scale, float& inv, int& exp_scale) {
+  unsigned e = __builtin_bit_cast(unsigned, m) >> 23;
+  e = e < 14u ? 14u : (e > 254u ? 254u : e);
+  scale = __builtin_bit_cast(float, (267u - e) << 23);
+  inv = __builtin_bit_cast(float, (e - 13u) << 23);
+  exp_scale = 140 - (int)e;
+}
 
 struct SplitImage {
   void* Wb = nullptr;      // [n_tiles][NS][3][64] x 8 bf16
@@ -33,6 +43,7 @@ struct PairImage {
   int identity = 0;
   int n_simd = 1024;
   float w_scale = 1.f, w_inv = 1.f;
+  int aux_rows = 0;        // aux rows (phi | c, M'beta) of the whole set
   int64_t bytes = 0;
 };
 

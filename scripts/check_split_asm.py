@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Safety check of the hand-placed loads of rayen_mfma_split.hip and rayen_mfma_pair.hip: between an asm `global_load` into a chunk of the
+"""Safety check of the hand-placed loads of rayen_mfma_split.hip, rayen_mfma_pair.hip and rayen_mfma_pair_io.hip: between an asm `global_load` into a chunk of the
 rolling A buffer and the `s_waitcnt` that covers it the compiler must not touch those registers (copy, spill):
 it does not know the data is still in flight.  Scans the gfx950 ISA of every instance of the kernel and lists
 any instruction inside the tile loops, other than the MFMAs and the loads themselves, that names a chunk register.
@@ -11,7 +11,7 @@ import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 lines, starts = [], []
-for name in ("rayen_mfma_split", "rayen_mfma_pair"):
+for name in ("rayen_mfma_split", "rayen_mfma_pair", "rayen_mfma_pair_io"):
     src = os.path.join(REPO, "rayen_amd", "csrc", name + ".hip")
     asm = f"/tmp/{name}.s"
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(REPO, "include"),
@@ -22,7 +22,7 @@ for name in ("rayen_mfma_split", "rayen_mfma_pair"):
     text = open(asm).read().split("\n")
     lines += text
     starts += [base + i for i, l in enumerate(text)
-               if l.startswith(("_ZN5rayen21mfma_split_fwd_kernel", "_ZN5rayen21mfma_split_map_kernel", "_ZN5rayen20mfma_pair_fwd_kernel", "_ZN5rayen20mfma_pair_map_kernel"))
+               if l.startswith(("_ZN5rayen21mfma_split_fwd_kernel", "_ZN5rayen21mfma_split_map_kernel", "_ZN5rayen20mfma_pair_fwd_kernel", "_ZN5rayen20mfma_pair_map_kernel", "_ZN5rayen19mfma_pair_io_kernel"))
                and l.split(";")[0].rstrip().endswith(":")]
     starts.append(base + len(text))          # (closes the last kernel of this file)
 
@@ -48,6 +48,9 @@ for s, e in zip(starts[:-1], starts[1:]):
     name = found.groups() if found else ("?", "?", "0")
     mapped = "split_map_kernel" in lines[s]
     nkx = re.search(r"ELb\dELb\dELi(\d)", lines[s]).group(1) if mapped else "0"
+    if "pair_io_kernel" in lines[s]:                     # <NKK, TRACK>: NA_E = I only
+        m2 = re.search(r"ILi(\d)ELb(\d)E", lines[s]).groups()
+        name = (m2[0], m2[1], "0")
     if "pair_map_kernel" in lines[s]:                    # <NKK, TRACK, NKX>: never staged
         m3 = re.search(r"ILi(\d)ELb(\d)ELi(\d)", lines[s]).groups()
         name, nkx = (m3[0], m3[1], "0"), m3[2]
@@ -73,7 +76,7 @@ for s, e in zip(starts[:-1], starts[1:]):
             continue
         if regs_of(l) & chunk:
             bad.append((i, l))
-    family = "pair " if "mfma_pair" in lines[s] else ""
+    family = "pair-io " if "pair_io_kernel" in lines[s] else ("pair " if "mfma_pair" in lines[s] else "")
     print(f"{family}NKK={name[0]} TRACK={name[1]} STAGED={name[2]} NKX={nkx}: {len(loads)} asm loads, chunk registers {min(chunk)}..{max(chunk)}"
           f" ({len(chunk)}), suspicious instructions in the loop: {len(bad)}")
     for i, l in bad[:12]:

@@ -55,3 +55,34 @@ def test_soft_cost_objective_and_loss():
             assert abs(sup.item() - y.size) <= 1e-9
     finally:
         torch.set_default_dtype(torch.float32)
+
+
+def test_objective_with_one_form_per_sample():
+    """The reference's harness passes DataLoader-batched objectives (examples/main.py:132-155: P [B,k,k], q [B,k,1],
+    r [B,1,1]); every sample is paired with ITS objective (rayen/utils.py:228-242), never with the others'."""
+    torch.set_default_dtype(torch.float64)
+    try:
+        raw = workloads.random_lin_quad_soc(k=6, m=4, n_quad=1, n_soc=1, seed=5)
+        cc = CostComputer(workloads.build_constraints(raw))
+        rng = np.random.default_rng(1)
+        B, k = 5, 6
+        y = rng.uniform(-2, 2, size=(B, k))
+        T = rng.uniform(-1, 1, size=(B, k, k))
+        P = T @ np.transpose(T, (0, 2, 1))
+        q = rng.uniform(-1, 1, size=(B, k, 1))
+        r = rng.uniform(-1, 1, size=(B, 1, 1))
+        want = sum(0.5 * y[b] @ P[b] @ y[b] + q[b, :, 0] @ y[b] + r[b, 0, 0] for b in range(B))
+        yt = torch.tensor(y).unsqueeze(2)
+        got = cc.getSumObjCostAllSamples(yt, torch.tensor(P), torch.tensor(q), torch.tensor(r)).item()
+        assert abs(got - want) <= 1e-12 * max(1.0, abs(want))
+        # a shared P with per-sample q, r (the reference's broadcasting accepts it too)
+        want2 = sum(0.5 * y[b] @ P[0] @ y[b] + q[b, :, 0] @ y[b] + r[b, 0, 0] for b in range(B))
+        got2 = cc.getSumObjCostAllSamples(yt, torch.tensor(P[0]), torch.tensor(q), torch.tensor(r)).item()
+        assert abs(got2 - want2) <= 1e-12 * max(1.0, abs(want2))
+        # gradients reach y
+        yt.requires_grad_(True)
+        cc.getSumObjCostAllSamples(yt, torch.tensor(P), torch.tensor(q), torch.tensor(r)).backward()
+        g = np.stack([P[b] @ y[b] + q[b, :, 0] for b in range(B)])
+        assert np.allclose(yt.grad[:, :, 0].numpy(), g, atol=1e-12)
+    finally:
+        torch.set_default_dtype(torch.float32)

@@ -1,0 +1,117 @@
+"""The f16-pair forward has two schedules of the same arithmetic: rayen_mfma_pair.hip, and the rows of v and y trickled
+through LDS under the tile walk (rayen_mfma_pair_io.hip).  Wherever the latter serves a call its outputs must equal the
+plain pair kernel's BIT FOR BIT (y, kappa, arg-max record), for every round structure a wave can
+see -- one group, first + last, first + middle + last, a ragged last group requested in one burst -- and both must
+meet the reference's bar against the oracle (rayen/constraint_module.py:351-474).  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_err_rows, csd_from_cs
+from oracle import rayen_oracle as oracle
+from rayen_amd import _lib, ops, workloads
+from rayen_amd.constraint_module import ConstraintModule
+
+pytestmark = pytest.mark.gpu
+
+
+def _pack(raw):
+    cs = workloads.build_constraints(raw)
+    layer = ConstraintModule(cs, method="RAYEN", create_map=False).to("cuda")
+    dp, _ = layer.device_pack(torch.device("cuda", torch.cuda.current_device()))
+    return cs, layer, dp
+
+
+def _sets():
+    return {
+        "c3": workloads.make_raw("c3", seed=7),                                                # n = 64: 16 blocks per group
+        "n32": workloads.random_lin_quad_soc(k=32, m=300, n_quad=3, n_soc=2, seed=17),         # n = 32: 8 blocks per group
+        "n32_many_aux": workloads.random_lin_quad_soc(k=32, m=200, n_quad=12, n_soc=3, seed=18),  # 18 aux rows (full patch)
+    }
+
+
+def _misaligned_copy(v):
+    """The same rows at an address that is not a multiple of 16 bytes: the trickled kernel declines, the plain one serves."""
+    B, n = v.shape
+    buf = torch.empty(B * n + 4, dtype=v.dtype, device=v.device)
+    w = buf[1:1 + B * n].view(B, n)
+    w.copy_(v)
+    assert w.data_ptr() % 16 != 0
+    return w
+
+
+def _run(dp, v, want_active):
+    y, kappa, active = ops.project_raw(v, dp, want_active=want_active)
+    return y, kappa, active, _lib.load().rayen_last_forward_kernel()
+
+
+SCHEDULES = {"rows": (1, _lib.KERNEL_PAIR_IO)}
+
+
+@pytest.fixture(params=["rows"])
+def schedule(request):
+    mode, family = SCHEDULES[request.param]
+    prev = _lib.load().rayen_pair_schedule(mode)
+    yield family
+    _lib.load().rayen_pair_schedule(prev)
+
+
+# group = 64 rows; a full chip holds 2048 waves: B = 131072 is one group per wave, 262144 two, 393216 three
+@pytest.mark.parametrize("B", [64, 1000, 4096 + 37, 131072, 131072 + 64 * 5 + 11, 262144, 393216 + 29, 655360])
+@pytest.mark.parametrize("name", ["c3", "n32", "n32_many_aux"])
+@pytest.mark.parametrize("want_active", [False, True])
+def test_trickled_rows_equal_the_plain_pair_kernel_bit_for_bit(name, B, want_active, schedule):
+    if name != "c3" and B > 300000:
+        pytest.skip("the round structures are covered on c3")
+    cs, layer, dp = _pack(_sets()[name])
+    if dp.info().mfma_f32 != 3:
+        pytest.skip("the f16-pair family does not serve this pack")
+    gen = torch.Generator(device="cuda").manual_seed(B)
+    v = torch.empty(B, cs.n, device="cuda").uniform_(-1.5, 1.5, generator=gen)
+    v[B // 3] = 0.0
+    v[B // 2] *= 1e-3
+    y1, k1, a1, fam1 = _run(dp, v, want_active)
+    y2, k2, a2, fam2 = _run(dp, _misaligned_copy(v), want_active)
+    assert fam1 == schedule, "the LDS-scheduled kernel was expected to serve an aligned call of this shape"
+    assert fam2 == _lib.KERNEL_PAIR
+    assert torch.equal(y1, y2)
+    assert torch.equal(k1, k2)
+    if want_active:
+        assert torch.equal(a1, a2)
+    # and against the oracle on a slice (the reference's bar)
+    take = torch.cat([torch.arange(0, min(B, 700)), torch.arange(max(B - 700, 0), B)]).unique()
+    x = v[take.cuda()].cpu().unsqueeze(2)
+    y_ref = oracle.forward(oracle.precompute(csd_from_cs(cs), torch.float32), x).numpy()[:, :, 0]
+    assert np.max(rel_err_rows(y1[take.cuda()].cpu().numpy(), y_ref)) <= 1e-5
+
+
+@pytest.mark.parametrize("name", ["c3", "n32"])
+def test_trickled_rows_with_padded_leading_dimensions_and_nan_rows(name, schedule):
+    """Rows at a stride (ldv, ldy > n, multiples of 4 floats): the LDS-DMA and the stores address every row on its own;
+    a NaN row raises the flag and touches no other row."""
+    cs, layer, dp = _pack(_sets()[name])
+    if dp.info().mfma_f32 != 3:
+        pytest.skip("the f16-pair family does not serve this pack")
+    B, n = 262144 + 77, cs.n
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    wide = torch.empty(B, n + 8, device="cuda").uniform_(-1.5, 1.5, generator=gen)
+    v = wide[:, :n]
+    out = torch.full((B, n + 12), -7.0, device="cuda")
+    y_ref, k_ref, _ = ops.project_raw(_misaligned_copy(v.contiguous()), dp, want_active=False)
+    assert _lib.load().rayen_last_forward_kernel() == _lib.KERNEL_PAIR
+    y, kappa, _ = ops.project_raw(v, dp, want_active=False, out=out)
+    assert _lib.load().rayen_last_forward_kernel() == schedule
+    assert torch.equal(out[:, :n], y_ref) and torch.equal(kappa, k_ref)
+    assert bool((out[:, n:] == -7.0).all())            # nothing written beyond the k columns
+    dp.nan_flag.zero_()
+    v2 = v.contiguous().clone()
+    v2[B - 5, 3] = float("nan")
+    v2[70000, 0] = float("inf")
+    y2, _, _ = ops.project_raw(v2, dp, want_active=False)
+    assert _lib.load().rayen_last_forward_kernel() == schedule
+    assert int(dp.nan_flag.item()) == 1
+    dp.nan_flag.zero_()
+    keep = torch.ones(B, dtype=torch.bool, device="cuda")
+    keep[B - 5] = False
+    keep[70000] = False
+    assert torch.equal(y2[keep], y_ref[keep])

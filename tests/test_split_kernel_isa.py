@@ -13,6 +13,6 @@ def test_no_compiler_access_to_in_flight_chunk_registers():
     run = subprocess.run([sys.executable, os.path.join(REPO, "scripts", "check_split_asm.py")],
                          capture_output=True, text=True)
     assert run.returncode == 0, run.stdout + run.stderr
-    lines = [l for l in run.stdout.splitlines() if l.startswith(("NKK=", "pair NKK="))]
-    assert len(lines) == 28, run.stdout                      # bf16 triples, plain: NKK in {1, 2} x TRACK x STAGED; mapped (NA_E = I only): (NKK, NKX) in {(1,1), (2,1), (2,2)} x TRACK; f16 pairs: the same 8 + 6
+    lines = [l for l in run.stdout.splitlines() if l.startswith(("NKK=", "pair NKK=", "pair-io NKK="))]
+    assert len(lines) == 32, run.stdout                      # bf16 triples, plain: NKK in {1, 2} x TRACK x STAGED; mapped (NA_E = I only): (NKK, NKX) in {(1,1), (2,1), (2,2)} x TRACK; f16 pairs: the same 8 + 6; f16 pairs with LDS-trickled rows: NKK in {1, 2} x TRACK
     assert all(l.rstrip().endswith("suspicious instructions in the loop: 0") for l in lines), run.stdout
