@@ -60,7 +60,8 @@ enum {
 };
 
 /* RayenPackDesc.prepare: the kernel families whose device images rayen_pack_create builds.  0 = everything
- * (fp32 + fp64, forward + backward).  A call into a family that was left out returns RAYEN_E_NOT_PREPARED. */
+ * (fp32 + fp64, forward + backward); neither precision bit set = both precisions (RAYEN_PREPARE_FWD_ONLY alone =
+ * forward only, fp32 and fp64).  A call into a family that was left out returns RAYEN_E_NOT_PREPARED. */
 enum {
   RAYEN_PREPARE_ALL = 0,
   RAYEN_PREPARE_F32 = 1,

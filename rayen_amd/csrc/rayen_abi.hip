@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <new>
 #include <vector>
 
@@ -95,8 +96,9 @@ int build_one(RayenPack* p, bool eligible, Image** slot, Build build) {
 }
 
 int build_images(RayenPack* p, int prepare) {
-  const bool f32 = prepare == 0 || (prepare & RAYEN_PREPARE_F32);
-  const bool f64 = prepare == 0 || (prepare & RAYEN_PREPARE_F64);
+  // (no precision bit = both precisions: RAYEN_PREPARE_FWD_ONLY alone means "forward only, fp32 and fp64")
+  const bool f32 = (prepare & (RAYEN_PREPARE_F32 | RAYEN_PREPARE_F64)) == 0 || (prepare & RAYEN_PREPARE_F32);
+  const bool f64 = (prepare & (RAYEN_PREPARE_F32 | RAYEN_PREPARE_F64)) == 0 || (prepare & RAYEN_PREPARE_F64);
   const bool bwd = !(prepare & RAYEN_PREPARE_FWD_ONLY);
   int rc = RAYEN_OK;
   if (f32) {
@@ -293,18 +295,28 @@ static int fp32_selfcheck(RayenPack* p) {
   if (own_g64) generic_free<double>(&p->g64);
   if (!ok) return rc != RAYEN_OK ? rc : RAYEN_E_ALLOC;
   double worst[3] = {0.0, 0.0, 0.0};
+  bool broken[3] = {false, false, false};   // a NaN / inf where the yardstick is finite: sticky, the family is out
   for (int64_t b = 0; b < B0; ++b) {
     double d[3] = {0.0, 0.0, 0.0}, size = 1e-30;
+    bool row_bad[3] = {false, false, false};
     for (int i = 0; i < k; ++i) {
       const double t = yt[(size_t)b * k + i];
-      for (int f = 0; f < 3; ++f) d[f] = std::fmax(d[f], std::fabs((double)yf[f * ny + (size_t)b * k + i] - t));
-      size = std::fmax(size, std::fabs(t));
+      for (int f = 0; f < 3; ++f) {
+        const double e = std::fabs((double)yf[f * ny + (size_t)b * k + i] - t);
+        if (std::isfinite(e)) d[f] = std::fmax(d[f], e);     // (fmax would drop a NaN silently)
+        else if (std::isfinite(t)) row_bad[f] = true;
+      }
+      if (std::isfinite(t)) size = std::fmax(size, std::fabs(t));
     }
-    for (int f = 0; f < 3; ++f)
-      if (!(d[f] / size <= worst[f])) worst[f] = d[f] / size;  // (NaN counts as a difference)
+    for (int f = 0; f < 3; ++f) {
+      broken[f] = broken[f] || row_bad[f];
+      worst[f] = std::fmax(worst[f], d[f] / size);
+    }
   }
+  for (int f = 0; f < 3; ++f)
+    if (broken[f]) worst[f] = std::numeric_limits<double>::infinity();
   p->check_exact = worst[1];
-  auto accept = [&](double w) { return (w <= 4e-6 || w <= 1.5 * worst[1]) ? 1 : 2; };
+  auto accept = [&](double w) { return (w <= 4e-6 || (std::isfinite(worst[1]) && w <= 1.5 * worst[1])) ? 1 : 2; };
   if (p->sp32 != nullptr) { p->check_split = worst[0]; p->sp32_state = accept(worst[0]); }
   if (p->pr32 != nullptr) { p->check_pair = worst[2]; p->pr32_state = accept(worst[2]); }
   return RAYEN_OK;

@@ -39,7 +39,7 @@ inline bool bwd_tiles_eligible(const RayenPack* p) {
   return tiles <= 64;
 }
 
-// Fills `b` (raw fp64 tiles: the item tiles, a no-op tile if their count is odd, one spare tile for
+// Fills `b` (raw fp64 tiles: the item tiles, a no-op tile if their count is odd, two spare tiles for
 // the prefetch) and `items` (never empty); returns the number of items the kernel walks (even).
 inline int layout_bwd_tiles(const RayenPack* p, TileLayout& b, std::vector<BItem>& items) {
   const int n = p->n, nkk = n_pad_of(n) / 32;
@@ -85,7 +85,10 @@ inline int layout_bwd_tiles(const RayenPack* p, TileLayout& b, std::vector<BItem
     items.push_back(it);
     b.add_tile({}, n);
   }
-  b.add_tile({}, n);  // spare tile: the prefetch runs one tile past the end
+  // two spare tiles: the bucketed walk of a form that ends the list fetches [it_lo, it_hi) two tiles ahead, so its last
+  // iteration touches it_hi and it_hi + 1 (never used; a read past the allocation could still fault)
+  b.add_tile({}, n);
+  b.add_tile({}, n);
   const int n_real = (int)items.size();
   if (items.empty()) {
     BItem it;
@@ -108,7 +111,7 @@ struct BPack {
 };
 
 
-// Fills `b` (item tiles, a no-op tile if their count is odd, one spare tile), `items`, `packs` (never
+// Fills `b` (item tiles, a no-op tile if their count is odd, two spare tiles), `items`, `packs` (never
 // empty) and `seg_aux` ([n_segments + 1]: W row of phi for factor segments, -1 otherwise); returns the
 // number of items the kernel walks (even).
 inline int layout_bwdg_tiles(const RayenPack* p, TileLayout& b, std::vector<BItem>& items,
@@ -223,7 +226,8 @@ inline int layout_bwdg_tiles(const RayenPack* p, TileLayout& b, std::vector<BIte
     items.push_back(blank(BI_NOP));
     b.add_tile({}, n);
   }
-  b.add_tile({}, n);  // spare tile for the prefetch
+  b.add_tile({}, n);  // two spare tiles for the prefetch (it looks two tiles ahead of the last item)
+  b.add_tile({}, n);
   const int n_real = (int)items.size();
   if (items.empty()) items.push_back(blank(BI_NOP));
   if (packs.empty()) { BPack pk; std::memset(&pk, 0, sizeof(pk)); packs.push_back(pk); }

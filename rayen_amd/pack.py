@@ -249,14 +249,22 @@ class DevicePack:
         return self.mapper_mode(in_dim) != 0
 
     def mapper_image(self, weight, bias, stream):
-        """The split-operand image of ``(weight, bias)`` for ``mapper_mode == 2``; cached per pack and rebuilt (one
-        small launch on ``stream``) when either tensor was modified in place or replaced."""
+        """The split-operand image of ``(weight, bias)`` for ``mapper_mode == 2``.
+
+        Parameters that are being trained (``requires_grad``) get a fresh image on EVERY call -- one 8-block launch on
+        ``stream`` -- because an optimiser may update them through ``.data`` (``p.data.add_()``, EMA code), which the
+        tensor's version counter does not see.  Frozen parameters are cached per pack: the key is the storage address,
+        the version counter, the shape and the stream the image was built on (a call from another stream rebuilds it
+        rather than reading an image whose conversion may still be in flight there).  Weights of a frozen module that
+        are nevertheless rewritten through ``.data`` need :meth:`invalidate_mapper_image`."""
         import torch
+        trained = weight.requires_grad or (bias is not None and bias.requires_grad)
         key = (weight.data_ptr(), weight._version, tuple(weight.shape), weight.stride(0),
-               None if bias is None else (bias.data_ptr(), bias._version))
+               None if bias is None else (bias.data_ptr(), bias._version), getattr(stream, "value", stream))
         cached = self.__dict__.get("_mapper_image")
         # (while a stream is being captured the conversion launch must be part of the graph: replays follow the weights)
-        if cached is not None and cached[0] == key and not torch.cuda.is_current_stream_capturing():
+        if (cached is not None and cached[0] == key and not trained
+                and not torch.cuda.is_current_stream_capturing()):
             return cached[1]
         lib = _lib.load()
         in_dim = weight.shape[1]
@@ -271,6 +279,12 @@ class DevicePack:
                                                     ctypes.c_void_p(image.data_ptr()), stream), "rayen_mapper_prepare_f32")
         self.__dict__["_mapper_image"] = (key, image)
         return image
+
+    def invalidate_mapper_image(self):
+        """Forget the cached mapper image (frozen weights rewritten behind the version counter, e.g. ``p.data.copy_``)."""
+        cached = self.__dict__.get("_mapper_image")
+        if cached is not None:
+            self.__dict__["_mapper_image"] = (None, cached[1])      # keep the buffer, drop the key
 
     def close(self):
         if getattr(self, "handle", None):

@@ -119,6 +119,15 @@ def test_prepare_mask_and_fp32_mode():
     with pytest.raises(_lib.RayenError) as exc:
         ops.backward_raw(v32, kappa, active, torch.ones(100, cs.k, device="cuda"), only32)
     assert exc.value.code == -8
+    # RAYEN_PREPARE_FWD_ONLY alone: no precision bit = both precisions, forward only
+    fwd_only = _pack.DevicePack(consts, 0, prepare=_lib.PREPARE_FWD_ONLY)
+    assert fwd_only.info().prepared == (_lib.PREPARE_F32 | _lib.PREPARE_F64)
+    assert torch.equal(ops.project_raw(v32, fwd_only)[0], y)
+    ops.project_raw(v64, fwd_only)
+    with pytest.raises(_lib.RayenError) as exc:
+        ops.backward_raw(v32, kappa, active, torch.ones(100, cs.k, device="cuda"), fwd_only)
+    assert exc.value.code == -8
+    fwd_only.close()
     full = _pack.DevicePack(consts, 0)
     assert full.info().prepared == 7 and full.info().device_bytes > info.device_bytes
     assert torch.equal(ops.project_raw(v32, full)[0], y)

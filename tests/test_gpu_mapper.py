@@ -105,6 +105,24 @@ def test_weight_updates_reach_the_fused_kernel():
     other.load_state_dict(layer.state_dict())
     with torch.no_grad():
         assert torch.equal(other(x.cuda()), y_b)
+    # updates BEHIND the version counter (p.data.mul_, what some optimisers and EMA code do): parameters that are being
+    # trained get a fresh image on every call ...
+    layer.mapper.weight.data.mul_(1.5)
+    with torch.no_grad():
+        y_c = layer(x.cuda()).clone()
+    y_ref, _ = _oracle_y(cs, layer, x)
+    assert not torch.equal(y_c, y_b) and rel_err_rows(y_c.cpu().numpy()[:, :, 0], y_ref).max() < 1e-5
+    # ... frozen ones are cached, and say so: invalidate_mapper_image() after such an update
+    for prm in layer.mapper.parameters():
+        prm.requires_grad_(False)
+    with torch.no_grad():
+        layer(x.cuda())                                   # (builds and caches the image of the frozen weights)
+        layer.mapper.weight.data.mul_(0.5)
+        dp, _ = layer.device_pack(torch.device("cuda", 0))
+        dp.invalidate_mapper_image()
+        y_d = layer(x.cuda()).clone()
+    y_ref, _ = _oracle_y(cs, layer, x)
+    assert rel_err_rows(y_d.cpu().numpy()[:, :, 0], y_ref).max() < 1e-5
 
 
 def test_no_bias_and_strided_input():
