@@ -78,8 +78,9 @@ __device__ __forceinline__ void mfma_pair_fwd_body(
   const unsigned lane_off = lane * 16;
   auto load_step_fresh = [&](const int sp) {
     const char* sb = reinterpret_cast<const char*>(Wh) + sp * 2048;
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(abuf[2 * sp + 0]) : "v"(lane_off), "s"(sb));
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(abuf[2 * sp + 1]) : "v"(lane_off), "s"(sb));
+    uint64_t asm_base;
+    asm volatile(RAYEN_ASM_BASE_COPY "global_load_dwordx4 %[d], %[off], " RAYEN_ASM_BASE "" : [d] "=v"(abuf[2 * sp + 0]), [b] "=&s"(asm_base) : [off] "v"(lane_off), [base] "s"(sb));
+    asm volatile(RAYEN_ASM_BASE_COPY "global_load_dwordx4 %[d], %[off], " RAYEN_ASM_BASE " offset:1024" : [d] "=v"(abuf[2 * sp + 1]), [b] "=&s"(asm_base) : [off] "v"(lane_off), [base] "s"(sb));
   };
   if constexpr (NKX == 0) {
     // tile 0 for the first group; no wait: the group's row loads queue behind these and loads return in order
@@ -302,7 +303,8 @@ __device__ __forceinline__ void mfma_pair_fwd_body(
       // in while the accumulator is still small, scripts/ubench/mfma_bf16_acc.hip)
       auto load_chunk = [&](const int idx) {
         const char* sb = next_tile + idx * 1024;
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(abuf[idx]) : "v"(lane_off), "s"(sb));
+        uint64_t asm_base;
+        asm volatile(RAYEN_ASM_BASE_COPY "global_load_dwordx4 %[d], %[off], " RAYEN_ASM_BASE "" : [d] "+v"(abuf[idx]), [b] "=&s"(asm_base) : [off] "v"(lane_off), [base] "s"(sb));
       };
 #pragma unroll
       for (int sp = 0; sp < NS; ++sp) {
@@ -520,14 +522,14 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_fwd
 }
 
 // the same walk behind the fused mapper (x in place of v; NKX 32-column blocks of x)
-template <int NKK, bool TRACK, int NKX>
+template <int NKK, bool TRACK, int NKX, bool STAGED = false>
 __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_map_kernel(
     const f16x8* __restrict__ Wh, const MItem* __restrict__ items, int n_items,
     const MPack* __restrict__ packs, const float* __restrict__ y0, int identity, int k, int n,
     const float* __restrict__ x, int64_t B, int64_t ldx, int vec_in, float* __restrict__ y, int64_t ldy,
     int vec_out, float* __restrict__ kappa_out, int32_t* __restrict__ active_out,
     int32_t* __restrict__ nan_flag, const float w_scale, const float w_inv, const PairMapper mp) {
-  mfma_pair_fwd_body<NKK, TRACK, false, NKX>(Wh, items, n_items, packs, y0, identity, k, n, x, B, ldx, vec_in, y, ldy,
+  mfma_pair_fwd_body<NKK, TRACK, STAGED, NKX>(Wh, items, n_items, packs, y0, identity, k, n, x, B, ldx, vec_in, y, ldy,
                                              vec_out, kappa_out, active_out, nan_flag, w_scale, w_inv, mp);
 }
 
@@ -681,10 +683,10 @@ static int launch_pair(const RayenPack* p, const PairImage* img, const float* v,
   return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
 }
 
-// ---- fused mapper: in_dim <= n_pad columns of x.  Sets without equality constraints only (as the bf16-triple form).
+// ---- fused mapper: in_dim <= n_pad columns of x (sets with equality constraints: the STAGED instances)
 int64_t mfma_pair_mapper_image_bytes(const RayenPack* p, const PairImage* img, int in_dim) {
   (void)p;
-  if (img == nullptr || !img->identity || in_dim < 1 || in_dim > img->nkk * 32) return 0;
+  if (img == nullptr || in_dim < 1 || in_dim > img->nkk * 32) return 0;
   const int nsx = (in_dim + 31) / 32 * 2;
   return (int64_t)img->nkk * nsx * 2 * 1024 + (int64_t)(img->nkk * 32 + 4) * sizeof(float);
 }
@@ -716,9 +718,13 @@ static int launch_pair_map(const RayenPack* p, const PairImage* img, const float
                        img->identity, p->k, p->n, x, B, ldx, vec_in, y, ldy, vec_out, kappa, active, nan_flag,
                        img->w_scale, img->w_inv, mp);
   };
-  if (!img->identity) return RAYEN_E_UNSUPPORTED;
-  if (active != nullptr) go(mfma_pair_map_kernel<NKK, true, NKX>);
-  else go(mfma_pair_map_kernel<NKK, false, NKX>);
+  if (img->identity) {
+    if (active != nullptr) go(mfma_pair_map_kernel<NKK, true, NKX>);
+    else go(mfma_pair_map_kernel<NKK, false, NKX>);
+  } else {
+    if (active != nullptr) go(mfma_pair_map_kernel<NKK, true, NKX, true>);
+    else go(mfma_pair_map_kernel<NKK, false, NKX, true>);
+  }
   return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
 }
 

@@ -68,23 +68,29 @@ __device__ __forceinline__ const char* uniform_ptr(const void* p) {
 // (M0 = the LDS base; written in the statement that reads it, restored behind it)
 __device__ __forceinline__ void dma16(const char* gbase, const unsigned voff, const unsigned lds) {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(voff), "s"(gbase), "s"(lds)
+  uint64_t asm_base;
+  asm volatile(RAYEN_ASM_BASE_COPY "s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[off], " RAYEN_ASM_BASE "\n\ts_mov_b32 m0, %[k]"
+               : [k] "=&s"(keep), [b] "=&s"(asm_base)
+               : [off] "v"(voff), [base] "s"(gbase), [lds] "s"(lds)
                : "memory");
 }
 
 // the stand-in: 4 bytes per lane of a cached word into a scratch slot of LDS (keeps the per-tile operation count)
 __device__ __forceinline__ void dma4_dummy(const char* gbase, const unsigned voff, const unsigned lds) {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(voff), "s"(gbase), "s"(lds)
+  uint64_t asm_base;
+  asm volatile(RAYEN_ASM_BASE_COPY "s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\tglobal_load_lds_dword %[off], " RAYEN_ASM_BASE "\n\ts_mov_b32 m0, %[k]"
+               : [k] "=&s"(keep), [b] "=&s"(asm_base)
+               : [off] "v"(voff), [base] "s"(gbase), [lds] "s"(lds)
                : "memory");
 }
 
 __device__ __forceinline__ void store16_nt(char* gbase, const unsigned voff, const f32x4 x) {
-  asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(voff), "v"(x), "s"(gbase) : "memory");
+  uint64_t asm_base;
+  asm volatile(RAYEN_ASM_BASE_COPY "global_store_dwordx4 %[off], %[x], " RAYEN_ASM_BASE " nt\n\ts_nop 1"
+               : [b] "=&s"(asm_base)
+               : [off] "v"(voff), [x] "v"(x), [base] "s"(gbase)
+               : "memory");
 }
 
 }  // namespace
@@ -142,8 +148,9 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_io_
 #pragma unroll
   for (int sp = 0; sp < NS; ++sp) {
     const char* sb = reinterpret_cast<const char*>(Wh) + sp * 2048;
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(abuf[2 * sp + 0]) : "v"(lane_off), "s"(sb));
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(abuf[2 * sp + 1]) : "v"(lane_off), "s"(sb));
+    uint64_t asm_base;
+    asm volatile(RAYEN_ASM_BASE_COPY "global_load_dwordx4 %[d], %[off], " RAYEN_ASM_BASE "" : [d] "=v"(abuf[2 * sp + 0]), [b] "=&s"(asm_base) : [off] "v"(lane_off), [base] "s"(sb));
+    asm volatile(RAYEN_ASM_BASE_COPY "global_load_dwordx4 %[d], %[off], " RAYEN_ASM_BASE " offset:1024" : [d] "=v"(abuf[2 * sp + 1]), [b] "=&s"(asm_base) : [off] "v"(lane_off), [base] "s"(sb));
   }
 
   // the whole group in one burst (first group of a wave; a ragged last group): rows beyond B are not requested
@@ -270,7 +277,8 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_io_
           __builtin_amdgcn_s_setprio(0);
           auto load_chunk = [&](const int idx) {
             const char* sb = next_tile + idx * 1024;
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(abuf[idx]) : "v"(lane_off), "s"(sb));
+            uint64_t asm_base;
+            asm volatile(RAYEN_ASM_BASE_COPY "global_load_dwordx4 %[d], %[off], " RAYEN_ASM_BASE "" : [d] "+v"(abuf[idx]), [b] "=&s"(asm_base) : [off] "v"(lane_off), [base] "s"(sb));
           };
           // Two passes over the K-steps, by product size (rayen_mfma_pair.hip).  The counted waits step over the two
           // I/O operations the previous tile issued behind its last re-load.  (Tile 0: everything it needs landed

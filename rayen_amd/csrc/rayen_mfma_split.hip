@@ -84,17 +84,19 @@ __device__ __forceinline__ void mfma_split_fwd_body(
   const unsigned lane_off = lane * 16;
   auto load_step = [&](const char* tile_base, const int sp) {
     const char* sb = tile_base + sp * 3072;
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(abuf[3 * sp + 0]) : "v"(lane_off), "s"(sb));
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "+v"(abuf[3 * sp + 1]) : "v"(lane_off), "s"(sb));
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "+v"(abuf[3 * sp + 2]) : "v"(lane_off), "s"(sb));
+    uint64_t asm_base;
+    asm volatile(RAYEN_ASM_BASE_COPY "global_load_dwordx4 %[d], %[off], " RAYEN_ASM_BASE "" : [d] "+v"(abuf[3 * sp + 0]), [b] "=&s"(asm_base) : [off] "v"(lane_off), [base] "s"(sb));
+    asm volatile(RAYEN_ASM_BASE_COPY "global_load_dwordx4 %[d], %[off], " RAYEN_ASM_BASE " offset:1024" : [d] "+v"(abuf[3 * sp + 1]), [b] "=&s"(asm_base) : [off] "v"(lane_off), [base] "s"(sb));
+    asm volatile(RAYEN_ASM_BASE_COPY "global_load_dwordx4 %[d], %[off], " RAYEN_ASM_BASE " offset:2048" : [d] "+v"(abuf[3 * sp + 2]), [b] "=&s"(asm_base) : [off] "v"(lane_off), [base] "s"(sb));
   };
   // mapped instances: the rolling buffer is dead while the mapper runs (its registers hold x and the mapper's
   // accumulators); tile 0 is fetched afresh once the mapper's MFMAs are issued -- the walk's counted waits cover it
   auto load_step_fresh = [&](const int sp) {
     const char* sb = reinterpret_cast<const char*>(Wb) + sp * 3072;
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(abuf[3 * sp + 0]) : "v"(lane_off), "s"(sb));
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(abuf[3 * sp + 1]) : "v"(lane_off), "s"(sb));
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(abuf[3 * sp + 2]) : "v"(lane_off), "s"(sb));
+    uint64_t asm_base;
+    asm volatile(RAYEN_ASM_BASE_COPY "global_load_dwordx4 %[d], %[off], " RAYEN_ASM_BASE "" : [d] "=v"(abuf[3 * sp + 0]), [b] "=&s"(asm_base) : [off] "v"(lane_off), [base] "s"(sb));
+    asm volatile(RAYEN_ASM_BASE_COPY "global_load_dwordx4 %[d], %[off], " RAYEN_ASM_BASE " offset:1024" : [d] "=v"(abuf[3 * sp + 1]), [b] "=&s"(asm_base) : [off] "v"(lane_off), [base] "s"(sb));
+    asm volatile(RAYEN_ASM_BASE_COPY "global_load_dwordx4 %[d], %[off], " RAYEN_ASM_BASE " offset:2048" : [d] "=v"(abuf[3 * sp + 2]), [b] "=&s"(asm_base) : [off] "v"(lane_off), [base] "s"(sb));
   };
   if constexpr (NKX == 0) {
     // tile 0 for the first group.  No wait here: the group's row loads are issued behind these and waited for by
@@ -289,7 +291,8 @@ __device__ __forceinline__ void mfma_split_fwd_body(
       // leading products loses its low bits, so the small ones go in while the accumulator is still small.
       auto load_chunk = [&](const int idx) {
         const char* sb = next_tile + idx * 1024;
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(abuf[idx]) : "v"(lane_off), "s"(sb));
+        uint64_t asm_base;
+        asm volatile(RAYEN_ASM_BASE_COPY "global_load_dwordx4 %[d], %[off], " RAYEN_ASM_BASE "" : [d] "+v"(abuf[idx]), [b] "=&s"(asm_base) : [off] "v"(lane_off), [base] "s"(sb));
       };
 #pragma unroll
       for (int sp = 0; sp < NS; ++sp) {
@@ -705,7 +708,7 @@ int64_t mfma_split_mapper_image_bytes(const RayenPack* p, const SplitImage* img,
   // (sets with equality constraints, NA_E != I: their mapped instances -- the walk's staged write-out next to the
   // mapper prologue, 255 VGPRs and ~200 spilled SGPRs -- fault on the device; until that is understood such packs run
   // the mapper as its own GEMM)
-  if (img == nullptr || !img->identity || in_dim < 1 || in_dim > img->nkk * 32) return 0;
+  if (img == nullptr || in_dim < 1 || in_dim > img->nkk * 32) return 0;
   const int nsx = (in_dim + 31) / 32 * 2;
   return (int64_t)img->nkk * nsx * 3 * 1024 + (int64_t)img->nkk * 32 * sizeof(float);
 }
@@ -736,9 +739,13 @@ static int launch_split_map(const RayenPack* p, const SplitImage* img, const flo
                        static_cast<const bf16x8*>(img->Wb), img->items, img->n_items, img->packs, img->y0,
                        img->identity, p->k, p->n, x, B, ldx, vec_in, y, ldy, vec_out, kappa, active, nan_flag, mp);
   };
-  if (!img->identity) return RAYEN_E_UNSUPPORTED;
-  if (active != nullptr) go(mfma_split_map_kernel<NKK, true, false, NKX>);
-  else go(mfma_split_map_kernel<NKK, false, false, NKX>);
+  if (img->identity) {
+    if (active != nullptr) go(mfma_split_map_kernel<NKK, true, false, NKX>);
+    else go(mfma_split_map_kernel<NKK, false, false, NKX>);
+  } else {
+    if (active != nullptr) go(mfma_split_map_kernel<NKK, true, true, NKX>);
+    else go(mfma_split_map_kernel<NKK, false, true, NKX>);
+  }
   return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
 }
 

@@ -9,6 +9,23 @@ namespace rayen {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Every hand-placed (inline asm) vector-memory instruction of the split-operand kernels takes its scalar base through an
+// SALU copy made INSIDE the statement.  Why: hipcc may restore the base from an SGPR spill lane (v_readlane_b32) with the
+// instruction right in front of the statement; a VALU write of an SGPR needs five wait states before a VMEM instruction
+// reads it, and the compiler pads such hazards only for instructions it emits itself.  The instances with ~200 spilled
+// SGPRs (fused mapper x staged NA_E write-out) read a stale base that way and faulted on wild addresses -- the device
+// fault that kept the fused mapper from sets with equality constraints in rounds 1 and 2.  An SALU read of a
+// VALU-written SGPR is interlocked by the hardware, and an SALU-written SGPR needs no wait state before VMEM.
+// scripts/check_split_asm.py scans every instance for the hazard (a VALU write of an SGPR within five instructions in
+// front of an asm VMEM instruction that reads it).
+#ifndef RAYEN_ASM_NO_BASE_COPY
+#define RAYEN_ASM_BASE_COPY "s_mov_b64 %[b], %[base]\n\t"
+#define RAYEN_ASM_BASE "%[b]"
+#else   // developer A/B builds only: the hazard is back
+#define RAYEN_ASM_BASE_COPY ""
+#define RAYEN_ASM_BASE "%[base]"
+#endif
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // 2^13 / 2^floor(log2 m) as a float and its inverse, from the biased exponent of m (clamped to [14, 254])

@@ -2,7 +2,10 @@
 """Safety check of the hand-placed loads of rayen_mfma_split.hip, rayen_mfma_pair.hip and rayen_mfma_pair_io.hip: between an asm `global_load` into a chunk of the
 rolling A buffer and the `s_waitcnt` that covers it the compiler must not touch those registers (copy, spill):
 it does not know the data is still in flight.  Scans the gfx950 ISA of every instance of the kernel and lists
-any instruction inside the tile loops, other than the MFMAs and the loads themselves, that names a chunk register.
+any instruction inside the tile loops, other than the MFMAs and the loads themselves, that names a chunk register --
+and any VALU write of an SGPR (a spilled SGPR restored by v_readlane_b32 ...) within the five wait states in front of
+an asm vector-memory instruction that reads it (the hazard behind the device fault of the fused mapper on sets with
+equality constraints, rounds 1-2: rayen_split_image.h).
     python scripts/check_split_asm.py        (exit code 1 if something is found)"""
 import os
 import re
@@ -51,13 +54,47 @@ for s, e in zip(starts[:-1], starts[1:]):
     if "pair_io_kernel" in lines[s]:                     # <NKK, TRACK>: NA_E = I only
         m2 = re.search(r"ILi(\d)ELb(\d)E", lines[s]).groups()
         name = (m2[0], m2[1], "0")
-    if "pair_map_kernel" in lines[s]:                    # <NKK, TRACK, NKX>: never staged
-        m3 = re.search(r"ILi(\d)ELb(\d)ELi(\d)", lines[s]).groups()
-        name, nkx = (m3[0], m3[1], "0"), m3[2]
+    if "pair_map_kernel" in lines[s]:                    # <NKK, TRACK, NKX, STAGED>
+        m3 = re.search(r"ILi(\d)ELb(\d)ELi(\d)ELb(\d)", lines[s]).groups()
+        name, nkx = (m3[0], m3[1], m3[3]), m3[2]
     # the hand-placed loads are the ones written as asm statements (the compiler's own loads of the mapper image or of
     # the rows are tracked by the compiler and need no check)
-    loads = [i for i, l in enumerate(body) if "global_load_dwordx4" in l and re.search(r", s\[\d+:\d+\]", l)
-             and i > 0 and "ASMSTART" in body[i - 1]]
+    in_asm, asm_lines = False, set()
+    for i, l in enumerate(body):
+        if "ASMSTART" in l:
+            in_asm = True
+        elif "ASMEND" in l:
+            in_asm = False
+        elif in_asm:
+            asm_lines.add(i)
+    loads = [i for i in sorted(asm_lines) if "global_load_dwordx4" in body[i] and re.search(r", s\[\d+:\d+\]", body[i])]
+    # ---- hazard scan: a VALU write of an SGPR (v_readlane_b32 restoring a spilled SGPR, v_readfirstlane_b32, a VOPC /
+    # carry-out into an SGPR pair) needs five wait states before a VMEM instruction reads that SGPR; hipcc pads this for
+    # its own instructions only.  Every hand-placed VMEM instruction must therefore read a base that the statement
+    # itself produced with an SALU copy (RAYEN_ASM_BASE_COPY); what is checked here is the emitted code: within the five
+    # instructions in front of an asm VMEM instruction nothing but SALU instructions may write its scalar base.
+    hazards = []
+    code = [(i, body[i].split(";")[0].strip()) for i in range(len(body))]
+    code = [(i, t) for i, t in code if t and not t.startswith(".") and not t.endswith(":")]
+    pos = {i: n for n, (i, _) in enumerate(code)}
+    for i in sorted(asm_lines):
+        t = body[i].split(";")[0].strip()
+        m = re.match(r"(global_load\w*|global_store\w*|buffer_\w+) .*\bs\[(\d+):(\d+)\]", t)
+        if not m:
+            continue
+        lo, hi = int(m.group(2)), int(m.group(3))
+        for back in range(1, 6):
+            n = pos[i] - back
+            if n < 0:
+                break
+            prev = code[n][1]
+            w = re.match(r"(v_readlane_b32|v_readfirstlane_b32) s(\d+),", prev)
+            if w and lo <= int(w.group(2)) <= hi:
+                hazards.append((i, t, back, prev))
+                break
+            if re.match(r"s_mov_b64 s\[%d:%d\]," % (lo, hi), prev):
+                break                                   # the statement's own SALU copy: what comes before it is interlocked
+
     chunk = set()
     for i in loads:
         chunk |= regs_of(body[i].split(",")[0])
@@ -78,7 +115,10 @@ for s, e in zip(starts[:-1], starts[1:]):
             bad.append((i, l))
     family = "pair-io " if "pair_io_kernel" in lines[s] else ("pair " if "mfma_pair" in lines[s] else "")
     print(f"{family}NKK={name[0]} TRACK={name[1]} STAGED={name[2]} NKX={nkx}: {len(loads)} asm loads, chunk registers {min(chunk)}..{max(chunk)}"
-          f" ({len(chunk)}), suspicious instructions in the loop: {len(bad)}")
+          f" ({len(chunk)}), SGPR hazards in front of asm VMEM: {len(hazards)}, suspicious instructions in the loop: {len(bad)}")
+    for i, t, back, prev in hazards[:6]:
+        print("      hazard:", i, t[:70], "<-", back, "back:", prev)
+    bad_total += len(hazards)
     for i, l in bad[:12]:
         print("     ", i, l[:110])
     bad_total += len(bad)
