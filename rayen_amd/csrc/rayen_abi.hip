@@ -110,6 +110,7 @@ int build_images(RayenPack* p, int prepare) {
       const bool split_ok = mode != 1 && mfma_split_eligible(p);
       if ((rc = build_one(p, split_ok && mode != 3, &p->sp32, mfma_split_build))) return rc;
       if ((rc = build_one(p, split_ok && (mode == 0 || mode == 3), &p->pr32, mfma_pair_build))) return rc;
+      if (p->pr32 != nullptr && (rc = mfma_pair_io_prepare(p, p->pr32))) return rc;
     }
     if ((rc = build_one(p, lmi_quad_eligible_f32(p), &p->q32, lmi_quad_build_f32))) return rc;
     if (bwd) {

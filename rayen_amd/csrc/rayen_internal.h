@@ -131,6 +131,7 @@ int mfma_pair_forward(const RayenPack* p, const PairImage* img, const float* v, 
 // the same arithmetic with the rows of v and y trickled through LDS under the tile walk (rayen_mfma_pair_io.hip)
 bool mfma_pair_io_serves(const RayenPack* p, const PairImage* img, const float* v, int64_t B, int64_t ldv,
                          const float* y, int64_t ldy);
+int mfma_pair_io_prepare(const RayenPack* p, const PairImage* img);   // function attributes (pack creation only)
 int mfma_pair_io_forward(const RayenPack* p, const PairImage* img, const float* v, int64_t B, int64_t ldv,
                          float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
                          hipStream_t stream);

@@ -602,6 +602,9 @@ int mfma_pair_build(const RayenPack* p, PairImage** out, int64_t* bytes) {
   img->identity = p->out_identity;
   img->n_items = (int)b.items.size();
   for (const RayenSegment& g : p->segs) img->aux_rows += aux_rows_of(g);
+  img->first_out = img->n_items;
+  for (int i = img->n_items - 1; i >= 0; --i)
+    if (b.items[i].type == MI_OUT) img->first_out = i;
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0)

@@ -481,19 +481,458 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_io_
   if (nan_flag && bad) atomicOr(nan_flag, 1);
 }
 
+// =============================================================================================
+// The same schedule for n <= 32 with rows stored back to back (ldv == n, ldy == k: what a contiguous torch tensor
+// is), any n, and for sets with equality constraints (k > n, rows of y from the NA_E tiles): config-5-like shapes.
+//
+// A group's 64 rows are ONE contiguous block of memory (256 n bytes of v, 256 k bytes of y), so the buffer holds a
+// flat copy: chunk c = bytes [1024 c, 1024 c + 1024) of the block, fetched / stored by one instruction as 64 pieces
+// of 16 bytes whatever n and k are -- every store covers whole 128-byte lines, where rayen_mfma_pair.hip writes the
+// 180-byte rows of config 5 with 4-byte stores at a stride of 45 floats (83 MB of HBM writes for 47 MB of y).  The
+// fragment-shaped accesses (a lane reads its sample's row, writes its sample's outputs) are 4-byte LDS operations on
+// the flat block.  With NA_E != I the rows of y come out of the NA_E tiles at the END of the walk, while the buffer
+// still holds v(next): the next rows are read into registers in front of the first of those tiles.
+// LDS (dynamic): the aux patch (64 KiB) + 8 x (256 max(n, k)) bytes.
+template <bool TRACK, bool STAGED>
+__global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_iof_kernel(
+    const f16x8* __restrict__ Wh, const MItem* __restrict__ items, int n_items,
+    const MPack* __restrict__ packs, const float* __restrict__ y0, int k, int n,
+    const float* __restrict__ v, int64_t B, float* __restrict__ y,
+    float* __restrict__ kappa_out, int32_t* __restrict__ active_out,
+    int32_t* __restrict__ nan_flag, const float w_scale, const float w_inv, const int buf_bytes) {
+  constexpr int NT = 2, NS = 2, NCH = 4, KK = 16, NQ = 4, AUXR = 32;
+  extern __shared__ __attribute__((aligned(1024))) char iof_smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float (*aux_lds)[AUXR][32] = reinterpret_cast<float (*)[AUXR][32]>(iof_smem) + wave * NT;   // [t][row][sample]
+  char* const io_all = iof_smem + kMfmaWaves * NT * AUXR * 32 * 4;
+  char* const io = io_all + wave * buf_bytes;
+  float* const io_f = reinterpret_cast<float*>(io);
+  char* const sink = io_all + kMfmaWaves * buf_bytes;
+  float* const y0_lds = reinterpret_cast<float*>(sink + 256);   // [32] (identity write-out)
+  const int col = lane & 31;
+  const int hi = lane >> 5;
+  const int64_t n_groups = (B + NT * 32 - 1) / (NT * 32);
+  const int64_t wave_id = (int64_t)blockIdx.x * kMfmaWaves + wave;
+  const int64_t wave_stride = (int64_t)gridDim.x * kMfmaWaves;
+  bool bad = false;
+  if (!STAGED)
+    for (int i = threadIdx.x; i < 32; i += kMfmaWaves * 64) y0_lds[i] = y0[i];   // (y0 is zero-padded)
+  __syncthreads();  // the only workgroup barrier
+
+  const unsigned io_addr = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(io));
+  const unsigned sink_addr = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(sink));
+  const int pieces_v = 16 * n, pieces_y = 16 * k;                           // 16-byte pieces of a whole group's block
+  const int chunks_v = (pieces_v + 63) / 64, chunks_y = (pieces_y + 63) / 64;
+
+  // ---- A operands: the rolling register buffer of rayen_mfma_split.hip, two chunks (a1, a2) per K-step
+  u32x4 abuf[NCH];
+  const unsigned lane_off = lane * 16;
+#pragma unroll
+  for (int sp = 0; sp < NS; ++sp) {
+    const char* sb = reinterpret_cast<const char*>(Wh) + sp * 2048;
+    uint64_t asm_base;
+    asm volatile(RAYEN_ASM_BASE_COPY "global_load_dwordx4 %[d], %[off], " RAYEN_ASM_BASE "" : [d] "=v"(abuf[2 * sp + 0]), [b] "=&s"(asm_base) : [off] "v"(lane_off), [base] "s"(sb));
+    asm volatile(RAYEN_ASM_BASE_COPY "global_load_dwordx4 %[d], %[off], " RAYEN_ASM_BASE " offset:1024" : [d] "=v"(abuf[2 * sp + 1]), [b] "=&s"(asm_base) : [off] "v"(lane_off), [base] "s"(sb));
+  }
+  auto drain = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(abuf[0]), "+v"(abuf[1]), "+v"(abuf[2]), "+v"(abuf[3]) : : "memory");
+  };
+
+  // a whole group in one burst (a wave's first group): LDS-DMA of its chunks; a ragged group (the last of the batch)
+  // word by word -- its last 16-byte piece could reach past the end of v
+  auto burst_load = [&](const int64_t s_base) {
+    const int64_t left = B - s_base;
+    if (left >= NT * 32) {
+      const char* vg = uniform_ptr(v + s_base * n);
+#pragma nounroll
+      for (int c = 0; c < chunks_v; ++c)
+        if (c * 64 + lane < pieces_v) dma16(vg, (unsigned)(c * 1024) + lane_off, io_addr + c * 1024);
+    } else {
+      const float* vg = v + s_base * n;
+      const int words = (int)left * n;
+      for (int i = lane; i < words; i += 64) io_f[i] = vg[i];
+    }
+  };
+  auto burst_store = [&](const int64_t s_base) {
+    const int64_t left = B - s_base;
+    if (left >= NT * 32) {
+      char* yg = const_cast<char*>(uniform_ptr(y + s_base * k));
+#pragma nounroll
+      for (int c = 0; c < chunks_y; ++c) {
+        if (c * 64 + lane < pieces_y) {
+          const f32x4 o = *reinterpret_cast<const f32x4*>(io + c * 1024 + lane * 16);
+          __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(yg + ((unsigned)(c * 1024) + lane_off)));
+        }
+      }
+    } else {
+      float* yg = y + s_base * k;
+      const int words = (int)left * k;
+      for (int i = lane; i < words; i += 64) yg[i] = io_f[i];
+    }
+  };
+
+  // vb[t][piece][k-step] = 8 f16 = the B operand of one MFMA; element i = column 16 sp + 8 (i >> 2) + 4 hi + (i & 3)
+  f16x8 vb[NT][2][NS];
+  float v_scl[NT], v_inv[NT];
+  bool live[NT];
+  // this lane's part of row 32 t + col of the flat block: columns 8 q + 4 hi + c (zero beyond n)
+  auto read_rows = [&](float (&vr)[KK], const int t) {
+    int l = lane;
+    asm volatile("" : "+v"(l));                       // (opaque: the addresses are not carried across the walk)
+    const float* row = io_f + (32 * t + (l & 31)) * n + 4 * (l >> 5);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) vr[4 * q + c] = (8 * q + 4 * (l >> 5) + c < n) ? row[8 * q + c] : 0.f;
+  };
+  auto split_rows = [&](const float (&vr)[KK], const int t) {
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < KK; ++i) m = fmaxf(m, __builtin_fabsf(vr[i]));
+    m = fmaxf(m, xhalf(m));
+    float sv;
+    int sv_exp;
+    pow2_scale(m, sv, v_inv[t], sv_exp);
+    v_scl[t] = sv;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int i = (q & 1) * 4 + c;
+        const float x = vr[4 * q + c] * sv;
+        const _Float16 p1 = (_Float16)x;
+        const float r1 = x - (float)p1;
+        vb[t][0][q >> 1][i] = p1;
+        vb[t][1][q >> 1][i] = (_Float16)r1;
+      }
+  };
+
+  int64_t grp = wave_id;
+  bool need_fetch = false;   // the buffer holds the rows of group `grp`, still to be split
+  if (grp < n_groups) {
+    burst_load(grp * (NT * 32));
+    drain();
+    need_fetch = true;
+  }
+  bool has_prev = false;
+  int64_t prev_base = 0;
+
+  while (grp < n_groups) {
+    const int64_t s_base = grp * (NT * 32);
+    const int64_t next = grp + wave_stride;
+    const bool has_next = next < n_groups;
+    const bool trickle_ld = has_next && (next + 1) * (NT * 32) <= B;   // whole groups only
+    const char* vnext = uniform_ptr(v + (has_next ? next : grp) * (NT * 32) * n);
+    char* yprev = const_cast<char*>(uniform_ptr(y + prev_base * k));
+    if (need_fetch) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        float vr[KK];
+        live[t] = (s_base + t * 32 + col) < B;
+        __builtin_amdgcn_sched_barrier(0);
+        read_rows(vr, t);
+        __builtin_amdgcn_sched_barrier(0);
+        split_rows(vr, t);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+
+    // kap, part, the aux patch and the accumulators live in the SCALED domain (gW sv times the natural value)
+    float kap[NT], part[NT], scale[NT], knat[NT];
+    int acode[NT];  // arg-max bookkeeping in one register: (segment << 20) | row, -1 = none
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { kap[t] = 0.f; part[t] = 0.f; scale[t] = 1.f; knat[t] = 0.f; acode[t] = -1; }
+    float vnx[NT][KK];   // STAGED: the next group's rows, read in front of the first NA_E tile
+
+    auto finish_kappa = [&]() {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float other = xhalf(kap[t]);
+        if (TRACK) {
+          const int ocode = __shfl_xor(acode[t], 32);
+          if (other > kap[t] || (other == kap[t] && hi == 1)) acode[t] = ocode;
+        }
+        kap[t] = fmaxf(kap[t], other);
+        knat[t] = (kap[t] * w_inv) * v_inv[t];
+        // what multiplies the scaled numbers on the way out: the accumulators of NA_E rows carry gW sv, the rebuilt
+        // direction of the NA_E = I write-out only sv
+        const float out = v_inv[t] * (1.0f / fmaxf(1.0f, knat[t]));
+        scale[t] = STAGED ? out * w_inv : out;
+      }
+    };
+
+    {
+      f32x16 acc[NT];
+      for (int it = 0; it < n_items; ++it) {
+        const MItem item = items[it];
+        if (STAGED && item.type == MI_OUT && (item.flags & MF_FIRST)) {
+          // kappa is final; the rows of v(next) leave the buffer (the DMAs that brought them were issued in the first
+          // tiles of this walk: the counted waits of the tiles since have stepped over them), y(prev) left it long ago
+          finish_kappa();
+          if (trickle_ld) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) read_rows(vnx[t], t);
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+        // the tile after this one; the last tile of a group fetches tile 0 for the next group
+        const char* next_tile = reinterpret_cast<const char*>(Wh) + (size_t)(it + 1 == n_items ? 0 : it + 1) * (NCH * 1024);
+        const bool st = has_prev && it < chunks_y, ld = trickle_ld && it < chunks_v;
+        f32x4 ytmp = {0.f, 0.f, 0.f, 0.f};
+        if (st && it * 64 + lane < pieces_y) ytmp = *reinterpret_cast<const f32x4*>(io + it * 1024 + lane * 16);
+        {
+          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          __builtin_amdgcn_s_setprio(0);
+          auto load_chunk = [&](const int idx) {
+            const char* sb = next_tile + idx * 1024;
+            uint64_t asm_base;
+            asm volatile(RAYEN_ASM_BASE_COPY "global_load_dwordx4 %[d], %[off], " RAYEN_ASM_BASE "" : [d] "+v"(abuf[idx]), [b] "=&s"(asm_base) : [off] "v"(lane_off), [base] "s"(sb));
+          };
+#pragma unroll
+          for (int sp = 0; sp < NS; ++sp) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(3)" : "+v"(abuf[2 * sp + 0]), "+v"(abuf[2 * sp + 1]));
+            const f16x8 a1 = __builtin_bit_cast(f16x8, abuf[2 * sp + 0]), a2 = __builtin_bit_cast(f16x8, abuf[2 * sp + 1]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, vb[t][0][sp], sp == 0 ? zero : acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, vb[t][1][sp], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_chunk(2 * sp + 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#pragma unroll
+          for (int sp = 0; sp < NS; ++sp) {
+            const f16x8 a1 = __builtin_bit_cast(f16x8, abuf[2 * sp + 0]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, vb[t][0][sp], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_chunk(2 * sp + 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          // ---- the tile's two I/O operations: 1 KiB of y(prev) out, 1 KiB of v(next) in (or their stand-ins)
+          {
+            const unsigned off = (unsigned)(it * 1024) + lane_off;
+            const int piece = it * 64 + lane;
+            if (st) { if (piece < pieces_y) store16_nt(yprev, off, ytmp); }
+            else dma4_dummy(reinterpret_cast<const char*>(Wh), lane_off >> 2, sink_addr);
+            if (ld) { if (piece < pieces_v) dma16(vnext, off, io_addr + it * 1024); }
+            else dma4_dummy(reinterpret_cast<const char*>(Wh), lane_off >> 2, sink_addr);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_setprio(1);
+        }
+        if (item.type == MI_LIN) {
+          const int lin_code = (item.seg << 20) + item.row0 + 4 * hi;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            if (TRACK) {
+#pragma unroll
+              for (int g = 0; g < 16; ++g)
+                if (acc[t][g] > kap[t]) {
+                  kap[t] = acc[t][g];
+                  acode[t] = lin_code + ((g & 3) + 8 * (g >> 2));
+                }
+            } else {
+#pragma unroll
+              for (int g = 0; g < 16; ++g) kap[t] = fmaxf(kap[t], acc[t][g]);
+            }
+          }
+        } else if (item.type == MI_QFAC || item.type == MI_SOC) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            f32x2 s2 = {(item.flags & MF_FIRST) ? 0.f : part[t], 0.f};
+#pragma unroll
+            for (int g = 0; g < 16; g += 2) {
+              const f32x2 a2 = {acc[t][g], acc[t][g + 1]};
+              s2 = __builtin_elementwise_fma(a2, a2, s2);
+            }
+            part[t] = s2[0] + s2[1];
+          }
+          if (item.flags & MF_LAST) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              const float total = part[t] + xhalf(part[t]);
+              const float a0 = aux_lds[t][item.aux][col];
+              float kc;
+              if (item.type != MI_SOC) {
+                kc = a0 + __builtin_amdgcn_sqrtf(fmaxf(total, 0.f));
+              } else {
+                // a' x^2 + b' x + c' = 0  (rayen/constraint_module.py:392-396, 339-348), a' < 0: natural units here
+                const float vi = v_inv[t];
+                const float cr = (a0 * w_inv) * vi;
+                const float br = (aux_lds[t][item.aux + 1][col] * w_inv) * vi;
+                const float rt = (__builtin_amdgcn_sqrtf(total) * w_inv) * vi;
+                const float cp = rt * rt - cr * cr;
+                const float bp = 2.f * br - 2.f * cr * item.f0;
+                const float disc = bp * bp - 4.f * item.f1 * cp;
+                kc = 0.f;
+                if (disc >= 0.f) {
+                  const float root = __builtin_amdgcn_sqrtf(disc);
+                  const float inv2a = 0.5f * __builtin_amdgcn_rcpf(item.f1);
+                  kc = (fmaxf((-bp - root) * inv2a, (-bp + root) * inv2a) * v_scl[t]) * w_scale;
+                }
+              }
+              if (kc > kap[t]) { kap[t] = kc; acode[t] = item.seg << 20; }
+            }
+          }
+        } else if (item.type == MI_AUX) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) aux_lds[t][(g & 3) + 8 * (g >> 2) + 4 * hi][col] = acc[t][g];
+          __builtin_amdgcn_wave_barrier();
+        } else if (item.type == MI_PACK) {
+          const MPack pk = packs[item.aux];
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            const int slot = hi ? pk.aux[a][1] : pk.aux[a][0];
+            const int sid = hi ? pk.seg[a][1] : pk.seg[a][0];
+            const bool pair = (item.row0 >> a) & 1;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              float qs = acc[t][4 * a] * acc[t][4 * a];
+#pragma unroll
+              for (int c = 1; c < 4; ++c) qs = fmaf(acc[t][4 * a + c], acc[t][4 * a + c], qs);
+              if (pair) qs += xhalf(qs);
+              const float kc = aux_lds[t][slot & 31][col] + __builtin_amdgcn_sqrtf(qs);
+              if (sid >= 0 && kc > kap[t]) { kap[t] = kc; acode[t] = sid << 20; }
+            }
+          }
+        } else if (STAGED && item.type == MI_OUT) {
+          // rows of NA_E: y = y0 + (N v) / max(1, kappa) into the flat block [64][k] (4-byte LDS stores at a stride of k
+          // words: conflict-free for odd k); it leaves as whole lines during the next walk
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            float* yrow = io_f + (32 * t + col) * k + item.row0 + 4 * hi;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+              const int r = (g & 3) + 8 * (g >> 2);
+              const float o = fmaf(acc[t][g], scale[t], y0[item.row0 + 4 * hi + r]);  // y0 is padded to a tile multiple
+              if (item.row0 + 4 * hi + r < k) {
+                bad |= live[t] && (o != o);
+                yrow[r] = o;
+              }
+            }
+          }
+        }
+      }
+    }
+    // every row of v(next) has landed, y(prev) is out, the next group's first tile is in the A buffer
+    drain();
+
+    if (!STAGED) finish_kappa();
+    if (hi == 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (!live[t]) continue;
+        const int64_t s = s_base + t * 32 + col;
+        if (kappa_out) kappa_out[s] = knat[t];
+        if (TRACK) { active_out[2 * s] = acode[t] >> 20; active_out[2 * s + 1] = acode[t] < 0 ? 0 : (acode[t] & 0xFFFFF); }
+      }
+    }
+
+    if constexpr (STAGED) {
+      // y(g) is in the buffer already; the next rows are in registers
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (trickle_ld) {
+          split_rows(vnx[t], t);
+          live[t] = true;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      // y = y0 + v / max(1, kappa) from the B-operand registers into the flat block, in place of the rows of v(next)
+      // (read first)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        float vr[KK];
+        __builtin_amdgcn_sched_barrier(0);
+        if (trickle_ld) read_rows(vr, t);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          int l = lane;
+          asm volatile("" : "+v"(l));
+          float* row = io_f + (32 * t + (l & 31)) * k + 4 * (l >> 5);
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const int i = (q & 1) * 4 + c;
+              const float val = (float)vb[t][0][q >> 1][i] + (float)vb[t][1][q >> 1][i];
+              const float o = fmaf(val, scale[t], y0_lds[8 * q + 4 * (l >> 5) + c]);
+              if (8 * q + 4 * (l >> 5) + c < k) {
+                bad |= live[t] && (o != o);
+                row[8 * q + c] = o;
+              }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (trickle_ld) {
+          split_rows(vr, t);
+          live[t] = true;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    has_prev = trickle_ld;
+    prev_base = s_base;
+    need_fetch = false;
+    if (!trickle_ld) {
+      burst_store(s_base);
+      if (has_next) {   // a ragged last group: requested only now
+        __builtin_amdgcn_wave_barrier();
+        burst_load(next * (NT * 32));
+        drain();
+        need_fetch = true;
+      }
+    }
+    grp = next;
+  }  // persistent loop over sample groups
+  if (nan_flag && bad) atomicOr(nan_flag, 1);
+}
+
 // ---------------------------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------------------------
+static int pair_iof_buf_bytes(const RayenPack* p) { return ((p->n > p->k ? p->n : p->k) * 256 + 255) / 256 * 256; }
+static int pair_iof_lds_bytes(const RayenPack* p) {
+  return kMfmaWaves * 2 * 32 * 32 * 4 + kMfmaWaves * pair_iof_buf_bytes(p) + 256 + 128;
+}
+
+// 0 = not served | 1 = rows at any 16-byte aligned stride, n = k = 32 NKK exactly (mfma_pair_io_kernel) |
+// 2 = n <= 32, rows stored back to back, NA_E = I or not (mfma_pair_iof_kernel)
+static int pair_io_mode(const RayenPack* p, const PairImage* img, const float* v, int64_t B, int64_t ldv,
+                        const float* y, int64_t ldy) {
+  if (img == nullptr || img->nkk < 1 || img->nkk > 2 || B < 64) return 0;
+  if ((reinterpret_cast<uintptr_t>(v) & 15) != 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0) return 0;
+  if (img->identity && p->n == img->nkk * 32 && p->k == p->n && (ldv % 4) == 0 && (ldy % 4) == 0 &&
+      ldv <= (1 << 22) && ldy <= (1 << 22) && !(img->nkk == 2 && img->aux_rows > IoGeom<2>::AUXR) &&
+      img->n_items >= (img->nkk == 2 ? IoGeom<2>::NBLK : IoGeom<1>::NBLK))
+    return 1;
+  if (img->nkk == 1 && ldv == p->n && ldy == p->k && (img->identity ? p->k == p->n : true)) {
+    const int chunks_v = (16 * p->n + 63) / 64, chunks_y = (16 * p->k + 63) / 64;
+    // the rows of v(next) are read in front of the first NA_E tile (two tiles behind the last fetch at the least),
+    // the last chunk of y(prev) has left before that tile writes
+    const int f = img->identity ? img->n_items : img->first_out;
+    if (chunks_y > f || chunks_v + (img->identity ? 0 : 2) > f) return 0;
+    // sets of a few tiles (config 2: five) carry two I/O operations per tile for little walk to hide them under:
+    // measured slower than the boundary bursts (config 2, B = 262144: 19.8 against 18.1 us)
+    if (img->n_items < 12) return 0;
+    if (pair_iof_lds_bytes(p) > 160 * 1024) return 0;
+    return 2;
+  }
+  return 0;
+}
+
 bool mfma_pair_io_serves(const RayenPack* p, const PairImage* img, const float* v, int64_t B, int64_t ldv,
                          const float* y, int64_t ldy) {
-  if (img == nullptr || !img->identity || img->nkk < 1 || img->nkk > 2) return false;
-  if (p->n != img->nkk * 32 || p->k != p->n) return false;
-  if (img->nkk == 2 && img->aux_rows > IoGeom<2>::AUXR) return false;
-  if (img->n_items < (img->nkk == 2 ? IoGeom<2>::NBLK : IoGeom<1>::NBLK)) return false;
-  if (B < 64) return false;
-  if ((ldv % 4) != 0 || (ldy % 4) != 0 || ldv > (1 << 22) || ldy > (1 << 22)) return false;
-  if ((reinterpret_cast<uintptr_t>(v) & 15) != 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0) return false;
-  return true;
+  return pair_io_mode(p, img, v, B, ldv, y, ldy) != 0;
 }
 
 template <int NKK>
@@ -516,11 +955,51 @@ static int launch_pair_io(const RayenPack* p, const PairImage* img, const float*
   return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
 }
 
+template <bool TRACK, bool STAGED>
+static int launch_pair_iof_one(const RayenPack* p, const PairImage* img, const float* v, int64_t B, float* y,
+                               float* kappa, int32_t* active, int32_t* nan_flag, unsigned grid, hipStream_t stream) {
+  // (more than 64 KiB of dynamic LDS has to be asked for, once per kernel and device context; the attribute is set
+  // at pack creation -- mfma_pair_io_prepare -- never on a launch path that may be under stream capture)
+  const int lds = pair_iof_lds_bytes(p);
+  hipLaunchKernelGGL((mfma_pair_iof_kernel<TRACK, STAGED>), dim3(grid), dim3(kMfmaWaves * 64), lds, stream,
+                     static_cast<const f16x8*>(img->Wh), img->items, img->n_items, img->packs, img->y0, p->k, p->n, v, B,
+                     y, kappa, active, nan_flag, img->w_scale, img->w_inv, pair_iof_buf_bytes(p));
+  return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
+}
+
+// called by rayen_pack_create (the only place that may touch function attributes)
+int mfma_pair_io_prepare(const RayenPack* p, const PairImage* img) {
+  if (img == nullptr || img->nkk != 1) return RAYEN_OK;
+  const int lds = pair_iof_lds_bytes(p);
+  if (lds > 160 * 1024) return RAYEN_OK;   // (such packs are never served by the flat kernel)
+  bool ok = true;
+  auto want = [&](auto kern) {
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+  };
+  if (img->identity) { want(mfma_pair_iof_kernel<false, false>); want(mfma_pair_iof_kernel<true, false>); }
+  else { want(mfma_pair_iof_kernel<false, true>); want(mfma_pair_iof_kernel<true, true>); }
+  return ok ? RAYEN_OK : RAYEN_E_LAUNCH;
+}
+
 int mfma_pair_io_forward(const RayenPack* p, const PairImage* img, const float* v, int64_t B, int64_t ldv,
                          float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
                          hipStream_t stream) {
   if (B == 0) return RAYEN_OK;
-  if (!mfma_pair_io_serves(p, img, v, B, ldv, y, ldy)) return RAYEN_E_UNSUPPORTED;
+  const int mode = pair_io_mode(p, img, v, B, ldv, y, ldy);
+  if (mode == 0) return RAYEN_E_UNSUPPORTED;
+  if (mode == 2) {
+    constexpr int per_wave = 64;
+    const int64_t n_groups = (B + per_wave - 1) / per_wave;
+    const int64_t slots = (int64_t)img->n_simd * kMfmaWavesPerSimd;
+    const int64_t rounds = (n_groups + slots - 1) / slots;
+    const int64_t waves = (n_groups + rounds - 1) / rounds;
+    const unsigned grid = (unsigned)((waves + kMfmaWaves - 1) / kMfmaWaves);
+    if (img->identity)
+      return active != nullptr ? launch_pair_iof_one<true, false>(p, img, v, B, y, kappa, active, nan_flag, grid, stream)
+                               : launch_pair_iof_one<false, false>(p, img, v, B, y, kappa, active, nan_flag, grid, stream);
+    return active != nullptr ? launch_pair_iof_one<true, true>(p, img, v, B, y, kappa, active, nan_flag, grid, stream)
+                             : launch_pair_iof_one<false, true>(p, img, v, B, y, kappa, active, nan_flag, grid, stream);
+  }
   if (img->nkk == 1) return launch_pair_io<1>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
   return launch_pair_io<2>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
 }

@@ -61,6 +61,7 @@ struct PairImage {
   int n_simd = 1024;
   float w_scale = 1.f, w_inv = 1.f;
   int aux_rows = 0;        // aux rows (phi | c, M'beta) of the whole set
+  int first_out = 0;       // index of the first NA_E tile in the item list (n_items when NA_E = I)
   int64_t bytes = 0;
 };
 

@@ -25,7 +25,7 @@ for name in ("rayen_mfma_split", "rayen_mfma_pair", "rayen_mfma_pair_io"):
     text = open(asm).read().split("\n")
     lines += text
     starts += [base + i for i, l in enumerate(text)
-               if l.startswith(("_ZN5rayen21mfma_split_fwd_kernel", "_ZN5rayen21mfma_split_map_kernel", "_ZN5rayen20mfma_pair_fwd_kernel", "_ZN5rayen20mfma_pair_map_kernel", "_ZN5rayen19mfma_pair_io_kernel"))
+               if l.startswith(("_ZN5rayen21mfma_split_fwd_kernel", "_ZN5rayen21mfma_split_map_kernel", "_ZN5rayen20mfma_pair_fwd_kernel", "_ZN5rayen20mfma_pair_map_kernel", "_ZN5rayen19mfma_pair_io_kernel", "_ZN5rayen20mfma_pair_iof_kernel"))
                and l.split(";")[0].rstrip().endswith(":")]
     starts.append(base + len(text))          # (closes the last kernel of this file)
 
@@ -54,6 +54,9 @@ for s, e in zip(starts[:-1], starts[1:]):
     if "pair_io_kernel" in lines[s]:                     # <NKK, TRACK>: NA_E = I only
         m2 = re.search(r"ILi(\d)ELb(\d)E", lines[s]).groups()
         name = (m2[0], m2[1], "0")
+    if "pair_iof_kernel" in lines[s]:                    # <TRACK, STAGED>: n <= 32, rows stored back to back
+        m2 = re.search(r"ILb(\d)ELb(\d)E", lines[s]).groups()
+        name = ("1", m2[0], m2[1])
     if "pair_map_kernel" in lines[s]:                    # <NKK, TRACK, NKX, STAGED>
         m3 = re.search(r"ILi(\d)ELb(\d)ELi(\d)ELb(\d)", lines[s]).groups()
         name, nkx = (m3[0], m3[1], m3[3]), m3[2]
@@ -113,7 +116,7 @@ for s, e in zip(starts[:-1], starts[1:]):
             continue
         if regs_of(l) & chunk:
             bad.append((i, l))
-    family = "pair-io " if "pair_io_kernel" in lines[s] else ("pair " if "mfma_pair" in lines[s] else "")
+    family = "pair-io flat " if "pair_iof_kernel" in lines[s] else "pair-io " if "pair_io_kernel" in lines[s] else ("pair " if "mfma_pair" in lines[s] else "")
     print(f"{family}NKK={name[0]} TRACK={name[1]} STAGED={name[2]} NKX={nkx}: {len(loads)} asm loads, chunk registers {min(chunk)}..{max(chunk)}"
           f" ({len(chunk)}), SGPR hazards in front of asm VMEM: {len(hazards)}, suspicious instructions in the loop: {len(bad)}")
     for i, t, back, prev in hazards[:6]:

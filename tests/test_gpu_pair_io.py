@@ -115,3 +115,69 @@ def test_trickled_rows_with_padded_leading_dimensions_and_nan_rows(name, schedul
     keep[B - 5] = False
     keep[70000] = False
     assert torch.equal(y2[keep], y_ref[keep])
+
+
+# --------------------------------------------------------------------------------------------------------------
+# rows stored back to back, n <= 32, NA_E = I or not (mfma_pair_iof_kernel: flat blocks, whole-line stores)
+# --------------------------------------------------------------------------------------------------------------
+def _flat_sets():
+    eq = workloads.corridor_like(k=28, n_eq=8, m=150, n_quad=10, rank=3, seed=31)          # n = 20 of k = 28
+    return {
+        "c5": workloads.make_raw("c5", seed=9),                                                # n = 30 of k = 45, 72 packed quadratics
+        "eq_n20": eq,
+        "id_n24": workloads.random_lin_quad_soc(k=24, m=260, n_quad=3, n_soc=1, seed=32),      # NA_E = I, ragged n
+        "id_n30_many": workloads.random_lin_quad_soc(k=30, m=300, n_quad=6, n_soc=2, seed=33),
+        "c2": workloads.make_raw("c2", seed=10),                                               # n = 16: four chunks per group
+    }
+
+
+@pytest.mark.parametrize("B", [64, 777, 131072, 131072 + 64 * 3 + 5, 262144, 393216 + 17])
+@pytest.mark.parametrize("name", ["c5", "eq_n20", "id_n24", "id_n30_many", "c2"])
+@pytest.mark.parametrize("want_active", [False, True])
+def test_flat_rows_equal_the_plain_pair_kernel_bit_for_bit(name, B, want_active):
+    if name not in ("c5", "id_n24") and B > 300000:
+        pytest.skip("the round structures are covered on two sets")
+    cs, layer, dp = _pack(_flat_sets()[name])
+    if dp.info().mfma_f32 != 3:
+        pytest.skip("the f16-pair family does not serve this pack")
+    gen = torch.Generator(device="cuda").manual_seed(B + 1)
+    v = torch.empty(B, cs.n, device="cuda").uniform_(-1.5, 1.5, generator=gen)
+    v[B // 3] = 0.0
+    v[B // 2] *= 1e-3
+    assert v.data_ptr() % 16 == 0
+    y1, k1, a1, fam1 = _run(dp, v, want_active)
+    y2, k2, a2, fam2 = _run(dp, _misaligned_copy(v), want_active)
+    assert fam2 == _lib.KERNEL_PAIR
+    if fam1 != _lib.KERNEL_PAIR_IO:
+        pytest.skip("this shape is not served by the flat-row kernel (too few tiles for its chunks)")
+    assert torch.equal(y1, y2)
+    assert torch.equal(k1, k2)
+    if want_active:
+        assert torch.equal(a1, a2)
+    # the reference's bar, against the fp64 oracle with the reference's own fp32 error as the yardstick (random sets)
+    take = torch.cat([torch.arange(0, min(B, 500)), torch.arange(max(B - 500, 0), B)]).unique()
+    x = v[take.cuda()].cpu().unsqueeze(2)
+    y_true = oracle.forward(oracle.precompute(csd_from_cs(cs), torch.float64), x.double()).numpy()[:, :, 0]
+    y_ref = oracle.forward(oracle.precompute(csd_from_cs(cs), torch.float32), x).numpy()[:, :, 0]
+    bound = max(1e-5, 2.0 * float(np.max(rel_err_rows(y_ref, y_true))))
+    assert np.max(rel_err_rows(y1[take.cuda()].cpu().numpy(), y_true)) <= bound
+
+
+def test_flat_rows_served_sets_are_really_served():
+    """Config 5 and the ragged identity set must be on the flat-row kernel at the BASELINE batch (no silent fallback)."""
+    for name in ("c5", "id_n24", "eq_n20"):
+        cs, layer, dp = _pack(_flat_sets()[name])
+        v = torch.empty(262144, cs.n, device="cuda").uniform_(-1, 1)
+        _, _, _, fam = _run(dp, v, False)
+        assert fam == _lib.KERNEL_PAIR_IO, name
+        # a NaN row raises the flag and touches no other row
+        dp.nan_flag.zero_()
+        y_ref, _, _ = ops.project_raw(v, dp, want_active=False)
+        v2 = v.clone()
+        v2[1234, 2] = float("nan")
+        y2, _, _ = ops.project_raw(v2, dp, want_active=False)
+        assert int(dp.nan_flag.item()) == 1
+        dp.nan_flag.zero_()
+        keep = torch.ones(v.shape[0], dtype=torch.bool, device="cuda")
+        keep[1234] = False
+        assert torch.equal(y2[keep], y_ref[keep])
