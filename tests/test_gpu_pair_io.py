@@ -121,7 +121,7 @@ def test_trickled_rows_with_padded_leading_dimensions_and_nan_rows(name, schedul
 # rows stored back to back, n <= 32, NA_E = I or not (mfma_pair_iof_kernel: flat blocks, whole-line stores)
 # --------------------------------------------------------------------------------------------------------------
 def _flat_sets():
-    eq = workloads.corridor_like(k=28, n_eq=8, m=150, n_quad=10, rank=3, seed=31)          # n = 20 of k = 28
+    eq = workloads.corridor_like(k=28, n_eq=8, m=330, n_quad=10, rank=3, seed=31)          # n = 20 of k = 28, 14 tiles
     return {
         "c5": workloads.make_raw("c5", seed=9),                                                # n = 30 of k = 45, 72 packed quadratics
         "eq_n20": eq,
