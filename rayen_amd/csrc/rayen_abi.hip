@@ -218,7 +218,8 @@ const char* rayen_strerror(int code) {
 // The split-operand kernels (bf16 triples, f16 pairs) are fp32-grade on well-conditioned sums; where a constraint set
 // makes the sums cancel heavily their error constants are larger than an fp32 FMA chain's.  So
 // every pack they could serve is measured ONCE, inside rayen_pack_create: probe directions (random at two
-// magnitudes, and +-every row of W -- the worst cancellation is along constraint normals) go through each of them,
+// magnitudes, +-every row of W -- the worst cancellation is along constraint normals --, directions outside the span
+// of every quadratic's / cone's factor rows, near-ties of neighbouring linear rows) go through each of them,
 // the exact-fp32 MFMA kernel and the fp64 lane kernel (the yardstick); a split-operand kernel may serve the pack only
 // if its worst row error against fp64 is below 4e-6 of the row's size or within 1.5x of the exact-fp32 kernel's own.
 // The f16-pair kernel is preferred when both pass.  Private stream, buffers freed before pack_create returns.
@@ -250,6 +251,75 @@ static int fp32_selfcheck(RayenPack* p) {
     if (!(big > 0.0) || !std::isfinite(big)) continue;
     for (int sign = -1; sign <= 1; sign += 2)
       for (int j = 0; j < n; ++j) hv.push_back((float)(sign * 1.5 * w[j] / big));
+  }
+  // Adversarial directions (round 3), built from where the error analysis of the pair scheme says a
+  // candidate of kappa is decided by cancellation:
+  //  * for every quadratic / cone, a direction (nearly) orthogonal to its factor rows -- ||U v|| is then a small
+  //    difference of large products and the candidate rests on phi . v alone: the component of a random direction
+  //    outside the rows' span (Gram-Schmidt), or, for a full-rank factor, its least represented direction;
+  //  * near-ties of two linear rows: d_i . v = d_j . v, both beyond the boundary.
+  {
+    std::vector<double> Q, r(n), u(n);
+    int quads = 0;
+    for (const RayenSegment& g : p->segs) {
+      if (g.type != RAYEN_SEG_QUAD_FAC && g.type != RAYEN_SEG_QUAD_SYM && g.type != RAYEN_SEG_SOC) continue;
+      if (++quads > 96) break;
+      Q.clear();
+      int rank = 0;
+      double weakest = 2.0;
+      std::vector<double> weak_dir(n, 0.0);
+      for (int t = 0; t < g.nrows && rank < n; ++t) {
+        const double* w = &p->W[(size_t)(g.row0 + t) * n];
+        double norm0 = 0.0;
+        for (int j = 0; j < n; ++j) { u[j] = w[j]; norm0 += w[j] * w[j]; }
+        if (!(norm0 > 0.0) || !std::isfinite(norm0)) continue;
+        for (int pass = 0; pass < 2; ++pass)
+          for (int q = 0; q < rank; ++q) {
+            double dot = 0.0;
+            for (int j = 0; j < n; ++j) dot += Q[(size_t)q * n + j] * u[j];
+            for (int j = 0; j < n; ++j) u[j] -= dot * Q[(size_t)q * n + j];
+          }
+        double norm1 = 0.0;
+        for (int j = 0; j < n; ++j) norm1 += u[j] * u[j];
+        const double ratio = std::sqrt(norm1 / norm0);
+        if (ratio < 1e-9) continue;
+        if (ratio < weakest) { weakest = ratio; for (int j = 0; j < n; ++j) weak_dir[j] = u[j] / std::sqrt(norm1); }
+        Q.resize((size_t)(rank + 1) * n);
+        for (int j = 0; j < n; ++j) Q[(size_t)rank * n + j] = u[j] / std::sqrt(norm1);
+        ++rank;
+      }
+      if (rank == 0) continue;
+      if (rank < n) {
+        for (int j = 0; j < n; ++j) r[j] = uniform();
+        for (int q = 0; q < rank; ++q) {
+          double dot = 0.0;
+          for (int j = 0; j < n; ++j) dot += Q[(size_t)q * n + j] * r[j];
+          for (int j = 0; j < n; ++j) r[j] -= dot * Q[(size_t)q * n + j];
+        }
+      } else {
+        r = weak_dir;
+      }
+      double big = 0.0;
+      for (int j = 0; j < n; ++j) big = std::fmax(big, std::fabs(r[j]));
+      if (!(big > 1e-12)) continue;
+      for (int sign = -1; sign <= 1; sign += 2)
+        for (int j = 0; j < n; ++j) hv.push_back((float)(sign * 1.5 * r[j] / big));
+    }
+    for (const RayenSegment& g : p->segs) {
+      if (g.type != RAYEN_SEG_LIN || g.nrows < 2) continue;
+      const int pairs = g.nrows - 1 < 32 ? g.nrows - 1 : 32;
+      for (int t = 0; t < pairs; ++t) {
+        const int i = g.row0 + (int)((int64_t)t * (g.nrows - 1) / pairs), j2 = i + 1;
+        const double* di = &p->W[(size_t)i * n];
+        const double* dj = &p->W[(size_t)j2 * n];
+        double ii = 0.0, ij = 0.0, jj = 0.0;
+        for (int j = 0; j < n; ++j) { ii += di[j] * di[j]; ij += di[j] * dj[j]; jj += dj[j] * dj[j]; }
+        const double det = ii * jj - ij * ij;
+        if (!(det > 1e-9 * ii * jj) || !std::isfinite(det)) continue;
+        const double c = 1.5, a = c * (jj - ij) / det, b = c * (ii - ij) / det;    // d_i . v = d_j . v = c
+        for (int j = 0; j < n; ++j) hv.push_back((float)(a * di[j] + b * dj[j]));
+      }
+    }
   }
   const int64_t B0 = (int64_t)(hv.size() / (size_t)n);
   const size_t ny = (size_t)B0 * k;

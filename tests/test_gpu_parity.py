@@ -92,6 +92,7 @@ def _fp32_bound(cs, x, y_true, layer=None, method="RAYEN"):
     set whose constants do not survive fp32 rounding -- four times the error that rounding ALONE causes (the packed
     fp32 constants evaluated in fp64 arithmetic, tests/packed_eval.py)."""
     bound = FP32_TOL
+    BOUND_LOG.append(None)           # (filled in below: every bar that was ever applied is on record)
     try:
         y32 = oracle.forward(oracle.precompute(csd_from_cs(cs), torch.float32), x.float(), method=method).numpy()[:, :, 0]
         bound = max(bound, 2.0 * rel_err_rows(y32, y_true).max())
@@ -101,7 +102,35 @@ def _fp32_bound(cs, x, y_true, layer=None, method="RAYEN"):
         import packed_eval
         y_const, _, _ = packed_eval.evaluate(layer.packed_constants(), x[:, :cs.n, 0].double().numpy())
         bound = max(bound, 4.0 * rel_err_rows(y_const, y_true).max())
+    BOUND_LOG[-1] = float(bound)
     return bound
+
+
+BOUND_LOG = []
+
+
+@pytest.mark.parametrize("name,B", [("c1", 500), ("c2", 4096), ("c3", 8192), ("c4", 4096), ("c5", 8192)])
+def test_fp32_bar_on_the_baseline_configs_is_the_north_star_itself(name, B, capsys):
+    """``_fp32_bound`` lets a set exceed 1e-5 where the reference's own fp32 arithmetic (or the fp32 rounding of its
+    constants) does.  On BASELINE.json's five configurations no yardstick is in play: the bar IS 1e-5, and the
+    ratio ours / bar is printed (and recorded in gpurun_out/fp32_bound_log.json by the last test of this file)."""
+    raw = workloads.make_raw(name, seed=33)
+    cs, layer = _layer(raw, torch.float32)
+    gen = torch.Generator().manual_seed(9)
+    rng = workloads.CONFIGS[name][3]
+    x = torch.empty(B, cs.n, 1).uniform_(-rng, rng, generator=gen)
+    y = layer(x.cuda()).cpu().numpy()[:, :, 0]
+    y_true = _oracle_forward(cs, x.double(), torch.float64)
+    bound = _fp32_bound(cs, x, y_true, layer)
+    worst = float(rel_err_rows(y, y_true).max())
+    RATIO_LOG[name] = {"ours": worst, "bar": bound, "ratio": worst / bound}
+    with capsys.disabled():
+        print(f"\n  [fp32 bar] {name}: ours {worst:.3e} / bar {bound:.3e} = {worst / bound:.3f}")
+    assert bound == FP32_TOL, (name, bound)
+    assert worst <= bound
+
+
+RATIO_LOG = {}
 
 
 # --------------------------------------------------------------------------- oracle on fresh seeds
@@ -152,19 +181,19 @@ FAMILIES = {"exact": ("1", (0, 1)), "triple": ("2", (2,)), "pair": ("3", (3,))}
 
 
 @pytest.mark.parametrize("family", ["exact", "triple", "pair"])
-@pytest.mark.parametrize("name", ["c2", "c3", "c5", "rand3", "rand17", "rand40"])
+@pytest.mark.parametrize("name", ["c2", "c3", "c5", "served0", "served1", "served2"])
 def test_every_fp32_mfma_family(name, family, monkeypatch):
     """RAYEN_FP32_MODE (read when a pack is created; RayenPackDesc.fp32_mode) pins the family that serves the fp32
     forward: 1 the exact-fp32 MFMA kernels (which otherwise serve only n > 64, the RAYEN_old head and their fused
     mapper), 2 the bf16-triple kernel, 3 the f16-pair kernel (the last two without the creation-time measurement).
     Each against the fp64 truth, with the reference's own fp32 arithmetic on the same inputs as yardstick."""
     mode, served = FAMILIES[family]
+    # random sets: the first ones the default dispatch puts on the f16 pairs (laid out for the split-operand kernels:
+    # every pinned family can serve them -- nothing is skipped)
+    raw = _served_random_set(int(name[6:]), 3) if name.startswith("served") else workloads.make_raw(name, seed=21)
     monkeypatch.setenv("RAYEN_FP32_MODE", mode)
-    raw = _random_set(1000 + int(name[4:])) if name.startswith("rand") else workloads.make_raw(name, seed=21)
     cs, layer = _layer(raw, torch.float32)
     dp, _ = layer.device_pack(torch.device("cuda", 0))
-    if name.startswith("rand") and family != "exact" and dp.info().mfma_f32 not in served:
-        pytest.skip("this random set is not laid out for the split-operand kernels")
     assert dp.info().mfma_f32 in served
     gen = torch.Generator().manual_seed(8)
     x = torch.empty(3001, cs.n, 1).uniform_(-1.5, 1.5, generator=gen)
@@ -918,3 +947,20 @@ def test_random_modules(seed):
         else:
             bound = _fp32_bound(cs, q.unsqueeze(2), y_true, layer, method=method)
             assert err <= bound, (seed, method, input_dim, err, bound)
+
+
+def test_zz_fp32_bars_on_record():
+    """Last test of the file: how often a yardstick lifted the fp32 bar above the north_star's 1e-5 in this run, and
+    by how much; written next to the other GPU artefacts."""
+    import json
+    import os
+    bars = [b for b in BOUND_LOG if b is not None]
+    lifted = [b for b in bars if b > FP32_TOL]
+    summary = {"bars_applied": len(bars), "lifted_above_1e-5": len(lifted),
+               "largest_bar": max(bars) if bars else None, "baseline_configs": RATIO_LOG}
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "fp32_bound_log.json"), "w") as fh:
+        json.dump(summary, fh, indent=1)
+    print("\n  [fp32 bars]", json.dumps(summary))
+    assert all(b >= FP32_TOL for b in bars)
