@@ -38,14 +38,14 @@ struct PairMapper {
   int64_t ldvo = 0;
 };
 
-template <int NKK, bool TRACK, bool STAGED, int NKX>
+template <int NKK, bool TRACK, bool STAGED, int NKX, int NT = 2>
 __device__ __forceinline__ void mfma_pair_fwd_body(
     const f16x8* __restrict__ Wh, const MItem* __restrict__ items, int n_items,
     const MPack* __restrict__ packs, const float* __restrict__ y0, int identity, int k, int n,
     const float* __restrict__ v, int64_t B, int64_t ldv, int vec_in, float* __restrict__ y, int64_t ldy,
     int vec_out, float* __restrict__ kappa_out, int32_t* __restrict__ active_out,
     int32_t* __restrict__ nan_flag, const float w_scale, const float w_inv, const PairMapper mp) {
-  constexpr int NT = 2, NS = NKK * 2, NCH = NS * 2, KK = NKK * 16;
+  constexpr int NS = NKK * 2, NCH = NS * 2, KK = NKK * 16;   // NT = sample tiles per wave (2; 1 for small batches)
   __shared__ float aux_lds[kMfmaWaves][NT][32][32];
   __shared__ __attribute__((aligned(16))) float y0_lds[NKK * 32];
   __shared__ __attribute__((aligned(16))) float bias_lds[NKX > 0 ? NKK * 32 : 4];   // gM b, zero-padded
@@ -510,15 +510,17 @@ __device__ __forceinline__ void mfma_pair_fwd_body(
   if (nan_flag && bad) atomicOr(nan_flag, 1);
 }
 
-template <int NKK, bool TRACK, bool STAGED>
+// NT = 1: 32 samples per wave for batches that cannot fill the chip with 64-sample groups (config 2 at B = 4096: 128
+// waves of half the work instead of 64; selected when B / 32 <= resident waves)
+template <int NKK, bool TRACK, bool STAGED, int NT = 2>
 __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_fwd_kernel(
     const f16x8* __restrict__ Wh, const MItem* __restrict__ items, int n_items,
     const MPack* __restrict__ packs, const float* __restrict__ y0, int identity, int k, int n,
     const float* __restrict__ v, int64_t B, int64_t ldv, int vec_in, float* __restrict__ y, int64_t ldy,
     int vec_out, float* __restrict__ kappa_out, int32_t* __restrict__ active_out,
     int32_t* __restrict__ nan_flag, const float w_scale, const float w_inv) {
-  mfma_pair_fwd_body<NKK, TRACK, STAGED, 0>(Wh, items, n_items, packs, y0, identity, k, n, v, B, ldv, vec_in, y, ldy,
-                                            vec_out, kappa_out, active_out, nan_flag, w_scale, w_inv, PairMapper());
+  mfma_pair_fwd_body<NKK, TRACK, STAGED, 0, NT>(Wh, items, n_items, packs, y0, identity, k, n, v, B, ldv, vec_in, y, ldy,
+                                                vec_out, kappa_out, active_out, nan_flag, w_scale, w_inv, PairMapper());
 }
 
 // the same walk behind the fused mapper (x in place of v; NKX 32-column blocks of x)
@@ -656,11 +658,11 @@ int mfma_pair_build(const RayenPack* p, PairImage** out, int64_t* bytes) {
   return RAYEN_OK;
 }
 
-template <int NKK>
+template <int NKK, int NT>
 static int launch_pair(const RayenPack* p, const PairImage* img, const float* v, int64_t B, int64_t ldv,
                        float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
                        hipStream_t stream) {
-  constexpr int per_wave = 64;
+  constexpr int per_wave = NT * 32;
   const int64_t n_groups = (B + per_wave - 1) / per_wave;
   const int64_t slots = (int64_t)img->n_simd * kMfmaWavesPerSimd;
   const int64_t rounds = (n_groups + slots - 1) / slots;
@@ -677,11 +679,11 @@ static int launch_pair(const RayenPack* p, const PairImage* img, const float* v,
                        img->w_scale, img->w_inv);
   };
   if (img->identity) {
-    if (active != nullptr) go(mfma_pair_fwd_kernel<NKK, true, false>);
-    else go(mfma_pair_fwd_kernel<NKK, false, false>);
+    if (active != nullptr) go(mfma_pair_fwd_kernel<NKK, true, false, NT>);
+    else go(mfma_pair_fwd_kernel<NKK, false, false, NT>);
   } else {
-    if (active != nullptr) go(mfma_pair_fwd_kernel<NKK, true, true>);
-    else go(mfma_pair_fwd_kernel<NKK, false, true>);
+    if (active != nullptr) go(mfma_pair_fwd_kernel<NKK, true, true, NT>);
+    else go(mfma_pair_fwd_kernel<NKK, false, true, NT>);
   }
   return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
 }
@@ -752,8 +754,15 @@ int mfma_pair_forward(const RayenPack* p, const PairImage* img, const float* v, 
                       float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
                       hipStream_t stream) {
   if (B == 0) return RAYEN_OK;
-  if (img->nkk == 1) return launch_pair<1>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
-  if (img->nkk == 2) return launch_pair<2>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+  // 32 samples per wave while that still is one round (config 3, B = 65536: 23.9 against 25.4 us with 64-sample groups;
+  // B = 98304, two rounds of 32-sample groups: 36.3 against ~30)
+  const bool small = (B + 31) / 32 <= (int64_t)img->n_simd * kMfmaWavesPerSimd;
+  if (img->nkk == 1)
+    return small ? launch_pair<1, 1>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream)
+                 : launch_pair<1, 2>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+  if (img->nkk == 2)
+    return small ? launch_pair<2, 1>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream)
+                 : launch_pair<2, 2>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
   return RAYEN_E_UNSUPPORTED;
 }
 

@@ -909,7 +909,10 @@ static int pair_iof_lds_bytes(const RayenPack* p) {
 // 2 = n <= 32, rows stored back to back, NA_E = I or not (mfma_pair_iof_kernel)
 static int pair_io_mode(const RayenPack* p, const PairImage* img, const float* v, int64_t B, int64_t ldv,
                         const float* y, int64_t ldy) {
-  if (img == nullptr || img->nkk < 1 || img->nkk > 2 || B < 64) return 0;
+  if (img == nullptr || img->nkk < 1 || img->nkk > 2) return 0;
+  // batches that cannot give every resident wave a 64-row group are launch-latency work: rayen_mfma_pair.hip runs them with 32
+  // rows per wave (nothing to trickle in a single short round)
+  if ((B + 63) / 64 < (int64_t)img->n_simd * kMfmaWavesPerSimd) return 0;
   if ((reinterpret_cast<uintptr_t>(v) & 15) != 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0) return 0;
   if (img->identity && p->n == img->nkk * 32 && p->k == p->n && (ldv % 4) == 0 && (ldy % 4) == 0 &&
       ldv <= (1 << 22) && ldy <= (1 << 22) && !(img->nkk == 2 && img->aux_rows > IoGeom<2>::AUXR) &&

@@ -50,7 +50,9 @@ def _check_input(v, pack):
 
 
 def _ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    """Device address of a tensor as a plain int (ctypes converts it to ``void*``; building a ``c_void_p`` object per
+    argument costs ~0.3 us each -- ten of them per call is a third of a small-batch forward's host time)."""
+    return t.data_ptr() if t is not None else None
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -61,8 +63,8 @@ def _stream(index=None):
     several microseconds of Python per call, which is most of a small-batch forward; the private accessor is what
     it ends in."""
     if _raw_stream is not None and index is not None:
-        return ctypes.c_void_p(_raw_stream(index))
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return _raw_stream(index) or None
+    return torch.cuda.current_stream().cuda_stream or None
 
 
 class _on_device:
@@ -83,6 +85,17 @@ class _on_device:
         if self.ctx is not None:
             self.ctx.__exit__(*exc)
         return False
+
+
+_ENTRY = {}
+
+
+def _entry(name):
+    """The ctypes function object of an entry point (looked up once)."""
+    fn = _ENTRY.get(name)
+    if fn is None:
+        fn = _ENTRY[name] = getattr(_lib.load(), name)
+    return fn
 
 
 _FWD = {(torch.float32, False): "rayen_ray_project_f32", (torch.float64, False): "rayen_ray_project_f64",
@@ -117,8 +130,7 @@ def project_raw(v, pack, want_y=True, force_generic=False, want_active=True, old
         y = torch.empty((B, k), dtype=v.dtype, device=v.device) if want_y else None
     kappa = torch.empty((B,), dtype=v.dtype, device=v.device) if want_kappa else None
     active = torch.empty((B, 2), dtype=torch.int32, device=v.device) if want_active else None
-    name = _FWD_OLD[v.dtype] if old_head else _FWD[(v.dtype, bool(force_generic))]
-    fn = getattr(_lib.load(), name)
+    fn = _entry(_FWD_OLD[v.dtype] if old_head else _FWD[(v.dtype, bool(force_generic))])
     with _on_device(v.device):
         code = fn(pack.handle, _ptr(v), B, v.stride(0) if B else pack.consts.n, _ptr(y),
                   y.stride(0) if (y is not None and B) else k,
