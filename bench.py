@@ -61,6 +61,8 @@ def parse(argv=None):
     ap.add_argument("--gather", action="store_true",
                     help="with --force-dist on one GPU: run the all-gather step anyway (one-rank RCCL group)")
     ap.add_argument("--chunks", type=int, default=2, help="row blocks per rank whose all-gathers overlap the next block's projection")
+    ap.add_argument("--reserve-cus", type=int, default=8,
+                    help="compute units the projection's persistent grid leaves to RCCL's kernels during the gather step")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the step from a HIP graph (auto: launch-bound batches, B*k < 2^20)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -124,13 +126,14 @@ def cpu_baseline(raw, cs, B, dtype, budget_s, rng=1.0):
                       f"(best of thread counts {sorted(rates)})"}
 
 
-def make_step(project_into, sizes, k, dtype, device, gather, chunks, group=None, gather_alone=False):
+def make_step(project_into, sizes, k, dtype, device, gather, chunks, group=None, gather_alone=False,
+              reserve_cus=0, set_reserve=None):
     """The multi-rank step ``bench.py`` times: ``rayen_amd.dist.ShardedStep`` around ``project_into(x_rows,
     out_rows)`` -- on the GPU the C-ABI projection writing straight into the gather's send buffer; in
     ``tests/test_dist_gloo.py`` a CPU stand-in, so the code the 8-GPU driver run executes is the code tested."""
     from rayen_amd.dist import ShardedStep
     return ShardedStep(project_into, sizes, k, dtype, device, chunks=chunks, gather=gather, group=group,
-                       gather_alone=gather_alone)
+                       gather_alone=gather_alone, reserve_cus=reserve_cus, set_reserve=set_reserve)
 
 
 def local_sizes(config_batch, per_gpu_batch, world, scaling):
@@ -269,8 +272,10 @@ def main():
     def project_into(x_rows, out_rows):
         ops.project_raw(x_rows.reshape(x_rows.shape[0], -1), dp, want_active=False, want_kappa=False, out=out_rows)
 
+    from rayen_amd import _lib as _rlib
     sharded = make_step(project_into, sizes, cs.k, dtype, device, gather=True, chunks=args.chunks,
-                        gather_alone=True) if gather else None
+                        gather_alone=True, reserve_cus=args.reserve_cus,
+                        set_reserve=_rlib.load().rayen_reserve_cus) if gather else None
 
     _note(f"{args.config} {args.dtype} B={B} per GPU, world {world}, graph={graph}, gather={gather}")
     with torch.no_grad():
@@ -289,6 +294,8 @@ def main():
         got = sharded.rows_of(rank).reshape(-1, cs.k)[:B]
         assert torch.equal(got, y[:, :, 0]), "gathered rows differ from the local projection"
         last["dev_ms_gather"] = dev_ms_g
+        sharded(x, trace=True)                                     # one more step, time-stamped per chunk (untimed)
+        last["gather_trace"] = sharded.last_trace
 
     t = torch.tensor([elapsed_p, dev_ms, elapsed_g or 0.0, last.get("dev_ms_gather", 0.0)], device=device,
                      dtype=torch.float64)
@@ -379,7 +386,11 @@ def main():
                                 "what": "the projection alone on every rank (no collective), same inputs and step count"}
             if gather:
                 out["gather"] = {"bytes_received_per_rank": (total_rows - B) * cs.k * (4 if dtype == torch.float32 else 8),
-                                 "chunks": sharded.chunks, "device_ms_per_step": dev_ms_g}
+                                 "chunks": sharded.chunks, "device_ms_per_step": dev_ms_g,
+                                 "reserved_cus": args.reserve_cus,
+                                 "per_chunk_rank0": last.get("gather_trace"),
+                                 "how_to_read": "overlap happened if chunk c's gather_end_ms is not behind chunk c+1's "
+                                                "projection_end_ms by the gather's own duration"}
         if args.mapper:
             fused = (not args.no_fuse) and dtype == torch.float32 and dp.mapper_fusable(args.mapper)
             out["config"]["mapper"] = f"nn.Linear({args.mapper}, {cs.n}) " + ("fused into the projection kernel" if fused else "as its own GEMM")

@@ -149,6 +149,13 @@ int rayen_last_forward_kernel(void);
  * only queries.  Returns the previous setting. */
 int rayen_pair_schedule(int mode);
 
+/* Multi-GPU step (ABI v4, process-wide): leave `cus` compute units out of the persistent grids of the projection
+ * kernels, for a collective that runs beside them -- the all-gather of y that BASELINE.json's multi-GPU layout adds
+ * (RCCL's kernels need CUs; a grid that fills every SIMD with resident waves serialises them behind the projection).
+ * 0 (default) = every CU.  Initial value from RAYEN_RESERVE_CUS.  cus < 0 only queries.  Returns the previous
+ * setting.  The reference has no counterpart (it has no parallelism of any kind). */
+int rayen_reserve_cus(int cus);
+
 /* Upload the constants to the CURRENT HIP device and build EVERY device image the entry points below will
  * read (all kernel families selected by desc->prepare), including the one-time accuracy measurement that
  * decides which fp32 forward family serves the pack (RayenPackInfo.mfma_f32).  This is the only call that

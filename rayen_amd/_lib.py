@@ -26,7 +26,7 @@ EXPORTS = (
     "rayen_ray_project_bwd_generic_f64", "rayen_mapper_image_bytes", "rayen_mapper_prepare_f32",
     "rayen_ray_project_mapped_image_f32", "rayen_bwd_workspace_bytes_f32", "rayen_ray_project_bwd_ws_f32",
     "rayen_bwd_workspace_bytes_f64", "rayen_ray_project_bwd_ws_f64", "rayen_last_forward_kernel",
-    "rayen_pair_schedule",
+    "rayen_pair_schedule", "rayen_reserve_cus",
 )
 KERNEL_NONE, KERNEL_LANE, KERNEL_MFMA, KERNEL_TRIPLE, KERNEL_PAIR, KERNEL_PAIR_IO, KERNEL_LMI_QUAD = range(7)
 
@@ -88,6 +88,8 @@ def load():
     lib.rayen_last_forward_kernel.argtypes = []
     lib.rayen_pair_schedule.restype = ctypes.c_int
     lib.rayen_pair_schedule.argtypes = [ctypes.c_int]
+    lib.rayen_reserve_cus.restype = ctypes.c_int
+    lib.rayen_reserve_cus.argtypes = [ctypes.c_int]
     lib.rayen_strerror.restype = ctypes.c_char_p
     lib.rayen_strerror.argtypes = [ctypes.c_int]
     lib.rayen_pack_create.restype = ctypes.c_int

@@ -58,6 +58,16 @@ std::atomic<int>& pair_schedule_cell() {
 }
 int pair_schedule() { return pair_schedule_cell().load(std::memory_order_relaxed); }
 
+// compute units left free by the persistent grids (rayen_reserve_cus; RAYEN_RESERVE_CUS sets the initial value)
+std::atomic<int>& reserved_cus_cell() {
+  static std::atomic<int> cus([] {
+    const char* e = std::getenv("RAYEN_RESERVE_CUS");
+    const int v = e != nullptr ? std::atoi(e) : 0;
+    return v < 0 ? 0 : (v > 128 ? 128 : v);
+  }());
+  return cus;
+}
+
 int check_device(const RayenPack* p) {
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess) return RAYEN_E_NO_DEVICE;
@@ -189,11 +199,23 @@ int project_bwd(const RayenPack* p, const T* v, int64_t B, int64_t ldv, const T*
 
 }  // namespace
 
+namespace rayen {
+int launch_simds(int n_simd) {
+  const int left = n_simd - 4 * reserved_cus_cell().load(std::memory_order_relaxed);
+  return left < 4 ? 4 : left;
+}
+}  // namespace rayen
+
 extern "C" {
 
 int rayen_abi_version(void) { return RAYEN_ABI_VERSION; }
 
 int rayen_last_forward_kernel(void) { return g_last_forward; }
+
+int rayen_reserve_cus(int cus) {
+  if (cus >= 0) return reserved_cus_cell().exchange(cus > 128 ? 128 : cus, std::memory_order_relaxed);
+  return reserved_cus_cell().load(std::memory_order_relaxed);
+}
 
 int rayen_pair_schedule(int mode) {
   if (mode >= 0 && mode <= 1) return pair_schedule_cell().exchange(mode, std::memory_order_relaxed);

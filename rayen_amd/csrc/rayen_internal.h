@@ -89,6 +89,10 @@ struct RayenPack {
 
 namespace rayen {
 
+// SIMDs the persistent grids may fill: all of the device's minus rayen_reserve_cus() compute units (a collective that
+// runs beside the projection -- RCCL's all-gather kernels in the multi-GPU step -- needs CUs of its own)
+int launch_simds(int n_simd);
+
 // generic path (rayen_generic.hip)
 template <typename T>
 int generic_build(const RayenPack* p, GenericImage<T>* img);

@@ -371,7 +371,7 @@ static int launch_bwd(const RayenPack* p, const MfmaBwdImage* img, const float* 
                       const float* kappa, const int32_t* active, const float* gy, int64_t ldg, float* gv,
                       int64_t ldgv, int old_mode, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   auto aligned = [](const void* ptr, int64_t ld) { return (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(ptr) & 15) == 0); };
-  const int64_t slots = (int64_t)img->n_simd * kMfmaWavesPerSimd;
+  const int64_t slots = (int64_t)launch_simds(img->n_simd) * kMfmaWavesPerSimd;
   const int64_t need = old_mode ? 0 : mfma_bwd_workspace_bytes(p, img, B);
   if (need > 0 && workspace != nullptr && workspace_bytes >= need) {
     const int nb = img->n_dense + 2;

@@ -327,7 +327,7 @@ template <int NKK>
 static int launch_bwd64(const RayenPack* p, const Mfma64BwdImage* img, const double* v, int64_t B, int64_t ldv,
                         const double* kappa, const int32_t* active, const double* gy, int64_t ldg, double* gv,
                         int64_t ldgv, int old_mode, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
-  const int64_t slots = (int64_t)img->n_simd * 2;
+  const int64_t slots = (int64_t)launch_simds(img->n_simd) * 2;
   const int64_t need = old_mode ? 0 : mfma64_bwd_workspace_bytes(p, img, B);
   const bool bucketed = need > 0 && workspace != nullptr && workspace_bytes >= need;
   const int nb = img->n_dense + 2;

@@ -458,7 +458,7 @@ static int launch_bwdg(const RayenPack* p, const MfmaBwdgImage* img, const float
   int32_t* ws = static_cast<int32_t*>(workspace);
   if (bucketed) launch_bucket_sort<float>(kappa, active, B, img->seg_bucket, nb, ws, stream);
   const int64_t n_groups = (B + per_wave - 1) / per_wave + (bucketed ? (64 / per_wave) * nb : 0);
-  const int64_t slots = (int64_t)img->n_simd * kMfmaWavesPerSimd;
+  const int64_t slots = (int64_t)launch_simds(img->n_simd) * kMfmaWavesPerSimd;
   const int64_t rounds = (n_groups + slots - 1) / slots;
   const int64_t waves = (n_groups + rounds - 1) / rounds;
   const int64_t grid = (waves + kMfmaWaves - 1) / kMfmaWaves;

@@ -422,7 +422,7 @@ static int launch_bwdg64(const RayenPack* p, const Mfma64BwdgImage* img, const d
                          const double* kappa, const int32_t* active, const double* gy, int64_t ldg, double* gv,
                          int64_t ldgv, int old_mode, hipStream_t stream) {
   const int64_t n_groups = (B + 31) / 32;
-  const int64_t slots = (int64_t)img->n_simd * 2;
+  const int64_t slots = (int64_t)launch_simds(img->n_simd) * 2;
   const int64_t rounds = (n_groups + slots - 1) / slots;
   const int64_t waves = (n_groups + rounds - 1) / rounds;
   const int64_t grid = (waves + kG64Waves - 1) / kG64Waves;

@@ -435,7 +435,7 @@ static int launch64(const RayenPack* p, const Mfma64Image* img, const double* v,
                     int old_mode, hipStream_t stream) {
   // persistent, balanced: 2 waves per SIMD, every wave the same number of 32-sample groups
   const int64_t n_groups = (B + 31) / 32;
-  const int64_t slots = (int64_t)img->n_simd * 2;
+  const int64_t slots = (int64_t)launch_simds(img->n_simd) * 2;
   const int64_t rounds = (n_groups + slots - 1) / slots;
   const int64_t waves = (n_groups + rounds - 1) / rounds;
   const int64_t grid = (waves + k64Waves - 1) / k64Waves;

@@ -608,7 +608,7 @@ static int launch_mfma(const RayenPack* p, const MfmaImage* img, const float* v,
                        int old_mode, const MapperArgs& mp, hipStream_t stream) {
   constexpr int per_wave = MfmaCfg<NKK>::NT * 32;
   const int64_t n_groups = (B + per_wave - 1) / per_wave;
-  const int64_t slots = (int64_t)img->n_simd * img->waves_per_simd;
+  const int64_t slots = (int64_t)launch_simds(img->n_simd) * img->waves_per_simd;
   const int64_t rounds = (n_groups + slots - 1) / slots;
   const int64_t waves = (n_groups + rounds - 1) / rounds;
   const int64_t grid = (waves + kMfmaWaves - 1) / kMfmaWaves;

@@ -664,7 +664,7 @@ static int launch_pair(const RayenPack* p, const PairImage* img, const float* v,
                        hipStream_t stream) {
   constexpr int per_wave = NT * 32;
   const int64_t n_groups = (B + per_wave - 1) / per_wave;
-  const int64_t slots = (int64_t)img->n_simd * kMfmaWavesPerSimd;
+  const int64_t slots = (int64_t)launch_simds(img->n_simd) * kMfmaWavesPerSimd;
   const int64_t rounds = (n_groups + slots - 1) / slots;
   const int64_t waves = (n_groups + rounds - 1) / rounds;
   const int64_t grid = (waves + kMfmaWaves - 1) / kMfmaWaves;
@@ -711,7 +711,7 @@ static int launch_pair_map(const RayenPack* p, const PairImage* img, const float
                            int32_t* nan_flag, hipStream_t stream) {
   constexpr int per_wave = 64;
   const int64_t n_groups = (B + per_wave - 1) / per_wave;
-  const int64_t slots = (int64_t)img->n_simd * kMfmaWavesPerSimd;
+  const int64_t slots = (int64_t)launch_simds(img->n_simd) * kMfmaWavesPerSimd;
   const int64_t rounds = (n_groups + slots - 1) / slots;
   const int64_t waves = (n_groups + rounds - 1) / rounds;
   const int64_t grid = (waves + kMfmaWaves - 1) / kMfmaWaves;

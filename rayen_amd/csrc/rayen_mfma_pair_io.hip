@@ -944,7 +944,7 @@ static int launch_pair_io(const RayenPack* p, const PairImage* img, const float*
                           hipStream_t stream) {
   constexpr int per_wave = 64;
   const int64_t n_groups = (B + per_wave - 1) / per_wave;
-  const int64_t slots = (int64_t)img->n_simd * kMfmaWavesPerSimd;
+  const int64_t slots = (int64_t)launch_simds(img->n_simd) * kMfmaWavesPerSimd;
   const int64_t rounds = (n_groups + slots - 1) / slots;
   const int64_t waves = (n_groups + rounds - 1) / rounds;
   const int64_t grid = (waves + kMfmaWaves - 1) / kMfmaWaves;
@@ -993,7 +993,7 @@ int mfma_pair_io_forward(const RayenPack* p, const PairImage* img, const float* 
   if (mode == 2) {
     constexpr int per_wave = 64;
     const int64_t n_groups = (B + per_wave - 1) / per_wave;
-    const int64_t slots = (int64_t)img->n_simd * kMfmaWavesPerSimd;
+    const int64_t slots = (int64_t)launch_simds(img->n_simd) * kMfmaWavesPerSimd;
     const int64_t rounds = (n_groups + slots - 1) / slots;
     const int64_t waves = (n_groups + rounds - 1) / rounds;
     const unsigned grid = (unsigned)((waves + kMfmaWaves - 1) / kMfmaWaves);

@@ -679,7 +679,7 @@ static int launch_split(const RayenPack* p, const SplitImage* img, const float* 
                         hipStream_t stream) {
   constexpr int per_wave = 64;
   const int64_t n_groups = (B + per_wave - 1) / per_wave;
-  const int64_t slots = (int64_t)img->n_simd * kMfmaWavesPerSimd;
+  const int64_t slots = (int64_t)launch_simds(img->n_simd) * kMfmaWavesPerSimd;
   const int64_t rounds = (n_groups + slots - 1) / slots;
   const int64_t waves = (n_groups + rounds - 1) / rounds;
   const int64_t grid = (waves + kMfmaWaves - 1) / kMfmaWaves;
@@ -728,7 +728,7 @@ static int launch_split_map(const RayenPack* p, const SplitImage* img, const flo
                             int32_t* nan_flag, hipStream_t stream) {
   constexpr int per_wave = 64;
   const int64_t n_groups = (B + per_wave - 1) / per_wave;
-  const int64_t slots = (int64_t)img->n_simd * kMfmaWavesPerSimd;
+  const int64_t slots = (int64_t)launch_simds(img->n_simd) * kMfmaWavesPerSimd;
   const int64_t rounds = (n_groups + slots - 1) / slots;
   const int64_t waves = (n_groups + rounds - 1) / rounds;
   const int64_t grid = (waves + kMfmaWaves - 1) / kMfmaWaves;

@@ -14,7 +14,9 @@ over xGMI when the backend is ``nccl``).
   writes the gather's input, no staging copy, no zero-fill),
 * ``all_gather_into_tensor`` of block ``c`` is issued asynchronously as soon as its
   projection is queued -- RCCL runs it on its own stream, after the kernel, while
-  the main stream already projects block ``c + 1``,
+  the main stream already projects block ``c + 1`` (whether they really overlap depends on the
+  projection's persistent grid leaving compute units for RCCL's kernels: ``reserve_cus``; ``trace=True``
+  time-stamps every chunk's projection end and gather end so that a run shows it),
 * the result is ONE buffer ``[chunks, world, rows, k]``; ``rows_of(rank)`` is a
   strided view of it in the rank's original row order (no reorder pass).
 
@@ -50,8 +52,15 @@ class ShardedStep:
     for fixed per-rank work).  Buffers are allocated once, here; a step allocates nothing.
     """
 
-    def __init__(self, project_into, sizes, k, dtype, device, chunks=4, gather=True, group=None, gather_alone=False):
+    def __init__(self, project_into, sizes, k, dtype, device, chunks=4, gather=True, group=None, gather_alone=False,
+                 reserve_cus=0, set_reserve=None):
+        """``reserve_cus`` / ``set_reserve``: compute units the projection's persistent grid leaves free while a
+        gather step runs (``set_reserve(n) -> previous`` = ``rayen_reserve_cus`` of the C ABI; ``None`` on CPU).
+        RCCL's all-gather kernels need CUs: behind a grid that fills every SIMD they would simply queue."""
         self.project_into = project_into
+        self.reserve_cus = int(reserve_cus)
+        self.set_reserve = set_reserve
+        self.last_trace = None
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -73,24 +82,58 @@ class ShardedStep:
             self.out = None
             self.send = torch.empty((1, max(self.n_local, 0), self.k), dtype=dtype, device=device)
 
-    def __call__(self, x_local):
-        """``x_local [n_local, ...]`` -> this rank's ``y [n_local, k]`` (no gather) or the gather buffer."""
+    def __call__(self, x_local, trace=False):
+        """``x_local [n_local, ...]`` -> this rank's ``y [n_local, k]`` (no gather) or the gather buffer.
+
+        ``trace``: also time-stamp every chunk -- its projection queued / finished, its all-gather finished (as the
+        main stream sees it) -- into ``self.last_trace`` (milliseconds from the start of the step; HIP events on a
+        device, ``perf_counter`` on the CPU).  One synchronisation at the end; not for timed loops."""
         if x_local.shape[0] != self.n_local:
             raise ValueError(f"rank {self.rank} holds {self.n_local} rows, got {x_local.shape[0]}")
         if not self.gather:
             y = self.send[0]
             self.project_into(x_local, y)
             return y
-        works = []
-        for c in range(self.chunks):
-            lo, hi = min(c * self.rows, self.n_local), min((c + 1) * self.rows, self.n_local)
-            send = self.send[c]
-            if hi > lo:
-                self.project_into(x_local[lo:hi], send[: hi - lo])          # rows beyond hi - lo: padding, never read
-            works.append(dist.all_gather_into_tensor(self.out[c].view(self.world * self.rows, self.k), send,
-                                                     group=self.group, async_op=True))
-        for work in works:
-            work.wait()
+        on_gpu = self.send.is_cuda
+        stamps = []
+
+        def stamp():
+            if not trace:
+                return None
+            if on_gpu:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                return ev
+            import time
+            return time.perf_counter()
+
+        prev = self.set_reserve(self.reserve_cus) if (self.set_reserve is not None and self.reserve_cus > 0) else None
+        try:
+            t0 = stamp()
+            works = []
+            for c in range(self.chunks):
+                lo, hi = min(c * self.rows, self.n_local), min((c + 1) * self.rows, self.n_local)
+                send = self.send[c]
+                if hi > lo:
+                    self.project_into(x_local[lo:hi], send[: hi - lo])      # rows beyond hi - lo: padding, never read
+                projected = stamp()
+                works.append(dist.all_gather_into_tensor(self.out[c].view(self.world * self.rows, self.k), send,
+                                                         group=self.group, async_op=True))
+                stamps.append([projected, None])
+            for c, work in enumerate(works):
+                work.wait()
+                stamps[c][1] = stamp()
+        finally:
+            if prev is not None:
+                self.set_reserve(prev)
+        if trace:
+            if on_gpu:
+                torch.cuda.synchronize()
+                ms = lambda ev: t0.elapsed_time(ev)                          # noqa: E731
+            else:
+                ms = lambda t: (t - t0) * 1e3                                # noqa: E731
+            self.last_trace = [{"chunk": c, "rows": int(min((c + 1) * self.rows, self.n_local) - min(c * self.rows, self.n_local)),
+                                "projection_end_ms": ms(a), "gather_end_ms": ms(b)} for c, (a, b) in enumerate(stamps)]
         return self.out
 
     def rows_of(self, rank):

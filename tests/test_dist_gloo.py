@@ -140,3 +140,65 @@ def test_bench_step_function_world2(tmp_path, scaling, chunks, config_batch, per
     mp.spawn(_bench_worker, args=(world, port, scaling, chunks, config_batch, per_gpu, str(tmp_path)), nprocs=world, join=True)
     for rank in range(world):
         assert os.path.exists(tmp_path / f"ok_{rank}.npy")
+
+
+def _world4_worker(rank, world, port, result_dir):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        from helpers import csd_from_cs
+        from oracle import rayen_oracle as oracle
+        from rayen_amd import workloads
+
+        torch.set_num_threads(1)
+        cs = workloads.build_constraints(workloads.make_raw("c2", seed=5))
+        buf = oracle.precompute(csd_from_cs(cs), torch.float32)
+
+        def project_into(x_rows, out_rows):
+            out_rows.copy_(oracle.forward(buf, x_rows)[:, :, 0])
+
+        # (a) the config's batch sharded over four ranks with a remainder: shards of 26, 26, 25, 25 rows
+        sizes = bench.local_sizes(102, 0, world, "strong")
+        assert sizes == [26, 26, 25, 25]
+        # (b) deliberately lopsided shards, one of them EMPTY (a rank with no rows still takes part in every collective)
+        lopsided = [40, 0, 7, 13]
+        reserved = []
+
+        def set_reserve(n):                                  # stand-in for rayen_reserve_cus: set and restored per step
+            reserved.append(n)
+            return 0
+
+        for shard, chunks in ((sizes, 3), (lopsided, 4), (lopsided, 1)):
+            xs = [torch.empty(shard[r], cs.n, 1).uniform_(-1, 1, generator=torch.Generator().manual_seed(2000 + r))
+                  for r in range(world)]
+            step = bench.make_step(project_into, shard, cs.k, torch.float32, torch.device("cpu"), gather=True, chunks=chunks,
+                                   reserve_cus=8, set_reserve=set_reserve)
+            step(xs[rank], trace=True)
+            for r in range(world):
+                want = oracle.forward(buf, xs[r])[:, :, 0]
+                got = step.rows_of(r).reshape(-1, cs.k)[: shard[r]]
+                assert torch.equal(got, want), f"rank {rank}: rows of rank {r} ({shard}, {chunks} chunks)"
+            assert torch.equal(step.gathered(), torch.cat([oracle.forward(buf, xx)[:, :, 0] for xx in xs]))
+            # the per-chunk time stamps: one record per chunk, projection before its gather, chunks in order
+            tr = step.last_trace
+            assert len(tr) == step.chunks and sum(t["rows"] for t in tr) == shard[rank]
+            assert all(t["projection_end_ms"] <= t["gather_end_ms"] for t in tr)
+            assert all(tr[i]["projection_end_ms"] <= tr[i + 1]["projection_end_ms"] for i in range(len(tr) - 1))
+        assert reserved == [8, 0] * 3                        # reserved for the step, handed back after it
+        np.save(os.path.join(result_dir, f"ok_{rank}.npy"), np.array([1]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_step_function_world4_unequal_shards(tmp_path):
+    """Four ranks, remainders, a lopsided split with an empty rank, the CU reservation handed to the projection for the
+    duration of a gather step, and the per-chunk trace the first multi-GPU run will be read by."""
+    world = 4
+    port = _free_port()
+    mp.spawn(_world4_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        assert os.path.exists(tmp_path / f"ok_{rank}.npy")

@@ -193,3 +193,26 @@ def test_example_sets_without_y0_on_the_hip_forward(index, dtype, tol):
         assert cs.getViolation(row.astype(np.float64)) <= (1e-10 if dtype == torch.float32 else 1e-14)
     far = 50.0 * np.ones(cs.k)
     assert cs.getViolation(far) > 1e-3 or cs.getMaxViolation(far[None]) <= 0
+
+
+def test_reserved_compute_units_change_the_launch_not_the_values():
+    """``rayen_reserve_cus`` (ABI v4) shrinks the persistent grids of the matrix-core kernels so that a collective can
+    run beside them (the multi-GPU gather step); outputs are the same bits, and the setting is restored by its caller."""
+    lib = _lib.load()
+    assert lib.rayen_reserve_cus(-1) == 0
+    for name in ("c3", "c5"):
+        cs, layer = _cold_layer(name)
+        dp, _ = layer.device_pack(torch.device("cuda", 0))
+        v = torch.empty(300000, cs.n, device="cuda").uniform_(-1.5, 1.5)
+        y0, k0, a0 = ops.project_raw(v, dp, want_active=True)
+        g = torch.randn(v.shape[0], cs.k, device="cuda")
+        grad0 = ops.backward_raw(v, k0, a0, g, dp)
+        for cus in (8, 64, 255):
+            prev = lib.rayen_reserve_cus(cus)
+            try:
+                y1, k1, a1 = ops.project_raw(v, dp, want_active=True)
+                grad1 = ops.backward_raw(v, k1, a1, g, dp)
+            finally:
+                lib.rayen_reserve_cus(prev)
+            assert torch.equal(y0, y1) and torch.equal(k0, k1) and torch.equal(a0, a1) and torch.equal(grad0, grad1)
+    assert lib.rayen_reserve_cus(-1) == 0
