@@ -167,11 +167,15 @@ def forward_rayen_old(buf: dict, q: torch.Tensor) -> torch.Tensor:
     return buf["NA_E"] @ (buf["z0"] + alpha * v_bar) + buf["yp"]
 
 
-def forward(buf: dict, x: torch.Tensor, method: str = "RAYEN") -> torch.Tensor:
-    """Layer forward with the identity mapper (CM:520-533, ``create_map=False``)."""
+def forward(buf: dict, x: torch.Tensor, method: str = "RAYEN", check_nan: bool = True) -> torch.Tensor:
+    """Layer forward with the identity mapper (CM:520-533, ``create_map=False``).
+
+    ``check_nan=False`` = the reference under ``python -O`` (CM:531's assert compiled out): used only where the
+    reference's own fp32 arithmetic is known to produce NaN (tests/golden/config_c5s.npz, helpers.load_golden)."""
     q = torch.flatten(x, 1).unsqueeze(2)  # == x.view(B, -1), and defined for B = 0
     y = forward_rayen(buf, q) if method == "RAYEN" else forward_rayen_old(buf, q)
-    assert not torch.isnan(y).any()
+    if check_nan:
+        assert not torch.isnan(y).any()
     return y
 
 

@@ -139,8 +139,30 @@ def pack_constants(buffers: dict, low_rank: bool = True, exact_quadratics=None) 
             return None
         return _true_rank(P, q, r, np.asarray(y0_exact, dtype=np.float64), N)[0]
 
+    def _vanishes_in_subspace(i):
+        """A quadratic that does not depend on z at all: P N = 0 and (P y0 + q)' N = 0 in the EXACT (fp64) constraint
+        data, relative to the data's own size -- e.g. ``||velocity control point||^2 <= v_max^2`` for a control point
+        the equality constraints pin to zero (config 5: 8 of 72).  Its kappa is identically 0 (CM:374 evaluates
+        rounding noise of 1e-18 there, and -- at fp32 -- NaN from a negative radicand): the segment is dropped, as
+        all-zero rows of D are."""
+        if exact_quadratics is None or P_buf is None:
+            return False
+        triples, y0_exact = exact_quadratics
+        if i >= len(triples):
+            return False
+        P, q, r = (np.asarray(a, dtype=np.float64) for a in triples[i])
+        Pb = P_buf[i].detach().cpu().numpy() if hasattr(P_buf, "detach") else np.asarray(P_buf[i])
+        if Pb.shape != P.shape or not np.array_equal(P.astype(Pb.dtype), Pb):
+            return False
+        g = P @ np.asarray(y0_exact, dtype=np.float64).reshape(-1, 1) + q.reshape(-1, 1)
+        size_p, size_g = float(np.abs(P).max()), float(np.abs(g).max())
+        return (float(np.abs(P @ N).max()) <= 1e-12 * max(size_p, 1e-300)
+                and float(np.abs(g.T @ N).max()) <= 1e-12 * max(size_g, size_p, 1e-300))
+
     if phi is not None and phi.ndim == 3:
         for i in range(phi.shape[0]):
+            if _vanishes_in_subspace(i):
+                continue
             aux = add_rows(phi[i].reshape(1, k) @ N)
             G = N.T @ delta[i] @ N
             G = 0.5 * (G + G.T)

@@ -92,13 +92,138 @@ def corridor_like(k=45, n_eq=15, m=288, n_quad=72, rank=3, seed=0):
     return raw
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Config 5 with the STRUCTURE of the reference's generator (examples/scripts/matlab/traj_planning_in_corridor.m:56-104,
+# getCorridorAndParamsSpline.m:23-48, getABVerticesgivenP1P2.m:9-80, MyClampedUniformSpline.m:26-37, 82-99, 682-736).
+# The data file itself (corridor_dim3.mat) is an absent git-LFS pointer and the MATLAB toolchain (casadi, MINVO basis
+# matrices, vert2lcon) is not vendored, so this is a restatement, not a reproduction:
+#   * 7 way-points -> 6 regions; a region = convex hull of 16 points drawn within radius 1 of the 8 vertices of a box of
+#     half-side 1 around its segment, outside the box (22-26 faces each; scipy's hull instead of vert2lcon, numpy's
+#     generator instead of MATLAB's rng(2));
+#   * trajectory = clamped uniform cubic B-spline, 12 intervals on [0, 15] -> 15 control points in R^3: k = 45;
+#   * corridor rows: the four control points of interval j lie in region ceil(j / 2) -- in the BEZIER basis (control
+#     points of the interval by blossoming), where the reference uses the MINVO basis, whose matrices are not in the
+#     tree; both enclose the interval, so the rows have the same form A_r (M_j Q) <= b_r;
+#   * 15 equality rows: position at t0, velocity and acceleration zero at t0 and tf -> n = 30;
+#   * 72 quadratics ||c||^2 <= ||limit||^2 on the (3 + 2 + 1) velocity / acceleration / jerk control points of every
+#     interval (B-spline basis of the derivative splines), limits 4 / 6 / 50 per axis: P = 2 C'C of rank 3;
+#   * exact duplicates among the rows (the last Bezier point of an interval is the first of the next) are dropped, the
+#     LP-based redundancy removal of rayen/constraints.py:256-286 is NOT applied (so that the golden vectors can come
+#     from the reference itself, which cannot run its LPs here): 1.1 k rows, as SURVEY.md 8(d) estimated;
+#   * the interior point is computed here once (max-margin conic program of rayen_amd/conic.py) and handed over as y0.
+# ---------------------------------------------------------------------------------------------------------------
+def _corridor_regions(rng):
+    from scipy.spatial import ConvexHull
+    way = 3.0 * np.array([[0, 1, 2, 3, 4, 3, 0], [0, 1, 1, 2, 4, 4, 4], [0, 1, 1, 1, 4, 1, 0]], dtype=float)
+    regions = []
+    for i in range(way.shape[1] - 1):
+        p1, p2 = way[:, i], way[:, i + 1]
+        h = np.linalg.norm(p2 - p1)
+        zb = (p2 - p1) / h
+        xb = np.cross(np.array([0.0, 1.0, 0.0]), zb)
+        xb /= np.linalg.norm(xb)
+        frame = np.stack([xb, np.cross(zb, xb), zb], axis=1)
+        verts = [p1 + frame @ np.array([sx, sy, sz]) for sz in (0.0, h) for sx in (1.0, -1.0) for sy in (1.0, -1.0)]
+        a_box = np.concatenate([frame.T, -frame.T])
+        b_box = np.array([max(a_box[r] @ vtx for vtx in verts) for r in range(6)])
+        pts = []
+        for vtx in verts:
+            kept = 0
+            while kept < 2:
+                d = rng.normal(size=3)
+                d *= rng.uniform() ** (1.0 / 3.0) / np.linalg.norm(d)       # uniform in the unit ball
+                if np.any(a_box @ (vtx + d) - b_box > 0.0):                 # outside the box
+                    pts.append(vtx + d)
+                    kept += 1
+        hull = ConvexHull(np.array(pts))
+        regions.append((hull.equations[:, :3].copy(), -hull.equations[:, 3].copy(), np.array(pts)))
+    return regions
+
+
+def _bezier_of_interval(knots, p, i):
+    """``[p+1, p+1]`` matrix taking the control points ``Q_{i-p..i}`` of a degree-``p`` B-spline to the Bezier
+    points of its interval ``[knots[i], knots[i+1]]``: point ``m`` is the blossom at ``knots[i]`` (p - m times),
+    ``knots[i+1]`` (m times), evaluated by the de Boor recursion."""
+    out = np.zeros((p + 1, p + 1))
+    for m in range(p + 1):
+        args = [knots[i]] * (p - m) + [knots[i + 1]] * m
+        d = np.eye(p + 1)                                   # row j: coefficients of Q_{i-p+j}
+        for r in range(1, p + 1):
+            nxt = d.copy()
+            for j in range(i - p + r, i + 1):
+                a = (args[r - 1] - knots[j]) / (knots[j + p - r + 1] - knots[j])
+                nxt[j - (i - p)] = (1.0 - a) * d[j - 1 - (i - p)] + a * d[j - (i - p)]
+            d = nxt
+        out[m] = d[p]
+    return out
+
+
+_CORRIDOR_CACHE = {}
+
+
+def corridor_spline(seed=0):
+    """Config 5: the corridor trajectory set restated from the reference's MATLAB generator (see the block comment above):
+    k = 45, 15 equalities (n = 30), ~1.1 k corridor rows, 72 rank-3 quadratics, interior point computed once."""
+    if seed in _CORRIDOR_CACHE:
+        return {key: (list(val) if isinstance(val, list) else (None if val is None else np.array(val)))
+                if key != "do_preprocessing_linear" else val for key, val in _CORRIDOR_CACHE[seed].items()}
+    rng = np.random.default_rng(1000 + seed)
+    regions = _corridor_regions(rng)
+    p, n_seg, dim, t0, tf = 3, 12, 3, 0.0, 15.0
+    n_cp = n_seg + p                                                      # 15
+    k = n_cp * dim
+    dt = (tf - t0) / n_seg
+    knots = np.concatenate([np.full(p + 1, t0), t0 + dt * np.arange(1, n_seg), np.full(p + 1, tf)])
+
+    def sel(l):                                                           # 3 x k: picks control point l
+        out = np.zeros((dim, k))
+        out[:, dim * l: dim * l + dim] = np.eye(dim)
+        return out
+
+    vel = [p * (sel(l + 1) - sel(l)) / (knots[l + p + 1] - knots[l + 1]) for l in range(n_cp - 1)]
+    acc = [(p - 1) * (vel[l + 1] - vel[l]) / (knots[l + p + 1] - knots[l + 2]) for l in range(n_cp - 2)]
+    jerk = [(p - 2) * (acc[l + 1] - acc[l]) / (knots[l + p + 1] - knots[l + 3]) for l in range(n_cp - 3)]
+
+    raw = _empty(k)
+    rows_a, rows_b = [], []
+    for j in range(1, n_seg + 1):
+        i = p + j - 1                                                     # interval [knots[i], knots[i + 1]]
+        bez = _bezier_of_interval(knots, p, i)
+        a_r, b_r, _ = regions[(j + 1) // 2 - 1]
+        for m in range(p + 1):
+            point = sum(bez[m, c] * sel(i - p + c) for c in range(p + 1))  # 3 x k
+            rows_a.append(a_r @ point)
+            rows_b.append(b_r.reshape(-1, 1))
+    a1, b1 = np.concatenate(rows_a), np.concatenate(rows_b)
+    _, keep = np.unique(np.round(np.concatenate([a1, b1], axis=1), 12), axis=0, return_index=True)
+    keep = np.sort(keep)
+    raw["A1"], raw["b1"] = a1[keep], b1[keep]
+    start = regions[0][2].mean(axis=0).reshape(dim, 1)
+    raw["A2"] = np.concatenate([sel(0), vel[0], vel[-1], acc[0], acc[-1]])
+    raw["b2"] = np.concatenate([start, np.zeros((4 * dim, 1))])
+    for j in range(1, n_seg + 1):
+        for c_mat, lim in ([(vel[j - 1 + c], 4.0) for c in range(3)] + [(acc[j - 1 + c], 6.0) for c in range(2)]
+                           + [(jerk[j - 1], 50.0)]):
+            raw["P"].append(2.0 * c_mat.T @ c_mat)
+            raw["q"].append(np.zeros((k, 1)))
+            raw["r"].append(np.array([[-dim * lim * lim]]))
+    # interior point: the package's own solver-free search, once
+    lc = constraints.LinearConstraint(raw["A1"], raw["b1"], raw["A2"], raw["b2"])
+    qcs = [constraints.ConvexQuadraticConstraint(P, q, r, do_checks_P=False) for P, q, r in zip(raw["P"], raw["q"], raw["r"])]
+    found = constraints.ConvexConstraints(lc=lc, qcs=qcs, y0=None, do_preprocessing_linear=False)
+    raw["y0"] = np.array(found.y0).reshape(k, 1)
+    _CORRIDOR_CACHE[seed] = raw
+    return corridor_spline(seed)
+
+
 CONFIGS = {
     # name: (builder, kwargs, batch named in BASELINE.json, input range)
     "c1": (cube, {}, 500, 5.0),
     "c2": (random_lin_quad_soc, dict(k=16, m=32, n_quad=2, n_soc=0), 4096, 1.0),
     "c3": (random_lin_quad_soc, dict(k=64, m=128, n_quad=4, n_soc=2), 262144, 1.0),
     "c4": (random_lmi, dict(k=10, r=20), 16384, 1.0),
-    "c5": (corridor_like, {}, 2097152, 1.0),
+    "c5": (corridor_spline, {}, 2097152, 1.0),
+    "c5r": (corridor_like, {}, 2097152, 1.0),     # the random stand-in of rounds 1-2 (288 rows), kept for comparison
 }
 
 

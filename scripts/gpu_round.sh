@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call of the round: GPU test suite, per-config bench lines, rocprofv3 stats + PMC per config.
 #   scripts/gpu_round.sh <tag> [tests|bench|prof ...]
-tag=${1:-r02a}; shift || true
+tag=${1:-r03}; shift || true
 what=${*:-tests bench prof}
 out=gpurun_out/$tag
 mkdir -p $out

@@ -199,6 +199,8 @@ def main():
     torch.manual_seed(0)
     # ---- the 15 example sets, 500 samples U(-5,5) (examples/test_layer.py:74-75) + two interior rows
     for index in range(15):
+        if sys.argv[1:] and f"example_{index:02d}" not in sys.argv[1:]:
+            continue
         cs = _example_cs(index)
         gen = torch.Generator().manual_seed(100 + index)
         x = torch.empty(500, cs.n, 1, dtype=torch.float32).uniform_(-5.0, 5.0, generator=gen)
@@ -223,8 +225,15 @@ def main():
     mixed["A2"] = rng.uniform(-1, 1, size=(3, 12))
     mixed["b2"] = np.zeros((3, 1))
     slices["config_mixed"] = mixed
+    # config 5 with the structure of the reference's corridor generator (rayen_amd.workloads.corridor_spline: 1050 rows,
+    # 15 equalities, 72 rank-3 quadratics; the interior point found there is handed to the reference as y0).  Added in
+    # round 3 behind the older slices: their seeds -- and files -- are unchanged.
+    slices["config_c5s"] = workloads.make_raw("c5", seed=0)
 
+    only = set(sys.argv[1:])
     for seed, (name, raw) in enumerate(slices.items()):
+        if only and name not in only:
+            continue
         cs = _ref_cs_from_raw(raw)
         gen = torch.Generator().manual_seed(500 + seed)
         x = torch.empty(256, cs.n, 1, dtype=torch.float32).uniform_(-1.0, 1.0, generator=gen)

@@ -17,7 +17,21 @@ def golden_names():
 
 
 def load_golden(name):
-    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    """(raw, csd, z).  ``z`` is a dict of the fixture's arrays.  Where the reference's OWN fp32 forward is not finite
+    (config_c5s: its ``sqrt(rho' delta rho)`` takes a slightly negative radicand on 119 of 256 directions of the
+    corridor set -- the hazard examples/main.py:288 trains in fp64 to avoid; generated under ``python -O``, without
+    which CM:342-381's asserts stop the reference first) the fp32 entries ``y32 / kappa_bar32 / y_old32`` of those rows
+    hold the reference's fp64 output rounded to fp32 -- the truth a finite fp32 implementation is held to -- and
+    ``z["nan_rows32"]`` marks them (all False for every other fixture)."""
+    z = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    nan_rows = ~np.isfinite(z["y32"]).all(axis=1)
+    z["nan_rows32"] = nan_rows
+    if nan_rows.any():
+        for key in ("y", "kappa_bar", "y_old"):
+            if key + "32" in z:
+                fixed = z[key + "32"].copy()
+                fixed[nan_rows] = z[key + "64"][nan_rows].astype(np.float32)
+                z[key + "32"] = fixed
     raw = dict(A1=None, b1=None, A2=None, b2=None, do_preprocessing_linear=False)
     for key in ("A1", "b1", "A2", "b2"):
         if "raw_" + key in z:

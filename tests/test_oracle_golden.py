@@ -26,14 +26,19 @@ def test_oracle_matches_reference(name, tag, dtype, tol):
             scale = max(1.0, float(np.max(np.abs(ref))))
             assert np.max(np.abs(got - ref)) <= tol * scale, bname
     x = torch.tensor(z["x"]).to(dtype)
-    y = oracle.forward(buf, x).numpy()[:, :, 0]
+    y = oracle.forward(buf, x, check_nan=False).numpy()[:, :, 0]
     assert y.shape == z["y" + tag].shape
-    assert np.max(rel_err_rows(y, z["y" + tag])) <= tol
+    # rows on which the reference's own fp32 arithmetic is NaN (helpers.load_golden): the oracle, issuing the same op
+    # sequence, must be NaN on exactly those rows -- and nowhere else, at either precision
+    ok = ~z["nan_rows32"] if tag == "32" else np.ones(len(y), dtype=bool)
+    assert np.array_equal(np.isfinite(y).all(axis=1), ok)
+    assert np.max(rel_err_rows(y[ok], z["y" + tag][ok])) <= tol
     n = csd["NA_E"].shape[1]
     v_bar = torch.nn.functional.normalize(x[:, 0:n, 0:1], dim=1)
     kappa = oracle.compute_kappa(buf, v_bar).numpy()[:, 0, 0]
     ref_k = z["kappa_bar" + tag]
-    assert np.max(np.abs(kappa - ref_k) / np.maximum(np.abs(ref_k), 1.0)) <= tol
+    assert np.array_equal(np.isfinite(kappa), ok)
+    assert np.max(np.abs(kappa[ok] - ref_k[ok]) / np.maximum(np.abs(ref_k[ok]), 1.0)) <= tol
 
 
 @pytest.mark.parametrize("name", golden_names())
@@ -59,5 +64,7 @@ def test_oracle_rayen_old_matches_reference(name, tag, dtype, tol):
     raw, csd, z = load_golden(name)
     buf = oracle.precompute(csd, dtype=dtype)
     x = torch.cat((torch.tensor(z["x"]), torch.tensor(z["beta"])), dim=1).to(dtype)
-    y = oracle.forward(buf, x, method="RAYEN_old").numpy()[:, :, 0]
-    assert np.max(rel_err_rows(y, z["y_old" + tag])) <= tol
+    y = oracle.forward(buf, x, method="RAYEN_old", check_nan=False).numpy()[:, :, 0]
+    ok = ~z["nan_rows32"] if tag == "32" else np.ones(len(y), dtype=bool)
+    assert np.array_equal(np.isfinite(y).all(axis=1), ok)
+    assert np.max(rel_err_rows(y[ok], z["y_old" + tag][ok])) <= tol
