@@ -52,7 +52,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="c3", choices=["c1", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--config", default="c3", choices=["c1", "c2", "c3", "c4", "c5", "c5r"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0 = the BASELINE.json size)")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp64"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -94,10 +94,14 @@ def cpu_baseline(raw, cs, B, dtype, budget_s, rng=1.0):
     Bs = min(B, 32768)
     x = torch.empty(Bs, cs.n, 1, dtype=dtype).uniform_(-rng, rng, generator=gen)
 
+    nan_rows = [0]
+
     def timed(xx):
         t0 = time.perf_counter()
-        oracle.forward(buf, xx)
-        return time.perf_counter() - t0
+        y_cpu = oracle.forward(buf, xx, check_nan=False)     # (the reference's NaN assert, CM:531, is not part of the timing)
+        dt = time.perf_counter() - t0
+        nan_rows[0] = int(torch.isnan(y_cpu).any(dim=1).sum())
+        return dt
 
     with torch.no_grad():
         # PyTorch-CPU does not scale to every core on this op mix: probe a few thread counts, keep the best
@@ -121,6 +125,9 @@ def cpu_baseline(raw, cs, B, dtype, budget_s, rng=1.0):
             reps += 1
     return {"value": Bs / best, "unit": "projections/s", "cores": threads, "kind": "port",
             "host_cores": cores,
+            # (config 5: the reference's own op sequence takes sqrt of slightly negative radicands at fp32 on the
+            # corridor set -- NaN outputs, which its assert at CM:531 would stop on; the HIP path is finite there)
+            "reference_nan_rows_in_sample": nan_rows[0],
             "sample": f"B={Bs} slice of the same workload, best of {reps} calls after warm-up, "
                       f"{str(dtype).split('.')[-1]}, torch {torch.__version__} CPU, {threads} threads "
                       f"(best of thread counts {sorted(rates)})"}
@@ -253,7 +260,7 @@ def main():
         layer = ConstraintModule(cs, method="RAYEN", create_map=False).to(device)
     layer.check_nan = False                      # no host sync inside the timed region
     config_batch = workloads.CONFIGS[args.config][2]
-    per_gpu = args.batch or (config_batch // 8 if args.config == "c5" else config_batch)   # c5: 2M = 8 x 262144
+    per_gpu = args.batch or (config_batch // 8 if args.config in ("c5", "c5r") else config_batch)   # c5: 2M = 8 x 262144
     sizes = local_sizes(args.batch * world if args.batch else config_batch, per_gpu, world, args.scaling)
     B = sizes[rank]
     total_rows = sum(sizes)
@@ -370,9 +377,13 @@ def main():
                                    f"{len(cs.qcs)} quadratic + {len(cs.socs)} SOC"
                                    f"{' + 1 LMI' if cs.has_lmi_constraints else ''}, "
                                    f"batch {B} per GPU, v~U(-{rng:g},{rng:g})"
-                                   + (" [random 288-row stand-in with the corridor set's structure: 15 equalities, "
-                                      "72 rank-3 quadratics; the real corridor_dim3.mat is an absent LFS pointer]"
-                                      if args.config == "c5" else ""),
+                                   + (" [the corridor trajectory set restated from the reference's MATLAB generator -- "
+                                      "clamped cubic B-spline, 12 intervals, 6 hull regions, Bezier points of every interval "
+                                      "inside its region, 15 boundary equalities, 72 rank-3 limits; corridor_dim3.mat itself "
+                                      "is an absent LFS pointer: rayen_amd/workloads.py::corridor_spline]"
+                                      if args.config == "c5" else
+                                      " [random 288-row stand-in of rounds 1-2 with the corridor set's counts: 15 equalities, "
+                                      "72 rank-3 quadratics]" if args.config == "c5r" else ""),
                        "batch_per_gpu": B, "global_batch": total_rows,
                        "parallelism": f"batch-sharded x{world}" + (f" + all-gather(y) in {sharded.chunks} chunks" if gather else ""),
                        "kernel": kernel_tag},

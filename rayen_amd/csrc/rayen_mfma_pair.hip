@@ -370,14 +370,14 @@ __device__ __forceinline__ void mfma_pair_fwd_body(
           const float a0 = aux_lds[wave][t][item.aux][col];
           float kc;
           if (item.type != MI_SOC) {
-            kc = a0 + __builtin_amdgcn_sqrtf(fmaxf(total, 0.f));
+            kc = (a0 + __builtin_amdgcn_sqrtf(fmaxf(total, 0.f))) * item.seg_inv;   // (the segment's own power of two undone)
           } else {
             // a' x^2 + b' x + c' = 0  (rayen/constraint_module.py:392-396, 339-348), a' < 0: the coefficients mix in
             // the set's constants f0 = tau, f1 = a' -- natural units here, the root goes back to the scaled domain
-            const float vi = v_inv[t];
-            const float cr = (a0 * w_inv) * vi;
-            const float br = (aux_lds[wave][t][item.aux + 1][col] * w_inv) * vi;
-            const float rt = (__builtin_amdgcn_sqrtf(total) * w_inv) * vi;
+            const float vi = v_inv[t], wi = w_inv * item.seg_inv;
+            const float cr = (a0 * wi) * vi;
+            const float br = (aux_lds[wave][t][item.aux + 1][col] * wi) * vi;
+            const float rt = (__builtin_amdgcn_sqrtf(total) * wi) * vi;
             const float cp = rt * rt - cr * cr;
             const float bp = 2.f * br - 2.f * cr * item.f0;
             const float disc = bp * bp - 4.f * item.f1 * cp;
@@ -459,7 +459,7 @@ __device__ __forceinline__ void mfma_pair_fwd_body(
 #pragma unroll
           for (int c = 1; c < 4; ++c) qs = fmaf(acc[t][4 * a + c], acc[t][4 * a + c], qs);
           if (pair) qs += xhalf(qs);
-          const float kc = aux_lds[wave][t][slot & 31][col] + __builtin_amdgcn_sqrtf(qs);
+          const float kc = (aux_lds[wave][t][slot & 31][col] + __builtin_amdgcn_sqrtf(qs)) * (hi ? pk.inv[a][1] : pk.inv[a][0]);
           if (sid >= 0 && kc > kap[t]) { kap[t] = kc; acode[t] = sid << 20; }
         }
       }
@@ -596,8 +596,69 @@ int mfma_pair_build(const RayenPack* p, PairImage** out, int64_t* bytes) {
   TileLayout b(p->n);
   const int rc = layout_tiles(p, b, /*allow_pack=*/true, /*allow_sym=*/false);
   if (rc != RAYEN_OK) return rc;
+  if (b.packs.empty()) { MPack none; std::memset(&none, 0, sizeof(none)); b.packs.push_back(none); }
+  // ---- one power of two per quadratic / cone on top of the image's gW (round 3).  f16 has five exponent bits: with ONE
+  // scale for the whole image, a constraint whose rows are 2^-15 of the image's largest entry keeps only its leading
+  // pieces (config 5's jerk limits next to its corridor rows: 3e-5 -- the creation-time measurement sent the set to the
+  // bf16 triples).  A candidate phi.v + ||U v|| is homogeneous in ITS OWN rows (aux rows and factor rows together), so
+  // every such segment's rows are boosted by f_s = 2^e_s into the band the image's largest entry sits in, and its
+  // candidate is multiplied by 1 / f_s (exact) before it meets the running maximum (MItem::seg_inv, MPack::inv).
+  // Linear rows keep the image's scale (their maximum runs over rows of different segments' worth of scale).
+  std::vector<float> seg_inv(p->segs.size(), 1.f);
+  {
+    const int n_tiles0 = b.n_tiles();
+    std::vector<int> row_seg((size_t)n_tiles0 * 32, -1);
+    int cur_aux = -1;
+    for (size_t idx = 0; idx < b.items.size(); ++idx) {
+      const MItem& it = b.items[idx];
+      if (it.type == MI_AUX) cur_aux = (int)idx;
+      if (it.type == MI_QFAC || it.type == MI_SOC) {
+        for (int r = 0; r < 32; ++r) row_seg[idx * 32 + r] = it.seg;
+        if (cur_aux >= 0) {
+          row_seg[(size_t)cur_aux * 32 + it.aux] = it.seg;
+          if (it.type == MI_SOC) row_seg[(size_t)cur_aux * 32 + it.aux + 1] = it.seg;
+        }
+      }
+      if (it.type == MI_PACK) {
+        const MPack& pk = b.packs[it.aux];
+        for (int a = 0; a < 4; ++a)
+          for (int h = 0; h < 2; ++h) {
+            if (pk.seg[a][h] < 0) continue;
+            for (int c = 0; c < 4; ++c) row_seg[idx * 32 + 8 * a + 4 * h + c] = pk.seg[a][h];
+            if (cur_aux >= 0) row_seg[(size_t)cur_aux * 32 + pk.aux[a][h]] = pk.seg[a][h];
+          }
+      }
+    }
+    double image_big = 0.0;
+    std::vector<double> seg_big(p->segs.size(), 0.0);
+    for (size_t r = 0; r < row_seg.size(); ++r)
+      for (int c = 0; c < b.n_pad; ++c) {
+        const double x = std::fabs(b.raw[r * b.n_pad + c]);
+        if (!std::isfinite(x)) continue;
+        image_big = x > image_big ? x : image_big;
+        if (row_seg[r] >= 0 && x > seg_big[row_seg[r]]) seg_big[row_seg[r]] = x;
+      }
+    std::vector<double> boost(p->segs.size(), 1.0);
+    for (size_t s = 0; s < p->segs.size(); ++s) {
+      if (!(seg_big[s] > 0.0) || !(image_big > 0.0)) continue;
+      int ex_seg = 0, ex_img = 0;
+      (void)std::frexp(seg_big[s], &ex_seg);
+      (void)std::frexp(image_big, &ex_img);
+      int e = ex_img - ex_seg;                    // the segment's largest entry into the binade of the image's
+      e = e < 0 ? 0 : (e > 60 ? 60 : e);
+      boost[s] = std::ldexp(1.0, e);
+      seg_inv[s] = (float)std::ldexp(1.0, -e);
+    }
+    for (size_t r = 0; r < row_seg.size(); ++r)
+      if (row_seg[r] >= 0 && boost[row_seg[r]] != 1.0)
+        for (int c = 0; c < b.n_pad; ++c) b.raw[r * b.n_pad + c] *= boost[row_seg[r]];
+    for (MItem& it : b.items)
+      if (it.type == MI_QFAC || it.type == MI_SOC) it.seg_inv = seg_inv[it.seg];
+    for (MPack& pk : b.packs)
+      for (int a = 0; a < 4; ++a)
+        for (int h = 0; h < 2; ++h) pk.inv[a][h] = pk.seg[a][h] >= 0 ? seg_inv[pk.seg[a][h]] : 1.f;
+  }
   const std::vector<float> frag = b.fragments_f32();
-  if (b.packs.empty()) b.packs.push_back(MPack());
 
   PairImage* img = new PairImage();
   img->nkk = b.n_pad / 32;

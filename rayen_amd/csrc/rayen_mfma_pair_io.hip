@@ -355,14 +355,14 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_io_
               const float a0 = aux_lds[wave][t][item.aux][col];
               float kc;
               if (item.type != MI_SOC) {
-                kc = a0 + __builtin_amdgcn_sqrtf(fmaxf(total, 0.f));
+                kc = (a0 + __builtin_amdgcn_sqrtf(fmaxf(total, 0.f))) * item.seg_inv;   // (the segment's own power of two undone)
               } else {
                 // a' x^2 + b' x + c' = 0  (rayen/constraint_module.py:392-396, 339-348), a' < 0: natural units here
                 // (the coefficients mix in the set's constants f0 = tau, f1 = a'), the root goes back to the scaled domain
-                const float vi = v_inv[t];
-                const float cr = (a0 * w_inv) * vi;
-                const float br = (aux_lds[wave][t][item.aux + 1][col] * w_inv) * vi;
-                const float rt = (__builtin_amdgcn_sqrtf(total) * w_inv) * vi;
+                const float vi = v_inv[t], wi = w_inv * item.seg_inv;
+                const float cr = (a0 * wi) * vi;
+                const float br = (aux_lds[wave][t][item.aux + 1][col] * wi) * vi;
+                const float rt = (__builtin_amdgcn_sqrtf(total) * wi) * vi;
                 const float cp = rt * rt - cr * cr;
                 const float bp = 2.f * br - 2.f * cr * item.f0;
                 const float disc = bp * bp - 4.f * item.f1 * cp;
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_io_
 #pragma unroll
               for (int c = 1; c < 4; ++c) qs = fmaf(acc[t][4 * a + c], acc[t][4 * a + c], qs);
               if (pair) qs += xhalf(qs);
-              const float kc = aux_lds[wave][t][slot & (AUXR - 1)][col] + __builtin_amdgcn_sqrtf(qs);
+              const float kc = (aux_lds[wave][t][slot & (AUXR - 1)][col] + __builtin_amdgcn_sqrtf(qs)) * (hi ? pk.inv[a][1] : pk.inv[a][0]);
               if (sid >= 0 && kc > kap[t]) { kap[t] = kc; acode[t] = sid << 20; }
             }
           }
@@ -758,13 +758,13 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_iof
               const float a0 = aux_lds[t][item.aux][col];
               float kc;
               if (item.type != MI_SOC) {
-                kc = a0 + __builtin_amdgcn_sqrtf(fmaxf(total, 0.f));
+                kc = (a0 + __builtin_amdgcn_sqrtf(fmaxf(total, 0.f))) * item.seg_inv;   // (the segment's own power of two undone)
               } else {
                 // a' x^2 + b' x + c' = 0  (rayen/constraint_module.py:392-396, 339-348), a' < 0: natural units here
-                const float vi = v_inv[t];
-                const float cr = (a0 * w_inv) * vi;
-                const float br = (aux_lds[t][item.aux + 1][col] * w_inv) * vi;
-                const float rt = (__builtin_amdgcn_sqrtf(total) * w_inv) * vi;
+                const float vi = v_inv[t], wi = w_inv * item.seg_inv;
+                const float cr = (a0 * wi) * vi;
+                const float br = (aux_lds[t][item.aux + 1][col] * wi) * vi;
+                const float rt = (__builtin_amdgcn_sqrtf(total) * wi) * vi;
                 const float cp = rt * rt - cr * cr;
                 const float bp = 2.f * br - 2.f * cr * item.f0;
                 const float disc = bp * bp - 4.f * item.f1 * cp;
@@ -797,7 +797,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_iof
 #pragma unroll
               for (int c = 1; c < 4; ++c) qs = fmaf(acc[t][4 * a + c], acc[t][4 * a + c], qs);
               if (pair) qs += xhalf(qs);
-              const float kc = aux_lds[t][slot & 31][col] + __builtin_amdgcn_sqrtf(qs);
+              const float kc = (aux_lds[t][slot & 31][col] + __builtin_amdgcn_sqrtf(qs)) * (hi ? pk.inv[a][1] : pk.inv[a][0]);
               if (sid >= 0 && kc > kap[t]) { kap[t] = kc; acode[t] = sid << 20; }
             }
           }

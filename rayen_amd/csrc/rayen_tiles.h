@@ -25,6 +25,8 @@ struct MItem {
   int32_t aux;     // row of phi | c (b is aux+1) inside the aux tile
   int32_t qbegin;  // first k-group this tile needs (QSYM: the block-lower-triangular part is folded away)
   float f0, f1;    // SOC: tau, a'
+  float seg_inv;   // f16-pair image: 1 / (the power of two the segment's rows were boosted by), see rayen_mfma_pair.hip
+  float pad_;
   double f0d, f1d; // the same in full precision (fp64 kernel)
 };
 
@@ -34,6 +36,7 @@ struct MItem {
 struct MPack {
   int32_t aux[4][2];  // [quad a][half]: aux row of phi for the segment sitting there
   int32_t seg[4][2];  // caller's segment index, -1 = empty
+  float inv[4][2];    // f16-pair image: 1 / (the power of two that segment's rows were boosted by)
 };
 
 
@@ -159,7 +162,7 @@ inline std::vector<std::vector<double>> psd_factor_rows(const double* G, int n) 
 inline int layout_tiles(const RayenPack* p, TileLayout& b, bool allow_pack, bool allow_sym = true) {
   const double* W = p->W.data();
   auto wrow = [&](int r) { return W + (size_t)r * p->n; };
-  auto blank = [](int type) { MItem it; std::memset(&it, 0, sizeof(it)); it.type = type; return it; };
+  auto blank = [](int type) { MItem it; std::memset(&it, 0, sizeof(it)); it.type = type; it.seg_inv = 1.f; return it; };
   const size_t nseg = p->segs.size();
   size_t s0 = 0;
   while (s0 < nseg) {
@@ -251,7 +254,7 @@ inline int layout_tiles(const RayenPack* p, TileLayout& b, bool allow_pack, bool
       int pair_bits = 0, used = 0;  // `used` counts half-quads handed out: slot = a * 2 + half
       auto reset = [&]() {
         std::fill(rows.begin(), rows.end(), nullptr);
-        for (int a = 0; a < 4; ++a) for (int h = 0; h < 2; ++h) { pk.aux[a][h] = 0; pk.seg[a][h] = -1; }
+        for (int a = 0; a < 4; ++a) for (int h = 0; h < 2; ++h) { pk.aux[a][h] = 0; pk.seg[a][h] = -1; pk.inv[a][h] = 1.f; }
         pair_bits = 0;
         used = 0;
       };

@@ -13,7 +13,7 @@ tests)
   echo "pytest rc=$?" >> $out/pytest.log
   tail -5 $out/pytest.log ;;
 bench)
-  for cfg in c3 c1 c2 c4 c5; do
+  for cfg in c3 c1 c2 c4 c5 c5r; do
     timeout 600 python bench.py --config $cfg > $out/bench_${cfg}_fp32.json 2> $out/bench_${cfg}_fp32.err
   done
   timeout 600 python bench.py --config c3 --dtype fp64 > $out/bench_c3_fp64.json 2> $out/bench_c3_fp64.err
@@ -22,7 +22,7 @@ bench)
   timeout 600 python bench.py --force-dist --no-cpu-baseline > $out/bench_c3_forcedist.json 2>&1
   head -c 600 $out/bench_c3_fp32.json; echo ;;
 prof)
-  for cfg in c3 c4 c2 c5 c1; do
+  for cfg in ${PROF_CONFIGS:-c3 c4 c2 c5 c1}; do
     timeout 900 scripts/profile_bench.sh ${tag}_$cfg --config $cfg > $out/prof_$cfg.log 2>&1
     timeout 120 python scripts/summarize_profile.py ${tag}_$cfg $out/prof_${cfg}_summary.json "config $cfg, fp32, default kernels" >> $out/prof_$cfg.log 2>&1
     rm -rf gpurun_out/prof_${tag}_$cfg          # raw rocprofv3 databases: ~20 MB per config, gpurun_out/ is capped at 64 MiB

@@ -18,7 +18,7 @@ def _cases():
         "c2": workloads.make_raw("c2", seed=31),
         "c3": workloads.make_raw("c3", seed=32),
         "c4": workloads.make_raw("c4", seed=33),
-        "c5": workloads.corridor_like(k=20, n_eq=6, m=24, n_quad=5, rank=2, seed=34),
+        "c5r": workloads.corridor_like(k=20, n_eq=6, m=24, n_quad=5, rank=2, seed=34),
         "mixed": mixed_raw,
     }
 
@@ -66,7 +66,7 @@ def _assert_gradient(got, want, cs, x, G, dtype, method="RAYEN", floor=None, wha
     assert np.median(err) <= GRAD_TOL[dtype] / 10
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4", "c5", "mixed"])
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4", "c5r", "mixed"])
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 def test_backward_matches_oracle_autograd(name, dtype):
     raw = _cases()[name]
@@ -181,7 +181,7 @@ def _bwd_sets():
     return {
         "eq_packed_n50": workloads.corridor_like(k=60, n_eq=10, m=96, n_quad=20, rank=3, seed=65),   # two blocks of v
         "many_packed": many_packed,
-        "c5": workloads.make_raw("c5", seed=55),                  # equalities + 72 packed rank-3 quadratics
+        "c5r": workloads.make_raw("c5r", seed=55),                  # equalities + 72 packed rank-3 quadratics
         "eq_dense": eq_dense,
         "packed_identity": packed_identity,
         "c2": workloads.make_raw("c2", seed=51),
@@ -192,7 +192,7 @@ def _bwd_sets():
     }
 
 
-@pytest.mark.parametrize("name", ["c2", "c3", "lin", "soc_only", "lowrank", "c5", "eq_dense", "packed_identity",
+@pytest.mark.parametrize("name", ["c2", "c3", "lin", "soc_only", "lowrank", "c5r", "eq_dense", "packed_identity",
                                   "many_packed", "eq_packed_n50"])
 @pytest.mark.parametrize("old_head", [False, True])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
@@ -406,7 +406,7 @@ def test_random_sets_gradients_match_oracle_autograd(seed):
     ("c3", 70001, torch.float64), ("eq_free_2quad", 40000, torch.float64), ("lowrank", 33000, torch.float64),
     ("soc_quad", 50000, torch.float64),
     # the general fp32 backward (equality constraints / packed low-rank quadratics): buckets = packed tile pairs + dense forms
-    ("c5", 66000, torch.float32), ("eq_packed_n50", 40000, torch.float32), ("many_packed", 50000, torch.float32),
+    ("c5r", 66000, torch.float32), ("eq_packed_n50", 40000, torch.float32), ("many_packed", 50000, torch.float32),
     ("packed_identity", 33333, torch.float32)])
 def test_bucketed_backward_equals_the_plain_walk(name, B, dtype):
     """Large batches of packs with several dense forms are grouped by active constraint first (three small

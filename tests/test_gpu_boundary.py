@@ -26,7 +26,7 @@ def _cold_layer(name, dtype=torch.float32, seed=3):
         torch.set_default_dtype(prev)
 
 
-@pytest.mark.parametrize("name", ["c2", "c3", "c4", "c5"])
+@pytest.mark.parametrize("name", ["c2", "c3", "c4", "c5r"])
 def test_cold_pack_is_captured_into_a_hip_graph(name):
     """The very FIRST projection call of a pack happens inside a stream capture (forward with the arg-max record,
     and the backward): nothing may allocate, synchronise or touch another stream.  Replays must equal a plain call."""
@@ -60,7 +60,7 @@ def test_cold_pack_is_captured_into_a_hip_graph(name):
     assert np.max(rel_err_rows(y[:512].cpu().numpy(), y_true)) <= 1e-5
 
 
-@pytest.mark.parametrize("name,dtype", [("c3", torch.float32), ("c5", torch.float32), ("c4", torch.float32),
+@pytest.mark.parametrize("name,dtype", [("c3", torch.float32), ("c5r", torch.float32), ("c4", torch.float32),
                                         ("c3", torch.float64)])
 def test_cold_pack_hammered_by_eight_threads(name, dtype):
     """Eight threads, each on its own stream, make their first calls on a pack nobody has used yet (forward, tracked
@@ -200,7 +200,7 @@ def test_reserved_compute_units_change_the_launch_not_the_values():
     run beside them (the multi-GPU gather step); outputs are the same bits, and the setting is restored by its caller."""
     lib = _lib.load()
     assert lib.rayen_reserve_cus(-1) == 0
-    for name in ("c3", "c5"):
+    for name in ("c3", "c5r"):
         cs, layer = _cold_layer(name)
         dp, _ = layer.device_pack(torch.device("cuda", 0))
         v = torch.empty(300000, cs.n, device="cuda").uniform_(-1.5, 1.5)

@@ -19,7 +19,7 @@ def _sets():
         "c1": workloads.make_raw("c1"),                      # 6 rows in R^3: generic path (tiles too empty)
         "c2": workloads.make_raw("c2", seed=41),             # n = 16
         "c3": workloads.make_raw("c3", seed=42),             # n = 64, NA_E = I
-        "c5": workloads.make_raw("c5", seed=43),             # n = 30 < k = 45: output through NA_E tiles
+        "c5r": workloads.make_raw("c5r", seed=43),             # n = 30 < k = 45: output through NA_E tiles
         "wide": workloads.random_lin_quad_soc(k=96, m=160, n_quad=2, n_soc=1, seed=44),   # n = 96 (NT = 1)
         "eq60": workloads.corridor_like(k=60, n_eq=10, m=120, n_quad=12, rank=3, seed=45),  # 32 < n = 50 <= 64, NA_E != I
         "ex13": mixed_raw,
@@ -57,8 +57,8 @@ def family(monkeypatch, request):
 @pytest.mark.parametrize("name,input_dim,fusable_exact,fusable_default", [
     ("c2", 8, True, True), ("c2", 64, True, False),          # n = 16: the default family keeps in_dim <= 32
     ("c3", 64, True, True), ("c3", 20, True, True), ("c3", 36, True, True),
-    ("c5", 32, True, True), ("c5", 64, True, False),         # equality constraints (NA_E != I): the staged instances; in_dim <= 32 there
-    ("c5", 16, True, True), ("eq60", 40, True, True),        # n = 50 of k = 60 with 10 equalities: NKK = 2 staged, NKX = 2
+    ("c5r", 32, True, True), ("c5r", 64, True, False),         # equality constraints (NA_E != I): the staged instances; in_dim <= 32 there
+    ("c5r", 16, True, True), ("eq60", 40, True, True),        # n = 50 of k = 60 with 10 equalities: NKK = 2 staged, NKX = 2
     ("wide", 48, True, True),                                 # n = 96: exact-fp32 family in both runs
     ("c3", 6, False, True),                                   # not a multiple of 4: only the image form takes it
     ("c3", 96, False, False),                                 # wider than either fused kernel keeps in registers
@@ -72,7 +72,7 @@ def test_fused_mapper_matches_oracle_and_two_op_path(name, input_dim, fusable_ex
     x = torch.empty(B, input_dim).uniform_(-2.0, 2.0, generator=gen)
     x[:4] *= 1e-4
     dp, _ = layer.device_pack(torch.device("cuda", 0))
-    if family == "default" and name in ("c2", "c3", "c5", "eq60"):
+    if family == "default" and name in ("c2", "c3", "c5r", "eq60"):
         assert dp.info().mfma_f32 == 3                        # the headline kernel, not a fallback
     assert ops.mapper_fusable(x.cuda(), layer.mapper.weight, layer.mapper.bias, dp) == fusable
 
@@ -151,7 +151,7 @@ def test_v_is_written_only_for_training_and_equals_the_linear_map():
     assert torch.equal(y.detach(), y2) and torch.equal(kappa.detach(), kappa2)
 
 
-@pytest.mark.parametrize("name,input_dim", [("c3", 64), ("c2", 8), ("c5", 32), ("eq60", 40)])
+@pytest.mark.parametrize("name,input_dim", [("c3", 64), ("c2", 8), ("c5r", 32), ("eq60", 40)])
 def test_gradients_of_the_fused_layer_match_the_two_op_path(name, input_dim):
     cs, layer = _module(_sets()[name], input_dim)
     gen = torch.Generator().manual_seed(8)

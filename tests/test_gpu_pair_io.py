@@ -72,7 +72,8 @@ def test_trickled_rows_equal_the_plain_pair_kernel_bit_for_bit(name, B, want_act
     v[B // 2] *= 1e-3
     y1, k1, a1, fam1 = _run(dp, v, want_active)
     y2, k2, a2, fam2 = _run(dp, _misaligned_copy(v), want_active)
-    assert fam1 == schedule, "the LDS-scheduled kernel was expected to serve an aligned call of this shape"
+    # (batches that do not give every resident wave a 64-row group -- 2048 waves: B < 131072 -- stay on the plain kernel)
+    assert fam1 == (schedule if B >= 131072 else _lib.KERNEL_PAIR), "which kernel served the aligned call"
     assert fam2 == _lib.KERNEL_PAIR
     assert torch.equal(y1, y2)
     assert torch.equal(k1, k2)
@@ -123,7 +124,8 @@ def test_trickled_rows_with_padded_leading_dimensions_and_nan_rows(name, schedul
 def _flat_sets():
     eq = workloads.corridor_like(k=28, n_eq=8, m=330, n_quad=10, rank=3, seed=31)          # n = 20 of k = 28, 14 tiles
     return {
-        "c5": workloads.make_raw("c5", seed=9),                                                # n = 30 of k = 45, 72 packed quadratics
+        "c5r": workloads.make_raw("c5r", seed=9),                                                # n = 30 of k = 45, 72 packed quadratics
+        "c5": workloads.make_raw("c5", seed=0),                                                  # the corridor set: 1050 rows, 47 tiles
         "eq_n20": eq,
         "id_n24": workloads.random_lin_quad_soc(k=24, m=260, n_quad=3, n_soc=1, seed=32),      # NA_E = I, ragged n
         "id_n30_many": workloads.random_lin_quad_soc(k=30, m=300, n_quad=6, n_soc=2, seed=33),
@@ -132,10 +134,10 @@ def _flat_sets():
 
 
 @pytest.mark.parametrize("B", [64, 777, 131072, 131072 + 64 * 3 + 5, 262144, 393216 + 17])
-@pytest.mark.parametrize("name", ["c5", "eq_n20", "id_n24", "id_n30_many", "c2"])
+@pytest.mark.parametrize("name", ["c5r", "c5", "eq_n20", "id_n24", "id_n30_many", "c2"])
 @pytest.mark.parametrize("want_active", [False, True])
 def test_flat_rows_equal_the_plain_pair_kernel_bit_for_bit(name, B, want_active):
-    if name not in ("c5", "id_n24") and B > 300000:
+    if name not in ("c5r", "id_n24") and B > 300000:
         pytest.skip("the round structures are covered on two sets")
     cs, layer, dp = _pack(_flat_sets()[name])
     if dp.info().mfma_f32 != 3:
@@ -157,15 +159,21 @@ def test_flat_rows_equal_the_plain_pair_kernel_bit_for_bit(name, B, want_active)
     # the reference's bar, against the fp64 oracle with the reference's own fp32 error as the yardstick (random sets)
     take = torch.cat([torch.arange(0, min(B, 500)), torch.arange(max(B - 500, 0), B)]).unique()
     x = v[take.cuda()].cpu().unsqueeze(2)
-    y_true = oracle.forward(oracle.precompute(csd_from_cs(cs), torch.float64), x.double()).numpy()[:, :, 0]
-    y_ref = oracle.forward(oracle.precompute(csd_from_cs(cs), torch.float32), x).numpy()[:, :, 0]
-    bound = max(1e-5, 2.0 * float(np.max(rel_err_rows(y_ref, y_true))))
-    assert np.max(rel_err_rows(y1[take.cuda()].cpu().numpy(), y_true)) <= bound
+    # (rows on which the reference's op sequence is NaN -- the corridor set, tests/test_gpu_parity.py::
+    # test_corridor_set_against_truth -- are left to that test)
+    y_true = oracle.forward(oracle.precompute(csd_from_cs(cs), torch.float64), x.double(), check_nan=False).numpy()[:, :, 0]
+    y_ref = oracle.forward(oracle.precompute(csd_from_cs(cs), torch.float32), x, check_nan=False).numpy()[:, :, 0]
+    ok = np.isfinite(y_true).all(axis=1) & np.isfinite(y_ref).all(axis=1)
+    if ok.sum() < 0.3 * len(ok):
+        assert name == "c5"          # (the reference's fp32 op sequence is NaN on practically every row of the corridor set)
+        return
+    bound = max(1e-5, 2.0 * float(np.max(rel_err_rows(y_ref[ok], y_true[ok]))))
+    assert np.max(rel_err_rows(y1[take.cuda()].cpu().numpy()[ok], y_true[ok])) <= bound
 
 
 def test_flat_rows_served_sets_are_really_served():
     """Config 5 and the ragged identity set must be on the flat-row kernel at the BASELINE batch (no silent fallback)."""
-    for name in ("c5", "id_n24", "eq_n20"):
+    for name in ("c5r", "c5", "id_n24", "eq_n20"):
         cs, layer, dp = _pack(_flat_sets()[name])
         v = torch.empty(262144, cs.n, device="cuda").uniform_(-1, 1)
         _, _, _, fam = _run(dp, v, False)

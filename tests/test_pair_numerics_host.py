@@ -23,7 +23,7 @@ def _bf16(x):
     return r.view(np.float32).astype(np.float64)
 
 
-@pytest.mark.parametrize("name", ["c2", "c3", "c5"])
+@pytest.mark.parametrize("name", ["c2", "c3", "c5r", "c5"])
 def test_row_results_of_the_pair_format_are_fp32_grade(name):
     cs = workloads.build_constraints(workloads.make_raw(name, seed=21))
     consts = ConstraintModule(cs, create_map=False).packed_constants()
