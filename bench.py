@@ -315,6 +315,7 @@ def main():
     # feasibility of what was just computed (fp64 residuals on a slice, outside the timed region)
     sl = y[: min(B, 65536), :, 0].double().cpu().numpy()
     max_violation = cs.getMaxViolation(sl) if B else 0.0
+    violation_detail = workloads.violation_report(cs, sl[:8192]) if B else None
 
     if rank == 0:
         bytes_pp, flops_pp = workloads.algorithmic_work(cs)
@@ -389,6 +390,9 @@ def main():
                        "kernel": kernel_tag},
             "max_violation": max_violation,
             "violations_gt_1e-6": int(max_violation > 1e-6),
+            # (per family: the residual next to what rounding a feasible y to fp32 alone can leave -- sets with large
+            # coefficients, configs 5 / 5r, sit above 1e-6 in absolute terms at a ratio of a few units)
+            "violation_detail": violation_detail,
             "roofline": roof,
         }
         if world > 1 or gather:

@@ -269,3 +269,44 @@ def algorithmic_work(cs):
         r = cs.lmic.all_F[0].shape[0]
         flops += 2 * n * r * r + (4 * r ** 3) // 3
     return 4 * (n + k), flops
+
+
+def violation_report(cs, y):
+    """Where the largest residual of a batch ``y [B,k]`` sits and how it compares with what ROUNDING ``y`` TO FP32 alone
+    can cause: per family the worst residual (``ConvexConstraints.getResiduals``) and the worst ratio
+    residual / (2^-24 x the sum of the absolute values of the terms the residual is made of) -- a feasible point of a
+    row ``a'y <= b`` rounded to fp32 can leave up to 2^-24 (|a|'|y|) of residual, a quadratic
+    2^-24 (|y|'|P||y| + |q|'|y|), and so on.  A ratio of a few units says the output is feasible to the working precision of
+    its storage format; the absolute number says how large the set's coefficients are (host code, fp64, no oracle)."""
+    y = np.asarray(y, dtype=np.float64).reshape(-1, cs.k)
+    ay = np.abs(y)
+    u = 2.0 ** -24
+    fam = {}
+    if cs.has_linear_ineq_constraints:
+        r = y @ cs.lc.A1.T - cs.lc.b1.T
+        t = ay @ np.abs(cs.lc.A1).T + np.abs(cs.lc.b1).T
+        fam["lin_ineq"] = (r, t)
+    if cs.has_linear_eq_constraints:
+        r = np.abs(y @ cs.lc.A2.T - cs.lc.b2.T)
+        t = ay @ np.abs(cs.lc.A2).T + np.abs(cs.lc.b2).T
+        fam["lin_eq"] = (r, t)
+    if cs.has_quadratic_constraints:
+        r = np.stack([0.5 * np.einsum("bi,ij,bj->b", y, qc.P, y) + y @ qc.q[:, 0] + qc.r[0, 0] for qc in cs.qcs], axis=1)
+        t = np.stack([np.einsum("bi,ij,bj->b", ay, np.abs(qc.P), ay) + ay @ np.abs(qc.q[:, 0]) for qc in cs.qcs], axis=1)
+        fam["quad"] = (r, t)
+    if cs.has_soc_constraints:
+        r = np.stack([np.linalg.norm(y @ soc.M.T + soc.s.T, axis=1) - (y @ soc.c[:, 0] + soc.d[0, 0]) for soc in cs.socs], axis=1)
+        t = np.stack([np.linalg.norm(ay @ np.abs(soc.M).T, axis=1) + ay @ np.abs(soc.c[:, 0]) for soc in cs.socs], axis=1)
+        fam["soc"] = (r, t)
+    if cs.has_lmi_constraints:
+        F = np.stack(cs.lmic.all_F[:-1], axis=0)
+        H = np.einsum("ba,ajk->bjk", y, F) + cs.lmic.all_F[-1][None]
+        r = -np.linalg.eigvalsh(H)[:, :1]
+        t = np.einsum("ba,a->b", ay, np.linalg.norm(F, ord=2, axis=(1, 2)))[:, None]
+        fam["lmi"] = (r, t)
+    out = {}
+    for name, (r, t) in fam.items():
+        out[name] = {"max_residual": float(np.max(r)),
+                     "over_f32_rounding_of_y": float(np.max(np.maximum(r, 0.0) / np.maximum(u * t, 1e-300)))}
+    worst = max(out, key=lambda f: out[f]["max_residual"])
+    return {"family_of_max": worst, "per_family": out}
