@@ -165,7 +165,7 @@ def test_flat_rows_equal_the_plain_pair_kernel_bit_for_bit(name, B, want_active)
     y_ref = oracle.forward(oracle.precompute(csd_from_cs(cs), torch.float32), x, check_nan=False).numpy()[:, :, 0]
     ok = np.isfinite(y_true).all(axis=1) & np.isfinite(y_ref).all(axis=1)
     if ok.sum() < 0.3 * len(ok):
-        assert name == "c5"          # (the reference's fp32 op sequence is NaN on practically every row of the corridor set)
+        assert name == "c5"          # (the reference's fp32 op sequence is NaN on 40-100 % of the corridor set's rows, by host BLAS path)
         return
     bound = max(1e-5, 2.0 * float(np.max(rel_err_rows(y_ref[ok], y_true[ok]))))
     assert np.max(rel_err_rows(y1[take.cuda()].cpu().numpy()[ok], y_true[ok])) <= bound

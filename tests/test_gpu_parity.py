@@ -1,5 +1,7 @@
 """Parity tests proper: the HIP path (through the C ABI) against the reference's golden vectors,
 the CPU oracle, closed-form answers and size-independent properties.  Needs an MI355X."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -103,10 +105,12 @@ def _fp32_bound(cs, x, y_true, layer=None, method="RAYEN"):
         y_const, _, _ = packed_eval.evaluate(layer.packed_constants(), x[:, :cs.n, 0].double().numpy())
         bound = max(bound, 4.0 * rel_err_rows(y_const, y_true).max())
     BOUND_LOG[-1] = float(bound)
+    BOUND_WHO.append((os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], float(bound)))
     return bound
 
 
 BOUND_LOG = []
+BOUND_WHO = []   # (test id, bar) of every call
 
 
 @pytest.mark.parametrize("name,B", [("c1", 500), ("c2", 4096), ("c3", 8192), ("c4", 4096), ("c5r", 8192)])
@@ -995,7 +999,8 @@ def test_zz_fp32_bars_on_record():
     bars = [b for b in BOUND_LOG if b is not None]
     lifted = [b for b in bars if b > FP32_TOL]
     summary = {"bars_applied": len(bars), "lifted_above_1e-5": len(lifted),
-               "largest_bar": max(bars) if bars else None, "baseline_configs": RATIO_LOG}
+               "largest_bar": max(bars) if bars else None, "baseline_configs": RATIO_LOG,
+               "lifted": sorted(({"test": w, "bar": b} for w, b in BOUND_WHO if b > FP32_TOL), key=lambda d: -d["bar"])}
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "fp32_bound_log.json"), "w") as fh:
