@@ -117,10 +117,14 @@ typedef struct RayenPackInfo {
   int32_t mfma_f64;             /* 1: the fp64 MFMA path serves this pack */
   int64_t device_bytes;         /* bytes of device memory the pack holds */
   int32_t prepared;             /* RAYEN_PREPARE_F32 | RAYEN_PREPARE_F64 | 4 (backward) */
-  int32_t reserved;
+  int32_t bwd_f32;              /* fp32 backward: 0 lane-per-sample kernel | 1 fp32 MFMA kernel (NA_E = I, dense forms) | 2 fp32
+                                   MFMA kernel, general shapes | 3 f16-pair kernel (packed low-rank quadratics, n <= 32; accepted
+                                   by a creation-time measurement like the forward's) | 4 the four-lanes-per-sample LMI kernel */
   double fp32_check_split;      /* worst row error (relative to the row's size) against fp64 on the creation-time probe */
   double fp32_check_exact;      /* directions: bf16-triple kernel, exact-fp32 kernel, */
   double fp32_check_pair;       /* f16-pair kernel; -1 = not measured */
+  double bwd32_check_pair;      /* worst gradient-row error against the fp64 lane backward on the creation-time probe: */
+  double bwd32_check_exact;     /* f16-pair backward, the exact-fp32 kernel it replaces; -1 = not measured */
 } RayenPackInfo;
 
 typedef struct RayenPack RayenPack;

@@ -53,9 +53,10 @@ class RayenPackInfo(ctypes.Structure):
                 ("n_segments", ctypes.c_int32), ("device", ctypes.c_int32),
                 ("mfma_f32", ctypes.c_int32), ("generic_block", ctypes.c_int32),
                 ("mfma_f64", ctypes.c_int32), ("device_bytes", ctypes.c_int64),
-                ("prepared", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("prepared", ctypes.c_int32), ("bwd_f32", ctypes.c_int32),
                 ("fp32_check_split", ctypes.c_double), ("fp32_check_exact", ctypes.c_double),
-                ("fp32_check_pair", ctypes.c_double)]
+                ("fp32_check_pair", ctypes.c_double),
+                ("bwd32_check_pair", ctypes.c_double), ("bwd32_check_exact", ctypes.c_double)]
 
 
 class RayenError(RuntimeError):

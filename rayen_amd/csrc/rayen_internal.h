@@ -50,6 +50,7 @@ struct Mfma64Image;  // rayen_mfma_f64.hip
 struct MfmaBwdImage; // rayen_mfma_bwd.hip
 struct Mfma64BwdImage;  // rayen_mfma_bwd64.hip
 struct MfmaBwdgImage;   // rayen_mfma_bwdg.hip
+struct MfmaBwdpImage;   // rayen_mfma_bwdp.hip
 struct Mfma64BwdgImage; // rayen_mfma_bwdg64.hip
 struct LmiQuadImage;    // rayen_lmi_quad.h
 struct SplitImage;      // rayen_mfma_split.hip
@@ -76,6 +77,9 @@ struct RayenPack {
   rayen::MfmaBwdImage* mb32 = nullptr;
   rayen::Mfma64BwdImage* mb64 = nullptr;
   rayen::MfmaBwdgImage* mbg32 = nullptr;
+  rayen::MfmaBwdpImage* mbp32 = nullptr;   // f16-pair backward (packed low-rank quadratics, n <= 32)
+  int mbp32_state = 0;           // 1: may serve the pack | 2: rejected by bwd32_selfcheck
+  double check_bwd_pair = -1.0, check_bwd_exact = -1.0;  // worst gradient-row errors against the fp64 lane backward
   rayen::Mfma64BwdgImage* mbg64 = nullptr;
   rayen::LmiQuadImage* q32 = nullptr;
   rayen::LmiQuadImage* q64 = nullptr;
@@ -185,6 +189,13 @@ int lmi_quad_forward_f64(const RayenPack* p, const LmiQuadImage* img, const doub
                          hipStream_t stream);
 
 // fp32 MFMA backward for sets with equalities / packed low-rank quadratics (rayen_mfma_bwdg.hip)
+// the same shapes with every quadratic in packed tiles, n <= 32: backward on f16 pairs (rayen_mfma_bwdp.hip)
+bool mfma_bwdp_eligible(const RayenPack* p);
+int mfma_bwdp_build(const RayenPack* p, MfmaBwdpImage** out, int64_t* bytes);
+void mfma_bwdp_free(MfmaBwdpImage* img);
+int mfma_bwdp_backward(const RayenPack* p, const MfmaBwdpImage* img, const float* v, int64_t B, int64_t ldv,
+                       const float* kappa, const int32_t* active, const float* grad_y, int64_t ldg,
+                       float* grad_v, int64_t ldgv, hipStream_t stream);
 bool mfma_bwdg_eligible(const RayenPack* p);
 int mfma_bwdg_build(const RayenPack* p, MfmaBwdgImage** out, int64_t* bytes);
 void mfma_bwdg_free(MfmaBwdgImage* img);

@@ -423,6 +423,12 @@ def test_bucketed_backward_equals_the_plain_walk(name, B, dtype):
     finally:
         torch.set_default_dtype(prev)
     dp, _ = layer.device_pack(torch.device("cuda", 0))
+    dp_layer = dp
+    if dtype == torch.float32 and dp.info().bwd_f32 == 3:
+        # (the f16-pair backward streams the batch in order and asks for no workspace: the bucketed walk of the exact-fp32
+        # kernel behind it is what this test is about)
+        from rayen_amd import pack as _pack
+        dp = _pack.DevicePack(layer.packed_constants(), 0, fp32_mode=1)
     query = getattr(_lib.load(), "rayen_bwd_workspace_bytes_" + ("f32" if dtype == torch.float32 else "f64"))
     assert int(query(dp.handle, B)) > 0, "the pack should take the bucketed walk"
     assert int(query(dp.handle, 1000)) == 0                 # small batches: plain walk
@@ -440,4 +446,7 @@ def test_bucketed_backward_equals_the_plain_walk(name, B, dtype):
     # through autograd (the registered op takes the bucketed path by itself)
     xg = v.clone().unsqueeze(2).requires_grad_(True)
     (layer(xg)[:, :, 0] * g).sum().backward()
+    if dp_layer is not dp:                                  # (the module's own pack: its record, its backward kernel)
+        _, kappa, active = ops.project_raw(v, dp_layer, want_active=True)
+        want = ops.backward_raw(v, kappa, active, g, dp_layer)
     assert torch.equal(xg.grad[:, :, 0], want)

@@ -88,7 +88,7 @@ def _violation_bound(raw, cs, v, dtype):
     return max(floor, 3.0 * oracle.max_violation(raw, y_ref))
 
 
-def _fp32_bound(cs, x, y_true, layer=None, method="RAYEN"):
+def _fp32_bound(cs, x, y_true, layer=None, method="RAYEN", reference_yardstick=True):
     """The fp32 parity bar with its yardsticks, all measured against the fp64 truth ``y_true`` on the same inputs:
     the north_star's 1e-5, or twice the error of the reference's own fp32 arithmetic (oracle at fp32), or -- for a
     set whose constants do not survive fp32 rounding -- four times the error that rounding ALONE causes (the packed
@@ -96,8 +96,11 @@ def _fp32_bound(cs, x, y_true, layer=None, method="RAYEN"):
     bound = FP32_TOL
     BOUND_LOG.append(None)           # (filled in below: every bar that was ever applied is on record)
     try:
-        y32 = oracle.forward(oracle.precompute(csd_from_cs(cs), torch.float32), x.float(), method=method).numpy()[:, :, 0]
-        bound = max(bound, 2.0 * rel_err_rows(y32, y_true).max())
+        # (reference_yardstick=False: inputs on which the reference's fp32 arithmetic overflows -- |v| ~ 1e12 -- would
+        # make this yardstick meaningless)
+        if reference_yardstick:
+            y32 = oracle.forward(oracle.precompute(csd_from_cs(cs), torch.float32), x.float(), method=method).numpy()[:, :, 0]
+            bound = max(bound, 2.0 * rel_err_rows(y32, y_true).max())
     except AssertionError:          # the reference's fp32 discriminant went negative (CM:342)
         pass
     if layer is not None and method == "RAYEN":
@@ -245,7 +248,7 @@ def test_pair_kernel_scales_every_row_on_its_own(name):
     y_true = _oracle_forward(cs, x.double().unsqueeze(2), torch.float64)
     y, kappa, _ = ops.project_raw(x.cuda(), dp)
     err = rel_err_rows(y.cpu().numpy(), y_true)
-    bound = _fp32_bound(cs, x.unsqueeze(2), y_true, layer)
+    bound = _fp32_bound(cs, x.unsqueeze(2), y_true, layer, reference_yardstick=False)
     assert err.max() <= bound, (err.max(), bound, int(err.argmax()))
     assert np.allclose(y[5].cpu().numpy(), cs.y0[:, 0], atol=1e-6)
     k_true = oracle.compute_kappa(oracle.precompute(csd_from_cs(cs), torch.float64), x.double().unsqueeze(2))[:, 0, 0].numpy()
