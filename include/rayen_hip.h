@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define RAYEN_ABI_VERSION 4
+#define RAYEN_ABI_VERSION 5
 
 enum {
   RAYEN_OK = 0,

@@ -10,7 +10,7 @@ import os
 
 from ._build import LIBRARY
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 SEG_LIN, SEG_QUAD_SYM, SEG_QUAD_FAC, SEG_SOC, SEG_LMI = range(5)
 PREPARE_ALL, PREPARE_F32, PREPARE_F64, PREPARE_FWD_ONLY = 0, 1, 2, 4

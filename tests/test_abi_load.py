@@ -40,7 +40,7 @@ def test_error_strings_and_null_handling():
 
 def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(_lib.RayenSegment) == 40
-    assert ctypes.sizeof(_lib.RayenPackInfo) == 72
+    assert ctypes.sizeof(_lib.RayenPackInfo) == 88    # (ABI v5: + the two backward check values)
     assert ctypes.sizeof(_lib.RayenPackDesc) == 32 + 4 * ctypes.sizeof(ctypes.c_void_p)
     bad = _lib.RayenPackDesc()
     bad.abi_version = 999
@@ -70,7 +70,7 @@ int main(void) {{
   desc.abi_version = 999;
   if (rayen_abi_version() != RAYEN_ABI_VERSION) return 2;
   if (rayen_pack_create(&desc, &pack) != RAYEN_E_ABI) return 3;
-  if (sizeof(RayenSegment) != 40 || sizeof(RayenPackInfo) != 72 || sizeof(RayenPackDesc) != 64) return 4;
+  if (sizeof(RayenSegment) != 40 || sizeof(RayenPackInfo) != 88 || sizeof(RayenPackDesc) != 64) return 4;
   for (int i = 0; i < n; ++i) if (table[i] == NULL) return 5;
   printf("%d %s\\n", n, rayen_strerror(RAYEN_E_UNSUPPORTED));
   return 0;
