@@ -29,17 +29,21 @@
 #include <cstring>
 #include <vector>
 
+#ifndef RAYEN_BWDP_ABL
+#define RAYEN_BWDP_ABL 0   // developer ablation builds (scripts/ubench/tu_variant.sh): 1 no walk | 2 no NA_E' g | 8 no store
+#endif
+
 namespace rayen {
 
 struct MfmaBwdpImage {
   f16x8* U = nullptr;        // [tile][2 K-steps][2 pieces][64] x 8 f16: PACK1 tile, its transpose, ...
   f16x8* NT = nullptr;       // NA_E' as [2 nkg K-steps][2 pieces][64] x 8 f16 (rows = subspace coordinates), null when NA_E = I
-  BItem* items = nullptr;
-  BPack* packs = nullptr;
-  float* pack_inv = nullptr;   // [n_packs][4][2]: 1 / f_s of the segment sitting in that half-quad
+  int32_t* seg_info = nullptr; // [n_segments + 1][4]: tile pair that holds the segment (-1: none) | quad a | half + 2 x (spans
+                               // both halves) | 1 / f_s (float bits)
   int32_t* seg_aux = nullptr;  // [n_segments + 1] W row of phi for factor segments, -1 otherwise
   float* Wrow = nullptr;       // [n_rows + 2][32] fp32 rows (linear rows and phi: gathered, never multiplied on the MFMA)
-  int n_items = 0, nkg = 0, n_simd = 1024;
+  int n_pairs = 0, nkg = 0, n_simd = 1024;   // n_pairs: (packed tile, its transpose) pairs = tiles / 2
+  int lds_bytes = 0;           // dynamic LDS of the resident instance (U image + NA_E' image + descriptors), 0: does not fit
   float u_unscale = 1.f;       // 1 / (gU 2^13)
   float n_inv = 1.f;           // 1 / gN
   int64_t bytes = 0;
@@ -49,11 +53,12 @@ namespace {
 
 // rows stored back to back (ld == width) behind a 16-byte aligned base: the 32 rows of a sample tile are ONE block of
 // 32 width floats (a multiple of 16 bytes), moved as whole 16-byte pieces through the patch as a flat array
-template <int NT, int NK, int LSTR>
-__device__ __forceinline__ void load_rows_flat(float (&dst)[NT][NK * 16], const float* __restrict__ src, const int width,
-                                               const int64_t s_base, const int64_t B, float (*patch)[LSTR], const int lane) {
-  float* flat = &patch[0][0];
-  const int col = lane & 31, hi = lane >> 5;
+// ... in two steps, so that a group can have all its row loads in flight before it waits for the first of them:
+// issue (global -> registers, 16-byte pieces idx = lane + 64 j of each tile's block) and land (through the patch into the
+// fragment layout of an MFMA B operand: this lane's 4-column groups of ITS sample's row)
+template <int NT, int NK>
+__device__ __forceinline__ void issue_rows_flat(f32x4 (&piece)[NT][NK * 4], const float* __restrict__ src, const int width,
+                                                const int64_t s_base, const int64_t B, const int lane) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int64_t row0 = s_base + 32 * t;
@@ -63,8 +68,8 @@ __device__ __forceinline__ void load_rows_flat(float (&dst)[NT][NK * 16], const 
 #pragma unroll
     for (int jj = 0; jj < NK * 4; ++jj) {
       const int i4 = lane + 64 * jj;
+      f32x4 x = {0.f, 0.f, 0.f, 0.f};
       if (i4 < 8 * width) {
-        f32x4 x = {0.f, 0.f, 0.f, 0.f};
         if (4 * i4 + 3 < nfl) {
           x = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(blk + 4 * i4));
         } else {
@@ -72,8 +77,23 @@ __device__ __forceinline__ void load_rows_flat(float (&dst)[NT][NK * 16], const 
           if (4 * i4 + 1 < nfl) x[1] = blk[4 * i4 + 1];
           if (4 * i4 + 2 < nfl) x[2] = blk[4 * i4 + 2];
         }
-        *reinterpret_cast<f32x4*>(flat + 4 * i4) = x;
       }
+      piece[t][jj] = x;
+    }
+  }
+}
+
+template <int NT, int NK, int LSTR>
+__device__ __forceinline__ void land_rows_flat(float (&dst)[NT][NK * 16], const f32x4 (&piece)[NT][NK * 4], const int width,
+                                               float (*patch)[LSTR], const int lane) {
+  float* flat = &patch[0][0];
+  const int col = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int jj = 0; jj < NK * 4; ++jj) {
+      const int i4 = lane + 64 * jj;
+      if (i4 < 8 * width) *reinterpret_cast<f32x4*>(flat + 4 * i4) = piece[t][jj];
     }
     __builtin_amdgcn_wave_barrier();
     const float* myrow = flat + col * width + 4 * hi;
@@ -134,20 +154,33 @@ __device__ __forceinline__ void split8(const float* x, const float scale, f16x8&
 
 }  // namespace
 
-// NKG: 32-column blocks of the incoming gradient (k_pad / 32; 0 = NA_E is the identity).  FLAT bits: 1 = v and grad_v
-// rows back to back, 2 = grad_y rows back to back (each behind a 16-byte aligned base).
-template <int NKG>
+// NKG: 32-column blocks of the incoming gradient (k_pad / 32; 0 = NA_E is the identity).  FLAT: the rows of v, grad_v and
+// grad_y are stored back to back, each tensor behind a 16-byte aligned base.
+// RES: the whole image (packed tiles, NA_E', descriptors) is copied into LDS once per workgroup and every wave reads its A
+// operands from there -- streamed from L2 instead, the eight waves of a CU pull 80 KB per 64 samples through the
+// vector-memory path (config 5r: 330 MB per launch, the walk 54 us of a 95 us kernel; resident: DESIGN.md 4.3).
+template <int NKG, bool RES, bool FLAT>
 __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwdp_kernel(
-    const f16x8* __restrict__ Uimg, const f16x8* __restrict__ NTimg, const BItem* __restrict__ items, const int n_items,
-    const BPack* __restrict__ packs, const float* __restrict__ pack_inv, const int32_t* __restrict__ seg_aux,
+    const f16x8* __restrict__ Uimg, const f16x8* __restrict__ NTimg, const int n_pairs,
+    const int32_t* __restrict__ seg_info, const int32_t* __restrict__ seg_aux,
     const float* __restrict__ Wrow, const int n, const int k, const float* __restrict__ v, const int64_t B,
     const int64_t ldv, const int vec_v, const float* __restrict__ kappa, const int32_t* __restrict__ active,
     const float* __restrict__ gy, const int64_t ldg, const int vec_g, float* __restrict__ gv, const int64_t ldgv,
-    const int vec_o, const int flat, const float u_unscale, const float n_inv) {
+    const int vec_o, const float u_unscale, const float n_inv) {
   constexpr int NT = 2, KK = 16, NP = 32;
   constexpr int NKL = NKG > 1 ? NKG : 1, LSTR = NKL * 32 + 4;
   constexpr int KG = NKG > 0 ? NKG * 16 : 16, NSG = NKG * 2;
   __shared__ __attribute__((aligned(16))) float line_lds[kMfmaWaves][32][LSTR];
+  extern __shared__ __attribute__((aligned(16))) char res_lds[];   // RES: [2 n_pairs + 2 tiles x 4 KiB][NA_E': NSG x 2 KiB]
+  const f16x8* u_res = reinterpret_cast<const f16x8*>(res_lds);
+  const f16x8* nt_res = u_res + (size_t)(n_pairs * 2 + 2) * 4 * 64;   // (two spare tiles: the walk looks ahead)
+  if constexpr (RES) {
+    f16x8* dst = reinterpret_cast<f16x8*>(res_lds);
+    const int n_u = (n_pairs * 2 + 2) * 4 * 64, n_nt = NSG * 2 * 64;
+    for (int i = threadIdx.x; i < n_u; i += kMfmaWaves * 64) dst[i] = Uimg[i];
+    for (int i = threadIdx.x; i < n_nt; i += kMfmaWaves * 64) dst[n_u + i] = NTimg[i];
+    __syncthreads();   // the only workgroup barrier
+  }
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -161,7 +194,8 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwdp_ker
 
   for (int64_t grp = wave_id; grp < n_groups; grp += wave_stride) {
     const int64_t s_base = grp * (NT * 32);
-    bool live[NT], clipped[NT], pmatched[NT];
+    bool live[NT], clipped[NT], pmatched[NT], mine_half[NT];
+    int mp[NT], myq[NT];         // tile pair and quad of the sample's active segment (-1: a linear row / interior)
     float tr[NT][KK];
     f16x8 vb[NT][2][2];          // v as MFMA B operand: [tile][piece][K-step]
     float tv[NT], sc[NT], sinv[NT];
@@ -170,51 +204,83 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwdp_ker
 #pragma unroll
     for (int t = 0; t < NT; ++t) live[t] = (s_base + t * 32 + col) < B;
 
+    // ---- every load of the group goes out first: the rows of g and v (flat: 16-byte pieces of the group's blocks, up
+    // to 96 registers -- nothing else is live yet), kappa and the arg-max record
+    f32x4 g_piece[FLAT ? NT : 1][NKL * 4], v_piece[FLAT ? NT : 1][4];
+    if constexpr (FLAT) {
+      issue_rows_flat<NT, NKL>(g_piece, gy, NKG == 0 ? n : k, s_base, B, lane);
+      issue_rows_flat<NT, 1>(v_piece, v, n, s_base, B, lane);
+    }
+    float kap_in[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int64_t smp = live[t] ? s_base + t * 32 + col : 0;
+      kap_in[t] = live[t] ? kappa[smp] : 0.f;
+      aseg[t] = live[t] ? active[2 * smp] : -1;
+      arow[t] = live[t] ? active[2 * smp + 1] : 0;
+    }
+
     // ---- t = NA_E' g (or g itself), in the register layout of v
     if constexpr (NKG == 0) {
-      if (flat & 2) load_rows_flat<NT, 1, LSTR>(tr, gy, n, s_base, B, patch, lane);
+      if constexpr (FLAT) land_rows_flat<NT, 1, LSTR>(tr, g_piece, n, patch, lane);
       else load_rows<NT, 1, LSTR, true>(tr, gy, ldg, n, vec_g, s_base, B, live, patch, lane);
     } else {
       float gr[NT][KG];
-      if (flat & 2) load_rows_flat<NT, NKL, LSTR>(gr, gy, k, s_base, B, patch, lane);
+      if constexpr (FLAT) land_rows_flat<NT, NKL, LSTR>(gr, g_piece, k, patch, lane);
       else load_rows<NT, NKL, LSTR, true>(gr, gy, ldg, k, vec_g, s_base, B, live, patch, lane);
       f16x8 a[NSG][2];
+      const f16x8* nsrc = (RES ? nt_res : NTimg) + lane;
 #pragma unroll
       for (int sp = 0; sp < NSG; ++sp) {
-        a[sp][0] = NTimg[(sp * 2 + 0) * 64 + lane];
-        a[sp][1] = NTimg[(sp * 2 + 1) * 64 + lane];
+        a[sp][0] = nsrc[(sp * 2 + 0) * 64];
+        a[sp][1] = nsrc[(sp * 2 + 1) * 64];
       }
+      f16x8 gb[NT][2][NSG];
+      float sg_inv[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         float m = 0.f;
 #pragma unroll
         for (int i = 0; i < KG; ++i) m = fmaxf(m, __builtin_fabsf(gr[t][i]));
         m = fmaxf(m, xhalf(m));
-        float sg, sg_inv;
+        float sg;
         int sg_exp;
-        pow2_scale(m, sg, sg_inv, sg_exp);
-        f16x8 gb[2][NSG > 0 ? NSG : 1];
+        pow2_scale(m, sg, sg_inv[t], sg_exp);
 #pragma unroll
-        for (int sp = 0; sp < NSG; ++sp) split8(&gr[t][8 * sp], sg, gb[0][sp], gb[1][sp]);
-        f32x16 acc = zero;
-        // (cross products first, leading products last: DESIGN.md 4.0b)
+        for (int sp = 0; sp < NSG; ++sp) split8(&gr[t][8 * sp], sg, gb[t][0][sp], gb[t][1][sp]);
+      }
+      f32x16 acc[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = zero;
+      // (cross products first, leading products last: DESIGN.md 4.0b; the two sample tiles alternate -- two independent
+      // accumulator chains keep the pipe busy)
+      if constexpr (!(RAYEN_BWDP_ABL & 2)) {
 #pragma unroll
         for (int sp = 0; sp < NSG; ++sp) {
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[sp][1], gb[0][sp], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[sp][0], gb[1][sp], acc, 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[sp][1], gb[t][0][sp], acc[t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[sp][0], gb[t][1][sp], acc[t], 0, 0, 0);
         }
 #pragma unroll
-        for (int sp = 0; sp < NSG; ++sp) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[sp][0], gb[0][sp], acc, 0, 0, 0);
+        for (int sp = 0; sp < NSG; ++sp)
 #pragma unroll
-        for (int g = 0; g < 16; ++g) tr[t][g] = (acc[g] * n_inv) * sg_inv;
+          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[sp][0], gb[t][0][sp], acc[t], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t][0] = (float)gb[t][0][0][0] + (float)gb[t][1][NSG - 1][7];
       }
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) tr[t][g] = (acc[t][g] * n_inv) * sg_inv[t];
     }
 
     // ---- v: t . v in fp32, then the pieces
     float v_inv[NT];
     {
       float vr[NT][KK];
-      if (flat & 1) load_rows_flat<NT, 1, LSTR>(vr, v, n, s_base, B, patch, lane);
+      if constexpr (FLAT) land_rows_flat<NT, 1, LSTR>(vr, v_piece, n, patch, lane);
       else load_rows<NT, 1, LSTR, true>(vr, v, ldv, n, vec_v, s_base, B, live, patch, lane);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -236,92 +302,125 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwdp_ker
     bool any = false;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const int64_t smp = live[t] ? s_base + t * 32 + col : 0;
-      const float kap = live[t] ? kappa[smp] : 0.f;
-      aseg[t] = live[t] ? active[2 * smp] : -1;
-      arow[t] = live[t] ? active[2 * smp + 1] : 0;
+      const float kap = kap_in[t];
       clipped[t] = live[t] && kap > 1.f && aseg[t] >= 0;
       sc[t] = 1.f / fmaxf(1.f, kap);
-      pmatched[t] = false;
-      sinv[t] = 0.f;
+      // where the active segment sits (every quadratic of these packs is in exactly one packed tile)
+      // (four plain loads: read as one int4 under the `clipped` predicate, hipcc 7.2 returned element 0 for element 3)
+      const int32_t* si = seg_info + 4 * (clipped[t] ? aseg[t] : 0);
+      const int where = clipped[t] ? si[2] : 0;
+      mp[t] = clipped[t] ? si[0] : -1;
+      myq[t] = clipped[t] ? si[1] : 0;
+      mine_half[t] = (where & 2) != 0 || (where & 1) == hi;
+      sinv[t] = clipped[t] ? reinterpret_cast<const float*>(si)[3] : 0.f;
+      pmatched[t] = mp[t] >= 0;
       u16[t] = zero;
-      any |= clipped[t];
+      any |= pmatched[t];
     }
 
-    if (__ballot(any) != 0 && n_items > 0) {  // wave-uniform: a wave of interior samples skips the walk
-      const f16x8* up = Uimg + lane;
-      f16x8 buf_a[2][2], buf_b[2][2];   // [K-step][piece]
+    if (!(RAYEN_BWDP_ABL & 1) && __ballot(any) != 0) {  // wave-uniform: a wave of interior samples skips the walk
       f16x8 wb[NT][2][2];               // step-1 result, masked and normalised, as the B operand of step 2
-      auto fetch_tile = [&](f16x8 (&buf)[2][2]) {
+      // one tile's A operands [K-step][piece]: LDS (resident) or L2
+      auto fetch_tile = [&](f16x8 (&buf)[2][2], const int tile) {
+        const f16x8* src = (RES ? u_res : Uimg) + (size_t)tile * (4 * 64) + lane;
 #pragma unroll
         for (int sp = 0; sp < 2; ++sp) {
-          buf[sp][0] = up[(sp * 2 + 0) * 64];
-          buf[sp][1] = up[(sp * 2 + 1) * 64];
+          buf[sp][0] = src[(sp * 2 + 0) * 64];
+          buf[sp][1] = src[(sp * 2 + 1) * 64];
         }
-        up += 4 * 64;
-        __builtin_amdgcn_sched_barrier(0);
       };
-      auto product = [&](const f16x8 (&a)[2][2], const f16x8 (&b)[2][2], f32x16 acc) {
+      // acc[t] (+)= A x b[t] for both sample tiles, alternating (two independent accumulator chains)
+      auto product2 = [&](const f16x8 (&a)[2][2], const f16x8 (&b)[NT][2][2], f32x16 (&acc)[NT]) {
 #pragma unroll
         for (int sp = 0; sp < 2; ++sp) {
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[sp][1], b[0][sp], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[sp][0], b[1][sp], acc, 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[sp][1], b[t][0][sp], acc[t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[sp][0], b[t][1][sp], acc[t], 0, 0, 0);
         }
 #pragma unroll
-        for (int sp = 0; sp < 2; ++sp) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[sp][0], b[0][sp], acc, 0, 0, 0);
-        return acc;
+        for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[sp][0], b[t][0][sp], acc[t], 0, 0, 0);
       };
-      auto process = [&](const BItem item, const f16x8 (&a)[2][2]) {
-        if (item.type == BI_PACK2) {
-          // u += U_tile' w (zero for every sample whose active segment is not in this tile)
+      f16x8 buf_a[2][2], buf_b[2][2];
+      // ---- phase A: w = U_tile v for every packed tile; a sample keeps the result of ITS tile (16 selects per tile and
+      // sample tile -- the normalisation and the split into pieces happen once per group, not once per tile)
+      f32x16 wsel[NT];
 #pragma unroll
-          for (int t = 0; t < NT; ++t) u16[t] = product(a, wb[t], u16[t]);
-          return;
+      for (int t = 0; t < NT; ++t) wsel[t] = zero;
+      fetch_tile(buf_a, 0);
+      for (int pr = 0; pr < n_pairs; pr += 2) {   // (two spare tiles behind the list: the look-ahead of an odd count is harmless)
+        f32x16 acc[NT];
+        fetch_tile(buf_b, 2 * pr + 2);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = zero;
+        product2(buf_a, vb, acc);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int g = 0; g < 16; ++g) wsel[t][g] = mp[t] == pr ? acc[t][g] : wsel[t][g];
+        if (pr + 1 < n_pairs) {
+          fetch_tile(buf_a, 2 * pr + 4);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t] = zero;
+          product2(buf_b, vb, acc);
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) wsel[t][g] = mp[t] == pr + 1 ? acc[t][g] : wsel[t][g];
         }
-        if (item.type != BI_PACK1) return;
-        const BPack pk = packs[item.aux_row];
-        const float* pinv = pack_inv + (size_t)item.aux_row * 8;
+      }
+      // ---- the unit vector w = U_s v / ||U_s v|| of the sample's own segment (the rows of its quad; of both halves for a
+      // segment of rank 5..8), as pieces of 2^13 w
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const f32x16 acc = product(a, vb[t], zero);
-          float w[16];
-          bool got = false;
+      for (int t = 0; t < NT; ++t) {
+        float qs = 0.f;
 #pragma unroll
-          for (int a4 = 0; a4 < 4; ++a4) {
-            const int sid = hi ? pk.seg[a4][1] : pk.seg[a4][0];
-            const bool mine = clipped[t] && sid >= 0 && sid == aseg[t];
-            float qs = 0.f;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) qs = fmaf(acc[4 * a4 + c], acc[4 * a4 + c], qs);
-            qs = mine ? qs : 0.f;
-            if ((pk.pair_bits >> a4) & 1) qs += xhalf(qs);  // the segment's other rows sit in the other half
-            // (2^13: the unit vector as pieces of an f16-range number; undone with the image's scale at the end)
-            const float cw = (mine && qs > 0.f) ? 8192.f * __builtin_amdgcn_rsqf(qs) : 0.f;
-            // (the product is NOT a power-of-two scaling: it must exist as ONE rounded fp32 value before it is split.  Left to
-            // itself hipcc fuses it into the conversions -- piece 1 from the rounded product, piece 2 as
-            // fma(acc, cw, -f16(acc cw)) with a singly rounded f16 -- and near a rounding tie the two disagree about piece 1
-            // by one f16 ulp: 6e-5 of the unit vector, one row in four thousand)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              float prod = acc[4 * a4 + c] * cw;
-              asm volatile("" : "+v"(prod));
-              w[4 * a4 + c] = prod;
-            }
-            if (mine) sinv[t] = pinv[2 * a4 + hi];
-            got |= mine;
-          }
-          split8(&w[0], 1.f, wb[t][0][0], wb[t][1][0]);
-          split8(&w[8], 1.f, wb[t][0][1], wb[t][1][1]);
-          const int both = (got ? 1 : 0) | __shfl_xor(got ? 1 : 0, 32);
-          pmatched[t] |= both != 0;
+        for (int g = 0; g < 16; ++g) {
+          const bool keep = pmatched[t] && mine_half[t] && (g >> 2) == myq[t];
+          wsel[t][g] = keep ? wsel[t][g] : 0.f;
+          qs = fmaf(wsel[t][g], wsel[t][g], qs);
         }
-      };
-      fetch_tile(buf_a);
-      for (int it = 0; it < n_items; it += 2) {  // (the item count is even; two spare tiles behind the list)
-        fetch_tile(buf_b);
-        process(items[it], buf_a);
-        fetch_tile(buf_a);
-        process(items[it + 1], buf_b);
+        qs += xhalf(qs);   // (the other half holds the rest of a rank 5..8 segment, zeros otherwise)
+        const float cw = qs > 0.f ? 8192.f * __builtin_amdgcn_rsqf(qs) : 0.f;
+        float w[16];
+        // (the product is NOT a power-of-two scaling: it must exist as ONE rounded fp32 value before it is split.  Left to
+        // itself hipcc fuses it into the conversions -- piece 1 from the rounded product, piece 2 as
+        // fma(acc, cw, -f16(acc cw)) with a singly rounded f16 -- and near a rounding tie the two disagree about piece 1
+        // by one f16 ulp: 6e-5 of the unit vector, one row in four thousand)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          float prod = wsel[t][g] * cw;
+          asm volatile("" : "+v"(prod));
+          w[g] = prod;
+        }
+        split8(&w[0], 1.f, wb[t][0][0], wb[t][1][0]);
+        split8(&w[8], 1.f, wb[t][0][1], wb[t][1][1]);
+      }
+      // ---- phase B: u += U_tile' w, every tile with the w of the samples that belong to it (zeros for the others)
+      const f16x8 none = {0, 0, 0, 0, 0, 0, 0, 0};
+      fetch_tile(buf_a, 1);
+      for (int pr = 0; pr < n_pairs; pr += 2) {
+        f16x8 bsel[NT][2][2];
+        fetch_tile(buf_b, 2 * pr + 3);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) bsel[t][pc][sp] = mp[t] == pr ? wb[t][pc][sp] : none;
+        product2(buf_a, bsel, u16);
+        if (pr + 1 < n_pairs) {
+          fetch_tile(buf_a, 2 * pr + 5);
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+              for (int sp = 0; sp < 2; ++sp) bsel[t][pc][sp] = mp[t] == pr + 1 ? wb[t][pc][sp] : none;
+          product2(buf_b, bsel, u16);
+        }
       }
     }
 
@@ -329,8 +428,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwdp_ker
     float out[NT][KK];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const float s_other = xhalf(sinv[t]);
-      const float us = u_unscale * fmaxf(sinv[t], s_other);
+      const float us = u_unscale * sinv[t];
       float gk[KK];
 #pragma unroll
       for (int i = 0; i < KK; ++i) gk[i] = pmatched[t] ? u16[t][i] * us : 0.f;
@@ -348,7 +446,9 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_bwdp_ker
 #pragma unroll
       for (int i = 0; i < KK; ++i) out[t][i] = fmaf(sc[t], tr[t][i], -coef * gk[i]);
     }
-    if (flat & 1) {
+    if (RAYEN_BWDP_ABL & 8) {
+      if (out[0][0] == 123.456f) gv[0] = out[1][3];
+    } else if constexpr (FLAT) {
       store_rows_flat<NT, 1, LSTR>(out, gv, n, s_base, B, patch, lane);
     } else {
       float one[NT];
@@ -380,9 +480,7 @@ void mfma_bwdp_free(MfmaBwdpImage* img) {
   if (img == nullptr) return;
   if (img->U) (void)hipFree(img->U);
   if (img->NT) (void)hipFree(img->NT);
-  if (img->items) (void)hipFree(img->items);
-  if (img->packs) (void)hipFree(img->packs);
-  if (img->pack_inv) (void)hipFree(img->pack_inv);
+  if (img->seg_info) (void)hipFree(img->seg_info);
   if (img->seg_aux) (void)hipFree(img->seg_aux);
   if (img->Wrow) (void)hipFree(img->Wrow);
   delete img;
@@ -438,8 +536,10 @@ int mfma_bwdp_build(const RayenPack* p, MfmaBwdpImage** out, int64_t* bytes) {
   std::vector<BPack> packs;
   std::vector<int32_t> seg_aux;
   const int n_real = layout_bwdg_tiles(p, b, items, packs, seg_aux);
-  for (int i = 0; i < n_real; ++i)
-    if (items[i].type != BI_PACK1 && items[i].type != BI_PACK2 && items[i].type != BI_NOP) return RAYEN_E_UNSUPPORTED;
+  // (packed tile, transpose) pairs and nothing else: pair i = items 2 i, 2 i + 1 = pack i
+  if (n_real == 0 || n_real % 2 != 0) return RAYEN_E_UNSUPPORTED;
+  for (int i = 0; i < n_real; i += 2)
+    if (items[i].type != BI_PACK1 || items[i + 1].type != BI_PACK2 || items[i].aux_row != i / 2) return RAYEN_E_UNSUPPORTED;
 
   // one power of two per segment on top of the image's (rayen_mfma_pair.hip): rows of the packed tile, columns of its
   // transpose
@@ -491,12 +591,26 @@ int mfma_bwdp_build(const RayenPack* p, MfmaBwdpImage** out, int64_t* bytes) {
 
   MfmaBwdpImage* img = new MfmaBwdpImage();
   img->nkg = p->out_identity ? 0 : n_pad_of(k) / 32;
-  img->n_items = n_real;
+  img->n_pairs = n_real / 2;
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0)
       img->n_simd = prop.multiProcessorCount * 4;
   }
+  std::vector<int32_t> seg_info((p->segs.size() + 1) * 4, 0);
+  for (size_t sidx = 0; sidx <= p->segs.size(); ++sidx) seg_info[4 * sidx] = -1;
+  for (int pr = 0; pr < img->n_pairs; ++pr)
+    for (int a = 0; a < 4; ++a)
+      for (int h = 0; h < 2; ++h) {
+        const int sidx = packs[pr].seg[a][h];
+        if (sidx < 0) continue;
+        const bool both = (packs[pr].pair_bits >> a) & 1;
+        int32_t* d = &seg_info[4 * (size_t)sidx];
+        d[0] = pr;
+        d[1] = a;
+        d[2] = (both ? 2 : 0) | (both ? 0 : h);
+        std::memcpy(&d[3], &pack_inv[(size_t)pr * 8 + 2 * a + h], 4);
+      }
   double big = 0.0;
   for (const double x : b.raw)
     if (std::isfinite(x)) big = std::fabs(x) > big ? std::fabs(x) : big;
@@ -513,9 +627,8 @@ int mfma_bwdp_build(const RayenPack* p, MfmaBwdpImage** out, int64_t* bytes) {
     ok = ok && upload(uh, &d, &img->bytes);
     img->U = reinterpret_cast<f16x8*>(d);
   }
-  ok = ok && upload(wrow, &img->Wrow, &img->bytes) && upload(items, &img->items, &img->bytes) &&
-       upload(packs, &img->packs, &img->bytes) && upload(seg_aux, &img->seg_aux, &img->bytes) &&
-       upload(pack_inv, &img->pack_inv, &img->bytes);
+  ok = ok && upload(wrow, &img->Wrow, &img->bytes) && upload(seg_aux, &img->seg_aux, &img->bytes) &&
+       upload(seg_info, &img->seg_info, &img->bytes);
   if (ok && !p->out_identity) {
     // NA_E' : rows = the n subspace coordinates, K = the k ambient coordinates
     TileLayout bn(k);
@@ -537,6 +650,24 @@ int mfma_bwdp_build(const RayenPack* p, MfmaBwdpImage** out, int64_t* bytes) {
     img->NT = reinterpret_cast<f16x8*>(d);
   }
   if (!ok) { mfma_bwdp_free(img); return RAYEN_E_ALLOC; }
+  // the resident instance: everything in LDS next to the kernel's static row patches (160 KiB per CU, one workgroup)
+  {
+    const int nkl = img->nkg > 1 ? img->nkg : 1;
+    const int64_t patch = (int64_t)kMfmaWaves * 32 * (nkl * 32 + 4) * 4;
+    const int64_t need = (int64_t)(img->n_pairs * 2 + 2) * 4096 + (int64_t)img->nkg * 2 * 2048;
+    img->lds_bytes = (need + patch + 512 <= 160 * 1024) ? (int)need : 0;
+    if (img->lds_bytes > 0) {
+      const void* fns[2] = {nullptr, nullptr};
+      if (img->nkg == 0) { fns[0] = reinterpret_cast<const void*>(&mfma_bwdp_kernel<0, true, true>); fns[1] = reinterpret_cast<const void*>(&mfma_bwdp_kernel<0, true, false>); }
+      if (img->nkg == 1) { fns[0] = reinterpret_cast<const void*>(&mfma_bwdp_kernel<1, true, true>); fns[1] = reinterpret_cast<const void*>(&mfma_bwdp_kernel<1, true, false>); }
+      if (img->nkg == 2) { fns[0] = reinterpret_cast<const void*>(&mfma_bwdp_kernel<2, true, true>); fns[1] = reinterpret_cast<const void*>(&mfma_bwdp_kernel<2, true, false>); }
+      for (const void* fn : fns)
+        if (fn == nullptr || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, img->lds_bytes) != hipSuccess) {
+          (void)hipGetLastError();
+          img->lds_bytes = 0;
+        }
+    }
+  }
   *bytes = img->bytes;
   *out = img;
   return RAYEN_OK;
@@ -553,12 +684,21 @@ static int launch_bwdp(const RayenPack* p, const MfmaBwdpImage* img, const float
   const int64_t grid = (waves + kMfmaWaves - 1) / kMfmaWaves;
   auto aligned = [](const void* ptr, int64_t ld) { return (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(ptr) & 15) == 0); };
   auto base16 = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; };
-  const int flat = ((ldv == p->n && ldgv == p->n && base16(v) && base16(gv)) ? 1 : 0) |
-                   ((ldg == p->k && base16(gy)) ? 2 : 0);
-  hipLaunchKernelGGL((mfma_bwdp_kernel<NKG>), dim3((unsigned)grid), dim3(kMfmaWaves * 64), 0, stream, img->U, img->NT,
-                     img->items, img->n_items, img->packs, img->pack_inv, img->seg_aux, img->Wrow, p->n, p->k, v, B, ldv,
-                     aligned(v, ldv) ? 1 : 0, kappa, active, gy, ldg, aligned(gy, ldg) ? 1 : 0, gv, ldgv,
-                     aligned(gv, ldgv) ? 1 : 0, flat, img->u_unscale, img->n_inv);
+  // rows of v, grad_v and grad_y stored back to back behind 16-byte aligned bases: whole 16-byte pieces of the group's blocks
+  const bool flat = ldv == p->n && ldgv == p->n && base16(v) && base16(gv) && ldg == p->k && base16(gy);
+  auto go = [&](auto kern, const unsigned lds) {
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kMfmaWaves * 64), lds, stream, img->U, img->NT, img->n_pairs,
+                       img->seg_info, img->seg_aux, img->Wrow, p->n, p->k, v, B, ldv, aligned(v, ldv) ? 1 : 0, kappa, active,
+                       gy, ldg, aligned(gy, ldg) ? 1 : 0, gv, ldgv, aligned(gv, ldgv) ? 1 : 0, img->u_unscale,
+                       img->n_inv);
+  };
+  // (resident wherever the image fits: one copy per workgroup against one stream per wave and group)
+  if (img->lds_bytes > 0 && n_groups >= 2) {
+    if (flat) go(mfma_bwdp_kernel<NKG, true, true>, (unsigned)img->lds_bytes);
+    else go(mfma_bwdp_kernel<NKG, true, false>, (unsigned)img->lds_bytes);
+  } else {
+    go(mfma_bwdp_kernel<NKG, false, false>, 0u);
+  }
   return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
 }
 
