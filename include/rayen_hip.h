@@ -143,7 +143,8 @@ enum {
   RAYEN_KERNEL_TRIPLE = 3,    /* bf16 triples */
   RAYEN_KERNEL_PAIR = 4,      /* f16 pairs */
   RAYEN_KERNEL_PAIR_IO = 5,   /* f16 pairs, rows of v and y trickled through LDS under the tile walk */
-  RAYEN_KERNEL_LMI_QUAD = 6   /* four lanes per sample (one LMI + linear rows) */
+  RAYEN_KERNEL_LMI_QUAD = 6,  /* four lanes per sample (one LMI + linear rows) */
+  RAYEN_KERNEL_LMI_WAVE = 7   /* one wave per sample, the matrix in LDS (one LMI beyond ~30 x 30 + linear rows) */
 };
 int rayen_last_forward_kernel(void);
 

@@ -105,6 +105,13 @@ int build_one(RayenPack* p, bool eligible, Image** slot, Build build) {
   return RAYEN_OK;
 }
 
+int lmi_dim(const RayenPack* p) {
+  int r = 0;
+  for (const RayenSegment& g : p->segs)
+    if (g.type == RAYEN_SEG_LMI && g.dim > r) r = g.dim;
+  return r;
+}
+
 int build_images(RayenPack* p, int prepare) {
   // (no precision bit = both precisions: RAYEN_PREPARE_FWD_ONLY alone means "forward only, fp32 and fp64")
   const bool f32 = (prepare & (RAYEN_PREPARE_F32 | RAYEN_PREPARE_F64)) == 0 || (prepare & RAYEN_PREPARE_F32);
@@ -123,6 +130,8 @@ int build_images(RayenPack* p, int prepare) {
       if (p->pr32 != nullptr && (rc = mfma_pair_io_prepare(p, p->pr32))) return rc;
     }
     if ((rc = build_one(p, lmi_quad_eligible_f32(p), &p->q32, lmi_quad_build_f32))) return rc;
+    // (the wave-per-sample LMI kernels take what neither the quad kernel nor the lane kernels hold: matrices beyond ~30 x 30)
+    if ((rc = build_one(p, lmi_wave_eligible_f32(p) && (p->q32 == nullptr || lmi_dim(p) > 28), &p->w32, lmi_wave_build_f32))) return rc;
     if (bwd) {
       if ((rc = build_one(p, mfma_bwd_eligible(p), &p->mb32, mfma_bwd_build))) return rc;
       if (p->mb32 == nullptr && (rc = build_one(p, mfma_bwdg_eligible(p), &p->mbg32, mfma_bwdg_build))) return rc;
@@ -137,6 +146,7 @@ int build_images(RayenPack* p, int prepare) {
     if ((rc = build_generic<double>(p))) return rc;
     if ((rc = build_one(p, mfma64_eligible(p), &p->m64, mfma64_build))) return rc;
     if ((rc = build_one(p, lmi_quad_eligible_f64(p), &p->q64, lmi_quad_build_f64))) return rc;
+    if ((rc = build_one(p, lmi_wave_eligible_f64(p) && (p->q64 == nullptr || lmi_dim(p) > 20), &p->w64, lmi_wave_build_f64))) return rc;
     if (bwd) {
       if ((rc = build_one(p, mfma64_bwd_eligible(p), &p->mb64, mfma64_bwd_build))) return rc;
       if (p->mb64 == nullptr && (rc = build_one(p, mfma64_bwdg_eligible(p), &p->mbg64, mfma64_bwdg_build))) return rc;
@@ -200,8 +210,20 @@ int project_bwd(const RayenPack* p, const T* v, int64_t B, int64_t ldv, const T*
                                     static_cast<hipStream_t>(stream));
     }
   }
-  return generic_backward<T>(p, image_of<T>(p), v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv,
-                             old_mode, static_cast<hipStream_t>(stream));
+  const int rcg = generic_backward<T>(p, image_of<T>(p), v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv,
+                                      old_mode, static_cast<hipStream_t>(stream));
+  if (rcg == RAYEN_E_UNSUPPORTED && !old_mode) {   // (nothing was launched)
+    if constexpr (sizeof(T) == 4) {
+      if (p->w32 != nullptr)
+        return lmi_wave_backward_f32(p, p->w32, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv,
+                                     static_cast<hipStream_t>(stream));
+    } else {
+      if (p->w64 != nullptr)
+        return lmi_wave_backward_f64(p, p->w64, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv,
+                                     static_cast<hipStream_t>(stream));
+    }
+  }
+  return rcg;
 }
 
 }  // namespace
@@ -583,6 +605,8 @@ void rayen_pack_destroy(RayenPack* p) {
   if (p->sp32) mfma_split_free(p->sp32);
   if (p->pr32) mfma_pair_free(p->pr32);
   if (p->q32) lmi_quad_free(p->q32);
+  if (p->w32) lmi_wave_free(p->w32);
+  if (p->w64) lmi_wave_free(p->w64);
   if (p->q64) lmi_quad_free(p->q64);
   if (switched) (void)hipSetDevice(prev);
   delete p;
@@ -659,7 +683,12 @@ static int project_f32(const RayenPack* p, const float* v, int64_t B, int64_t ld
                                 static_cast<hipStream_t>(stream));
   }
   g_last_forward = RAYEN_KERNEL_LANE;
-  return project_generic<float>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, old_mode);
+  const int rcg = project_generic<float>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, old_mode);
+  if (rcg == RAYEN_E_UNSUPPORTED && p->w32 != nullptr && y != nullptr && !old_mode) {   // (nothing was launched)
+    g_last_forward = RAYEN_KERNEL_LMI_WAVE;
+    return lmi_wave_forward_f32(p, p->w32, v, B, ldv, y, ldy, kappa, active, nan_flag, static_cast<hipStream_t>(stream));
+  }
+  return rcg;
 }
 
 int rayen_ray_project_f32(const RayenPack* p, const float* v, int64_t B, int64_t ldv, float* y,
@@ -754,7 +783,12 @@ static int project_f64(const RayenPack* p, const double* v, int64_t B, int64_t l
                                 static_cast<hipStream_t>(stream));
   }
   g_last_forward = RAYEN_KERNEL_LANE;
-  return project_generic<double>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, old_mode);
+  const int rcg = project_generic<double>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, old_mode);
+  if (rcg == RAYEN_E_UNSUPPORTED && p->w64 != nullptr && y != nullptr && !old_mode) {
+    g_last_forward = RAYEN_KERNEL_LMI_WAVE;
+    return lmi_wave_forward_f64(p, p->w64, v, B, ldv, y, ldy, kappa, active, nan_flag, static_cast<hipStream_t>(stream));
+  }
+  return rcg;
 }
 
 int rayen_ray_project_f64(const RayenPack* p, const double* v, int64_t B, int64_t ldv, double* y,

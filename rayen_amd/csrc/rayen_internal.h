@@ -53,6 +53,7 @@ struct MfmaBwdgImage;   // rayen_mfma_bwdg.hip
 struct MfmaBwdpImage;   // rayen_mfma_bwdp.hip
 struct Mfma64BwdgImage; // rayen_mfma_bwdg64.hip
 struct LmiQuadImage;    // rayen_lmi_quad.h
+struct LmiWaveImage;    // rayen_lmi_wave.h
 struct SplitImage;      // rayen_mfma_split.hip
 struct PairImage;       // rayen_mfma_pair.hip
 
@@ -83,6 +84,8 @@ struct RayenPack {
   rayen::Mfma64BwdgImage* mbg64 = nullptr;
   rayen::LmiQuadImage* q32 = nullptr;
   rayen::LmiQuadImage* q64 = nullptr;
+  rayen::LmiWaveImage* w32 = nullptr;   // wave-per-sample LMI kernels: matrices beyond the other LMI kernels' sizes
+  rayen::LmiWaveImage* w64 = nullptr;
   rayen::SplitImage* sp32 = nullptr;
   int sp32_state = 0;            // 1: the bf16-triple kernel may serve this pack | 2: rejected by fp32_selfcheck
   rayen::PairImage* pr32 = nullptr;
@@ -212,6 +215,23 @@ void mfma64_bwdg_free(Mfma64BwdgImage* img);
 int mfma64_bwdg_backward(const RayenPack* p, const Mfma64BwdgImage* img, const double* v, int64_t B, int64_t ldv,
                          const double* kappa, const int32_t* active, const double* grad_y, int64_t ldg,
                          double* grad_v, int64_t ldgv, int old_mode, hipStream_t stream);
+
+// one wave per sample, the matrix in LDS: sets = [linear rows] + one LMI of any size the LDS holds (rayen_lmi_wave.h)
+bool lmi_wave_eligible_f32(const RayenPack* p);
+bool lmi_wave_eligible_f64(const RayenPack* p);
+int lmi_wave_build_f32(const RayenPack* p, LmiWaveImage** out, int64_t* bytes);
+int lmi_wave_build_f64(const RayenPack* p, LmiWaveImage** out, int64_t* bytes);
+void lmi_wave_free(LmiWaveImage* img);
+int lmi_wave_forward_f32(const RayenPack* p, const LmiWaveImage* img, const float* v, int64_t B, int64_t ldv, float* y,
+                         int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream);
+int lmi_wave_forward_f64(const RayenPack* p, const LmiWaveImage* img, const double* v, int64_t B, int64_t ldv, double* y,
+                         int64_t ldy, double* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream);
+int lmi_wave_backward_f32(const RayenPack* p, const LmiWaveImage* img, const float* v, int64_t B, int64_t ldv,
+                          const float* kappa, const int32_t* active, const float* grad_y, int64_t ldg, float* grad_v,
+                          int64_t ldgv, hipStream_t stream);
+int lmi_wave_backward_f64(const RayenPack* p, const LmiWaveImage* img, const double* v, int64_t B, int64_t ldv,
+                          const double* kappa, const int32_t* active, const double* grad_y, int64_t ldg, double* grad_v,
+                          int64_t ldgv, hipStream_t stream);
 
 bool lmi_quad_bwd_serves_f32(const RayenPack* p, const LmiQuadImage* img);
 bool lmi_quad_bwd_serves_f64(const RayenPack* p, const LmiQuadImage* img);

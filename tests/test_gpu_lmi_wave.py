@@ -1,0 +1,139 @@
+"""LMIs beyond the sizes of the four-lanes-per-sample kernel (32 x 32 fp32 / 24 x 24 fp64) and of the lane-per-sample
+kernels (~30 x 30): one wave per sample with the matrix in LDS (rayen_amd/csrc/rayen_lmi_wave.h) -- Householder
+tridiagonalisation, Sturm-count multisection over the 64 lanes; the backward maps the tridiagonal eigenvector back
+through the reflectors.  The reference (rayen/constraint_module.py:401-449) handles any size and its own timing sweep
+(examples/scripts/time_analysis.py:159-160) starts at 100 x 100.  Forward against the oracle (fp64: 1e-9; fp32: the
+north_star's 1e-5 or twice what LAPACK's fp32 eigvalsh -- the reference's arithmetic -- leaves against the fp64 truth),
+backward against autograd through the fp64 oracle's eigvalsh.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import csd_from_cs, rel_err_rows
+from oracle import rayen_oracle as oracle
+from rayen_amd import _lib, ops, workloads
+from rayen_amd.constraint_module import ConstraintModule
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(k, r, m, n_eq, seed):
+    rng = np.random.default_rng(seed)
+    raw = workloads.random_lmi(k, r, seed=seed)
+    F = []
+    for _ in range(k):
+        T = rng.uniform(-1, 1, size=(r, r))
+        F.append((T + T.T) / 2)
+    T = rng.uniform(-1, 1, size=(r, r))
+    F.append(T @ T.T + 0.5 * np.eye(r))
+    raw["F"] = F
+    if m:
+        raw["A1"] = rng.uniform(-1, 1, size=(m, k))
+        raw["b1"] = rng.uniform(0.1, 1.0, size=(m, 1))
+    if n_eq:
+        raw["A2"] = rng.uniform(-1, 1, size=(n_eq, k))
+        raw["b2"] = np.zeros((n_eq, 1))                      # y0 = 0 satisfies them
+    return raw
+
+
+CASES = {
+    "r30_eq": dict(k=7, r=30, m=0, n_eq=2, seed=1),          # fp64: beyond the quad kernel's 24 x 24
+    "r33": dict(k=6, r=33, m=0, n_eq=0, seed=2),             # the first size no other fp32 kernel takes
+    "r48_lin": dict(k=9, r=48, m=30, n_eq=0, seed=3),
+    "r64_lin_eq": dict(k=12, r=64, m=70, n_eq=3, seed=4),    # 70 linear rows: two row chunks per wave
+    "r100": dict(k=10, r=100, m=0, n_eq=0, seed=5),          # the reference's own sweep starts here
+    "r128_k70": dict(k=70, r=128, m=5, n_eq=0, seed=6),      # n > 64 as well; two rows per lane
+}
+
+
+def _layer(raw, dtype):
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        cs = workloads.build_constraints(raw)
+        return cs, ConstraintModule(cs, create_map=False).cuda()
+    finally:
+        torch.set_default_dtype(prev)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_large_lmi_forward_and_backward(name, dtype):
+    raw = _case(**CASES[name])
+    r = CASES[name]["r"]
+    cs, layer = _layer(raw, dtype)
+    dp, _ = layer.device_pack(torch.device("cuda", 0))
+    gen = torch.Generator().manual_seed(6)
+    B = 300 if r <= 64 else 96
+    x = torch.empty(B, cs.n).uniform_(-2.0, 2.0, generator=gen)
+    x[:2] *= 1e-4                                             # interior
+    x[2] = 0.0
+    xd = x.to(dtype).cuda()
+    y, kappa, active = ops.project_raw(xd, dp, want_active=True)
+    fam = _lib.load().rayen_last_forward_kernel()
+    if name == "r30_eq" and dtype == torch.float32:
+        assert fam == _lib.KERNEL_LMI_QUAD                    # (the small kernels keep what they can hold)
+    else:
+        assert fam == _lib.KERNEL_LMI_WAVE, (name, fam)
+    buf64 = oracle.precompute(csd_from_cs(cs), torch.float64)
+    xr = x.double().unsqueeze(2).requires_grad_(True)
+    y_true_t = oracle.forward(buf64, xr)
+    y_true = y_true_t.detach().numpy()[:, :, 0]
+    err = rel_err_rows(y.cpu().double().numpy(), y_true)
+    if dtype == torch.float64:
+        assert err.max() <= 1e-9, (name, err.max())
+    else:
+        y32 = oracle.forward(oracle.precompute(csd_from_cs(cs), torch.float32), x.unsqueeze(2)).numpy()[:, :, 0]
+        theirs = rel_err_rows(y32.astype(np.float64), y_true).max()
+        assert err.max() <= max(1e-5, 2.0 * theirs), (name, err.max(), theirs)
+    # feasibility of what came out (fp64 residuals)
+    assert cs.getMaxViolation(y.cpu().double().numpy()) <= (1e-9 if dtype == torch.float64 else 2e-4)
+    assert np.allclose(y[2].cpu().double().numpy(), cs.y0[:, 0], atol=1e-12 if dtype == torch.float64 else 1e-6)
+
+    # ---- backward against autograd through the fp64 oracle
+    g = torch.empty(B, cs.k).uniform_(-1, 1, generator=gen)
+    (y_true_t[:, :, 0] * g.double()).sum().backward()
+    want = xr.grad[:, :, 0].numpy()
+    got = ops.backward_raw(xd, kappa, active, g.to(dtype).cuda(), dp).cpu().double().numpy()
+    assert np.all(np.isfinite(got))
+    size = np.maximum(np.abs(want).max(axis=1), 1e-30)
+    gerr = np.abs(got - want).max(axis=1) / size
+    gerr[2] = 0.0                                             # v = 0: eigvalsh of the zero matrix has no derivative worth comparing
+    # kinks: the two largest eigenvalues (nearly) tie, or kappa within rounding of 1 / of the linear rows' maximum
+    terms = oracle.compute_kappa(buf64, torch.nn.functional.normalize(x.double().unsqueeze(2), dim=1), terms=True).numpy()
+    lam_gap = np.abs(terms[:, -1] - terms[:, -2]) / np.maximum(np.abs(terms[:, -1]), 1e-30)
+    kap = kappa.cpu().double().numpy()
+    kink = (lam_gap < (1e-3 if dtype == torch.float32 else 1e-7)) | (np.abs(kap - 1.0) < 1e-4)
+    if terms.shape[1] > 2:
+        top_lin = terms[:, :-2].max(axis=1)
+        kink |= np.abs(top_lin - np.maximum(terms[:, -1], 0.0)) < 1e-4 * np.maximum(np.abs(top_lin), 1e-30)
+    tol = 2e-3 if dtype == torch.float32 else 1e-7
+    # (nearly repeated top eigenvalues that are no kink yet: what a backward-stable eigen-solver delivers,
+    # eps r ||S|| / gap, next to the flat tolerance)
+    eps = 6e-8 if dtype == torch.float32 else 1.1e-16
+    bound = np.maximum(tol, 8.0 * r * eps / np.maximum(lam_gap, 1e-30))
+    bad = (~kink) & ~(gerr <= bound)
+    assert not bad.any(), (name, int(bad.sum()), np.flatnonzero(bad)[:5], gerr[bad][:5], bound[bad][:5])
+    assert kink.sum() <= max(3, 0.05 * B)
+
+
+def test_wave_kernel_small_and_ragged_batches_and_nan_rows():
+    raw = _case(**CASES["r48_lin"])
+    cs, layer = _layer(raw, torch.float32)
+    dp, _ = layer.device_pack(torch.device("cuda", 0))
+    gen = torch.Generator().manual_seed(9)
+    x = torch.empty(67, cs.n).uniform_(-2, 2, generator=gen).cuda()
+    y_all, k_all, _ = ops.project_raw(x, dp)
+    assert _lib.load().rayen_last_forward_kernel() == _lib.KERNEL_LMI_WAVE
+    for B in (1, 5, 64):
+        y, kap, _ = ops.project_raw(x[:B].contiguous(), dp)
+        assert torch.equal(y, y_all[:B]) and torch.equal(kap, k_all[:B])
+    dp.nan_flag.zero_()
+    xb = x.clone()
+    xb[7, 1] = float("nan")
+    yb, _, _ = ops.project_raw(xb, dp)
+    assert int(dp.nan_flag.item()) == 1
+    dp.nan_flag.zero_()
+    keep = torch.ones(67, dtype=torch.bool, device="cuda")
+    keep[7] = False
+    assert torch.equal(yb[keep], y_all[keep])

@@ -759,11 +759,8 @@ def test_lmi_with_linear_rows_and_equalities(name, dtype, tol):
     raw = _lmi_cases()[name]
     cs, layer = _layer(raw, dtype)
     gen = torch.Generator().manual_seed(6)
-    if dtype == torch.float64 and name == "r30_eq":
-        # 30 x 30 in fp64 fits neither the quad kernel's registers nor a lane's LDS column: refused, loudly
-        with pytest.raises(RayenError):
-            layer(torch.zeros(4, cs.n, 1, dtype=dtype).cuda())
-        return
+    # (30 x 30 in fp64 fits neither the quad kernel's registers nor a lane's LDS column: the wave-per-sample kernel of
+    # rayen_lmi_wave.h serves it since round 3 -- tests/test_gpu_lmi_wave.py)
     for B in (1, 67, 1500):
         x = torch.empty(B, cs.n, 1, dtype=torch.float32).uniform_(-2.0, 2.0, generator=gen).to(dtype)
         x[: min(B, 2)] *= 1e-3
