@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun call of the round: GPU test suite, per-config bench lines, rocprofv3 stats + PMC per config.
-#   scripts/gpu_round.sh <tag> [tests|bench|prof ...]
+#   scripts/gpu_round.sh <tag> [tests|bench|prof|bwd|mapper ...]
 tag=${1:-r03}; shift || true
 what=${*:-tests bench prof}
 out=gpurun_out/$tag
@@ -27,6 +27,14 @@ prof)
     timeout 120 python scripts/summarize_profile.py ${tag}_$cfg $out/prof_${cfg}_summary.json "config $cfg, fp32, default kernels" >> $out/prof_$cfg.log 2>&1
     rm -rf gpurun_out/prof_${tag}_$cfg          # raw rocprofv3 databases: ~20 MB per config, gpurun_out/ is capped at 64 MiB
   done ;;
+bwd)
+  timeout 600 python scripts/ubench/bwd_c5.py c5 c5r > $out/bwd_c5.txt 2> $out/bwd_c5.err
+  timeout 600 python scripts/ubench/bwd_split.py > $out/backward_split.txt 2>&1
+  for cfg in c5 c5r c3; do
+    timeout 600 python scripts/ubench/bwd_profile_summary.py $cfg $out/prof_backward_$cfg.json > /dev/null 2>&1
+  done
+  timeout 2000 python scripts/ubench/lmi_sweep.py --oracle 2>&1 | grep "^{" > $out/lmi_sweep.txt
+  cat $out/bwd_c5.txt ;;
 mapper)
   timeout 600 python bench.py --mapper 64 --no-cpu-baseline > $out/bench_c3_mapper64_fused.json 2> $out/bench_c3_mapper64_fused.err
   timeout 600 python bench.py --mapper 64 --no-fuse --no-cpu-baseline > $out/bench_c3_mapper64_twoop.json 2> $out/bench_c3_mapper64_twoop.err
