@@ -450,3 +450,30 @@ def test_bucketed_backward_equals_the_plain_walk(name, B, dtype):
         _, kappa, active = ops.project_raw(v, dp_layer, want_active=True)
         want = ops.backward_raw(v, kappa, active, g, dp_layer)
     assert torch.equal(xg.grad[:, :, 0], want)
+
+
+def test_bucketed_walk_of_the_last_form_of_an_even_item_list():
+    """n <= 32 (one tile per form), four dense quadratics, NA_E = I: the bucket of the last form walks [it_lo, it_hi) with
+    a look-ahead of two tiles, i.e. it touches two tiles behind the list -- they exist since round 3 (ADVICE round 2:
+    one spare tile was one too few; a read past a hipMalloc allocation can fault).  Bucketed and plain walks agree bit
+    for bit and with the lane-per-sample backward."""
+    from rayen_amd import _lib, ops
+    raw = workloads.random_lin_quad_soc(k=32, m=48, n_quad=4, n_soc=0, seed=91)
+    cs = workloads.build_constraints(raw)
+    layer = ConstraintModule(cs, create_map=False).cuda()
+    dp, _ = layer.device_pack(torch.device("cuda", 0))
+    assert dp.info().bwd_f32 == 1
+    B = 40000
+    assert int(_lib.load().rayen_bwd_workspace_bytes_f32(dp.handle, B)) > 0
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    v = torch.empty(B, cs.n, device="cuda").uniform_(-1.5, 1.5, generator=gen)
+    g = torch.empty(B, cs.k, device="cuda").uniform_(-1, 1, generator=gen)
+    _, kappa, active = ops.project_raw(v, dp, want_active=True)
+    segs = active[:, 0][kappa > 1]
+    assert int((segs == segs.max()).sum()) > 0                      # the last form is somebody's active constraint
+    want = ops.backward_raw(v, kappa, active, g, dp, bucketed=False)
+    for _ in range(3):
+        assert torch.equal(ops.backward_raw(v, kappa, active, g, dp, bucketed=True), want)
+    lane = ops.backward_raw(v, kappa, active, g, dp, force_generic=True)
+    size = lane.abs().amax(1).clamp_min(1e-20)
+    assert float(((want - lane).abs().amax(1) / size).max()) <= 2e-4
