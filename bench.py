@@ -406,6 +406,22 @@ def main():
                                  "per_chunk_rank0": last.get("gather_trace"),
                                  "how_to_read": "overlap happened if chunk c's gather_end_ms is not behind chunk c+1's "
                                                 "projection_end_ms by the gather's own duration"}
+        if world == 1 and not args.mapper and not args.no_families and B:
+            # the training step of the same workload: forward with the arg-max record, then the backward (the two launches
+            # `loss.backward()` through the layer costs, examples/main.py:166-171), timed the same way, outside `value`
+            g_in = torch.empty(B, cs.k, device=device, dtype=dtype).uniform_(-1, 1)
+            xv = x[:, :cs.n, 0].contiguous() if x.dim() == 3 else x[:, :cs.n].contiguous()
+            with torch.no_grad():
+                _, k_rec, a_rec = ops.project_raw(xv, dp, want_active=True)
+                _, ms_ft = timed_loop(lambda t_: ops.project_raw(t_, dp, want_active=True), xv, args.steps, args.warmup, False)
+                _, ms_b = timed_loop(lambda t_: ops.backward_raw(t_, k_rec, a_rec, g_in, dp), xv, args.steps, args.warmup, False)
+            bwd_names = {0: "lane-per-sample", 1: "exact-fp32 MFMA (dense forms)", 2: "exact-fp32 MFMA (general shapes)",
+                         3: "f16 pairs (packed low-rank forms)", 4: "four lanes per sample (LMI)"}
+            out["training_step"] = {
+                "forward_with_record_ms": ms_ft, "backward_ms": ms_b, "unit": "ms per call, eager, HIP events",
+                "backward_kernel": bwd_names.get(int(info.bwd_f32), str(info.bwd_f32)) if dtype == torch.float32 else "fp64 kernels",
+                "backward_check_pair_vs_fp64": info.bwd32_check_pair, "backward_check_exact_vs_fp64": info.bwd32_check_exact,
+                "clipped_fraction": float((k_rec > 1).double().mean())}
         if args.mapper:
             fused = (not args.no_fuse) and dtype == torch.float32 and dp.mapper_fusable(args.mapper)
             out["config"]["mapper"] = f"nn.Linear({args.mapper}, {cs.n}) " + ("fused into the projection kernel" if fused else "as its own GEMM")
