@@ -68,9 +68,18 @@ template <typename T>
 __device__ __forceinline__ void form_S(T* A, const int LD, const T* __restrict__ gt, const T* vs, const int n, const int P,
                                        const int Pp, const int lane) {
   for (int idx = lane; idx < P; idx += 64) {
-    T acc = T(0);
+    // (four partial sums: the loads of consecutive generators are independent, one accumulator would serialise them)
+    T p0 = T(0), p1 = T(0), p2 = T(0), p3 = T(0);
     const T* col = gt + idx;
-    for (int a = 0; a < n; ++a) acc = fma(vs[a], col[(size_t)a * Pp], acc);
+    int a = 0;
+    for (; a + 3 < n; a += 4) {
+      p0 = fma(vs[a + 0], col[(size_t)(a + 0) * Pp], p0);
+      p1 = fma(vs[a + 1], col[(size_t)(a + 1) * Pp], p1);
+      p2 = fma(vs[a + 2], col[(size_t)(a + 2) * Pp], p2);
+      p3 = fma(vs[a + 3], col[(size_t)(a + 3) * Pp], p3);
+    }
+    for (; a < n; ++a) p0 = fma(vs[a], col[(size_t)a * Pp], p0);
+    const T acc = (p0 + p1) + (p2 + p3);
     int i = (int)((sqrtf(8.f * (float)idx + 1.f) - 1.f) * 0.5f);
     while ((i + 1) * (i + 2) / 2 <= idx) ++i;
     while (i * (i + 1) / 2 > idx) --i;
@@ -114,8 +123,16 @@ __device__ __forceinline__ void tridiagonalise(T* A, const int LD, const int r, 
     T pv = T(0);
     for (int i = i0 + lane; i < r; i += 64) {
       const T* row = A + i * LD;
-      T acc = T(0);
-      for (int j = i0; j < r; ++j) acc = fma(row[j], vv[j], acc);
+      T q0 = T(0), q1 = T(0), q2 = T(0), q3 = T(0);
+      int j = i0;
+      for (; j + 3 < r; j += 4) {
+        q0 = fma(row[j + 0], vv[j + 0], q0);
+        q1 = fma(row[j + 1], vv[j + 1], q1);
+        q2 = fma(row[j + 2], vv[j + 2], q2);
+        q3 = fma(row[j + 3], vv[j + 3], q3);
+      }
+      for (; j < r; ++j) q0 = fma(row[j], vv[j], q0);
+      const T acc = (q0 + q1) + (q2 + q3);
       const T pi = taup * acc;
       ww[i] = pi;
       pv = fma(pi, vv[i], pv);
