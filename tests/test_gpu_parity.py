@@ -247,9 +247,18 @@ def test_pair_kernel_scales_every_row_on_its_own(name):
     x[5] = 0.0
     y_true = _oracle_forward(cs, x.double().unsqueeze(2), torch.float64)
     y, kappa, _ = ops.project_raw(x.cuda(), dp)
-    err = rel_err_rows(y.cpu().numpy(), y_true)
-    bound = _fp32_bound(cs, x.unsqueeze(2), y_true, layer, reference_yardstick=False)
+    # (rows with ||v|| < 1e-12: the reference divides by max(||v||, 1e-12) -- F.normalize's eps, CM:469 -- and so returns
+    # y0 + v ||v|| / 1e-12 instead of y0 + v; the kernels have no such floor (documented deviation).  Those
+    # rows are held to y0 + v itself, every other row to the fp64 truth.)
+    tiny = (x.double().norm(dim=1) < 1e-11).numpy()
+    assert 0 < tiny.sum() < B // 4
+    big = ~tiny
+    err = rel_err_rows(y.cpu().numpy()[big], y_true[big])
+    bound = _fp32_bound(cs, x[big].unsqueeze(2), y_true[big], layer, reference_yardstick=False)
+    assert bound <= 1e-4, bound                                  # (the yardstick itself must stay meaningful)
     assert err.max() <= bound, (err.max(), bound, int(err.argmax()))
+    plain = (torch.as_tensor(cs.y0[:, 0])[None, :] + x.double()[tiny] @ torch.as_tensor(np.asarray(cs.NA_E)).T).numpy()
+    assert np.max(rel_err_rows(y.cpu().double().numpy()[tiny], plain)) <= 1e-6
     assert np.allclose(y[5].cpu().numpy(), cs.y0[:, 0], atol=1e-6)
     k_true = oracle.compute_kappa(oracle.precompute(csd_from_cs(cs), torch.float64), x.double().unsqueeze(2))[:, 0, 0].numpy()
     # (kappa against the truth, with what the fp32 rounding of the constants alone does to it as yardstick: config 5)
