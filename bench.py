@@ -416,7 +416,7 @@ def main():
                 _, ms_ft = timed_loop(lambda t_: ops.project_raw(t_, dp, want_active=True), xv, args.steps, args.warmup, False)
                 _, ms_b = timed_loop(lambda t_: ops.backward_raw(t_, k_rec, a_rec, g_in, dp), xv, args.steps, args.warmup, False)
             bwd_names = {0: "lane-per-sample", 1: "exact-fp32 MFMA (dense forms)", 2: "exact-fp32 MFMA (general shapes)",
-                         3: "f16 pairs (packed low-rank forms)", 4: "four lanes per sample (LMI)"}
+                         3: "f16 pairs (packed low-rank forms)", 4: "four lanes per sample (LMI)", 5: "one wave per sample (LMI)"}
             out["training_step"] = {
                 "forward_with_record_ms": ms_ft, "backward_ms": ms_b, "unit": "ms per call, eager, HIP events",
                 "backward_kernel": bwd_names.get(int(info.bwd_f32), str(info.bwd_f32)) if dtype == torch.float32 else "fp64 kernels",

@@ -119,7 +119,8 @@ typedef struct RayenPackInfo {
   int32_t prepared;             /* RAYEN_PREPARE_F32 | RAYEN_PREPARE_F64 | 4 (backward) */
   int32_t bwd_f32;              /* fp32 backward: 0 lane-per-sample kernel | 1 fp32 MFMA kernel (NA_E = I, dense forms) | 2 fp32
                                    MFMA kernel, general shapes | 3 f16-pair kernel (packed low-rank quadratics, n <= 32; accepted
-                                   by a creation-time measurement like the forward's) | 4 the four-lanes-per-sample LMI kernel */
+                                   by a creation-time measurement like the forward's) | 4 the four-lanes-per-sample LMI kernel | 5 the
+                                   wave-per-sample LMI kernel (matrices the lane kernels cannot hold) */
   double fp32_check_split;      /* worst row error (relative to the row's size) against fp64 on the creation-time probe */
   double fp32_check_exact;      /* directions: bf16-triple kernel, exact-fp32 kernel, */
   double fp32_check_pair;       /* f16-pair kernel; -1 = not measured */
