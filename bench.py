@@ -44,7 +44,9 @@ PEAK_BF16_TFLOPS = 2516.8  # dense bf16 MFMA = 16 x the fp32 MFMA rate (same gui
 PEAK_FP64_TFLOPS = 78.6    # MI355X datasheet: FP64 vector = FP64 matrix (v_mfma_f64_16x16x4_f64)
 PEAK_HBM_GBS = 8000.0      # HBM3E spec (≈6.3 TB/s achievable)
 GRAPH_STEPS = 50          # steps captured per HIP graph when the step is launch-bound
-SETTLE_LAUNCHES = 150      # untimed launches before the warm-up: the clocks of a cold device settle after ~100
+SETTLE_LAUNCHES = 150      # untimed launches before the warm-up, at least; and at least SETTLE_SECONDS of them:
+SETTLE_SECONDS = float(os.environ.get("RAYEN_BENCH_SETTLE_S", "0.12"))   # the clocks of a cold device settle after ~60 ms
+                           # of load (measured: a 20-step run reads 0.0655 ms behind 10 ms of launches, 0.0620 behind 60 ms)
 
 
 def parse(argv=None):
@@ -286,8 +288,13 @@ def main():
 
     _note(f"{args.config} {args.dtype} B={B} per GPU, world {world}, graph={graph}, gather={gather}")
     with torch.no_grad():
-        for _ in range(SETTLE_LAUNCHES):         # clocks settle; not part of W or K
-            module_step(x)
+        t_settle = time.perf_counter()
+        n_settle = 0
+        while n_settle < SETTLE_LAUNCHES or time.perf_counter() - t_settle < SETTLE_SECONDS:   # clocks settle; not part of W or K
+            for _ in range(50):
+                module_step(x)
+            n_settle += 50
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     _note("settled; timing the projection")
     # ---- the projection alone (the whole step at N = 1)
