@@ -499,7 +499,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_iof
     const MPack* __restrict__ packs, const float* __restrict__ y0, int k, int n,
     const float* __restrict__ v, int64_t B, float* __restrict__ y,
     float* __restrict__ kappa_out, int32_t* __restrict__ active_out,
-    int32_t* __restrict__ nan_flag, const float w_scale, const float w_inv, const int buf_bytes) {
+    int32_t* __restrict__ nan_flag, const float w_scale, const float w_inv, const int buf_bytes, const int first_out) {
   constexpr int NT = 2, NS = 2, NCH = 4, KK = 16, NQ = 4, AUXR = 32;
   extern __shared__ __attribute__((aligned(1024))) char iof_smem[];
   const int lane = threadIdx.x & 63;
@@ -666,7 +666,8 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_iof
       f32x16 acc[NT];
       for (int it = 0; it < n_items; ++it) {
         const MItem item = items[it];
-        if (STAGED && item.type == MI_OUT && (item.flags & MF_FIRST)) {
+        // (the index, not the descriptor: the scalar loads of `item` then wait behind the MFMA burst instead of in front of it)
+        if (STAGED && it == first_out) {
           // kappa is final; the rows of v(next) leave the buffer (the DMAs that brought them were issued in the first
           // tiles of this walk: the counted waits of the tiles since have stepped over them), y(prev) left it long ago
           finish_kappa();
@@ -966,7 +967,8 @@ static int launch_pair_iof_one(const RayenPack* p, const PairImage* img, const f
   const int lds = pair_iof_lds_bytes(p);
   hipLaunchKernelGGL((mfma_pair_iof_kernel<TRACK, STAGED>), dim3(grid), dim3(kMfmaWaves * 64), lds, stream,
                      static_cast<const f16x8*>(img->Wh), img->items, img->n_items, img->packs, img->y0, p->k, p->n, v, B,
-                     y, kappa, active, nan_flag, img->w_scale, img->w_inv, pair_iof_buf_bytes(p));
+                     y, kappa, active, nan_flag, img->w_scale, img->w_inv, pair_iof_buf_bytes(p),
+                     img->identity ? img->n_items : img->first_out);
   return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
 }
 

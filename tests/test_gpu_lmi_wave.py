@@ -64,7 +64,7 @@ def test_large_lmi_forward_and_backward(name, dtype):
     cs, layer = _layer(raw, dtype)
     dp, _ = layer.device_pack(torch.device("cuda", 0))
     gen = torch.Generator().manual_seed(6)
-    B = 300 if r <= 64 else 96
+    B = 300 if r <= 48 else (128 if r <= 64 else 48)          # (the fp64 oracle's eigvalsh + autograd on the CPU sets the pace)
     x = torch.empty(B, cs.n).uniform_(-2.0, 2.0, generator=gen)
     x[:2] *= 1e-4                                             # interior
     x[2] = 0.0
