@@ -509,15 +509,16 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_iof
   char* const io = io_all + wave * buf_bytes;
   float* const io_f = reinterpret_cast<float*>(io);
   char* const sink = io_all + kMfmaWaves * buf_bytes;
-  float* const y0_lds = reinterpret_cast<float*>(sink + 256);   // [32] (identity write-out)
+  float* const y0_lds = reinterpret_cast<float*>(sink + 256);   // [32] (identity write-out) | [96] (NA_E tiles: k <= 64, padded)
   const int col = lane & 31;
   const int hi = lane >> 5;
   const int64_t n_groups = (B + NT * 32 - 1) / (NT * 32);
   const int64_t wave_id = (int64_t)blockIdx.x * kMfmaWaves + wave;
   const int64_t wave_stride = (int64_t)gridDim.x * kMfmaWaves;
   bool bad = false;
-  if (!STAGED)
-    for (int i = threadIdx.x; i < 32; i += kMfmaWaves * 64) y0_lds[i] = y0[i];   // (y0 is zero-padded)
+  // (y0 is zero-padded to a tile multiple + 32.  In LDS for the NA_E tiles too: a global read of y0 inside the walk makes
+  // hipcc wait with vmcnt(0), which drains the trickled rows and the A prefetch -- twice per group on config 5)
+  for (int i = threadIdx.x; i < (STAGED ? 96 : 32); i += kMfmaWaves * 64) y0_lds[i] = (!STAGED || i < ((k + 31) / 32) * 32 + 32) ? y0[i] : 0.f;
   __syncthreads();  // the only workgroup barrier
 
   const unsigned io_addr = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(io));
@@ -811,7 +812,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_iof
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
               const int r = (g & 3) + 8 * (g >> 2);
-              const float o = fmaf(acc[t][g], scale[t], y0[item.row0 + 4 * hi + r]);  // y0 is padded to a tile multiple
+              const float o = fmaf(acc[t][g], scale[t], y0_lds[item.row0 + 4 * hi + r]);  // (padded to a tile multiple)
               if (item.row0 + 4 * hi + r < k) {
                 bad |= live[t] && (o != o);
                 yrow[r] = o;
@@ -903,7 +904,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_iof
 // ---------------------------------------------------------------------------------------------
 static int pair_iof_buf_bytes(const RayenPack* p) { return ((p->n > p->k ? p->n : p->k) * 256 + 255) / 256 * 256; }
 static int pair_iof_lds_bytes(const RayenPack* p) {
-  return kMfmaWaves * 2 * 32 * 32 * 4 + kMfmaWaves * pair_iof_buf_bytes(p) + 256 + 128;
+  return kMfmaWaves * 2 * 32 * 32 * 4 + kMfmaWaves * pair_iof_buf_bytes(p) + 256 + 384;
 }
 
 // 0 = not served | 1 = rows at any 16-byte aligned stride, n = k = 32 NKK exactly (mfma_pair_io_kernel) |
