@@ -46,13 +46,14 @@ template <> GenericImage<double>& image_of<double>(const RayenPack* p) { return 
 // which kernel family served this thread's most recent forward call (rayen_last_forward_kernel)
 thread_local int g_last_forward = RAYEN_KERNEL_NONE;
 
-// Schedules of the f16-pair forward (same arithmetic): 1 (default) = rows of v and y trickled through LDS under the tile
-// walk (rayen_mfma_pair_io.hip) where the call's shape allows it | 0 = rayen_mfma_pair.hip always.  RAYEN_PAIR_IO /
-// rayen_pair_schedule select (A/B runs).
+// Schedules of the f16-pair forward (same arithmetic): 2 (default) = W-stationary (rayen_mfma_pair_ws.hip) where the pack
+// and the call's shape allow it, else as 1 | 1 = rows of v and y trickled through LDS under the tile walk
+// (rayen_mfma_pair_io.hip) where allowed | 0 = rayen_mfma_pair.hip always.  RAYEN_PAIR_IO / rayen_pair_schedule select
+// (A/B runs).
 std::atomic<int>& pair_schedule_cell() {
   static std::atomic<int> mode([] {
     const char* e = std::getenv("RAYEN_PAIR_IO");
-    return (e != nullptr && e[0] >= '0' && e[0] <= '1') ? e[0] - '0' : 1;
+    return (e != nullptr && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;   // (2 once it is the faster one)
   }());
   return mode;
 }
@@ -128,6 +129,7 @@ int build_images(RayenPack* p, int prepare) {
       if ((rc = build_one(p, split_ok && mode != 3, &p->sp32, mfma_split_build))) return rc;
       if ((rc = build_one(p, split_ok && (mode == 0 || mode == 3), &p->pr32, mfma_pair_build))) return rc;
       if (p->pr32 != nullptr && (rc = mfma_pair_io_prepare(p, p->pr32))) return rc;
+      if (p->pr32 != nullptr && (rc = mfma_pair_ws_build(p, p->pr32, &p->ws32))) return rc;
     }
     if ((rc = build_one(p, lmi_quad_eligible_f32(p), &p->q32, lmi_quad_build_f32))) return rc;
     // (the wave-per-sample LMI kernels take what neither the quad kernel nor the lane kernels hold: matrices beyond ~30 x 30)
@@ -247,7 +249,7 @@ int rayen_reserve_cus(int cus) {
 }
 
 int rayen_pair_schedule(int mode) {
-  if (mode >= 0 && mode <= 1) return pair_schedule_cell().exchange(mode, std::memory_order_relaxed);
+  if (mode >= 0 && mode <= 2) return pair_schedule_cell().exchange(mode, std::memory_order_relaxed);
   return pair_schedule();
 }
 
@@ -604,6 +606,7 @@ void rayen_pack_destroy(RayenPack* p) {
   if (p->mbg64) mfma64_bwdg_free(p->mbg64);
   if (p->sp32) mfma_split_free(p->sp32);
   if (p->pr32) mfma_pair_free(p->pr32);
+  if (p->ws32) mfma_pair_ws_free(p->ws32);
   if (p->q32) lmi_quad_free(p->q32);
   if (p->w32) lmi_wave_free(p->w32);
   if (p->w64) lmi_wave_free(p->w64);
@@ -659,6 +662,10 @@ static int project_f32(const RayenPack* p, const float* v, int64_t B, int64_t ld
   const int rc = check_ready<float>(p, false);
   if (rc) return rc;
   if (p->pr32 != nullptr && p->pr32_state == 1 && y != nullptr && !old_mode) {
+    if (pair_schedule() >= 2 && mfma_pair_ws_serves(p, p->pr32, p->ws32, v, B, ldv, y, ldy, active)) {
+      g_last_forward = RAYEN_KERNEL_PAIR_WS;
+      return mfma_pair_ws_forward(p, p->pr32, p->ws32, v, B, ldv, y, ldy, kappa, active, nan_flag, static_cast<hipStream_t>(stream));
+    }
     if (pair_schedule() >= 1 && mfma_pair_io_serves(p, p->pr32, v, B, ldv, y, ldy)) {
       g_last_forward = RAYEN_KERNEL_PAIR_IO;
       return mfma_pair_io_forward(p, p->pr32, v, B, ldv, y, ldy, kappa, active, nan_flag, static_cast<hipStream_t>(stream));

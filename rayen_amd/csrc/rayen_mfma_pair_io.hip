@@ -357,21 +357,8 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_io_
               if (item.type != MI_SOC) {
                 kc = (a0 + __builtin_amdgcn_sqrtf(fmaxf(total, 0.f))) * item.seg_inv;   // (the segment's own power of two undone)
               } else {
-                // a' x^2 + b' x + c' = 0  (rayen/constraint_module.py:392-396, 339-348), a' < 0: natural units here
-                // (the coefficients mix in the set's constants f0 = tau, f1 = a'), the root goes back to the scaled domain
-                const float vi = v_inv[t], wi = w_inv * item.seg_inv;
-                const float cr = (a0 * wi) * vi;
-                const float br = (aux_lds[wave][t][item.aux + 1][col] * wi) * vi;
-                const float rt = (__builtin_amdgcn_sqrtf(total) * wi) * vi;
-                const float cp = rt * rt - cr * cr;
-                const float bp = 2.f * br - 2.f * cr * item.f0;
-                const float disc = bp * bp - 4.f * item.f1 * cp;
-                kc = 0.f;
-                if (disc >= 0.f) {
-                  const float root = __builtin_amdgcn_sqrtf(disc);
-                  const float inv2a = 0.5f * __builtin_amdgcn_rcpf(item.f1);
-                  kc = (fmaxf((-bp - root) * inv2a, (-bp + root) * inv2a) * v_scl[t]) * w_scale;
-                }
+                kc = pair_soc_candidate(a0, aux_lds[wave][t][item.aux + 1][col], total, w_inv * item.seg_inv, v_inv[t],
+                                        item.f0, item.f1, v_scl[t], w_scale);
               }
               if (kc > kap[t]) { kap[t] = kc; acode[t] = item.seg << 20; }
             }
@@ -762,20 +749,8 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_iof
               if (item.type != MI_SOC) {
                 kc = (a0 + __builtin_amdgcn_sqrtf(fmaxf(total, 0.f))) * item.seg_inv;   // (the segment's own power of two undone)
               } else {
-                // a' x^2 + b' x + c' = 0  (rayen/constraint_module.py:392-396, 339-348), a' < 0: natural units here
-                const float vi = v_inv[t], wi = w_inv * item.seg_inv;
-                const float cr = (a0 * wi) * vi;
-                const float br = (aux_lds[t][item.aux + 1][col] * wi) * vi;
-                const float rt = (__builtin_amdgcn_sqrtf(total) * wi) * vi;
-                const float cp = rt * rt - cr * cr;
-                const float bp = 2.f * br - 2.f * cr * item.f0;
-                const float disc = bp * bp - 4.f * item.f1 * cp;
-                kc = 0.f;
-                if (disc >= 0.f) {
-                  const float root = __builtin_amdgcn_sqrtf(disc);
-                  const float inv2a = 0.5f * __builtin_amdgcn_rcpf(item.f1);
-                  kc = (fmaxf((-bp - root) * inv2a, (-bp + root) * inv2a) * v_scl[t]) * w_scale;
-                }
+                kc = pair_soc_candidate(a0, aux_lds[t][item.aux + 1][col], total, w_inv * item.seg_inv, v_inv[t], item.f0,
+                                        item.f1, v_scl[t], w_scale);
               }
               if (kc > kap[t]) { kap[t] = kc; acode[t] = item.seg << 20; }
             }

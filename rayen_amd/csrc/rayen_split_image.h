@@ -37,6 +37,31 @@ __device__ __forceinline__ void pow2_scale(const float m, float& scale, float& i
   exp_scale = 140 - (int)e;
 }
 
+// kappa candidate of a second-order cone from the walk's scaled quantities (f16-pair kernels): a' x^2 + b' x + c' = 0
+// (rayen/constraint_module.py:392-396, 339-348), a' < 0.  The coefficients mix in the set's constants f0 = tau,
+// f1 = a', so they are formed in natural units (wi = 1 / (gW f_s), vi = 1 / sv) and the root goes back to the scaled
+// domain.  ONE definition for every schedule of the pair forward, with floating-point contraction off: the schedules
+// must agree bit for bit, and which of `rt*rt - cr*cr`'s products hipcc fuses depends on the code around it (the
+// W-stationary kernel differed from the plain one by one ulp on 1 row in 30 000 until this was shared).
+__device__ __forceinline__ float pair_soc_candidate(const float a0, const float a1, const float total, const float wi,
+                                                    const float vi, const float f0, const float f1, const float v_scl,
+                                                    const float w_scale) {
+#pragma clang fp contract(off)
+  const float cr = (a0 * wi) * vi;
+  const float br = (a1 * wi) * vi;
+  const float rt = (__builtin_amdgcn_sqrtf(total) * wi) * vi;
+  const float cp = rt * rt - cr * cr;
+  const float bp = 2.f * br - 2.f * cr * f0;
+  const float disc = bp * bp - 4.f * f1 * cp;
+  float kc = 0.f;
+  if (disc >= 0.f) {
+    const float root = __builtin_amdgcn_sqrtf(disc);
+    const float inv2a = 0.5f * __builtin_amdgcn_rcpf(f1);
+    kc = (fmaxf((-bp - root) * inv2a, (-bp + root) * inv2a) * v_scl) * w_scale;
+  }
+  return kc;
+}
+
 struct SplitImage {
   void* Wb = nullptr;      // [n_tiles][NS][3][64] x 8 bf16
   MItem* items = nullptr;
@@ -63,6 +88,7 @@ struct PairImage {
   int aux_rows = 0;        // aux rows (phi | c, M'beta) of the whole set
   int first_out = 0;       // index of the first NA_E tile in the item list (n_items when NA_E = I)
   int64_t bytes = 0;
+  std::vector<MItem> host_items;   // the item list as uploaded (rayen_mfma_pair_ws.hip deals it out to four waves)
 };
 
 }  // namespace rayen
