@@ -153,6 +153,18 @@ __device__ __forceinline__ const char* ws_uniform(const void* p) {
 
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
+// x of this lane and of lane ^ 32, as (value of the lower half-wave's lane, value of the upper one's) in every lane:
+// v_permlane32_swap exchanges the upper half of its first operand with the lower half of its second (gfx950; measured in
+// scripts/ubench/permlane32.hip -- through the builtin this hipcc gets it wrong) -- one VALU instruction
+// where xhalf() is a round trip through the LDS crossbar, which a kernel at one wave per SIMD has nothing to hide under.
+// (lo op hi) equals (x op xhalf(x)) bit for bit for a commutative op.
+__device__ __forceinline__ void ws_halves(const float x, float& lo, float& hi) {
+  lo = x;
+  hi = x;
+  // (two wait states: the copies above are VALU writes right in front, and hipcc pads nothing inside a statement)
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+}
+
 }  // namespace
 
 template <int NKK, int TPW, bool TRACK>
@@ -232,7 +244,7 @@ __global__ __launch_bounds__(kWsWaves * 64) __attribute__((amdgpu_num_vgpr(kWsNu
     }
   };
 
-  // ---- publish: rows(g+1) -> scaled f16 pairs -> image, as fourteen chunks of a few instructions (P0 .. P13).
+  // ---- publish: rows(g+1) -> scaled f16 pairs -> image, as sixteen chunks of a few instructions (P0 .. P15).
   // sv = 2^(13 - floor(log2 max|v|)): exponent arithmetic only (rayen_mfma_pair.hip)
   f32x4 raw[4];
   float pub_m = 0.f, pub_sv = 1.f;
@@ -247,29 +259,29 @@ __global__ __launch_bounds__(kWsWaves * 64) __attribute__((amdgpu_num_vgpr(kWsNu
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
       for (int i = 0; i < 4; ++i) raw[i] = *reinterpret_cast<const f32x4*>(&rows_lds[buf][qr][4 * ((4 * qq + i) ^ qx)]);
-    } else if constexpr (k == 2 || k == 3) {
-      float m = k == 2 ? 0.f : pub_m;    // (fmaxf drops NaNs: a NaN row keeps a finite scale and stays NaN, as in rayen_mfma_pair.hip)
+    } else if constexpr (k == 4 || k == 5) {
+      float m = k == 4 ? 0.f : pub_m;    // (fmaxf drops NaNs: a NaN row keeps a finite scale and stays NaN, as in rayen_mfma_pair.hip)
 #pragma unroll
-      for (int i = 2 * (k - 2); i < 2 * (k - 2) + 2; ++i)
+      for (int i = 2 * (k - 4); i < 2 * (k - 4) + 2; ++i)
 #pragma unroll
         for (int c = 0; c < 4; ++c) m = fmaxf(m, __builtin_fabsf(raw[i][c]));
       pub_m = m;
       asm volatile("" : : "v"(pub_m));
-    } else if constexpr (k == 4) {
+    } else if constexpr (k == 6) {
       float m = pub_m;
       m = fmaxf(m, dpp_xor1(m));
       m = fmaxf(m, dpp_xor2(m));
       pub_m = m;
       asm volatile("" : : "v"(pub_m));
-    } else if constexpr (k == 5) {
+    } else if constexpr (k == 7) {
       float inv;
       int sv_exp;
       pow2_scale(pub_m, pub_sv, inv, sv_exp);
       sc_lds[gen][0][qr] = pub_sv;       // (the four lanes of a row store the same two words)
       sc_lds[gen][1][qr] = inv;
-    } else if constexpr (k >= 6 && k < 14) {
+    } else if constexpr (k >= 8 && k < 16) {
       // pieces in the order 0, 2 (lane (col, 0)'s operand), 1, 3 (lane (col, 1)'s); two elements per chunk
-      constexpr int pi = (k - 6) >> 1, i = pi == 0 ? 0 : pi == 1 ? 2 : pi == 2 ? 1 : 3, e = 2 * ((k - 6) & 1);
+      constexpr int pi = (k - 8) >> 1, i = pi == 0 ? 0 : pi == 1 ? 2 : pi == 2 ? 1 : 3, e = 2 * ((k - 8) & 1);
       f16x2 h, l;
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
@@ -291,13 +303,13 @@ __global__ __launch_bounds__(kWsWaves * 64) __attribute__((amdgpu_num_vgpr(kWsNu
       }
     }
   };
-  constexpr int NP = 14;
+  constexpr int NP = 16;      // (P1..P3 are empty: the LDS reads of P0 are used three slots later)
 
   // ---- write-out: y = y0 + v / max(1, kappa) for the rows of the previous group, v rebuilt from the image (22 bits;
-  // scaled by sv), staged through rows_lds and stored as whole lines: twenty chunks (W0 .. W19)
+  // scaled by sv), staged through rows_lds and stored as whole lines: twenty-three chunks (W0 .. W22)
   float wo_k[kWsWaves], wo_inv = 1.f, wo_scale = 1.f, wo_knat = 0.f, wo_den = 1.f, nan_acc = 0.f;
   f16x8 wo_fh[2], wo_fl[2];
-  f32x4 wo_y0[4], wo_o, wo_back[2];
+  f32x4 wo_y0[4], wo_o, wo_back[4];
   auto wout_item = [&](auto FULL, auto K, const int64_t grp, const int gen, const int par, const int buf) {
     constexpr int k = decltype(K)::value;
     // operand (col, hh) of K-step q = pieces hh and hh + 2; y0 of piece i
@@ -308,39 +320,44 @@ __global__ __launch_bounds__(kWsWaves * 64) __attribute__((amdgpu_num_vgpr(kWsNu
     };
     auto read_y0 = [&](auto I) { wo_y0[decltype(I)::value] = *reinterpret_cast<const f32x4*>(&y0_lds[4 * (4 * qq + decltype(I)::value)]); };
     auto read_back = [&](auto J) {
-      wo_back[decltype(J)::value & 1] = *reinterpret_cast<const f32x4*>(&rows_lds[buf][16 * wave + 4 * decltype(J)::value][4 * lane]);
+      wo_back[decltype(J)::value] = *reinterpret_cast<const f32x4*>(&rows_lds[buf][16 * wave + 4 * decltype(J)::value][4 * lane]);
     };
     auto store_back = [&](auto J) {
       constexpr int j = decltype(J)::value;
       if constexpr ((RAYEN_WS_ABL & 2) != 0) return;
       const int64_t s0 = grp * 64 + 16 * wave + 4 * j;
       char* yb = const_cast<char*>(ws_uniform(y + s0 * ldy));
-      if (decltype(FULL)::value || s0 + lr < B) __builtin_nontemporal_store(wo_back[j & 1], reinterpret_cast<f32x4*>(yb + line_y));
+      if (decltype(FULL)::value || s0 + lr < B) __builtin_nontemporal_store(wo_back[j], reinterpret_cast<f32x4*>(yb + line_y));
     };
+    // every LDS read is issued three or more slots (100+ cycles) ahead of its first use: at one wave per SIMD a wait is
+    // a hole in the MFMA stream
     if constexpr (k == 0) {
 #pragma unroll
       for (int w = 0; w < kWsWaves; ++w) wo_k[w] = kap_lds[par][w][qr];
       wo_inv = sc_lds[gen][1][qr];
+    } else if constexpr (k == 1) {
+      read_frag(ic<0>{});
+      read_y0(ic<0>{});
     } else if constexpr (k == 2) {
+      read_frag(ic<1>{});
+      read_y0(ic<2>{});
+    } else if constexpr (k == 3) {
+      read_y0(ic<1>{});
+      read_y0(ic<3>{});
+    } else if constexpr (k == 4) {
       float kap = wo_k[0];
 #pragma unroll
       for (int w = 1; w < kWsWaves; ++w) kap = fmaxf(kap, wo_k[w]);
       wo_knat = (kap * w_inv) * wo_inv;
       wo_den = fmaxf(1.0f, wo_knat);
       asm volatile("" : : "v"(wo_den), "v"(wo_knat));
-    } else if constexpr (k == 3) {
+    } else if constexpr (k == 5) {
       wo_scale = wo_inv * (1.0f / wo_den);
       asm volatile("" : : "v"(wo_scale));
-    } else if constexpr (k == 4) {
-      read_frag(ic<0>{});
-      read_y0(ic<0>{});
     } else if constexpr (k >= 6 && k < 14) {
-      // pieces in the order 0, 2, 1, 3 (as published); two elements per chunk; what the next pieces need is read ahead
+      // pieces in the order 0, 2, 1, 3 (as published); two elements per chunk
       constexpr int pi = (k - 6) >> 1, i = pi == 0 ? 0 : pi == 1 ? 2 : pi == 2 ? 1 : 3, e = 2 * ((k - 6) & 1);
       constexpr int hh = i & 1, off = 4 * (i >> 1);
-      if constexpr (k == 6) read_y0(ic<2>{});
-      if constexpr (k == 8) { read_frag(ic<1>{}); read_y0(ic<1>{}); }
-      if constexpr (k == 10) read_y0(ic<3>{});
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         const float val = (float)wo_fh[hh][off + e + c] + (float)wo_fl[hh][off + e + c];
@@ -351,24 +368,25 @@ __global__ __launch_bounds__(kWsWaves * 64) __attribute__((amdgpu_num_vgpr(kWsNu
       nan_acc = fmaf(wo_o[e], 0.f, fmaf(wo_o[e + 1], 0.f, nan_acc));
       if constexpr (e == 2) *reinterpret_cast<f32x4*>(&rows_lds[buf][qr][4 * ((4 * qq + i) ^ qx)]) = wo_o;
       else asm volatile("" : : "v"(wo_o), "v"(nan_acc));
-    } else if constexpr (k == 15) {
+    } else if constexpr (k == 17) {
       read_back(ic<0>{});
       read_back(ic<1>{});
-    } else if constexpr (k == 17) {
-      store_back(ic<0>{});
-      store_back(ic<1>{});
+    } else if constexpr (k == 18) {
       read_back(ic<2>{});
       read_back(ic<3>{});
+    } else if constexpr (k == 21) {
+      store_back(ic<0>{});
+      store_back(ic<1>{});
       if (kappa_out != nullptr && !(RAYEN_WS_ABL & 256)) {
         const int64_t s = grp * 64 + qr;
         if (qq == 0 && (decltype(FULL)::value || s < B)) kappa_out[s] = wo_knat;
       }
-    } else if constexpr (k == 19) {
+    } else if constexpr (k == 22) {
       store_back(ic<2>{});
       store_back(ic<3>{});
     }
   };
-  constexpr int NW = 20;
+  constexpr int NW = 23;
 
   // vb[t][piece][k-step] = 8 f16 = the B operand of one MFMA; element i = column 16 sp + 8 (i >> 2) + 4 hi + (i & 3)
   f16x8 vb[NT][2][NS];
@@ -390,6 +408,25 @@ __global__ __launch_bounds__(kWsWaves * 64) __attribute__((amdgpu_num_vgpr(kWsNu
     } else if constexpr (kind == MI_QFAC || kind == MI_SOC) {
       // a running sum of squares over the segment's tiles (even registers into s0, odd ones into s1: the two lanes of
       // rayen_mfma_pair.hip's packed FMA), closed on its last tile
+      if constexpr (c == 0) {
+        if (item.flags & MF_LAST) {
+          // what the closers need of the aux tile and the samples' scales: read here, used behind chunk 8.
+          // (the item's constants are made opaque where they are used: hipcc otherwise hoists what it derives from
+          // them -- LDS addresses of the aux rows, 1 / (2 a'), 4 a', w_inv / f_s of EVERY tile of the wave -- out of the
+          // loop into ~30 VGPRs this kernel does not have)
+          int aux = item.aux();
+          asm volatile("" : "+s"(aux));
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            ep_a0[t] = aux_lds[par][t][aux][col];
+            if constexpr (kind == MI_SOC) {
+              ep_a1[t] = aux_lds[par][t][aux + 1][col];
+              ep_vi[t] = sc_lds[gen][1][32 * t + col];
+              ep_vs[t] = sc_lds[gen][0][32 * t + col];
+            }
+          }
+        }
+      }
       if constexpr (c < 8) {
         constexpr int t = c >> 2, r = abase + 16 * t + 4 * (c & 3);
         if constexpr ((c & 3) == 0) {
@@ -403,27 +440,18 @@ __global__ __launch_bounds__(kWsWaves * 64) __attribute__((amdgpu_num_vgpr(kWsNu
         asm volatile("v_add_f32 %0, v[%c2], v[%c3]\n\tv_add_f32 %1, v[%c4], v[%c5]"
                      : "=v"(part[0]), "=v"(part[1]) : "i"(kWsS0), "i"(kWsS1), "i"(kWsS0 + 1), "i"(kWsS1 + 1));
         if (item.flags & MF_LAST) {
-          // (the item's constants are made opaque where they are used: hipcc otherwise hoists what it derives from
-          // them -- LDS addresses of the aux rows, 1 / (2 a'), 4 a', w_inv / f_s of EVERY tile of the wave -- out of the
-          // loop into ~30 VGPRs this kernel does not have)
-          int aux = item.aux();
-          asm volatile("" : "+s"(aux));
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
-            ep_oth[t] = xhalf(part[t]);
-            ep_a0[t] = aux_lds[par][t][aux][col];
-            if constexpr (kind == MI_SOC) {
-              ep_a1[t] = aux_lds[par][t][aux + 1][col];
-              ep_vi[t] = sc_lds[gen][1][32 * t + col];
-              ep_vs[t] = sc_lds[gen][0][32 * t + col];
-            }
+            float lo, hi2;
+            ws_halves(part[t], lo, hi2);
+            ep_oth[t] = lo + hi2;          // = part + xhalf(part), bit for bit
           }
         }
       } else if constexpr (c == 10 || c == 11) {
         // (one sample tile per chunk: a cone's closed form is ~30 instructions)
         constexpr int t = c - 10;
         if (item.flags & MF_LAST) {
-          const float total = part[t] + ep_oth[t];
+          const float total = ep_oth[t];
           float seg_inv = item.seg_inv, f0 = item.f0, f1 = item.f1;
           asm volatile("" : "+s"(seg_inv), "+s"(f0), "+s"(f1));
           float kc;
@@ -584,8 +612,11 @@ __global__ __launch_bounds__(kWsWaves * 64) __attribute__((amdgpu_num_vgpr(kWsNu
       stamp(1 + TPW);
       float k0, k1;
       asm volatile("v_mov_b32 %0, v[%c2]\n\tv_mov_b32 %1, v[%c3]" : "=v"(k0), "=v"(k1) : "i"(kWsKap), "i"(kWsKap + 1));
-      kap_lds[par][wave][col] = fmaxf(k0, xhalf(k0));            // (both half-waves store the same word)
-      kap_lds[par][wave][32 + col] = fmaxf(k1, xhalf(k1));
+      float k0l, k0h, k1l, k1h;
+      ws_halves(k0, k0l, k0h);
+      ws_halves(k1, k1l, k1h);
+      kap_lds[par][wave][col] = fmaxf(k0l, k0h);            // (both half-waves store the same word)
+      kap_lds[par][wave][32 + col] = fmaxf(k1l, k1h);
       reset_kappa();
       stamp(2 + TPW);
     }
