@@ -100,6 +100,12 @@ __device__ __forceinline__ float dpp_xor2(float m) {
 #ifndef RAYEN_WS_ABL
 #define RAYEN_WS_ABL 0
 #endif
+// workgroup b starts (b & 7) * RAYEN_WS_STAGGER * 64 cycles late: the workgroups run the same schedule from the same
+// start, so that the row requests and row stores of all 256 CUs would reach the memory system in the same few hundred
+// cycles of every iteration (4 MB bursts each way, the vector-memory queues full, the issuing waves stalled)
+#ifndef RAYEN_WS_STAGGER
+#define RAYEN_WS_STAGGER 16
+#endif
 constexpr int kWsAcc0 = 192;
 constexpr int kWsNumVgpr = 184;
 constexpr int kWsKap = 184, kWsS0 = 186, kWsS1 = 188;     // + sample tile
@@ -225,12 +231,12 @@ __global__ __launch_bounds__(kWsWaves * 64) __attribute__((amdgpu_num_vgpr(kWsNu
   const unsigned rows_addr = (unsigned)reinterpret_cast<uintptr_t>(&rows_lds[0][0][0]);
   const unsigned line_v = (unsigned)(lr * ldv * 4 + lpiece * 16), line_y = (unsigned)(lr * ldy * 4 + lpiece * 16);   // (ld <= 2^22: host)
 
-  // rows of group `grp` -> rows_lds[buf] (this wave's sixteen): instructions j0, j0 + 1.  FULL: every row of the group
+  // rows of group `grp` -> rows_lds[buf] (this wave's sixteen): instructions j0 .. j0 + nj - 1.  FULL: every row of the group
   // exists; else rows beyond the batch fetch the batch's last row (their results are never stored)
-  auto dma_rows = [&](auto FULL, const int64_t grp, const int buf, const int j0) {
+  auto dma_rows = [&](auto FULL, const int64_t grp, const int buf, const int j0, const int nj) {
     if constexpr ((RAYEN_WS_ABL & 1) != 0) return;
 #pragma unroll
-    for (int j = j0; j < j0 + 2; ++j) {
+    for (int j = j0; j < j0 + nj; ++j) {
       const int64_t s0 = grp * 64 + 16 * wave + 4 * j;
       const unsigned lds = rows_addr + (unsigned)(buf * 16384 + (16 * wave + 4 * j) * 256);
       if constexpr (decltype(FULL)::value) {
@@ -306,7 +312,7 @@ __global__ __launch_bounds__(kWsWaves * 64) __attribute__((amdgpu_num_vgpr(kWsNu
   constexpr int NP = 16;      // (P1..P3 are empty: the LDS reads of P0 are used three slots later)
 
   // ---- write-out: y = y0 + v / max(1, kappa) for the rows of the previous group, v rebuilt from the image (22 bits;
-  // scaled by sv), staged through rows_lds and stored as whole lines: twenty-three chunks (W0 .. W22)
+  // scaled by sv), staged through rows_lds and stored as whole lines: twenty-eight chunks (W0 .. W27; the four row stores two slots apart)
   float wo_k[kWsWaves], wo_inv = 1.f, wo_scale = 1.f, wo_knat = 0.f, wo_den = 1.f, nan_acc = 0.f;
   f16x8 wo_fh[2], wo_fl[2];
   f32x4 wo_y0[4], wo_o, wo_back[4];
@@ -376,17 +382,19 @@ __global__ __launch_bounds__(kWsWaves * 64) __attribute__((amdgpu_num_vgpr(kWsNu
       read_back(ic<3>{});
     } else if constexpr (k == 21) {
       store_back(ic<0>{});
-      store_back(ic<1>{});
       if (kappa_out != nullptr && !(RAYEN_WS_ABL & 256)) {
         const int64_t s = grp * 64 + qr;
         if (qq == 0 && (decltype(FULL)::value || s < B)) kappa_out[s] = wo_knat;
       }
-    } else if constexpr (k == 22) {
+    } else if constexpr (k == 23) {
+      store_back(ic<1>{});
+    } else if constexpr (k == 25) {
       store_back(ic<2>{});
+    } else if constexpr (k == 27) {
       store_back(ic<3>{});
     }
   };
-  constexpr int NW = 23;
+  constexpr int NW = 28;
 
   // vb[t][piece][k-step] = 8 f16 = the B operand of one MFMA; element i = column 16 sp + 8 (i >> 2) + 4 hi + (i & 3)
   f16x8 vb[NT][2][NS];
@@ -521,7 +529,7 @@ __global__ __launch_bounds__(kWsWaves * 64) __attribute__((amdgpu_num_vgpr(kWsNu
       // structurised control flow).  Everything that does not depend on the kind sits in the other slots, OUTSIDE the
       // switch (whatever a switch arm writes meets the other arms' versions behind it), a few instructions per slot:
       //   stage 0, slots 0..13: rows(g+1) -> image(g+1) (P0..P13)
-      //   stage 2, slots 0, 1: rows(g+2) requested;  slots 14.. and the free slots of the later stages: y(g-1) (W0..W19)
+      //   stage 1, slots 14, 17, 20, 23: rows(g+2) requested;  the free slots of the stages >= 2: y(g-1) (W0..W27)
       //   last stage, slots 16..23: image(g+1) -> B registers as the MFMAs release them (second pieces are dead
       //   behind the first pass, a leading piece behind its second-pass MFMAs)
       // (A tile without rows -- padding of a wave's list -- still issues its MFMAs: a second copy of the stage without
@@ -529,10 +537,10 @@ __global__ __launch_bounds__(kWsWaves * 64) __attribute__((amdgpu_num_vgpr(kWsNu
       auto free_slot = [&](auto SLOT) {
         constexpr int i = decltype(SLOT)::value;
         if constexpr (tt == 0 && i < NP) { if (has_next) publish_item(STEADY, ic<i>{}, (int)((it + 1) & 1), gen_next); }
-        if constexpr (tt == 2 && i < 2) { if (has_next2) dma_rows(STEADY, grp + 2 * gstride, par, 2 * i); }
+        if constexpr (tt == 1 && i >= 14 && (i - 14) % 3 == 0) { if (has_next2) dma_rows(STEADY, grp + 2 * gstride, par, (i - 14) / 3, 1); }
         if constexpr (tt >= 2 && (i < 2 || i >= 14)) {
-          // free slots of the stages >= 2 in order: stage 2 has 14..23 (0 and 1 carry the DMAs), later stages 0, 1, 14..23
-          constexpr int fs = tt == 2 ? i - 14 : 10 + 12 * (tt - 3) + (i < 2 ? i : i - 12);
+          // free slots of the stages >= 2 in order: 0, 1, 14..23 of each
+          constexpr int fs = 12 * (tt - 2) + (i < 2 ? i : i - 12);
           if constexpr (fs >= 0 && fs < NW) { if (has_prev) wout_item(STEADY, ic<fs>{}, grp - gstride, gen_prev, par ^ 1, (int)((it + 1) & 1)); }
         }
         if constexpr (tt == TPW - 1) {
@@ -593,7 +601,7 @@ __global__ __launch_bounds__(kWsWaves * 64) __attribute__((amdgpu_num_vgpr(kWsNu
     });
     // ---- what the free slots could not take (instances with few stages)
     {
-      constexpr int NFS = 10 + 12 * (TPW - 3);      // free slots of the stages >= 2
+      constexpr int NFS = 12 * (TPW - 2);      // free slots of the stages >= 2
       static_for<NW - NFS>([&](auto D) { if (has_prev) wout_item(STEADY, ic<NFS + decltype(D)::value>{}, grp - gstride, gen_prev, par ^ 1, (int)((it + 1) & 1)); });
     }
     // ---- the last tile's epilogue, then this wave's candidates of the group -> LDS
@@ -624,12 +632,14 @@ __global__ __launch_bounds__(kWsWaves * 64) __attribute__((amdgpu_num_vgpr(kWsNu
 
   // ---- the persistent loop over this workgroup's groups
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tiles of W have landed
+  if constexpr (RAYEN_WS_STAGGER > 0) {
+    for (int i = 0; i < (int)(blockIdx.x & 7); ++i) __builtin_amdgcn_s_sleep(RAYEN_WS_STAGGER);
+  }
   if (g0 < n_groups) {
-    dma_rows(std::false_type{}, g0, 0, 0);
-    dma_rows(std::false_type{}, g0, 0, 2);
+    dma_rows(std::false_type{}, g0, 0, 0, 4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     static_for<NP>([&](auto K) { publish_item(std::false_type{}, K, 0, 0); });
-    if (g0 + gstride < n_groups) { dma_rows(std::false_type{}, g0 + gstride, 1, 0); dma_rows(std::false_type{}, g0 + gstride, 1, 2); }
+    if (g0 + gstride < n_groups) dma_rows(std::false_type{}, g0 + gstride, 1, 0, 4);
   }
   __syncthreads();
   if (g0 < n_groups) {
