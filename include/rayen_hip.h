@@ -146,15 +146,15 @@ enum {
   RAYEN_KERNEL_PAIR_IO = 5,   /* f16 pairs, rows of v and y trickled through LDS under the tile walk */
   RAYEN_KERNEL_LMI_QUAD = 6,  /* four lanes per sample (one LMI + linear rows) */
   RAYEN_KERNEL_LMI_WAVE = 7,  /* one wave per sample, the matrix in LDS (one LMI beyond ~30 x 30 + linear rows) */
-  RAYEN_KERNEL_PAIR_WS = 8    /* f16 pairs, W-stationary (ABI v6): the tiles of W resident in the registers of a workgroup's four
+  RAYEN_KERNEL_PAIR_WS = 8    /* f16 pairs, W-stationary (ABI v6): the tiles of W resident in the registers of a workgroup's eight
                                  waves, the batch streamed through a shared B-operand image in LDS */
 };
 int rayen_last_forward_kernel(void);
 
 /* Tuning / A-B switch (ABI v4, process-wide): which SCHEDULE of the f16-pair forward serves the calls whose shape
- * allows it -- 2 (default since ABI v6): the W-stationary kernel, then 1 where it does not serve | 1: rows of v and y
- * trickled through LDS under the tile walk | 0: the plain kernel.  All compute the same values bit for bit.  Initial
- * value from the environment variable RAYEN_PAIR_IO.  mode outside 0..2 only queries.  Returns the previous setting. */
+ * allows it -- 1 (default): rows of v and y trickled through LDS under the tile walk | 0: the plain kernel | 2 (ABI v6):
+ * the W-stationary kernel where it serves, else as 1.  All compute the same values bit for bit.  Initial value from the
+ * environment variable RAYEN_PAIR_IO.  mode outside 0..2 only queries.  Returns the previous setting. */
 int rayen_pair_schedule(int mode);
 
 /* Multi-GPU step (ABI v4, process-wide): leave `cus` compute units out of the persistent grids of the projection

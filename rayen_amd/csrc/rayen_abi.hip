@@ -46,10 +46,10 @@ template <> GenericImage<double>& image_of<double>(const RayenPack* p) { return 
 // which kernel family served this thread's most recent forward call (rayen_last_forward_kernel)
 thread_local int g_last_forward = RAYEN_KERNEL_NONE;
 
-// Schedules of the f16-pair forward (same arithmetic): 2 (default) = W-stationary (rayen_mfma_pair_ws.hip) where the pack
-// and the call's shape allow it, else as 1 | 1 = rows of v and y trickled through LDS under the tile walk
-// (rayen_mfma_pair_io.hip) where allowed | 0 = rayen_mfma_pair.hip always.  RAYEN_PAIR_IO / rayen_pair_schedule select
-// (A/B runs).
+// Schedules of the f16-pair forward (same arithmetic): 1 (default) = rows of v and y trickled through LDS under the tile
+// walk (rayen_mfma_pair_io.hip) where the call's shape allows it | 0 = rayen_mfma_pair.hip always | 2 = W-stationary
+// (rayen_mfma_pair_ws8.hip) where the pack and the call allow it, else as 1: bit-exact and measured ~12 % slower than 1 on
+// config 3, kept selectable.  RAYEN_PAIR_IO / rayen_pair_schedule select (A/B runs).
 std::atomic<int>& pair_schedule_cell() {
   static std::atomic<int> mode([] {
     const char* e = std::getenv("RAYEN_PAIR_IO");
@@ -129,7 +129,7 @@ int build_images(RayenPack* p, int prepare) {
       if ((rc = build_one(p, split_ok && mode != 3, &p->sp32, mfma_split_build))) return rc;
       if ((rc = build_one(p, split_ok && (mode == 0 || mode == 3), &p->pr32, mfma_pair_build))) return rc;
       if (p->pr32 != nullptr && (rc = mfma_pair_io_prepare(p, p->pr32))) return rc;
-      if (p->pr32 != nullptr && (rc = mfma_pair_ws_build(p, p->pr32, &p->ws32))) return rc;
+      if (p->pr32 != nullptr && (rc = mfma_pair_ws8_build(p, p->pr32, &p->ws8_32))) return rc;
     }
     if ((rc = build_one(p, lmi_quad_eligible_f32(p), &p->q32, lmi_quad_build_f32))) return rc;
     // (the wave-per-sample LMI kernels take what neither the quad kernel nor the lane kernels hold: matrices beyond ~30 x 30)
@@ -606,7 +606,7 @@ void rayen_pack_destroy(RayenPack* p) {
   if (p->mbg64) mfma64_bwdg_free(p->mbg64);
   if (p->sp32) mfma_split_free(p->sp32);
   if (p->pr32) mfma_pair_free(p->pr32);
-  if (p->ws32) mfma_pair_ws_free(p->ws32);
+  if (p->ws8_32) mfma_pair_ws8_free(p->ws8_32);
   if (p->q32) lmi_quad_free(p->q32);
   if (p->w32) lmi_wave_free(p->w32);
   if (p->w64) lmi_wave_free(p->w64);
@@ -662,9 +662,9 @@ static int project_f32(const RayenPack* p, const float* v, int64_t B, int64_t ld
   const int rc = check_ready<float>(p, false);
   if (rc) return rc;
   if (p->pr32 != nullptr && p->pr32_state == 1 && y != nullptr && !old_mode) {
-    if (pair_schedule() >= 2 && mfma_pair_ws_serves(p, p->pr32, p->ws32, v, B, ldv, y, ldy, active)) {
+    if (pair_schedule() == 2 && mfma_pair_ws8_serves(p, p->pr32, p->ws8_32, v, B, ldv, y, ldy)) {
       g_last_forward = RAYEN_KERNEL_PAIR_WS;
-      return mfma_pair_ws_forward(p, p->pr32, p->ws32, v, B, ldv, y, ldy, kappa, active, nan_flag, static_cast<hipStream_t>(stream));
+      return mfma_pair_ws8_forward(p, p->pr32, p->ws8_32, v, B, ldv, y, ldy, kappa, active, nan_flag, static_cast<hipStream_t>(stream));
     }
     if (pair_schedule() >= 1 && mfma_pair_io_serves(p, p->pr32, v, B, ldv, y, ldy)) {
       g_last_forward = RAYEN_KERNEL_PAIR_IO;

@@ -56,7 +56,7 @@ struct LmiQuadImage;    // rayen_lmi_quad.h
 struct LmiWaveImage;    // rayen_lmi_wave.h
 struct SplitImage;      // rayen_mfma_split.hip
 struct PairImage;       // rayen_mfma_pair.hip
-struct WsImage;         // rayen_mfma_pair_ws.hip
+struct Ws8Image;        // rayen_mfma_pair_ws8.hip
 
 }  // namespace rayen
 
@@ -90,7 +90,7 @@ struct RayenPack {
   rayen::SplitImage* sp32 = nullptr;
   int sp32_state = 0;            // 1: the bf16-triple kernel may serve this pack | 2: rejected by fp32_selfcheck
   rayen::PairImage* pr32 = nullptr;
-  rayen::WsImage* ws32 = nullptr;   // the same image dealt out to four W-stationary waves (null: not served)
+  rayen::Ws8Image* ws8_32 = nullptr;   // the same image dealt out to eight W-stationary waves (null: not served)
   int pr32_state = 0;            // the same for the f16-pair kernel (which is preferred when both are accepted)
   double check_split = -1.0, check_exact = -1.0, check_pair = -1.0;  // worst row errors against fp64 (fp32_selfcheck)
   int64_t device_bytes = 0;
@@ -149,14 +149,15 @@ int mfma_pair_io_forward(const RayenPack* p, const PairImage* img, const float* 
                          float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
                          hipStream_t stream);
 
-// the same arithmetic, W-stationary: the tiles in the registers of four waves, the batch through LDS (rayen_mfma_pair_ws.hip)
-int mfma_pair_ws_build(const RayenPack* p, const PairImage* img, WsImage** out);   // *out = null: not served
-void mfma_pair_ws_free(WsImage* ws);
-bool mfma_pair_ws_serves(const RayenPack* p, const PairImage* img, const WsImage* ws, const float* v, int64_t B,
-                         int64_t ldv, const float* y, int64_t ldy, const int32_t* active);
-int mfma_pair_ws_forward(const RayenPack* p, const PairImage* img, const WsImage* ws, const float* v, int64_t B,
-                         int64_t ldv, float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
-                         hipStream_t stream);
+// the same arithmetic, W-stationary: the tiles of W in the registers of a workgroup's eight waves, the batch through an
+// LDS image (rayen_mfma_pair_ws8.hip)
+int mfma_pair_ws8_build(const RayenPack* p, const PairImage* img, Ws8Image** out);   // *out = null: not served
+void mfma_pair_ws8_free(Ws8Image* ws);
+bool mfma_pair_ws8_serves(const RayenPack* p, const PairImage* img, const Ws8Image* ws, const float* v, int64_t B,
+                          int64_t ldv, const float* y, int64_t ldy);
+int mfma_pair_ws8_forward(const RayenPack* p, const PairImage* img, const Ws8Image* ws, const float* v, int64_t B,
+                          int64_t ldv, float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
+                          hipStream_t stream);
 
 int64_t mfma_pair_mapper_image_bytes(const RayenPack* p, const PairImage* img, int in_dim);
 int mfma_pair_mapper_prepare(const RayenPack* p, const PairImage* img, const float* w, int64_t ldw, int in_dim,

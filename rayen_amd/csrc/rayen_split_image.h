@@ -88,7 +88,7 @@ struct PairImage {
   int aux_rows = 0;        // aux rows (phi | c, M'beta) of the whole set
   int first_out = 0;       // index of the first NA_E tile in the item list (n_items when NA_E = I)
   int64_t bytes = 0;
-  std::vector<MItem> host_items;   // the item list as uploaded (rayen_mfma_pair_ws.hip deals it out to four waves)
+  std::vector<MItem> host_items;   // the item list as uploaded (rayen_mfma_pair_ws8.hip deals it out to eight waves)
 };
 
 }  // namespace rayen

@@ -6,7 +6,7 @@ cd "$REPO"
 export PYTHONPATH=$REPO
 python scripts/ubench/io_bench.py --schedule 2 --batches 32768,131072,262144,1048576 2>&1 | grep -v amdgpu.ids
 python scripts/ubench/io_bench.py --schedule 1 --batches 131072,262144,1048576 2>&1 | grep -v amdgpu.ids
-for lib in scripts/ubench/variants/librayen_mfma_pair_ws_*.so; do
+for lib in scripts/ubench/variants/librayen_mfma_pair_ws*.so; do
   [ -f "$lib" ] || continue
   RAYEN_HIP_LIBRARY=$lib python scripts/ubench/io_bench.py --schedule 2 --batches 131072,262144,1048576 2>&1 | grep -v amdgpu.ids
 done

@@ -1,7 +1,7 @@
-"""The W-stationary schedule of the f16-pair forward (rayen_mfma_pair_ws.hip: the tiles of W resident in the registers
-of a workgroup's four waves, the batch streamed through a shared B-operand image in LDS) issues the MFMAs of every row
-tile in rayen_mfma_pair.hip's order on the same operands, so wherever it serves a call its outputs must equal the plain
-pair kernel's BIT FOR BIT -- for every structure a workgroup's loop can see (one group per workgroup, two, many, a
+"""The W-stationary schedule of the f16-pair forward (rayen_mfma_pair_ws8.hip, schedule 2: the tiles of W resident in the
+registers of a workgroup's eight waves, the batch streamed through a shared B-operand image in LDS) issues the MFMAs of
+every row tile in rayen_mfma_pair.hip's order on the same operands, so wherever it serves a call its outputs must equal
+the plain pair kernel's BIT FOR BIT -- for every structure a workgroup's loop can see (one group per workgroup, two, many, a
 ragged last group), padded leading dimensions, NaN rows -- and meet the reference's bar against the oracle
 (rayen/constraint_module.py:351-474).  Needs an MI355X."""
 import numpy as np
@@ -29,6 +29,7 @@ def _sets():
         "lin_only": workloads.random_lin_quad_soc(k=64, m=300, n_quad=0, n_soc=0, seed=41),  # 10 tiles of rows, no aux tile
         "few": workloads.random_lin_quad_soc(k=64, m=40, n_quad=1, n_soc=1, seed=42),        # 7 tiles: the three-stage instance
         "quads": workloads.random_lin_quad_soc(k=64, m=100, n_quad=6, n_soc=1, seed=43),     # 19 tiles
+        "n32": workloads.random_lin_quad_soc(k=32, m=300, n_quad=3, n_soc=2, seed=17),       # n = 32 (eight waves only)
     }
 
 
@@ -42,15 +43,17 @@ def _misaligned_copy(v):
     return w
 
 
-def _run(dp, v, **kw):
-    y, kappa, _ = ops.project_raw(v, dp, want_active=False, **kw)
+def _run(dp, v, want_active=False, **kw):
+    y, kappa, active = ops.project_raw(v, dp, want_active=want_active, **kw)
+    if want_active:
+        return y, kappa, active, _lib.load().rayen_last_forward_kernel()
     return y, kappa, _lib.load().rayen_last_forward_kernel()
 
 
-@pytest.fixture(autouse=True)
-def w_stationary_schedule():
-    prev = _lib.load().rayen_pair_schedule(2)
-    yield
+@pytest.fixture(autouse=True, params=[2], ids=["eight_waves"])
+def w_stationary_schedule(request):
+    prev = _lib.load().rayen_pair_schedule(request.param)
+    yield request.param
     _lib.load().rayen_pair_schedule(prev)
 
 
@@ -62,7 +65,7 @@ def _served(dp, cs):
 # a group = 64 rows, one workgroup per CU (256): B = 32768 is two groups per workgroup (the least the kernel takes),
 # 262144 sixteen; ragged batches leave some workgroups a group short and the last group part empty
 @pytest.mark.parametrize("B", [32768, 32768 + 64 * 7 + 5, 49152 + 1, 131072, 262144, 262144 + 64 * 100 + 63, 655360 + 17])
-@pytest.mark.parametrize("name", ["c3", "lin_only", "few", "quads"])
+@pytest.mark.parametrize("name", ["c3", "lin_only", "few", "quads", "n32"])
 def test_w_stationary_equals_the_plain_pair_kernel_bit_for_bit(name, B):
     if name != "c3" and B > 300000:
         pytest.skip("the long loops are covered on c3")
@@ -88,14 +91,35 @@ def test_w_stationary_equals_the_plain_pair_kernel_bit_for_bit(name, B):
     assert np.max(rel_err_rows(y1[take.cuda()].cpu().numpy(), y_ref)) <= 1e-5
 
 
-def test_c3_is_served_at_the_baseline_batch():
+def test_c3_is_served_at_the_baseline_batch(w_stationary_schedule):
     cs, layer, dp = _pack(_sets()["c3"])
     v = torch.empty(262144, cs.n, device="cuda").uniform_(-1, 1)
     assert _run(dp, v)[2] == _lib.KERNEL_PAIR_WS
-    # the arg-max record (training forward) and small batches stay on the other schedules
+    # the training forward (arg-max record) too; small batches stay on the plain kernel
     ops.project_raw(v, dp, want_active=True)
-    assert _lib.load().rayen_last_forward_kernel() == _lib.KERNEL_PAIR_IO
+    assert _lib.load().rayen_last_forward_kernel() == _lib.KERNEL_PAIR_WS
     assert _run(dp, v[:4096])[2] == _lib.KERNEL_PAIR
+
+
+@pytest.mark.parametrize("B", [32768 + 64 * 7 + 5, 262144])
+@pytest.mark.parametrize("name", ["c3", "lin_only", "few", "quads", "n32", "n32_packed"])
+def test_arg_max_record_equals_the_plain_pair_kernel(name, B, w_stationary_schedule):
+    """Training forward: kappa and the (segment, row) record, ties included (a cube-like set has them)."""
+    sets = dict(_sets())
+    sets["n32"] = workloads.random_lin_quad_soc(k=32, m=300, n_quad=3, n_soc=2, seed=17)
+    sets["n32_packed"] = workloads.make_raw("c2", seed=10) if False else workloads.random_lin_quad_soc(k=32, m=64, n_quad=6, n_soc=1, seed=19)
+    cs, layer, dp = _pack(sets[name])
+    if dp.info().mfma_f32 != 3 or not _served(dp, cs):
+        pytest.skip("not served by the W-stationary kernel")
+    gen = torch.Generator(device="cuda").manual_seed(B + 5)
+    v = torch.empty(B, cs.n, device="cuda").uniform_(-1.5, 1.5, generator=gen)
+    v[7] = 0.0
+    v[11] = 1.0            # ties between rows of symmetric sets
+    y1, k1, a1, fam1 = _run(dp, v, want_active=True)
+    y2, k2, a2, fam2 = _run(dp, _misaligned_copy(v), want_active=True)
+    assert fam1 == _lib.KERNEL_PAIR_WS and fam2 == _lib.KERNEL_PAIR
+    assert torch.equal(k1, k2) and torch.equal(y1, y2)
+    assert torch.equal(a1, a2)
 
 
 @pytest.mark.parametrize("name", ["c3", "quads"])
@@ -130,7 +154,7 @@ def test_w_stationary_with_padded_leading_dimensions_and_nan_rows(name):
 
 
 def test_repeated_launches_give_the_same_bits():
-    """Hand-placed wait states and barriers: a hazard shows as run-to-run differences before it shows as a wrong value."""
+    """Counted vmcnt waits behind LDS-DMA and two skewed teams of waves: a race shows as run-to-run differences first."""
     cs, layer, dp = _pack(_sets()["c3"])
     gen = torch.Generator(device="cuda").manual_seed(11)
     v = torch.empty(262144, cs.n, device="cuda").uniform_(-1.5, 1.5, generator=gen)
