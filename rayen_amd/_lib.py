@@ -13,6 +13,7 @@ from ._build import LIBRARY
 ABI_VERSION = 6
 
 SEG_LIN, SEG_QUAD_SYM, SEG_QUAD_FAC, SEG_SOC, SEG_LMI = range(5)
+E_UNSUPPORTED = -6      # RAYEN_E_UNSUPPORTED (include/rayen_hip.h)
 PREPARE_ALL, PREPARE_F32, PREPARE_F64, PREPARE_FWD_ONLY = 0, 1, 2, 4
 
 # every symbol include/rayen_hip.h declares

@@ -9,7 +9,10 @@ What differs is how ``forwardForRAYEN`` (:468-474) is executed: instead of ~165
 PyTorch ops and 10 host syncs per call, one hand-written gfx950 kernel computes
 ``kappa`` for every constraint family and writes ``y = y0 + NA_E v / max(1, kappa(v))``
 (the homogeneity identity of SURVEY.md §0, equal to :468-474 for every ``v``).
-The layer only runs on an MI355X: CPU tensors raise (no fallback path exists).
+Tensors on a HIP device go to those kernels (a missing ``librayen_hip.so`` is a loud error, never a detour);
+tensors on the host -- the reference's own smoke test runs there -- and constraint sets no kernel serves
+(with a one-time ``RuntimeWarning``; ``RAYEN_STRICT_HIP=1`` makes it an error) are evaluated from the same packed
+constants with plain torch ops on the caller's device (``rayen_amd/eager.py``; this is not the test oracle).
 
 ``method='RAYEN'`` (the default) is the hot path this package accelerates; its older step rule
 ``'RAYEN_old'`` (:460-466) runs on the same kernels; ``'UU'`` is the identity and kept because it
@@ -23,15 +26,19 @@ discriminant with ``c' < 0``) the reference's assert at :342 fires (or NaN under
 from __future__ import annotations
 
 import copy
+import os
+import warnings
 
 import numpy as np
 import torch
 import torch.nn as nn
 
-from . import ops, pack as _pack, utils
+from . import _lib, eager, ops, pack as _pack, utils
 
 
 class ConstraintModule(torch.nn.Module):
+    _hip_unsupported = False      # set per instance (with a warning) when no HIP kernel serves the set: eager.py runs instead
+
     def __init__(self, cs, input_dim=None, method='RAYEN', create_map=True, args_DC3=None):
         super().__init__()
 
@@ -127,6 +134,7 @@ class ConstraintModule(torch.nn.Module):
     def _invalidate_packs(self):
         self._device_packs = {}
         self._consts = None
+        self.__dict__.pop("_eager", None)
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
@@ -175,22 +183,40 @@ class ConstraintModule(torch.nn.Module):
         """``q [B, >=n, 1]`` (or ``[B, >=n]``) -> ``(y [B,k], kappa [B])`` through the fused HIP op."""
         v = torch.flatten(q, 1)
         if not v.is_cuda:
-            raise RuntimeError(
-                "rayen_amd.ConstraintModule runs on an MI355X (HIP) device only; got a "
-                f"{v.device} tensor. Call .to('cuda') on the model and the input.")
-        dp, pack_id = self.device_pack(v.device)
-        need_active = torch.is_grad_enabled() and v.requires_grad
-        if not need_active and type(v) is torch.Tensor and not torch.compiler.is_compiling():
-            # plain inference call: straight to the C ABI (the same code the registered op runs; the dispatcher
-            # layers around a custom op cost ~10 us per call, as much as the kernel at small batches)
-            y, _, _ = ops.project_raw(v, dp, want_active=False, old_head=old_head, want_kappa=False)
-            return y, None
-        y, kappa, _ = torch.ops.rayen_amd.ray_project(v, pack_id, need_active, old_head)
-        return y, kappa
+            # tensors on the host (the reference's own smoke runs there, examples/test_layer.py:70-117): the packed form
+            # in plain torch ops on the caller's device, differentiable through autograd -- rayen_amd/eager.py
+            return eager.project(self, v, old_head=old_head)
+        if v.dtype not in (torch.float32, torch.float64):
+            y, kappa = self._project(v.float(), old_head=old_head)       # 16-bit activations: computed in fp32
+            return y.to(v.dtype), (None if kappa is None else kappa.to(v.dtype))
+        if self._hip_unsupported:
+            return eager.project(self, v, old_head=old_head)
+        try:
+            dp, pack_id = self.device_pack(v.device)
+            need_active = torch.is_grad_enabled() and v.requires_grad
+            if not need_active and type(v) is torch.Tensor and not torch.compiler.is_compiling():
+                # plain inference call: straight to the C ABI (the same code the registered op runs; the dispatcher
+                # layers around a custom op cost ~10 us per call, as much as the kernel at small batches)
+                y, _, _ = ops.project_raw(v, dp, want_active=False, old_head=old_head, want_kappa=False)
+                return y, None
+            y, kappa, _ = torch.ops.rayen_amd.ray_project(v, pack_id, need_active, old_head)
+            return y, kappa
+        except _lib.RayenError as err:
+            if err.code != _lib.E_UNSUPPORTED or os.environ.get("RAYEN_STRICT_HIP", "0") == "1":
+                raise
+            # a shape no HIP kernel serves (DESIGN.md §7): say so ONCE, then evaluate the packed form with torch ops on
+            # the same device.  Never silent, never for a missing library (that raises in _lib.load), and
+            # RAYEN_STRICT_HIP=1 turns it back into the error.
+            warnings.warn(f"rayen_amd: no HIP kernel serves this constraint set ({err}); this module now runs the "
+                          "packed torch evaluator (rayen_amd/eager.py) on " + str(v.device), RuntimeWarning, stacklevel=3)
+            self._hip_unsupported = True
+            return eager.project(self, v, old_head=old_head)
 
     def computeKappa(self, v_bar):
         """``kappa [B,1,1]`` of directions ``v_bar [B,n,1]`` (rayen/constraint_module.py:351-458)."""
         v = torch.flatten(v_bar, 1)
+        if not v.is_cuda or self._hip_unsupported or v.dtype not in (torch.float32, torch.float64):
+            return eager.evaluator_for(self, v).kappa(v[:, :self.n]).reshape(-1, 1, 1)
         dp, _ = self.device_pack(v.device)
         _, kappa, _ = ops.project_raw(v, dp, want_y=False)
         return kappa.reshape(-1, 1, 1)
@@ -224,9 +250,13 @@ class ConstraintModule(torch.nn.Module):
         """mapper + projection as ONE kernel launch (``rayen_amd::ray_project_mapped``) or ``None`` when
         the fused kernel does not serve this layer/input (then the two-op path below runs)."""
         if (self.method != 'RAYEN' or not getattr(self, "fuse_mapper", True)
-                or not isinstance(self.mapper, nn.Linear) or not x2.is_cuda or x2.dtype != torch.float32):
+                or not isinstance(self.mapper, nn.Linear) or not x2.is_cuda or x2.dtype != torch.float32
+                or self._hip_unsupported):
             return None
-        dp, pack_id = self.device_pack(x2.device)
+        try:
+            dp, pack_id = self.device_pack(x2.device)
+        except _lib.RayenError:
+            return None           # (the two-op path below reports it)
         weight, bias = self.mapper.weight, self.mapper.bias
         if not ops.mapper_fusable(x2, weight, bias, dp):
             return None
@@ -243,10 +273,12 @@ class ConstraintModule(torch.nn.Module):
             q = torch.unsqueeze(self.mapper(x2), dim=2)
             y = self.forwardForMethod(q)
 
-        if (__debug__ and self.check_nan and self.method in ('RAYEN', 'RAYEN_old')
-                and not torch.cuda.is_current_stream_capturing()):  # the flag read is a host sync
-            dp, _ = self.device_pack(y.device)
-            if int(dp.nan_flag.item()) != 0:
-                dp.nan_flag.zero_()
-                raise AssertionError("the projection produced NaN (NaN in the input?)")
+        if __debug__ and self.check_nan and self.method in ('RAYEN', 'RAYEN_old'):
+            if not y.is_cuda or self._hip_unsupported:
+                assert not torch.isnan(y).any(), "the projection produced NaN (NaN in the input?)"     # CM:531
+            elif not torch.cuda.is_current_stream_capturing():  # the flag read is a host sync
+                dp, _ = self.device_pack(y.device)
+                if int(dp.nan_flag.item()) != 0:
+                    dp.nan_flag.zero_()
+                    raise AssertionError("the projection produced NaN (NaN in the input?)")
         return y

@@ -6,12 +6,16 @@ asynchronous on torch's current HIP stream and differentiable (the backward is
 ``rayen_amd::ray_project_bwd``, another HIP kernel).  PyTorch is used here for
 device memory and the stream only.
 
-There is no CPU or eager fallback: a tensor that does not live on a HIP device,
-or a dtype other than float32/float64, raises.
+These ops serve tensors on a HIP device only (anything else raises HERE; ``ConstraintModule`` sends host tensors
+to ``rayen_amd/eager.py`` before it gets this far).  One detour exists and it is loud: a backward the kernels
+decline with ``RAYEN_E_UNSUPPORTED`` (n beyond what they stage) is evaluated by autograd through the
+packed torch evaluator on the same device, with a ``RuntimeWarning``; ``RAYEN_STRICT_HIP=1`` keeps the error.
 """
 from __future__ import annotations
 
 import ctypes
+import os
+import warnings
 import weakref
 from typing import Optional
 
@@ -199,7 +203,31 @@ def backward_raw(v, kappa, active, grad_y, pack, old_head=False, force_generic=F
 @torch.library.custom_op("rayen_amd::ray_project_bwd", mutates_args=())
 def ray_project_bwd(v: torch.Tensor, kappa: torch.Tensor, active: torch.Tensor,
                     grad_y: torch.Tensor, pack_id: int, old_head: bool = False) -> torch.Tensor:
-    return backward_raw(v, kappa, active, grad_y, _pack(pack_id), old_head)
+    pack = _pack(pack_id)
+    try:
+        return backward_raw(v, kappa, active, grad_y, pack, old_head)
+    except _lib.RayenError as err:
+        if err.code != _lib.E_UNSUPPORTED or os.environ.get("RAYEN_STRICT_HIP", "0") == "1":
+            raise
+        if not pack.__dict__.get("_warned_bwd"):
+            warnings.warn(f"rayen_amd: no HIP backward kernel serves this constraint set ({err}); gradients come from "
+                          "autograd through the packed torch evaluator (rayen_amd/eager.py) on " + str(v.device),
+                          RuntimeWarning, stacklevel=2)
+            pack.__dict__["_warned_bwd"] = True
+        return _eager_backward(pack, v, grad_y, old_head)
+
+
+def _eager_backward(pack, v, grad_y, old_head):
+    from . import eager
+    key = ("_eager", v.dtype)
+    ev = pack.__dict__.get(key)
+    if ev is None:
+        ev = pack.__dict__[key] = eager.PackedEvaluator(pack.consts, v.dtype, v.device)
+    with torch.enable_grad():
+        leaf = v.detach().clone().requires_grad_(True)
+        y, _ = ev.project(leaf, old_head=old_head)
+        (grad_v,) = torch.autograd.grad(y, leaf, grad_y.to(y.dtype))
+    return grad_v
 
 
 @ray_project_bwd.register_fake

@@ -216,3 +216,40 @@ def test_reserved_compute_units_change_the_launch_not_the_values():
                 lib.rayen_reserve_cus(prev)
             assert torch.equal(y0, y1) and torch.equal(k0, k1) and torch.equal(a0, a1) and torch.equal(grad0, grad1)
     assert lib.rayen_reserve_cus(-1) == 0
+
+
+def test_a_set_no_kernel_serves_is_evaluated_by_the_packed_torch_evaluator_loudly(monkeypatch):
+    """an LMI above 30 x 30 mixed with a quadratic has no HIP kernel.  The module says so once
+    (RuntimeWarning) and evaluates the packed form with torch ops ON THE DEVICE (rayen_amd/eager.py);
+    RAYEN_STRICT_HIP=1 keeps the C ABI's error.  A set the kernels serve never takes this path (every other test)."""
+    import warnings
+    from helpers import csd_from_cs
+    from oracle import rayen_oracle as oracle
+    from rayen_amd import _lib
+    raw = workloads.random_lmi(5, 40, seed=2)
+    rng = np.random.default_rng(0)
+    T = rng.uniform(-1, 1, size=(5, 5))
+    raw["P"], raw["q"], raw["r"] = [T @ T.T], [rng.uniform(-1, 1, size=(5, 1))], [np.array([[-0.5]])]
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        cs = workloads.build_constraints(raw)
+        layer = ConstraintModule(cs, create_map=False).cuda()
+        x = torch.empty(64, cs.n, 1, dtype=torch.float64).uniform_(-2, 2)
+        monkeypatch.setenv("RAYEN_STRICT_HIP", "1")
+        with pytest.raises(_lib.RayenError):
+            layer(x.cuda())
+        monkeypatch.delenv("RAYEN_STRICT_HIP")
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            y = layer(x.cuda())
+            layer(x.cuda())
+        assert sum(issubclass(w.category, RuntimeWarning) for w in caught) == 1
+        assert y.is_cuda and layer._hip_unsupported
+        want = oracle.forward(oracle.precompute(csd_from_cs(cs), torch.float64), x)
+        assert float((y.cpu() - want).abs().max()) < 1e-9
+        xg = x.cuda().requires_grad_(True)
+        layer(xg).sum().backward()
+        assert torch.isfinite(xg.grad).all()
+    finally:
+        torch.set_default_dtype(prev)

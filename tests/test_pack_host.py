@@ -110,7 +110,7 @@ def test_row_reductions():
     assert consts.out_identity
 
 
-def test_unsupported_methods_and_cpu_input_fail_loudly():
+def test_unsupported_methods_fail_loudly_and_host_tensors_stay_on_the_host():
     cs = workloads.build_constraints(workloads.cube())
     with pytest.raises(NotImplementedError):
         ConstraintModule(cs, method="DC3", create_map=False)
@@ -118,8 +118,11 @@ def test_unsupported_methods_and_cpu_input_fail_loudly():
     with pytest.raises(RuntimeError):
         ConstraintModule(cs, create_map=True)              # input_dim missing (utils.verify)
     layer = ConstraintModule(cs, create_map=False)
-    with pytest.raises(RuntimeError, match="MI355X"):
-        layer(torch.zeros(4, 3, 1))                        # CPU tensor: no fallback path
+    y = layer(torch.zeros(4, 3, 1))                        # host tensor: the packed torch evaluator (rayen_amd/eager.py)
+    assert y.device.type == "cpu" and torch.equal(y[:, :, 0], torch.tensor(cs.y0.T, dtype=y.dtype).expand(4, 3))
+    from rayen_amd import ops, pack as _pack
+    with pytest.raises(RuntimeError, match="MI355X"):      # ... but the HIP ops themselves never take one
+        ops._check_input(torch.zeros(4, 3), type("P", (), {"consts": layer.packed_constants(), "device_index": 0})())
 
 
 def test_state_dict_and_pickle_roundtrip():
