@@ -44,9 +44,17 @@ PEAK_BF16_TFLOPS = 2516.8  # dense bf16 MFMA = 16 x the fp32 MFMA rate (same gui
 PEAK_FP64_TFLOPS = 78.6    # MI355X datasheet: FP64 vector = FP64 matrix (v_mfma_f64_16x16x4_f64)
 PEAK_HBM_GBS = 8000.0      # HBM3E spec (≈6.3 TB/s achievable)
 GRAPH_STEPS = 50          # steps captured per HIP graph when the step is launch-bound
-SETTLE_LAUNCHES = 150      # untimed launches before the warm-up, at least; and at least SETTLE_SECONDS of them:
-SETTLE_SECONDS = float(os.environ.get("RAYEN_BENCH_SETTLE_S", "0.12"))   # the clocks of a cold device settle after ~60 ms
-                           # of load (measured: a 20-step run reads 0.0655 ms behind 10 ms of launches, 0.0620 behind 60 ms)
+SETTLE_LAUNCHES = 150      # untimed launches of a comparison family before its own timing
+# Clocks of a fresh box: the device needs an unknown stretch of load before its clocks stop moving (round 3: a fixed
+# 120 ms settle read 0.0646 ms on the driver's box where a warm device reads 0.060).  The settle is ADAPTIVE: untimed
+# windows of the invocation's own shape (W + K steps) are repeated until two consecutive windows agree within
+# SETTLE_TOL -- at least SETTLE_MIN_S of load, at most SETTLE_MAX_S -- and the line reports the first and the last
+# window next to the official W + K measurement that follows.
+SETTLE_TOL = 0.02
+SETTLE_MIN_S = float(os.environ.get("RAYEN_BENCH_SETTLE_MIN_S", "0.25"))
+SETTLE_MAX_S = float(os.environ.get("RAYEN_BENCH_SETTLE_MAX_S", "2.0"))
+XGMI_GBPS_PER_LINK_PER_DIRECTION = 76.8   # MI355X: 7 links x 153.6 GB/s bidirectional per GPU, one direct link per peer
+BACKEND = os.environ.get("RAYEN_BENCH_BACKEND", "nccl")   # "gloo": CPU dry run of exactly this entry (tests/test_dist_gloo.py)
 
 
 def parse(argv=None):
@@ -63,7 +71,7 @@ def parse(argv=None):
     ap.add_argument("--gather", action="store_true",
                     help="with --force-dist on one GPU: run the all-gather step anyway (one-rank RCCL group)")
     ap.add_argument("--chunks", type=int, default=2, help="row blocks per rank whose all-gathers overlap the next block's projection")
-    ap.add_argument("--reserve-cus", type=int, default=8,
+    ap.add_argument("--reserve-cus", type=int, default=0,
                     help="compute units the projection's persistent grid leaves to RCCL's kernels during the gather step")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the step from a HIP graph (auto: launch-bound batches, B*k < 2^20)")
@@ -153,11 +161,16 @@ def local_sizes(config_batch, per_gpu_batch, world, scaling):
     return [per_gpu_batch] * world
 
 
-def timed_loop(step, x, steps, warmup, use_dist, graph=False):
+def _sync(on_gpu):
+    if on_gpu:
+        torch.cuda.synchronize()
+
+
+def timed_loop(step, x, steps, warmup, use_dist, graph=False, on_gpu=True):
     """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize; returns (wall seconds,
-    device ms per step from HIP events recorded on the launch stream)."""
+    device ms per step from HIP events recorded on the launch stream; on the CPU dry run: the wall time)."""
     with torch.no_grad():
-        replay = step
+        replay, per = step, 1
         if graph:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -172,41 +185,61 @@ def timed_loop(step, x, steps, warmup, use_dist, graph=False):
             with torch.cuda.graph(g):
                 for _ in range(per):
                     step(x)
-            for _ in range(-(-warmup // per)):
-                g.replay()
-            torch.cuda.synchronize()
-            if use_dist:
-                dist.barrier()
-            torch.cuda.synchronize()
+            replay = lambda _x: g.replay()          # noqa: E731
+        for _ in range(-(-warmup // per)):
+            replay(x)
+        _sync(on_gpu)
+        if use_dist:
+            dist.barrier()
+        _sync(on_gpu)
+        if on_gpu:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            t0 = time.perf_counter()
-            ev0.record()
-            for _ in range(steps // per):
-                g.replay()
-            ev1.record()
-            torch.cuda.synchronize()
-            if use_dist:
-                dist.barrier()
-            torch.cuda.synchronize()
-            return time.perf_counter() - t0, ev0.elapsed_time(ev1) / steps
-        for _ in range(warmup):
-            replay(x)
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        ev0.record()
-        for _ in range(steps):
+        if on_gpu:
+            ev0.record()
+        for _ in range(steps // per):
             replay(x)
-        ev1.record()
-        torch.cuda.synchronize()
+        if on_gpu:
+            ev1.record()
+        _sync(on_gpu)
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        _sync(on_gpu)
         elapsed = time.perf_counter() - t0
-    return elapsed, ev0.elapsed_time(ev1) / steps
+    return elapsed, (ev0.elapsed_time(ev1) if on_gpu else elapsed * 1e3) / steps
+
+
+def settle(step, x, steps, warmup, graph, on_gpu):
+    """Untimed windows of W + K steps until two consecutive windows agree within SETTLE_TOL (clocks of a fresh box);
+    returns {"first_window_ms", "settled_ms", "windows", "seconds", "converged"} -- per-step device times."""
+    t_start = time.perf_counter()
+    history = []
+    while True:
+        _, ms = timed_loop(step, x, steps, warmup, False, graph=graph, on_gpu=on_gpu)
+        history.append(ms)
+        spent = time.perf_counter() - t_start
+        agree = len(history) >= 2 and abs(history[-1] - history[-2]) <= SETTLE_TOL * history[-1]
+        if (agree and spent >= SETTLE_MIN_S) or spent >= SETTLE_MAX_S:
+            return {"first_window_ms": history[0], "settled_ms": history[-1], "windows": len(history),
+                    "seconds": spent, "converged": bool(agree),
+                    "what": f"untimed windows of W+K steps until two in a row agree within {SETTLE_TOL:.0%} "
+                            f"(at least {SETTLE_MIN_S:g} s, at most {SETTLE_MAX_S:g} s); the W+K measurement follows"}
+
+
+def self_launch(argv, gpus):
+    """``python bench.py --gpus N`` without torchrun: re-run this file under ``torch.distributed.run`` (one process per
+    GPU on this node, rendezvous on 127.0.0.1) and hand its exit code back.  Rank 0's JSON line is the child's stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    _note(f"WORLD_SIZE is not set: launching {gpus} ranks -- {' '.join(cmd[1:8])} bench.py ...")
+    return subprocess.call(cmd, env=env)
 
 
 def profiled_traffic(config, dtype_tag, batch, kernel_tag):
@@ -230,28 +263,39 @@ def profiled_traffic(config, dtype_tag, batch, kernel_tag):
     return best
 
 
-def main():
-    args = parse()
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(argv, args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+        _note(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size is what runs")
+    on_gpu = BACKEND != "gloo"
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+    else:
+        device = torch.device("cpu")             # dry run of the launcher and the step on the host (not a measurement)
+        torch.set_num_threads(1)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if on_gpu:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from rayen_amd import ops, workloads
     from rayen_amd.constraint_module import ConstraintModule
 
     dtype = torch.float32 if args.dtype == "fp32" else torch.float64
     torch.set_default_dtype(dtype)
+    t_setup = time.perf_counter()
     raw = workloads.make_raw(args.config, seed=0)
     cs = workloads.build_constraints(raw)
     if args.mapper:
@@ -261,6 +305,7 @@ def main():
     else:
         layer = ConstraintModule(cs, method="RAYEN", create_map=False).to(device)
     layer.check_nan = False                      # no host sync inside the timed region
+    t_module = time.perf_counter() - t_setup
     config_batch = workloads.CONFIGS[args.config][2]
     per_gpu = args.batch or (config_batch // 8 if args.config in ("c5", "c5r") else config_batch)   # c5: 2M = 8 x 262144
     sizes = local_sizes(args.batch * world if args.batch else config_batch, per_gpu, world, args.scaling)
@@ -269,59 +314,79 @@ def main():
     rng = workloads.CONFIGS[args.config][3]
     gen = torch.Generator(device=device).manual_seed(1000 + rank)
     x = torch.empty(B, args.mapper or cs.n, 1, device=device, dtype=dtype).uniform_(-rng, rng, generator=gen)
-    dp, _ = layer.device_pack(device)
+    t_pack = time.perf_counter()
+    dp = layer.device_pack(device)[0] if on_gpu else None
+    _sync(on_gpu)
+    t_pack = time.perf_counter() - t_pack
     gather = (world > 1 or (args.gather and use_dist)) and not args.no_gather and not args.mapper
-    graph = args.graph == "on" or (args.graph == "auto" and B * cs.k < (1 << 20) and not gather)
+    graph = on_gpu and (args.graph == "on" or (args.graph == "auto" and B * cs.k < (1 << 20) and not gather))
 
     def module_step(xx):
         return layer(xx)
 
     last = {}
 
-    def project_into(x_rows, out_rows):
-        ops.project_raw(x_rows.reshape(x_rows.shape[0], -1), dp, want_active=False, want_kappa=False, out=out_rows)
+    if on_gpu:
+        def project_into(x_rows, out_rows):
+            ops.project_raw(x_rows.reshape(x_rows.shape[0], -1), dp, want_active=False, want_kappa=False, out=out_rows)
+        from rayen_amd import _lib as _rlib
+        set_reserve = _rlib.load().rayen_reserve_cus
+    else:
+        def project_into(x_rows, out_rows):       # the product's host evaluator (rayen_amd/eager.py) stands in
+            out_rows.copy_(layer(x_rows)[:, :, 0])
+        set_reserve = None
 
-    from rayen_amd import _lib as _rlib
-    sharded = make_step(project_into, sizes, cs.k, dtype, device, gather=True, chunks=args.chunks,
-                        gather_alone=True, reserve_cus=args.reserve_cus,
-                        set_reserve=_rlib.load().rayen_reserve_cus) if gather else None
+    def gather_step(project):
+        return make_step(project, sizes, cs.k, dtype, device, gather=True, chunks=args.chunks, gather_alone=True,
+                         reserve_cus=args.reserve_cus, set_reserve=set_reserve)
 
-    _note(f"{args.config} {args.dtype} B={B} per GPU, world {world}, graph={graph}, gather={gather}")
-    with torch.no_grad():
-        t_settle = time.perf_counter()
-        n_settle = 0
-        while n_settle < SETTLE_LAUNCHES or time.perf_counter() - t_settle < SETTLE_SECONDS:   # clocks settle; not part of W or K
-            for _ in range(50):
-                module_step(x)
-            n_settle += 50
-            torch.cuda.synchronize()
-    torch.cuda.synchronize()
-    _note("settled; timing the projection")
+    sharded = gather_step(project_into) if gather else None
+
+    _note(f"{args.config} {args.dtype} B={B} per GPU, world {world}, graph={graph}, gather={gather}, backend={BACKEND}")
+    settled = settle(module_step, x, args.steps, args.warmup, graph, on_gpu)
+    _note(f"settled after {settled['windows']} windows / {settled['seconds']:.2f} s "
+          f"(first {settled['first_window_ms']:.4f} ms, last {settled['settled_ms']:.4f} ms); timing the projection")
+    # ---- rank 0 alone (the others wait at the barrier behind it): what one GPU does with nobody else on the node busy
+    solo_ms = None
+    if world > 1:
+        if rank == 0:
+            _, solo_ms = timed_loop(module_step, x, args.steps, args.warmup, False, graph=graph, on_gpu=on_gpu)
+        dist.barrier()
     # ---- the projection alone (the whole step at N = 1)
-    elapsed_p, dev_ms = timed_loop(module_step, x, args.steps, args.warmup, use_dist, graph=graph)
+    elapsed_p, dev_ms = timed_loop(module_step, x, args.steps, args.warmup, use_dist, graph=graph, on_gpu=on_gpu)
     with torch.no_grad():
         y = module_step(x)
     # ---- projection + all-gather of y (the north_star's multi-GPU step)
     elapsed_g = None
     if gather:
-        elapsed_g, dev_ms_g = timed_loop(sharded, x, args.steps, args.warmup, use_dist)
+        elapsed_g, dev_ms_g = timed_loop(sharded, x, args.steps, args.warmup, use_dist, on_gpu=on_gpu)
         got = sharded.rows_of(rank).reshape(-1, cs.k)[:B]
         assert torch.equal(got, y[:, :, 0]), "gathered rows differ from the local projection"
         last["dev_ms_gather"] = dev_ms_g
         sharded(x, trace=True)                                     # one more step, time-stamped per chunk (untimed)
         last["gather_trace"] = sharded.last_trace
+        # the collective alone, same buffers and chunks, nothing projected: what the links do with the CUs idle
+        alone = gather_step(lambda x_rows, out_rows: None)
+        elapsed_a, _ = timed_loop(alone, x, args.steps, args.warmup, use_dist, on_gpu=on_gpu)
+        last["gather_alone_s"] = elapsed_a
+        del alone
 
-    t = torch.tensor([elapsed_p, dev_ms, elapsed_g or 0.0, last.get("dev_ms_gather", 0.0)], device=device,
-                     dtype=torch.float64)
+    ranks_seen = 1
+    t = torch.tensor([elapsed_p, dev_ms, elapsed_g or 0.0, last.get("dev_ms_gather", 0.0), last.get("gather_alone_s", 0.0)],
+                     device=device, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed_p, dev_ms, elapsed_g, dev_ms_g = (float(v) for v in t)
+        ones = torch.ones(1, device=device, dtype=torch.float64)
+        dist.all_reduce(ones)                    # every rank of the group adds one: the number of ranks the backend reached
+        ranks_seen = int(round(float(ones)))
+    elapsed_p, dev_ms, elapsed_g, dev_ms_g, elapsed_a = (float(v) for v in t)
     elapsed = elapsed_g if gather else elapsed_p
 
     _note("timed; checking feasibility")
     # feasibility of what was just computed (fp64 residuals on a slice, outside the timed region)
     sl = y[: min(B, 65536), :, 0].double().cpu().numpy()
-    max_violation = cs.getMaxViolation(sl) if B else 0.0
+    row_violation = cs.getViolationRows(sl) if B else sl[:, 0]
+    max_violation = float(row_violation.max()) if B else 0.0
     violation_detail = workloads.violation_report(cs, sl[:8192]) if B else None
 
     if rank == 0:
@@ -335,16 +400,22 @@ def main():
         tflops = flops_pp * B / kern_s / 1e12
         gbs = bytes_pp * B / kern_s / 1e9
         ai = flops_pp / bytes_pp
-        info = dp.info()
-        split = dtype == torch.float32 and info.mfma_f32 in (2, 3)
-        pieces = {2: 6.0, 3: 3.0}.get(info.mfma_f32, 1.0)    # piece products per fp32 product
         lmi = cs.has_lmi_constraints
-        kernel_tag = (({3: "mfma_pair_f16x2 (fp32-grade)", 2: "mfma_split_bf16x3 (fp32-grade)", 1: "mfma_f32"}.get(info.mfma_f32, "lmi_lanes" if lmi else "generic"))
-                      if dtype == torch.float32 else ("mfma_f64" if info.mfma_f64 else ("lmi_lanes" if lmi else "generic")))
         from rayen_amd import _lib
-        served_by = _lib.load().rayen_last_forward_kernel()      # which instruction stream the last call ran
-        if served_by == _lib.KERNEL_PAIR_IO:
-            kernel_tag = "mfma_pair_io_f16x2 (fp32-grade; rows of v and y trickled through LDS under the tile walk)"
+        if on_gpu:
+            info = dp.info()
+            split = dtype == torch.float32 and info.mfma_f32 in (2, 3)
+            pieces = {2: 6.0, 3: 3.0}.get(info.mfma_f32, 1.0)    # piece products per fp32 product
+            kernel_tag = (({3: "mfma_pair_f16x2 (fp32-grade)", 2: "mfma_split_bf16x3 (fp32-grade)", 1: "mfma_f32"}.get(info.mfma_f32, "lmi_lanes" if lmi else "generic"))
+                          if dtype == torch.float32 else ("mfma_f64" if info.mfma_f64 else ("lmi_lanes" if lmi else "generic")))
+            served_by = _lib.load().rayen_last_forward_kernel()      # which instruction stream the last call ran
+            if served_by == _lib.KERNEL_PAIR_IO:
+                kernel_tag = "mfma_pair_io_f16x2 (fp32-grade; rows of v and y trickled through LDS under the tile walk)"
+            elif served_by == getattr(_lib, "KERNEL_PAIR_WS", -1):
+                kernel_tag = "mfma_pair_ws_f16x2 (fp32-grade; W resident in the registers of a workgroup's waves, batch streamed through LDS)"
+        else:
+            info, split, pieces, served_by = None, False, 1.0, -1
+            kernel_tag = "HOST DRY RUN of the launcher and the step (RAYEN_BENCH_BACKEND=gloo): packed torch evaluator, not a measurement"
         # The split-operand kernels rebuild every fp32 product from three f16 (pairs) or six bf16 (triples) MFMA products
         # (fp32-grade results), so their matrix ceiling in ALGORITHMIC fp32 flops is the dense 16-bit peak / 3 or / 6,
         # not the fp32 MFMA peak
@@ -396,24 +467,55 @@ def main():
                        "parallelism": f"batch-sharded x{world}" + (f" + all-gather(y) in {sharded.chunks} chunks" if gather else ""),
                        "kernel": kernel_tag},
             "max_violation": max_violation,
-            "violations_gt_1e-6": int(max_violation > 1e-6),
+            "violations_gt_1e-6": int((row_violation > 1e-6).sum()) if B else 0,
+            "violations_checked_rows": int(sl.shape[0]),
+            "settle": settled,
+            "first_window_ms": settled["first_window_ms"], "settled_ms": settled["settled_ms"],
+            "kernel_ms": dev_ms,
+            "setup": {"module_s": t_module, "pack_create_s": t_pack,
+                      "what": "ConvexConstraints + ConstraintModule construction | rayen_pack_create (device images + "
+                              "the creation-time measurement of the fp32 families), once per module and device"},
             # (per family: the residual next to what rounding a feasible y to fp32 alone can leave -- sets with large
             # coefficients, configs 5 / 5r, sit above 1e-6 in absolute terms at a ratio of a few units)
             "violation_detail": violation_detail,
             "roofline": roof,
         }
+        if use_dist:
+            out["rccl_ranks"] = ranks_seen
+            out["backend"] = {"name": dist.get_backend() if dist.is_initialized() else BACKEND, "world_size": world,
+                              "what": "rccl_ranks = sum over ranks of 1 through an all-reduce on this backend"}
         if world > 1 or gather:
             out["no_gather"] = {"value": total_rows * args.steps / elapsed_p, "unit": "projections/s",
                                 "ms_per_step": elapsed_p / args.steps * 1e3,
                                 "what": "the projection alone on every rank (no collective), same inputs and step count"}
+            if solo_ms is not None:
+                # rank 0 alone on the node at the same per-rank rows, against all ranks at once (max over ranks)
+                solo_rate = sizes[0] / (solo_ms * 1e-3)
+                out["no_gather"].update({"solo_rank0_ms_per_step": solo_ms, "all_ranks_device_ms_per_step": dev_ms,
+                                         "scaling_efficiency": (total_rows / (dev_ms * 1e-3)) / (world * solo_rate),
+                                         "scaling_efficiency_basis": "device time: (rows of all ranks / slowest rank's "
+                                                                     "step) / (N x rank 0's rate with the other ranks idle)"})
             if gather:
-                out["gather"] = {"bytes_received_per_rank": (total_rows - B) * cs.k * (4 if dtype == torch.float32 else 8),
+                recv = (total_rows - B) * cs.k * (4 if dtype == torch.float32 else 8)
+                peers = max(world - 1, 1)
+                link_peak = peers * XGMI_GBPS_PER_LINK_PER_DIRECTION
+                ga_s = elapsed_a / args.steps if elapsed_a else None
+                gbps = recv / ga_s / 1e9 if ga_s else None
+                out["gather"] = {"bytes_received_per_rank": recv,
+                                 "alone_ms_per_step": ga_s * 1e3 if ga_s else None,
+                                 "GBps_per_rank": gbps,
+                                 "xgmi_peak_GBps_per_rank": link_peak if world > 1 else None,
+                                 "xgmi_frac": (gbps / link_peak) if (gbps and world > 1) else None,
+                                 "xgmi_basis": f"{peers} direct links x {XGMI_GBPS_PER_LINK_PER_DIRECTION} GB/s inbound "
+                                               "(153.6 GB/s per link, both directions); the collective alone on the "
+                                               "step's buffers, nothing projected",
+                                 "step_minus_projection_ms": (elapsed_g - elapsed_p) / args.steps * 1e3,
                                  "chunks": sharded.chunks, "device_ms_per_step": dev_ms_g,
                                  "reserved_cus": args.reserve_cus,
                                  "per_chunk_rank0": last.get("gather_trace"),
                                  "how_to_read": "overlap happened if chunk c's gather_end_ms is not behind chunk c+1's "
                                                 "projection_end_ms by the gather's own duration"}
-        if world == 1 and not args.mapper and not args.no_families and B:
+        if on_gpu and world == 1 and not args.mapper and not args.no_families and B:
             # the training step of the same workload: forward with the arg-max record, then the backward (the two launches
             # `loss.backward()` through the layer costs, examples/main.py:166-171), timed the same way, outside `value`
             g_in = torch.empty(B, cs.k, device=device, dtype=dtype).uniform_(-1, 1)
@@ -434,7 +536,7 @@ def main():
                 "backward_check_pair_vs_fp64": info.bwd32_check_pair, "backward_check_exact_vs_fp64": info.bwd32_check_exact,
                 "clipped_fraction": float((k_rec > 1).double().mean())}
         if args.mapper:
-            fused = (not args.no_fuse) and dtype == torch.float32 and dp.mapper_fusable(args.mapper)
+            fused = on_gpu and (not args.no_fuse) and dtype == torch.float32 and dp.mapper_fusable(args.mapper)
             out["config"]["mapper"] = f"nn.Linear({args.mapper}, {cs.n}) " + ("fused into the projection kernel" if fused else "as its own GEMM")
         if split and world == 1 and not args.mapper and not args.no_families:
             # the same workload on the other fp32 families (RayenPackDesc.fp32_mode / RAYEN_FP32_MODE at pack
@@ -479,7 +581,7 @@ def main():
             out["fp32_family_check"] = {"pair_vs_fp64": info.fp32_check_pair, "triple_vs_fp64": info.fp32_check_split,
                                         "exact_vs_fp64": info.fp32_check_exact,
                                         "what": "worst row error on the pack-creation probe directions (-1: not measured)"}
-        if world == 1 and not args.no_cpu_baseline and not args.mapper:
+        if on_gpu and world == 1 and not args.no_cpu_baseline and not args.mapper:
             out["cpu_baseline"] = cpu_baseline(raw, cs, B, dtype, args.cpu_seconds, rng)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         line = json.dumps(out)

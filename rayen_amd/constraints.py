@@ -500,6 +500,11 @@ class ConvexConstraints:
             res["lmi"] = -np.linalg.eigvalsh(H)[:, 0]
         return res
 
+    def getViolationRows(self, y):
+        """Per sample: its largest residual over all families, ``[B]`` (<=0 = that sample is feasible)."""
+        res = self.getResiduals(y)
+        return np.max(np.stack(list(res.values()), axis=0), axis=0)
+
     def getMaxViolation(self, y):
         """Largest residual over all families and samples (<=0 means every sample is feasible)."""
         res = self.getResiduals(y)

@@ -26,7 +26,9 @@
 #include "rayen_split_image.h"
 
 #include <cmath>
+#include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #ifndef RAYEN_BWDP_ABL
@@ -657,12 +659,19 @@ int mfma_bwdp_build(const RayenPack* p, MfmaBwdpImage** out, int64_t* bytes) {
     const int64_t need = (int64_t)(img->n_pairs * 2 + 2) * 4096 + (int64_t)img->nkg * 2 * 2048;
     img->lds_bytes = (need + patch + 512 <= 160 * 1024) ? (int)need : 0;
     if (img->lds_bytes > 0) {
+      // (per kernel instance, never lowered: a later pack with fewer pairs must not take back what an earlier one was
+      // promised -- every pack asks for the running maximum of its instance)
+      static std::mutex mu;
+      static int promised[3] = {0, 0, 0};
+      std::lock_guard<std::mutex> hold(mu);
+      int ask = img->lds_bytes;
+      if (img->nkg >= 0 && img->nkg <= 2) { promised[img->nkg] = std::max(promised[img->nkg], ask); ask = promised[img->nkg]; }
       const void* fns[2] = {nullptr, nullptr};
       if (img->nkg == 0) { fns[0] = reinterpret_cast<const void*>(&mfma_bwdp_kernel<0, true, true>); fns[1] = reinterpret_cast<const void*>(&mfma_bwdp_kernel<0, true, false>); }
       if (img->nkg == 1) { fns[0] = reinterpret_cast<const void*>(&mfma_bwdp_kernel<1, true, true>); fns[1] = reinterpret_cast<const void*>(&mfma_bwdp_kernel<1, true, false>); }
       if (img->nkg == 2) { fns[0] = reinterpret_cast<const void*>(&mfma_bwdp_kernel<2, true, true>); fns[1] = reinterpret_cast<const void*>(&mfma_bwdp_kernel<2, true, false>); }
       for (const void* fn : fns)
-        if (fn == nullptr || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, img->lds_bytes) != hipSuccess) {
+        if (fn == nullptr || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ask) != hipSuccess) {
           (void)hipGetLastError();
           img->lds_bytes = 0;
         }

@@ -33,6 +33,8 @@
 // x 16 KiB of rows + the aux patch), n_items >= blocks per group.  Everything else stays on rayen_mfma_pair.hip.
 #include "rayen_split_image.h"
 
+#include <algorithm>
+#include <mutex>
 #include <type_traits>
 
 namespace rayen {
@@ -953,9 +955,16 @@ int mfma_pair_io_prepare(const RayenPack* p, const PairImage* img) {
   if (img == nullptr || img->nkk != 1) return RAYEN_OK;
   const int lds = pair_iof_lds_bytes(p);
   if (lds > 160 * 1024) return RAYEN_OK;   // (such packs are never served by the flat kernel)
+  // The attribute belongs to the kernel instance, not to the pack: a later, smaller pack must not lower what an
+  // earlier one was promised (c5 followed by an n = 20 set in one process).  Every pack asks for the running maximum.
+  static std::mutex mu;
+  static int promised = 0;
+  std::lock_guard<std::mutex> hold(mu);
+  promised = std::max(promised, lds);
+  const int ask = promised;
   bool ok = true;
   auto want = [&](auto kern) {
-    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ask) == hipSuccess;
   };
   if (img->identity) { want(mfma_pair_iof_kernel<false, false>); want(mfma_pair_iof_kernel<true, false>); }
   else { want(mfma_pair_iof_kernel<false, true>); want(mfma_pair_iof_kernel<true, true>); }

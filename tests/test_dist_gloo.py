@@ -202,3 +202,59 @@ def test_bench_step_function_world4_unequal_shards(tmp_path):
     mp.spawn(_world4_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     for rank in range(world):
         assert os.path.exists(tmp_path / f"ok_{rank}.npy")
+
+
+# --------------------------------------------------------------------------- the bench entry itself, as the driver calls it
+def _bench_line(args, env_extra=None, launcher=None):
+    """Run ``bench.py`` (optionally under ``torch.distributed.run``) on the host backend and parse rank 0's JSON line."""
+    import json
+    import subprocess
+    env = dict(os.environ, RAYEN_BENCH_BACKEND="gloo", RAYEN_BENCH_SETTLE_MIN_S="0.02", RAYEN_BENCH_SETTLE_MAX_S="0.2")
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(key, None)
+    env.update(env_extra or {})
+    cmd = [sys.executable]
+    if launcher:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={launcher}", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port())]
+    cmd += [os.path.join(REPO, "bench.py"), *args]
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_entry_self_launches_for_gpus_2():
+    """``python bench.py --gpus 2`` WITHOUT torchrun (WORLD_SIZE unset) must produce the line: it re-runs itself under
+    torch.distributed.run.  Host dry run (gloo, the product's packed torch evaluator as the projection): what is under
+    test is the launcher, the rank plumbing, the step and every field the first hardware run will be read by."""
+    line = _bench_line(["--gpus", "2", "--config", "c2", "--batch", "200", "--steps", "3", "--warmup", "1", "--chunks", "2"])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["backend"]["name"] == "gloo"
+    assert line["config"]["global_batch"] == 400 and line["scaling"] == "weak"
+    assert line["value"] > 0 and line["steps"] == 3 and line["warmup"] == 1
+    assert line["no_gather"]["scaling_efficiency"] > 0 and line["no_gather"]["solo_rank0_ms_per_step"] > 0
+    g = line["gather"]
+    assert g["bytes_received_per_rank"] == 200 * 16 * 4 and g["GBps_per_rank"] > 0
+    assert g["xgmi_peak_GBps_per_rank"] == pytest.approx(76.8) and 0 < g["xgmi_frac"] < 1
+    assert len(g["per_chunk_rank0"]) == 2
+    assert line["settle"]["windows"] >= 2 and line["first_window_ms"] > 0 and line["settled_ms"] > 0
+    assert line["violations_gt_1e-6"] == 0 and line["violations_checked_rows"] == 200
+    assert "DRY RUN" in line["config"]["kernel"]
+
+
+def test_bench_entry_under_the_launcher_with_one_rank_is_the_plain_run():
+    """N = 1 through ``torch.distributed.run`` and N = 1 as a plain process describe the same job (the values
+    themselves are host timings here)."""
+    args = ["--gpus", "1", "--config", "c2", "--batch", "128", "--steps", "2", "--warmup", "1"]
+    plain = _bench_line(args)
+    launched = _bench_line(args, launcher=1)
+    for key in ("metric", "unit", "n_gpus", "steps", "warmup", "scaling", "dtype", "config"):
+        assert plain[key] == launched[key], key
+    assert "rccl_ranks" not in plain and "gather" not in plain and "gather" not in launched
+
+
+def test_bench_entry_strong_scaling_shards_the_config_batch():
+    line = _bench_line(["--gpus", "2", "--config", "c1", "--scaling", "strong", "--steps", "2", "--warmup", "1", "--no-gather"])
+    assert line["config"]["global_batch"] == 500 and line["config"]["batch_per_gpu"] == 250
+    assert "gather" not in line and line["no_gather"]["value"] > 0

@@ -189,3 +189,25 @@ def test_flat_rows_served_sets_are_really_served():
         keep = torch.ones(v.shape[0], dtype=torch.bool, device="cuda")
         keep[1234] = False
         assert torch.equal(y2[keep], y_ref[keep])
+
+
+def test_dynamic_lds_promise_survives_a_later_smaller_pack():
+    """hipFuncAttributeMaxDynamicSharedMemorySize belongs to the kernel instance, not to the pack: a
+    pack with smaller rows created AFTER config 5 must not lower what config 5's launches of the same flat-row forward
+    instance and of the resident pair backward ask for.  Large pack, small pack, then the large one again."""
+    big = workloads.make_raw("c5", seed=0)
+    cs_b, layer_b, dp_b = _pack(big)
+    v = torch.empty(131072 + 64, cs_b.n, device="cuda").uniform_(-1, 1)
+    g = torch.empty(v.shape[0], cs_b.k, device="cuda").uniform_(-1, 1)
+    y0, k0, a0, fam0 = _run(dp_b, v, True)
+    gv0 = ops.backward_raw(v, k0, a0, g, dp_b)
+    small = workloads.corridor_like(k=24, n_eq=4, m=96, n_quad=6, rank=3, seed=4)     # n = 20, same instances, less LDS
+    cs_s, layer_s, dp_s = _pack(small)
+    vs = torch.empty(131072 + 64, cs_s.n, device="cuda").uniform_(-1, 1)
+    ys, ks, as_, fam_s = _run(dp_s, vs, True)
+    ops.backward_raw(vs, ks, as_, torch.ones(vs.shape[0], cs_s.k, device="cuda"), dp_s)
+    y1, k1, a1, fam1 = _run(dp_b, v, True)
+    gv1 = ops.backward_raw(v, k1, a1, g, dp_b)
+    torch.cuda.synchronize()
+    assert fam0 == fam1 == _lib.KERNEL_PAIR_IO
+    assert torch.equal(y0, y1) and torch.equal(k0, k1) and torch.equal(a0, a1) and torch.equal(gv0, gv1)
