@@ -19,6 +19,7 @@
 // Linear rows (if any) are split over the four lanes as well.  Serves packs = [linear rows] + one LMI.
 #pragma once
 
+#include <cstdlib>
 #include <type_traits>
 #include <vector>
 
@@ -30,12 +31,27 @@ struct LmiQuadImage {
   void* data = nullptr;   // device: [Wf n*R*R | Wlin m*n | N k*n (absent when identity) | y0 k] of T
   int32_t* lin_id = nullptr;  // device: [m][2] (segment, W row) of every linear row
   void* wrow = nullptr;       // device: [n_rows][n] of T, row-major W (backward: the active linear row)
+  void* wm = nullptr;         // device: [ks][R4 * R4][64] of T: the generators as v_mfma_*_16x16x4 A operands (forward)
+  int ks = 0;                 // K-steps of that image: ceil(n / 4)
   int r = 0, R = 0, n = 0, k = 0, m = 0, identity = 0, lmi_seg = 0;
   int64_t elems = 0;      // number of T elements in `data`
   int64_t bytes = 0;
 };
 
 namespace lq {
+
+// developer build (scripts/ubench/lq_stamps.hip): s_memtime at the phase boundaries of the forward kernel, one wave per
+// block, into a __device__ array the micro-benchmark reads back.  Expands to nothing in the library.
+#ifdef RAYEN_LQ_STAMPS
+__device__ unsigned long long lq_stamp_buf[4096 * 8];
+#define RAYEN_LQ_STAMP(slot)                                                                         \
+  do {                                                                                               \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024)                                                \
+      lq_stamp_buf[((blockIdx.x << 2) + (threadIdx.x >> 6)) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define RAYEN_LQ_STAMP(slot) do { } while (0)
+#endif
 
 template <int I, int N, class F>
 __device__ __forceinline__ void sfor(F&& f) {
@@ -171,16 +187,24 @@ __device__ __forceinline__ void hh_step(V2<T> (&a)[R4][2 * R4], T (&dd)[4 * R4],
     hb[jj][0] = (j0 >= I1) ? qb<(j0 & 3)>(hv[j0 >> 2]) : T(0);
     hb[jj][1] = qb<(j1 & 3)>(hv[j1 >> 2]);
   });
-  // p = beta A u over the live block
-  sfor<T0, R4>([&](auto it) {
-    constexpr int t = decltype(it)::value;
-    V2<T> acc = splat(T(0));
+  // p = beta A u over the live block.  Column pairs outermost: the R4 - T0 row groups' sums are independent chains, and a
+  // packed fma that reads the accumulator the previous instruction wrote costs a wait state on gfx950 (hipcc fills it
+  // with s_nop when the source order offers nothing else: one row group after the other was 45 s_nops per step).
+  {
+    V2<T> accs[R4];
+    sfor<T0, R4>([&](auto it) { accs[decltype(it)::value] = splat(T(0)); });
     sfor<J0, H>([&](auto ij) {
       constexpr int jj = decltype(ij)::value;
-      acc = fma2<T>(a[t][jj], hb[jj], acc);
+      sfor<T0, R4>([&](auto it) {
+        constexpr int t = decltype(it)::value;
+        accs[t] = fma2<T>(a[t][jj], hb[jj], accs[t]);
+      });
     });
-    p[t] = acc[0] + acc[1];
-  });
+    sfor<T0, R4>([&](auto it) {
+      constexpr int t = decltype(it)::value;
+      p[t] = accs[t][0] + accs[t][1];
+    });
+  }
   T pv = T(0);
   sfor<T0, R4>([&](auto it) {
     constexpr int t = decltype(it)::value;
@@ -239,6 +263,7 @@ __device__ __forceinline__ T lambda_max_quad(V2<T> (&a)[R4][2 * R4], const int r
     e2[R - 2] = e * e;
   }
   e2[R - 1] = T(0);
+  RAYEN_LQ_STAMP(3);
 
   // Gershgorin bracket of lambda_max over the true rows: max diag <= lambda_max <= max(d_i + |e_{i-1}| + |e_i|)
   T lo = dd[0], hi = dd[0] + Lim<T>::sqrt_(e2[0]), dmin = dd[0], emax = T(0), eprev = T(0);
@@ -316,6 +341,93 @@ __device__ __forceinline__ void form_S(V2<T> (&a)[R4][2 * R4], const T* Wf, cons
   }
 }
 
+// ---- S on the matrix cores (round 4).  form_S above reads every generator entry from LDS once per LANE: 1 MB per
+// 64-sample block at config 4, 8000 clocks of the CU's 128 B/clk -- a quarter of the kernel (s_memtime stamps,
+// scripts/ubench/lq_stamps.hip), although it is only 500 packed fmas.  The matrix cores broadcast operands in hardware:
+// per wave (16 samples) S^T[entry][sample] = sum_a G_a[entry] v_a[sample] is R4*R4 tiles of v_mfma_*_16x16x4 (exact
+// fp32 / fp64: an fma chain over a in ascending order, the same bits as form_S), A operands = the generators from an LDS
+// image in operand order (one ds_read_b32 per tile and k-step: 77 KB per block instead of 1 MB; read straight from
+// global memory by every wave they took as long as the LDS version of form_S -- four waves x 75 loads per CU through
+// the vector-memory path at kernel start), B operands = the wave's 16 rows of v.  The
+// tile rows are ORDERED so that lane group q = lane >> 4 receives exactly the entries of matrix rows 4t + q -- the
+// quad kernel's distribution -- and one trip through a wave-private LDS patch moves them from lane 16 q + s to lane
+// 4 s + q (the DPP quad of sample s).
+template <typename T> struct Mma16;
+template <> struct Mma16<float> {
+  typedef float acc_t __attribute__((ext_vector_type(4)));
+  __device__ static __forceinline__ acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  // C/D: col = lane & 15, row = 4 (lane >> 4) + reg   ->   tile row m carries (sub = m >> 2, entry 4 tau + (m & 3))
+  __host__ __device__ static constexpr int sub_of_row(int m) { return m >> 2; }
+  __host__ __device__ static constexpr int reg_of_row(int m) { return m & 3; }
+};
+template <> struct Mma16<double> {
+  typedef double acc_t __attribute__((ext_vector_type(4)));
+  __device__ static __forceinline__ acc_t mma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  // C/D: col = lane & 15, row = (lane >> 4) + 4 reg   ->   tile row m carries (sub = m & 3, entry 4 tau + (m >> 2))
+  __host__ __device__ static constexpr int sub_of_row(int m) { return m & 3; }
+  __host__ __device__ static constexpr int reg_of_row(int m) { return m >> 2; }
+};
+
+// tiles per trip through a wave's LDS patch (64 lanes x 4 T each): all R4 * R4 of them when four such patches fit next to
+// the image (one write phase, one read phase: every trip costs two LDS round trips of latency), else R4 per trip
+template <typename T, int R4> constexpr int quad_stage_tiles() { return (R4 * R4 * 64 * 4 * sizeof(T) * 4 <= 104 * 1024) ? R4 * R4 : R4; }
+
+template <typename T, int R4>
+__device__ __forceinline__ void form_S_mfma(V2<T> (&a)[R4][2 * R4], const T* wm, const int ks, const T* vt16,
+                                            const int LDV, const int n, const int r, T* stage, const int lane) {
+  // wm: the A-operand image in LDS, [k-step][tile][lane]; vt16: the wave's 16 rows of v in LDS (row stride LDV)
+  constexpr int R = 4 * R4, NT = R4 * R4, CH = quad_stage_tiles<T, R4>();
+  typedef typename Mma16<T>::acc_t acc_t;
+  acc_t acc[NT];
+  sfor<0, NT>([&](auto it) { acc[decltype(it)::value] = acc_t{T(0), T(0), T(0), T(0)}; });
+  const int col = lane & 15, kq = lane >> 4;
+  const T* vrow = vt16 + col * LDV;
+  const T* wl = wm + lane;
+  for (int kk = 0; kk < ks; ++kk) {
+    T ac[NT];
+    sfor<0, NT>([&](auto it) { ac[decltype(it)::value] = wl[decltype(it)::value * 64]; });
+    const int aa = 4 * kk + kq;
+    const T bc = aa < n ? vrow[aa] : T(0);
+    wl += NT * 64;
+    sfor<0, NT>([&](auto it) {
+      constexpr int tau = decltype(it)::value;
+      acc[tau] = Mma16<T>::mma(ac[tau], bc, acc[tau]);
+    });
+  }
+  // lane 16 q + s  ->  lane 4 s + q, CH tiles per trip.  Slot of (q, s): 16 q + ((s + 2 q) & 15) -- eight consecutive
+  // writers and eight consecutive readers each touch eight different 16-byte columns.
+  const int wq = lane >> 4, ws = lane & 15, rq = lane & 3, rs = lane >> 2;
+  acc_t* wslot = reinterpret_cast<acc_t*>(stage) + (16 * wq + ((ws + 2 * wq) & 15));
+  const acc_t* rslot = reinterpret_cast<const acc_t*>(stage) + (16 * rq + ((rs + 2 * rq) & 15));
+  const int sub = rq;
+  sfor<0, (NT + CH - 1) / CH>([&](auto ic) {
+    constexpr int c0 = decltype(ic)::value * CH;
+    sfor<0, CH>([&](auto iu) {
+      constexpr int tau = c0 + decltype(iu)::value;
+      if constexpr (tau < NT) wslot[decltype(iu)::value * 64] = acc[tau];
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    sfor<0, CH>([&](auto iu) {
+      constexpr int tau = c0 + decltype(iu)::value;
+      if constexpr (tau < NT) {
+        const acc_t got = rslot[decltype(iu)::value * 64];
+        sfor<0, 4>([&](auto ii) {
+          constexpr int idx = 4 * tau + decltype(ii)::value, t = idx / R, c = idx % R;
+          // (pad rows / columns: decoupled and far below the spectrum, as form_S leaves them; only an entry that can be
+          // on some lane's diagonal needs the select)
+          if constexpr (c - 4 * t >= 0 && c - 4 * t < 4)
+            a[t][c >> 1][c & 1] = (4 * t + sub == c && c >= r) ? T(-1e18) : got[decltype(ii)::value];
+          else
+            a[t][c >> 1][c & 1] = got[decltype(ii)::value];
+        });
+      }
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  });
+}
+
 // the constant image into LDS: 16-byte pieces, all of a thread's loads in flight before its first store
 template <typename T>
 __device__ __forceinline__ void fill_image(T* img, const T* image, const int64_t elems, const int tid) {
@@ -340,16 +452,18 @@ __device__ __forceinline__ void fill_image(T* img, const T* image, const int64_t
   for (int64_t i = n16 * PER + tid; i < elems; i += 256) img[i] = image[i];
 }
 
-template <typename T, int R4>
+// MF: S on the matrix cores (form_S_mfma) -- `image` is then [Wm | Wlin | N | y0] with the generators in A-operand
+// order (LmiQuadImage::wm, `ks` K-steps) instead of [Wf | ...].
+template <typename T, int R4, bool MF = false>
 __global__ __launch_bounds__(256) void lmi_quad_kernel(
     const T* __restrict__ image, const int32_t* __restrict__ lin_id, int r, int n, int k, int m, int identity,
     int lmi_seg, int64_t elems, const T* __restrict__ v, int64_t B, int64_t ldv, T* __restrict__ y, int64_t ldy,
-    T* __restrict__ kappa_out, int32_t* __restrict__ active_out, int32_t* __restrict__ nan_flag) {
+    T* __restrict__ kappa_out, int32_t* __restrict__ active_out, int32_t* __restrict__ nan_flag, int ks = 0) {
   constexpr int R = 4 * R4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* img = reinterpret_cast<T*>(smem_raw);               // the whole constant image
-  const T* Wf = img;                                      // [n][R][R]
-  const T* Wlin = Wf + (size_t)n * R * R;                 // [m][n]
+  T* img = reinterpret_cast<T*>(smem_raw);               // the constant image (Wf or Wm | Wlin | N | y0)
+  const T* Wf = img;                                      // [n][R][R]; with MF: Wm [ks][R4 R4][64], the A operands
+  const T* Wlin = Wf + (MF ? (size_t)ks * R4 * R4 * 64 : (size_t)n * R * R);      // [m][n]
   const T* Nmat = Wlin + (size_t)m * n;                   // [k][n] (absent when identity)
   const T* y0 = Nmat + (identity ? 0 : (size_t)k * n);    // [k]
   T* vt = img + ((elems + 3) & ~int64_t(3));              // [64][n + 1]
@@ -359,17 +473,44 @@ __global__ __launch_bounds__(256) void lmi_quad_kernel(
   const int sl = tid >> 2, sub = tid & 3;
   const int64_t b0 = (int64_t)blockIdx.x * 64;
   const int nb = (int)((B - b0) < 64 ? (B - b0) : 64);
-  fill_image<T>(img, image, elems, tid);
-  for (int idx = tid; idx < 64 * n; idx += 256) {
-    const int bl = idx / n, j = idx - bl * n;
-    vt[bl * LDV + j] = bl < nb ? v[(b0 + bl) * ldv + j] : T(0);
+  RAYEN_LQ_STAMP(0);
+  // rows of v and the image in ONE round trip to memory: every load is issued before the first LDS store waits for it
+  // (fill_image first and the rows of v behind its stores were two dependent round trips: 2 of the kernel's 15 us)
+  if constexpr (MF) {
+    // (thread tid moves columns (tid & 3) + 4 u of sample tid >> 2: n <= 64 is at most 16 of them, no division)
+    T vreg[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int j = sub + 4 * u;
+      vreg[u] = (j < n && sl < nb) ? v[(b0 + sl) * ldv + j] : T(0);
+    }
+    fill_image<T>(img, image, elems, tid);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int j = sub + 4 * u;
+      if (j < n) vt[sl * LDV + j] = vreg[u];
+    }
+  } else {
+    fill_image<T>(img, image, elems, tid);
+    for (int idx = tid; idx < 64 * n; idx += 256) {
+      const int bl = idx / n, j = idx - bl * n;
+      vt[bl * LDV + j] = bl < nb ? v[(b0 + bl) * ldv + j] : T(0);
+    }
   }
   __syncthreads();
+  RAYEN_LQ_STAMP(1);
   const T* vs = vt + sl * LDV;
   const bool live = sl < nb;
 
   V2<T> a[R4][R / 2];
-  form_S<T, R4>(a, Wf, vs, n, r, sub);
+  if constexpr (MF) {
+    // every wave forms the S of its own 16 samples on the matrix cores; the LDS image starts with the A operands
+    T* stage = vt + (((size_t)64 * LDV + 3) & ~size_t(3)) + (size_t)(tid >> 6) * (quad_stage_tiles<T, R4>() * 64 * 4);
+    form_S_mfma<T, R4>(a, img, ks, vt + 16 * (tid >> 6) * LDV, LDV, n, r, stage, tid & 63);
+  } else {
+    form_S<T, R4>(a, Wf, vs, n, r, sub);
+  }
+  RAYEN_LQ_STAMP(2);
 
   // ---- linear rows, split over the quad
   T kap = T(0);
@@ -395,6 +536,7 @@ __global__ __launch_bounds__(256) void lmi_quad_kernel(
   }
 
   const T lam = lambda_max_quad<T, R4>(a, r, sub);
+  RAYEN_LQ_STAMP(4);
   if (lam > kap) { kap = lam; aseg = lmi_seg; arow = 0; }
 
   const T scale = T(1) / fmax(T(1), kap);
@@ -419,6 +561,7 @@ __global__ __launch_bounds__(256) void lmi_quad_kernel(
     }
   }
   if (nan_flag && bad) atomicOr(nan_flag, 1);
+  RAYEN_LQ_STAMP(5);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -526,6 +669,7 @@ __global__ __launch_bounds__(256) void lmi_quad_bwd_kernel(
   const int sl = tid >> 2, sub = tid & 3;
   const int64_t b0 = (int64_t)blockIdx.x * 64;
   const int nb = (int)((B - b0) < 64 ? (B - b0) : 64);
+  RAYEN_LQ_STAMP(0);
   fill_image<T>(img, image, elems, tid);
   for (int idx = tid; idx < 64 * n; idx += 256) {
     const int bl = idx / n, j = idx - bl * n;
@@ -661,40 +805,86 @@ int lmi_quad_build_t(const RayenPack* p, LmiQuadImage** out, int64_t* bytes) {
   for (int i = 0; i < k; ++i) host[off + i] = (T)p->y0[i];
   if (ids.empty()) ids.assign(2, 0);
   img->elems = (int64_t)host.size();
+  // the generators as 16x16x4 A operands: [k-step][tile][lane]; lane (m = lane & 15, kq = lane >> 4) of tile tau holds
+  // G_a[4 t + sub][c] with a = 4 kk + kq and (sub, entry 4 tau + reg = t R + c) from the instruction's C/D row map
+  const int R4 = R / 4, NT = R4 * R4, ks = (n + 3) / 4;
+  std::vector<T> wm((size_t)ks * NT * 64, T(0));
+  for (int kk = 0; kk < ks; ++kk)
+    for (int tau = 0; tau < NT; ++tau)
+      for (int l = 0; l < 64; ++l) {
+        const int mrow = l & 15, a = 4 * kk + (l >> 4);
+        const int sub = Mma16<T>::sub_of_row(mrow), idx = 4 * tau + Mma16<T>::reg_of_row(mrow);
+        const int row = 4 * (idx / R) + sub, c = idx % R;
+        if (a < n && row < r && c < r) wm[((size_t)kk * NT + tau) * 64 + l] = host[((size_t)a * R + row) * R + c];
+      }
+  img->ks = ks;
+  wm.insert(wm.end(), host.begin() + (size_t)n * R * R, host.end());     // ... | Wlin | N | y0 behind the operands
   std::vector<T> wr((size_t)(p->n_rows > 0 ? p->n_rows : 1) * n, T(0));
   for (size_t i = 0; i < (size_t)p->n_rows * n; ++i) wr[i] = (T)p->W[i];
   const bool ok = hipMalloc(&img->data, host.size() * sizeof(T)) == hipSuccess &&
                   hipMemcpy(img->data, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice) == hipSuccess &&
                   hipMalloc(&img->wrow, wr.size() * sizeof(T)) == hipSuccess &&
                   hipMemcpy(img->wrow, wr.data(), wr.size() * sizeof(T), hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMalloc(&img->wm, wm.size() * sizeof(T)) == hipSuccess &&
+                  hipMemcpy(img->wm, wm.data(), wm.size() * sizeof(T), hipMemcpyHostToDevice) == hipSuccess &&
                   hipMalloc(&img->lin_id, ids.size() * sizeof(int32_t)) == hipSuccess &&
                   hipMemcpy(img->lin_id, ids.data(), ids.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess;
   if (!ok) {
     if (img->data) (void)hipFree(img->data);
     if (img->wrow) (void)hipFree(img->wrow);
+    if (img->wm) (void)hipFree(img->wm);
     if (img->lin_id) (void)hipFree(img->lin_id);
     delete img;
     return RAYEN_E_ALLOC;
   }
-  img->bytes = (int64_t)((host.size() + wr.size()) * sizeof(T) + ids.size() * sizeof(int32_t));
+  img->bytes = (int64_t)((host.size() + wr.size() + wm.size()) * sizeof(T) + ids.size() * sizeof(int32_t));
   *bytes = img->bytes;
   *out = img;
   return RAYEN_OK;
 }
 
+// LDS of the matrix-core instance: [Wm | Wlin | N | y0] + the rows of v + four wave-private transposition patches
+template <typename T>
+size_t quad_mf_lds_bytes(const RayenPack* p, int R, int m) {
+  const size_t ks = (size_t)(p->n + 3) / 4;
+  const size_t elems = ks * (R / 4) * (R / 4) * 64 + (size_t)m * p->n + (p->out_identity ? 0 : (size_t)p->k * p->n) + p->k;
+  const int R4 = R / 4;
+  const size_t tiles = ((size_t)R4 * R4 * 64 * 4 * sizeof(T) * 4 <= 104 * 1024) ? (size_t)R4 * R4 : (size_t)R4;   // quad_stage_tiles
+  return sizeof(T) * (((elems + 3) & ~size_t(3)) + ((64 * (size_t)(p->n + 1) + 3) & ~size_t(3)) + 4 * tiles * 64 * 4);
+}
+
+inline bool quad_mfma_enabled() {     // RAYEN_LMI_QUAD_MFMA=0: the round-3 kernel (S from the LDS image), for A/B runs
+  static const bool on = [] { const char* e = getenv("RAYEN_LMI_QUAD_MFMA"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 template <typename T, int R4>
 int launch_quad(const RayenPack* p, const LmiQuadImage* img, const T* v, int64_t B, int64_t ldv, T* y, int64_t ldy,
                 T* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream) {
+  const int64_t grid = (B + 63) / 64;
+  if (img->wm != nullptr && quad_mfma_enabled() && quad_mf_lds_bytes<T>(p, img->R, img->m) <= 150 * 1024) {
+    const size_t lds = quad_mf_lds_bytes<T>(p, img->R, img->m);
+    auto kern = lmi_quad_kernel<T, R4, true>;
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) !=
+            hipSuccess)
+      return RAYEN_E_LAUNCH;
+    const int64_t gen = (int64_t)img->n * img->R * img->R;
+    const int64_t ops = (int64_t)img->ks * R4 * R4 * 64;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, static_cast<const T*>(img->wm), img->lin_id,
+                       img->r, img->n, img->k, img->m, img->identity, img->lmi_seg, img->elems - gen + ops, v, B, ldv, y,
+                       ldy, kappa, active, nan_flag, img->ks);
+    return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
+  }
   const size_t lds = quad_lds_bytes<T>(p, img->R, img->m);
-  auto kern = lmi_quad_kernel<T, R4>;
+  auto kern = lmi_quad_kernel<T, R4, false>;
   if (lds > 48 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) !=
           hipSuccess)
     return RAYEN_E_LAUNCH;
-  const int64_t grid = (B + 63) / 64;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, static_cast<const T*>(img->data), img->lin_id,
                      img->r, img->n, img->k, img->m, img->identity, img->lmi_seg, img->elems, v, B, ldv, y, ldy, kappa,
-                     active, nan_flag);
+                     active, nan_flag, 0);
   return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
 }
 

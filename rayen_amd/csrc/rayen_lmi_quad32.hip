@@ -16,6 +16,7 @@ void lmi_quad_free(LmiQuadImage* img) {
   if (img == nullptr) return;
   if (img->data) (void)hipFree(img->data);
   if (img->wrow) (void)hipFree(img->wrow);
+  if (img->wm) (void)hipFree(img->wm);
   if (img->lin_id) (void)hipFree(img->lin_id);
   delete img;
 }
