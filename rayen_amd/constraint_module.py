@@ -37,6 +37,7 @@ from . import _lib, eager, ops, pack as _pack, utils
 
 
 class ConstraintModule(torch.nn.Module):
+    _fast = {}                    # (replaced per instance; a pickle written before round 4 has no such attribute)
     _hip_unsupported = False      # set per instance (with a warning) when no HIP kernel serves the set: eager.py runs instead
 
     def __init__(self, cs, input_dim=None, method='RAYEN', create_map=True, args_DC3=None):
@@ -129,11 +130,13 @@ class ConstraintModule(torch.nn.Module):
         self.fuse_mapper = True
         self._device_packs = {}
         self._consts = None
+        self._fast = {}
 
     # ------------------------------------------------------------------ constant packs
     def _invalidate_packs(self):
         self._device_packs = {}
         self._consts = None
+        self._fast = {}
         self.__dict__.pop("_eager", None)
 
     def _apply(self, fn, *args, **kwargs):
@@ -170,11 +173,14 @@ class ConstraintModule(torch.nn.Module):
         state = self.__dict__.copy()
         state["_device_packs"] = {}   # device handles are not picklable; rebuilt lazily
         state["_consts"] = None
+        state["_fast"] = {}
+        state.pop("_eager", None)
         state.pop("forwardForMethod", None)
         return state
 
     def __setstate__(self, state):
         super().__setstate__(state)
+        self._fast = {}
         self.forwardForMethod = {'RAYEN': self.forwardForRAYEN, 'RAYEN_old': self.forwardForRAYENOld,
                                  'UU': self.forwardForUU}[self.method]
 
@@ -265,8 +271,52 @@ class ConstraintModule(torch.nn.Module):
         y, _, _, _ = torch.ops.rayen_amd.ray_project_mapped(x2, weight, bias, pack_id, need_grad)
         return y.unsqueeze(2)
 
+    # ------------------------------------------------------------------ small-batch inference fast path
+    def _fast_entry(self, x):
+        """Per-(device, dtype) prebuilt call of the C ABI for plain inference with the identity mapper: pack handle,
+        ctypes entry point, NaN-flag address and sizes looked up ONCE (round 4: the generic route -- flatten, the empty
+        nn.Sequential, unsqueeze, _project, ops.project_raw and their re-validation -- cost ~13 us of Python per call in
+        front of a 4.5 us kernel at config 1).  ``None`` when the layer has a mapper, another method, or no HIP kernel."""
+        key = (x.device.index, x.dtype)
+        entry = self._fast.get(key, False)
+        if entry is False:
+            entry = None
+            if (self.method == 'RAYEN' and isinstance(self.mapper, nn.Sequential) and len(self.mapper) == 0
+                    and not self._hip_unsupported and x.dtype in (torch.float32, torch.float64)):
+                try:
+                    dp, _ = self.device_pack(x.device)
+                    fn = ops._entry(ops._FWD[(x.dtype, False)])
+                    entry = (fn, dp.handle, dp.nan_flag.data_ptr(), self.k, self.n, x.device.index, dp)
+                except _lib.RayenError:
+                    entry = None           # (the generic route reports it)
+            self._fast[key] = entry
+        return entry
+
     def forward(self, x):
         # x: [nsib, numel_input_mapper, 1]; after the mapper q is [nsib, numel_output_mapper, 1]
+        if (type(x) is torch.Tensor and x.is_cuda and x.dim() >= 2 and x.is_contiguous()
+                and not (x.requires_grad and torch.is_grad_enabled()) and not torch.compiler.is_compiling()):
+            entry = self._fast_entry(x)
+            if entry is not None:
+                fn, handle, nan_ptr, k, n, index, dp = entry
+                B = x.shape[0]
+                width = x.numel() // B if B else n
+                if width >= n and dp.handle is not None:
+                    y = torch.empty((B, k, 1), dtype=x.dtype, device=x.device)
+                    if torch.cuda.current_device() == index:
+                        code = fn(handle, x.data_ptr(), B, width, y.data_ptr(), k, None, None, nan_ptr,
+                                  ops._stream(index))
+                    else:
+                        with torch.cuda.device(index):
+                            code = fn(handle, x.data_ptr(), B, width, y.data_ptr(), k, None, None, nan_ptr,
+                                      ops._stream(index))
+                    if code != 0:
+                        _lib.check(code, "rayen_ray_project")
+                    if __debug__ and self.check_nan and not torch.cuda.is_current_stream_capturing():
+                        if int(dp.nan_flag.item()) != 0:      # the flag read is a host sync (CM:531 is one too)
+                            dp.nan_flag.zero_()
+                            raise AssertionError("the projection produced NaN (NaN in the input?)")
+                    return y
         x2 = torch.flatten(x, 1)  # == x.view(B, -1), and defined for B = 0
         y = self._forward_fused_mapper(x2)
         if y is None:

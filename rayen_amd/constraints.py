@@ -298,6 +298,33 @@ class ConvexConstraints:
 
         utils.verify(np.allclose(NA_E.T @ NA_E, np.eye(NA_E.shape[1])))
 
+    def _interior_point_with_cvxpy(self):
+        """The reference's own margin program on the reference's own modelling layer, when cvxpy is importable
+        ("lazy import cvxpy when installed so behaviour matches the reference exactly where it
+        can"; constraints.py:412-432): maximise eps subject to every constraint of the subspace holding with margin eps,
+        0 <= eps <= 0.5, handed to whichever solver cvxpy picks -- so the solver-chosen ``z0`` is the one the reference
+        would have got on the same installation.  ``None`` when cvxpy is absent (this image), when
+        ``RAYEN_NO_CVXPY=1``, or when its solve does not end optimal (the built-in program below then runs)."""
+        import os
+        if os.environ.get("RAYEN_NO_CVXPY", "0") == "1":
+            return None
+        try:
+            import cvxpy as cp
+        except Exception:               # not installed (or a broken install): the built-in solvers serve
+            return None
+        try:
+            eps = cp.Variable()
+            z = cp.Variable((self.n, 1))
+            cons = self.getConstraintsInSubspaceCvxpy(z, eps) + [eps >= 0, eps <= 0.5]
+            prob = cp.Problem(cp.Minimize(-eps), cons)
+            prob.solve(verbose=False)
+            if prob.status not in ("optimal", "optimal_inaccurate") or z.value is None or float(eps.value) <= 1e-8:
+                return None
+            z0 = np.asarray(z.value, dtype=np.float64).reshape(self.n, 1)
+            return z0 if float(np.min(self.margins(z0))) > 1e-8 else None
+        except Exception:
+            return None
+
     # ------------------------------------------------------------------ linear preprocessing
     def _stacked_inequalities(self):
         """``A y <= b`` with equalities as two opposite inequalities (constraints.py:239-250)."""
@@ -410,6 +437,9 @@ class ConvexConstraints:
         """
         n = self.n
         m = self.A_p.shape[0]
+        z_cvx = self._interior_point_with_cvxpy()
+        if z_cvx is not None:
+            return z_cvx
         # LP over (z, eps): A_p z + eps <= b_p
         c = np.zeros(n + 1)
         c[-1] = -1.0

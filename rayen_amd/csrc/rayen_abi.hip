@@ -634,7 +634,8 @@ int rayen_pack_info(const RayenPack* p, RayenPackInfo* info) {
                   : (p->q32 != nullptr && lmi_quad_bwd_serves_f32(p, p->q32)) ? 4
                   : p->mb32 != nullptr ? 1
                   : (p->mbp32 != nullptr && p->mbp32_state == 1) ? 3
-                  : p->mbg32 != nullptr ? 2 : (p->w32 != nullptr && lmi_dim(p) > 30) ? 5 : 0;
+                  : p->mbg32 != nullptr ? 2
+                  : (p->w32 != nullptr && !generic_backward_serves<float>(p, image_of<float>(p))) ? 5 : 0;
   info->bwd32_check_pair = p->check_bwd_pair;
   info->bwd32_check_exact = p->check_bwd_exact;
   int lmi_words = 0;

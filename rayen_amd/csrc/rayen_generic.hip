@@ -929,6 +929,17 @@ int generic_backward(const RayenPack* p, const GenericImage<T>& img, const T* v,
   }
 }
 
+// does the lane-per-sample backward stage this pack at all?  (the predicate generic_backward dispatches on: what
+// rayen_pack_info reports as the backward family must be what a call would run)
+template <typename T>
+bool generic_backward_serves(const RayenPack* p, const GenericImage<T>& img) {
+  int w_rows, lmi_words;
+  bwd_shape<T>(p, img, &w_rows, &lmi_words);
+  return bwd_lds_bytes<T>(p, w_rows, lmi_words, 64) <= kLdsHard;
+}
+template bool generic_backward_serves<float>(const RayenPack*, const GenericImage<float>&);
+template bool generic_backward_serves<double>(const RayenPack*, const GenericImage<double>&);
+
 #define RAYEN_INSTANTIATE(T)                                                                        \
   template int generic_build<T>(const RayenPack*, GenericImage<T>*);                               \
   template void generic_free<T>(GenericImage<T>*);                                                  \

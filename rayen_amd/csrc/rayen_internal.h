@@ -114,6 +114,8 @@ int generic_forward(const RayenPack* p, const GenericImage<T>& img, const T* v, 
                     int64_t ldv, T* y, int64_t ldy, T* kappa, int32_t* active, int32_t* nan_flag,
                     int old_mode, hipStream_t stream);
 template <typename T>
+bool generic_backward_serves(const RayenPack* p, const GenericImage<T>& img);
+template <typename T>
 int generic_backward(const RayenPack* p, const GenericImage<T>& img, const T* v, int64_t B,
                      int64_t ldv, const T* kappa, const int32_t* active, const T* grad_y,
                      int64_t ldg, T* grad_v, int64_t ldgv, int old_mode, hipStream_t stream);

@@ -705,9 +705,9 @@ static int launch_split(const RayenPack* p, const SplitImage* img, const float* 
 // ---- fused mapper: in_dim <= n_pad columns of x (the transposition patch and the register budget are the walk's)
 int64_t mfma_split_mapper_image_bytes(const RayenPack* p, const SplitImage* img, int in_dim) {
   (void)p;
-  // (sets with equality constraints, NA_E != I: their mapped instances -- the walk's staged write-out next to the
-  // mapper prologue, 255 VGPRs and ~200 spilled SGPRs -- fault on the device; until that is understood such packs run
-  // the mapper as its own GEMM)
+  // (sets with equality constraints, NA_E != I, are served too since round 3: the device fault of their mapped
+  // instances was an SGPR restored by v_readlane right in front of an inline-asm VMEM instruction -- five wait states
+  // hipcc cannot insert into an asm string; RAYEN_ASM_BASE_COPY)
   if (img == nullptr || in_dim < 1 || in_dim > img->nkk * 32) return 0;
   const int nsx = (in_dim + 31) / 32 * 2;
   return (int64_t)img->nkk * nsx * 3 * 1024 + (int64_t)img->nkk * 32 * sizeof(float);

@@ -56,7 +56,11 @@ class ShardedStep:
                  reserve_cus=0, set_reserve=None):
         """``reserve_cus`` / ``set_reserve``: compute units the projection's persistent grid leaves free while a
         gather step runs (``set_reserve(n) -> previous`` = ``rayen_reserve_cus`` of the C ABI; ``None`` on CPU).
-        RCCL's all-gather kernels need CUs: behind a grid that fills every SIMD they would simply queue."""
+        RCCL's all-gather kernels need CUs: behind a grid that fills every SIMD they would simply queue.
+        The reservation is PROCESS-WIDE state of the library for the duration of the step (``rayen_reserve_cus`` is one
+        atomic): another thread or pack that launches a projection inside that window gets the smaller grid too (same
+        results, fewer workgroups).  One stepping thread per process is the supported arrangement; the default is 0
+        (no reservation) until a multi-GPU run shows that leaving CUs free pays."""
         self.project_into = project_into
         self.reserve_cus = int(reserve_cus)
         self.set_reserve = set_reserve

@@ -60,6 +60,7 @@ class PackedConstants:
     NA_E: np.ndarray = None            # [k, n]
     y0: np.ndarray = None              # [k]  (= NA_E z0 + yp)
     out_identity: bool = False
+    dropped_segments: int = 0          # quadratics that vanish identically in the subspace and were left out (kappa = 0)
 
     @property
     def n_rows(self):
@@ -110,6 +111,7 @@ def pack_constants(buffers: dict, low_rank: bool = True, exact_quadratics=None) 
     yp = _f64(buffers["yp"]).reshape(k)
 
     rows, segments = [], []
+    dropped = 0
 
     def add_rows(block):
         start = sum(r.shape[0] for r in rows)
@@ -162,6 +164,7 @@ def pack_constants(buffers: dict, low_rank: bool = True, exact_quadratics=None) 
     if phi is not None and phi.ndim == 3:
         for i in range(phi.shape[0]):
             if _vanishes_in_subspace(i):
+                dropped += 1
                 continue
             aux = add_rows(phi[i].reshape(1, k) @ N)
             G = N.T @ delta[i] @ N
@@ -218,7 +221,8 @@ def pack_constants(buffers: dict, low_rank: bool = True, exact_quadratics=None) 
     W = np.concatenate(rows, axis=0) if rows else np.zeros((0, n))
     identity = (k == n) and np.array_equal(N, np.eye(k))
     return PackedConstants(k=k, n=n, W=np.ascontiguousarray(W), segments=segments,
-                           NA_E=np.ascontiguousarray(N), y0=N @ z0 + yp, out_identity=identity)
+                           NA_E=np.ascontiguousarray(N), y0=N @ z0 + yp, out_identity=identity,
+                           dropped_segments=dropped)
 
 
 def _as_double_ptr(a):

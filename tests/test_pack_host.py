@@ -184,3 +184,15 @@ def test_low_rank_factoring_never_drops_curvature():
     layer32._invalidate_packs()
     kinds = [s.type for s in layer32.packed_constants().segments]
     assert _lib.SEG_QUAD_FAC not in kinds and kinds.count(_lib.SEG_QUAD_SYM) == 3
+
+
+def test_config5_drops_the_same_segments_at_both_precisions():
+    """the quadratics that vanish identically in the subspace are left out of the pack (kappa = 0); the
+    decision is made on the fp64 constraint data against the module's own NA_E, so an fp32 module (rounded NA_E) and an
+    fp64 one must agree -- 8 of config 5's 72 -- and the count is on record in the packed constants."""
+    raw = workloads.make_raw("c5", seed=0)
+    _, l32 = _module_from_raw(raw, torch.float32)
+    _, l64 = _module_from_raw(raw, torch.float64)
+    c32, c64 = l32.packed_constants(), l64.packed_constants()
+    assert c32.dropped_segments == c64.dropped_segments == 8
+    assert [(s.type, s.row0, s.nrows) for s in c32.segments] == [(s.type, s.row0, s.nrows) for s in c64.segments]

@@ -170,3 +170,53 @@ def test_projection_of_example_sets_is_feasible_and_idempotent(index):
         # no feasible point is closer: compare with the interior point and random feasible points on the segment
         assert d2 <= float(np.sum((cs.y0 - p) ** 2)) + 1e-9
     assert cs.getViolation(cs.y0[:, 0]) < 1e-12
+
+
+def test_interior_point_uses_cvxpy_when_it_is_importable(monkeypatch):
+    """SURVEY section 8 (f2), second half: with cvxpy importable the reference's margin program is posed on cvxpy itself
+    (so the solver-chosen z0 is the reference's); without it -- this image -- the built-in program runs.  cvxpy is absent
+    here, so a stand-in module records that it was asked and hands back a strictly interior point."""
+    import sys
+    import types
+    asked = {}
+
+    class Var:
+        def __init__(self, shape=()):
+            self.shape, self.value = shape, None
+        def _e(self, *_):
+            return self
+        __add__ = __radd__ = __sub__ = __rsub__ = __mul__ = __rmul__ = __matmul__ = __rmatmul__ = __neg__ = _e
+        __le__ = __ge__ = __eq__ = __rshift__ = __getitem__ = _e
+        __array_ufunc__ = None
+        T = property(lambda self: self)
+        __hash__ = object.__hash__
+
+    class Problem:
+        def __init__(self, objective, constraints):
+            self.status = None
+        def solve(self, **kw):
+            asked["solved"] = True
+            self.status = "optimal"
+            asked["z"].value = np.full(asked["z"].shape, 0.5)
+            asked["eps"].value = 0.5
+
+    def variable(shape=()):
+        var = Var(shape)
+        asked["z" if shape else "eps"] = var
+        return var
+
+    fake = types.ModuleType("cvxpy")
+    fake.Variable, fake.Problem = variable, Problem
+    fake.Minimize = fake.Maximize = lambda e: e
+    fake.sum_squares = fake.quad_form = fake.norm = lambda *a, **k: Var()
+    fake.installed_solvers = lambda: ["SCS"]
+    monkeypatch.setitem(sys.modules, "cvxpy", fake)
+    A1 = np.concatenate((np.eye(3), -np.eye(3)))
+    b1 = np.array([[1.0], [1.0], [1.0], [0.0], [0.0], [0.0]])
+    cs = constraints.ConvexConstraints(lc=constraints.LinearConstraint(A1, b1, None, None))
+    assert asked.get("solved") and np.allclose(cs.y0[:, 0], 0.5)
+    # ... and RAYEN_NO_CVXPY=1 pins the built-in program (same set: its own strictly interior point)
+    asked.clear()
+    monkeypatch.setenv("RAYEN_NO_CVXPY", "1")
+    cs2 = constraints.ConvexConstraints(lc=constraints.LinearConstraint(A1, b1, None, None))
+    assert "solved" not in asked and np.min(cs2.margins(cs2.z0)) > 1e-6
