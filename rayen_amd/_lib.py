@@ -81,7 +81,7 @@ def load():
     if not os.path.exists(LIBRARY):
         raise RuntimeError(
             f"{LIBRARY} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "(hipcc --offload-arch=gfx950). rayen_amd has no CPU or eager fallback.")
+            "(hipcc --offload-arch=gfx950). Tensors on a HIP device are never routed anywhere else.")
     lib = ctypes.CDLL(LIBRARY)
     p, i64, i32p = ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p
     lib.rayen_abi_version.restype = ctypes.c_int

@@ -310,13 +310,15 @@ class ConstraintModule(torch.nn.Module):
                         with torch.cuda.device(index):
                             code = fn(handle, x.data_ptr(), B, width, y.data_ptr(), k, None, None, nan_ptr,
                                       ops._stream(index))
-                    if code != 0:
+                    if code == 0:
+                        if __debug__ and self.check_nan and not torch.cuda.is_current_stream_capturing():
+                            if int(dp.nan_flag.item()) != 0:      # the flag read is a host sync (CM:531 is one too)
+                                dp.nan_flag.zero_()
+                                raise AssertionError("the projection produced NaN (NaN in the input?)")
+                        return y
+                    if code != _lib.E_UNSUPPORTED:
                         _lib.check(code, "rayen_ray_project")
-                    if __debug__ and self.check_nan and not torch.cuda.is_current_stream_capturing():
-                        if int(dp.nan_flag.item()) != 0:      # the flag read is a host sync (CM:531 is one too)
-                            dp.nan_flag.zero_()
-                            raise AssertionError("the projection produced NaN (NaN in the input?)")
-                    return y
+                    self._fast[(x.device.index, x.dtype)] = None     # no kernel for this set: the route below says so
         x2 = torch.flatten(x, 1)  # == x.view(B, -1), and defined for B = 0
         y = self._forward_fused_mapper(x2)
         if y is None:

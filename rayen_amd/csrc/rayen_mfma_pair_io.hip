@@ -236,6 +236,11 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_io_
 
   int64_t grp = wave_id;
   bool need_fetch = false;   // the buffer holds the rows of group `grp`, still to be split
+#ifdef RAYEN_IO_STAGGER
+  // developer build: the second wave of every SIMD (waves 4..7 of the workgroup) asks for its first rows RAYEN_IO_STAGGER
+  // x 64 clocks later -- the first waves' 16 MB then arrive in half the time and their walks start while the others' load
+  if ((threadIdx.x >> 6) >= 4) __builtin_amdgcn_s_sleep(RAYEN_IO_STAGGER);
+#endif
   if (grp < n_groups) {
     burst_load(grp * (NT * 32));
     drain();

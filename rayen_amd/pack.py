@@ -211,8 +211,13 @@ def pack_constants(buffers: dict, low_rank: bool = True, exact_quadratics=None) 
     if F is not None and F.ndim == 3:
         L = _f64(buffers["L"])
         r = L.shape[0]
-        G_a = -np.einsum("pi,aij,jq->apq", L.T, F[:-1], L)      # [k, r, r], symmetric
-        G_b = np.einsum("ab,apq->bpq", N, G_a)                   # fold NA_E: [n, r, r]
+        # (BLAS products: as einsum contractions these two took 84 s on the host for k = 1000, r = 100 -- the LMI sweep's
+        # 50 s of `setup_s` in round 3)
+        G_a = -np.matmul(L.T[None, :, :], np.matmul(F[:-1], L))  # [k, r, r], symmetric
+        if k == n and np.array_equal(N, np.eye(k)):
+            G_b = G_a
+        else:
+            G_b = (N.T @ G_a.reshape(k, r * r)).reshape(n, r, r)  # fold NA_E: [n, r, r]
         G_b = 0.5 * (G_b + np.transpose(G_b, (0, 2, 1)))
         il, jl = np.tril_indices(r)                              # packed index p(p+1)/2 + q, p >= q
         row0 = add_rows(G_b[:, il, jl].T)
