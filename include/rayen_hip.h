@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define RAYEN_ABI_VERSION 6
+#define RAYEN_ABI_VERSION 7
 
 enum {
   RAYEN_OK = 0,
@@ -146,8 +146,9 @@ enum {
   RAYEN_KERNEL_PAIR_IO = 5,   /* f16 pairs, rows of v and y trickled through LDS under the tile walk */
   RAYEN_KERNEL_LMI_QUAD = 6,  /* four lanes per sample (one LMI + linear rows) */
   RAYEN_KERNEL_LMI_WAVE = 7,  /* one wave per sample, the matrix in LDS (one LMI beyond ~30 x 30 + linear rows) */
-  RAYEN_KERNEL_PAIR_WS = 8    /* f16 pairs, W-stationary (ABI v6): the tiles of W resident in the registers of a workgroup's eight
+  RAYEN_KERNEL_PAIR_WS = 8,   /* f16 pairs, W-stationary (ABI v6): the tiles of W resident in the registers of a workgroup's eight
                                  waves, the batch streamed through a shared B-operand image in LDS */
+  RAYEN_KERNEL_PRODUCTS = 9   /* wide sets (ABI v7): the epilogue over products T = v W_ext' of a library GEMM */
 };
 int rayen_last_forward_kernel(void);
 
@@ -198,6 +199,23 @@ int rayen_ray_project_generic_f32(const RayenPack* pack, const float* v, int64_t
 int rayen_ray_project_generic_f64(const RayenPack* pack, const double* v, int64_t B, int64_t ldv,
                                   double* y, int64_t ldy, double* kappa, int32_t* active,
                                   int32_t* nan_flag, void* stream);
+
+/* Wide sets (ABI v7): n beyond what the matrix-core kernels keep in registers (64 split-operand / 128 exact fp32).
+ * There T = v W_ext' is a PLAIN GEMM and belongs to the vendor library (hipBLASLt / rocBLAS: the host side calls it on
+ * the caller's stream -- torch.mm in rayen_amd/ops.py); this entry is the rest of constraint_module.py:351-458 +
+ * 468-474 as ONE bandwidth-bound kernel over T: a wave per sample reduces its row of T segment by segment (max /
+ * phi.v + sqrt / cone root), takes kappa = relu(max) and writes y = y0 + (NA_E v) / max(1, kappa).
+ *   W_ext = [W ; NA_E]   (rayen_products_rows() rows: n_rows, + k when the set has equality constraints; the caller
+ *                         builds it from the RayenPackDesc it created the pack with)
+ *   T [B, ldt] row-major with ldt >= rayen_products_rows(); v, y, kappa, active, nan_flag as in rayen_ray_project_*.
+ * Packs with an LMI segment are not served (RAYEN_E_UNSUPPORTED; rayen_products_rows() == 0). */
+int64_t rayen_products_rows(const RayenPack* pack);
+int rayen_ray_project_from_products_f32(const RayenPack* pack, const float* T, int64_t ldt, const float* v, int64_t B,
+                                        int64_t ldv, float* y, int64_t ldy, float* kappa, int32_t* active,
+                                        int32_t* nan_flag, void* stream);
+int rayen_ray_project_from_products_f64(const RayenPack* pack, const double* T, int64_t ldt, const double* v, int64_t B,
+                                        int64_t ldv, double* y, int64_t ldy, double* kappa, int32_t* active,
+                                        int32_t* nan_flag, void* stream);
 
 /* Backward of y w.r.t. v (vector-Jacobian product):
  *   grad_v = s N'g - [kappa > 1] s^2 (g . N v) grad kappa(v),   s = 1/max(1,kappa)

@@ -10,7 +10,7 @@ import os
 
 from ._build import LIBRARY
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 SEG_LIN, SEG_QUAD_SYM, SEG_QUAD_FAC, SEG_SOC, SEG_LMI = range(5)
 E_UNSUPPORTED = -6      # RAYEN_E_UNSUPPORTED (include/rayen_hip.h)
@@ -28,8 +28,9 @@ EXPORTS = (
     "rayen_ray_project_mapped_image_f32", "rayen_bwd_workspace_bytes_f32", "rayen_ray_project_bwd_ws_f32",
     "rayen_bwd_workspace_bytes_f64", "rayen_ray_project_bwd_ws_f64", "rayen_last_forward_kernel",
     "rayen_pair_schedule", "rayen_reserve_cus",
+    "rayen_products_rows", "rayen_ray_project_from_products_f32", "rayen_ray_project_from_products_f64",
 )
-KERNEL_NONE, KERNEL_LANE, KERNEL_MFMA, KERNEL_TRIPLE, KERNEL_PAIR, KERNEL_PAIR_IO, KERNEL_LMI_QUAD, KERNEL_LMI_WAVE, KERNEL_PAIR_WS = range(9)
+KERNEL_NONE, KERNEL_LANE, KERNEL_MFMA, KERNEL_TRIPLE, KERNEL_PAIR, KERNEL_PAIR_IO, KERNEL_LMI_QUAD, KERNEL_LMI_WAVE, KERNEL_PAIR_WS, KERNEL_PRODUCTS = range(10)
 
 
 class RayenSegment(ctypes.Structure):
@@ -105,6 +106,11 @@ def load():
                  "rayen_ray_project_generic_f64", "rayen_ray_project_old_f32", "rayen_ray_project_old_f64"):
         getattr(lib, name).restype = ctypes.c_int
         getattr(lib, name).argtypes = fwd
+    for name in ("rayen_ray_project_from_products_f32", "rayen_ray_project_from_products_f64"):
+        getattr(lib, name).restype = ctypes.c_int
+        getattr(lib, name).argtypes = [p, p, i64, p, i64, i64, p, i64, p, i32p, i32p, p]
+    lib.rayen_products_rows.restype = ctypes.c_int64
+    lib.rayen_products_rows.argtypes = [p]
     bwd = [p, p, i64, i64, p, i32p, p, i64, p, i64, p]
     for name in ("rayen_ray_project_bwd_f32", "rayen_ray_project_bwd_f64", "rayen_ray_project_bwd_generic_f32",
                  "rayen_ray_project_bwd_generic_f64",

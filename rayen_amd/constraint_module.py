@@ -282,7 +282,8 @@ class ConstraintModule(torch.nn.Module):
         if entry is False:
             entry = None
             if (self.method == 'RAYEN' and isinstance(self.mapper, nn.Sequential) and len(self.mapper) == 0
-                    and not self._hip_unsupported and x.dtype in (torch.float32, torch.float64)):
+                    and not self._hip_unsupported and x.dtype in (torch.float32, torch.float64)
+                    and self.n < ops._WIDE_MIN_N[x.dtype]):      # (wide sets: GEMM + products epilogue, ops.project_raw)
                 try:
                     dp, _ = self.device_pack(x.device)
                     fn = ops._entry(ops._FWD[(x.dtype, False)])

@@ -119,6 +119,7 @@ int build_images(RayenPack* p, int prepare) {
   const bool f64 = (prepare & (RAYEN_PREPARE_F32 | RAYEN_PREPARE_F64)) == 0 || (prepare & RAYEN_PREPARE_F64);
   const bool bwd = !(prepare & RAYEN_PREPARE_FWD_ONLY);
   int rc = RAYEN_OK;
+  if ((rc = build_one(p, true, &p->wide, wide_build))) return rc;
   if (f32) {
     p->prepared |= RAYEN_PREPARE_F32;
     if ((rc = build_generic<float>(p))) return rc;
@@ -226,6 +227,19 @@ int project_bwd(const RayenPack* p, const T* v, int64_t B, int64_t ldv, const T*
     }
   }
   return rcg;
+}
+
+template <typename T>
+int project_from_products(const RayenPack* p, const T* Tm, int64_t ldt, const T* v, int64_t B, int64_t ldv, T* y,
+                                 int64_t ldy, T* kappa, int32_t* active, int32_t* nan_flag, void* stream) {
+  if (p == nullptr || B < 0 || (B > 0 && (v == nullptr || Tm == nullptr)) || ldv < p->n || (y != nullptr && ldy < p->k) ||
+      ldt < (int64_t)p->n_rows + (p->out_identity ? 0 : p->k))
+    return RAYEN_E_BAD_ARG;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return RAYEN_E_NO_DEVICE;
+  if (dev != p->device) return RAYEN_E_DEVICE_MISMATCH;
+  return wide_epilogue<T>(p, p->wide, Tm, ldt, v, B, ldv, y, ldy, kappa, active, nan_flag,
+                          static_cast<hipStream_t>(stream));
 }
 
 }  // namespace
@@ -607,6 +621,7 @@ void rayen_pack_destroy(RayenPack* p) {
   if (p->sp32) mfma_split_free(p->sp32);
   if (p->pr32) mfma_pair_free(p->pr32);
   if (p->ws8_32) mfma_pair_ws8_free(p->ws8_32);
+  if (p->wide) wide_free(p->wide);
   if (p->q32) lmi_quad_free(p->q32);
   if (p->w32) lmi_wave_free(p->w32);
   if (p->w64) lmi_wave_free(p->w64);
@@ -653,6 +668,25 @@ int rayen_ray_project_generic_f32(const RayenPack* p, const float* v, int64_t B,
                                   void* stream) {
   g_last_forward = RAYEN_KERNEL_LANE;
   return project_generic<float>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+}
+
+int rayen_ray_project_from_products_f32(const RayenPack* p, const float* T, int64_t ldt, const float* v, int64_t B,
+                                        int64_t ldv, float* y, int64_t ldy, float* kappa, int32_t* active,
+                                        int32_t* nan_flag, void* stream) {
+  g_last_forward = RAYEN_KERNEL_PRODUCTS;
+  return project_from_products<float>(p, T, ldt, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+}
+
+int rayen_ray_project_from_products_f64(const RayenPack* p, const double* T, int64_t ldt, const double* v, int64_t B,
+                                        int64_t ldv, double* y, int64_t ldy, double* kappa, int32_t* active,
+                                        int32_t* nan_flag, void* stream) {
+  g_last_forward = RAYEN_KERNEL_PRODUCTS;
+  return project_from_products<double>(p, T, ldt, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+}
+
+int64_t rayen_products_rows(const RayenPack* p) {
+  if (p == nullptr || p->wide == nullptr) return 0;
+  return (int64_t)p->n_rows + (p->out_identity ? 0 : p->k);
 }
 
 static int project_f32(const RayenPack* p, const float* v, int64_t B, int64_t ldv, float* y, int64_t ldy,

@@ -57,6 +57,7 @@ struct LmiWaveImage;    // rayen_lmi_wave.h
 struct SplitImage;      // rayen_mfma_split.hip
 struct PairImage;       // rayen_mfma_pair.hip
 struct Ws8Image;        // rayen_mfma_pair_ws8.hip
+struct WideImage;       // rayen_wide.hip
 
 }  // namespace rayen
 
@@ -92,11 +93,19 @@ struct RayenPack {
   rayen::PairImage* pr32 = nullptr;
   rayen::Ws8Image* ws8_32 = nullptr;   // the same image dealt out to eight W-stationary waves (null: not served)
   int pr32_state = 0;            // the same for the f16-pair kernel (which is preferred when both are accepted)
+  rayen::WideImage* wide = nullptr;    // segment tables of the products epilogue (any n; packs without an LMI)
   double check_split = -1.0, check_exact = -1.0, check_pair = -1.0;  // worst row errors against fp64 (fp32_selfcheck)
   int64_t device_bytes = 0;
 };
 
 namespace rayen {
+
+// products epilogue for wide sets (rayen_wide.hip)
+int wide_build(const RayenPack* p, WideImage** out, int64_t* bytes);
+void wide_free(WideImage* img);
+template <typename T>
+int wide_epilogue(const RayenPack* p, const WideImage* img, const T* Tm, int64_t ldt, const T* v, int64_t B, int64_t ldv,
+                  T* y, int64_t ldy, T* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream);
 
 // SIMDs the persistent grids may fill: all of the device's minus rayen_reserve_cus() compute units (a collective that
 // runs beside the projection -- RCCL's all-gather kernels in the multi-GPU step -- needs CUs of its own)

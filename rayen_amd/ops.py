@@ -111,6 +111,18 @@ _BWD = {(torch.float32, False): "rayen_ray_project_bwd_f32", (torch.float64, Fal
         (torch.float64, True): "rayen_ray_project_old_bwd_f64"}
 
 
+# Where the matrix-core kernels stop (n they keep in registers; include/rayen_hip.h) the forward
+# goes GEMM + epilogue: T = v W_ext' on the vendor library (torch.mm -> hipBLASLt / rocBLAS on the caller's stream),
+# then ONE hand-written kernel over T (rayen_wide.hip).  ``RAYEN_WIDE_ROUTE=0`` pins the lane-per-sample kernel.
+_WIDE_MIN_N = {torch.float32: 129, torch.float64: 65}
+
+
+def _wide_route(v, pack, force_generic, old_head):
+    if force_generic or old_head or pack.consts.n < _WIDE_MIN_N[v.dtype] or os.environ.get("RAYEN_WIDE_ROUTE", "1") == "0":
+        return None
+    return pack.products_matrix(v.dtype)
+
+
 def project_raw(v, pack, want_y=True, force_generic=False, want_active=True, old_head=False, out=None,
                 want_kappa=True):
     """Direct call of the C ABI on an existing ``DevicePack``; returns (y|None, kappa|None, active|None).
@@ -134,11 +146,21 @@ def project_raw(v, pack, want_y=True, force_generic=False, want_active=True, old
         y = torch.empty((B, k), dtype=v.dtype, device=v.device) if want_y else None
     kappa = torch.empty((B,), dtype=v.dtype, device=v.device) if want_kappa else None
     active = torch.empty((B, 2), dtype=torch.int32, device=v.device) if want_active else None
-    fn = _entry(_FWD_OLD[v.dtype] if old_head else _FWD[(v.dtype, bool(force_generic))])
+    Wt = _wide_route(v, pack, force_generic, old_head) if B else None
     with _on_device(v.device):
-        code = fn(pack.handle, _ptr(v), B, v.stride(0) if B else pack.consts.n, _ptr(y),
-                  y.stride(0) if (y is not None and B) else k,
-                  _ptr(kappa), _ptr(active), _ptr(pack.nan_flag), _stream(v.device.index))
+        if Wt is not None:
+            n = pack.consts.n
+            prods = torch.mm(v if v.shape[1] == n else v[:, :n], Wt)         # [B, rows of W_ext]: the library GEMM
+            fn = _entry("rayen_ray_project_from_products_f32" if v.dtype == torch.float32
+                        else "rayen_ray_project_from_products_f64")
+            code = fn(pack.handle, _ptr(prods), prods.stride(0), _ptr(v), B, v.stride(0), _ptr(y),
+                      y.stride(0) if y is not None else k, _ptr(kappa), _ptr(active), _ptr(pack.nan_flag),
+                      _stream(v.device.index))
+        else:
+            fn = _entry(_FWD_OLD[v.dtype] if old_head else _FWD[(v.dtype, bool(force_generic))])
+            code = fn(pack.handle, _ptr(v), B, v.stride(0) if B else pack.consts.n, _ptr(y),
+                      y.stride(0) if (y is not None and B) else k,
+                      _ptr(kappa), _ptr(active), _ptr(pack.nan_flag), _stream(v.device.index))
     _lib.check(code, "rayen_ray_project")
     return y, kappa, active
 

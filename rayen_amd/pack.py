@@ -265,6 +265,24 @@ class DevicePack:
         _lib.check(_lib.load().rayen_pack_info(self.handle, ctypes.byref(out)), "rayen_pack_info")
         return out
 
+    def products_matrix(self, dtype):
+        """``W_ext' [n, rows]`` on the device at ``dtype`` (``W_ext = [W ; NA_E]``, ``NA_E`` only for sets with equality
+        constraints) for the wide route -- ``T = v W_ext'`` by the vendor GEMM, then ``rayen_ray_project_from_products_*``
+        (include/rayen_hip.h, ABI v7).  ``None`` when the pack has no such route (an LMI segment).  Built once per dtype."""
+        import torch
+        cache = self.__dict__.setdefault("_products", {})
+        if dtype not in cache:
+            rows = int(_lib.load().rayen_products_rows(self.handle))
+            if rows <= 0:
+                cache[dtype] = None
+            else:
+                c = self.consts
+                W_ext = c.W if c.out_identity else np.concatenate((c.W, c.NA_E), axis=0)
+                assert W_ext.shape[0] == rows, (W_ext.shape, rows)
+                cache[dtype] = torch.as_tensor(np.ascontiguousarray(W_ext.T), dtype=torch.float64).to(
+                    device=f"cuda:{self.device_index}", dtype=dtype).contiguous()
+        return cache[dtype]
+
     def mapper_mode(self, in_dim):
         """``rayen_mapper_fusable``: 0 = no fused form | 1 = weights read in place (exact-fp32 family) |
         2 = through a split-operand image of the weights (``rayen_mapper_prepare_f32``)."""

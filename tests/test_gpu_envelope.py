@@ -81,3 +81,76 @@ def test_backward_of_a_wide_set_detours_loudly_and_matches_autograd():
     err = (xg.grad.cpu() - x2.grad).abs().amax(dim=(1, 2)) / x2.grad.abs().amax(dim=(1, 2)).clamp_min(1e-30)
     # (kinks -- ties of the arg-max, kappa = 1 -- are measure-zero for these random directions at fp64)
     assert float(err.max()) <= 1e-7
+
+
+# --------------------------------------------------------------------------- the wide route: library GEMM + products epilogue
+def _wide_sets():
+    rng = np.random.default_rng(3)
+    a = workloads.random_lin_quad_soc(k=200, m=700, n_quad=3, n_soc=2, r_M=150, seed=31)           # dense forms, NA_E = I
+    b = workloads.random_lin_quad_soc(k=300, m=120, n_quad=2, n_soc=1, r_M=40, seed=32)            # + equalities: n = 260
+    b["A2"] = rng.uniform(-1, 1, size=(40, 300))
+    b["b2"] = np.zeros((40, 1))
+    c = workloads.corridor_like(k=260, n_eq=20, m=400, n_quad=30, rank=4, seed=33)                 # low-rank factors, equalities
+    d = workloads.random_lin_quad_soc(k=1000, m=3000, n_quad=0, n_soc=0, seed=34)                  # time_analysis.py:62-63
+    return {"dense_n200": a, "eq_n260": b, "lowrank_n240": c, "lin_k1000": d}
+
+
+@pytest.mark.parametrize("name", ["dense_n200", "eq_n260", "lowrank_n240", "lin_k1000"])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.float64, 1e-9)])
+def test_wide_route_against_oracle_and_the_lane_kernel(name, dtype, tol):
+    """n beyond the matrix-core kernels: T = v W_ext' on the vendor GEMM, then ONE kernel over T
+    (rayen_ray_project_from_products_*).  Against the reference's op sequence, and against the lane-per-sample kernel
+    on the same pack (kappa, the active record, y)."""
+    from rayen_amd import ops
+    raw = _wide_sets()[name]
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        cs = workloads.build_constraints(raw)
+        layer = ConstraintModule(cs, create_map=False).cuda()
+    finally:
+        torch.set_default_dtype(prev)
+    gen = torch.Generator().manual_seed(4)
+    B = 1500
+    x = torch.empty(B, cs.n, 1, dtype=torch.float32).uniform_(-1, 1, generator=gen).to(dtype)
+    x[:4] *= 1e-4
+    x[4] = 0
+    y, warned = _run(layer, x.cuda())
+    assert not warned and _lib.load().rayen_last_forward_kernel() == _lib.KERNEL_PRODUCTS
+    want = oracle.forward(oracle.precompute(csd_from_cs(cs), dtype), x).numpy()[:, :, 0]
+    assert np.max(rel_err_rows(y.cpu().numpy()[:, :, 0], want)) <= tol
+    floor = 1e-6 if dtype == torch.float32 else 1e-10
+    assert cs.getMaxViolation(y.cpu().numpy()[:, :, 0]) <= max(floor, 3 * cs.getMaxViolation(want))
+    assert np.allclose(y[4, :, 0].cpu().numpy(), cs.y0[:, 0], atol=1e-6)
+    dp, _ = layer.device_pack(torch.device("cuda", 0))
+    v = x[:, :, 0].cuda()
+    yw, kw, aw = ops.project_raw(v, dp)
+    assert _lib.load().rayen_last_forward_kernel() == _lib.KERNEL_PRODUCTS
+    yl, kl, al = ops.project_raw(v, dp, force_generic=True)
+    assert _lib.load().rayen_last_forward_kernel() == _lib.KERNEL_LANE
+    ktol = 2e-5 if dtype == torch.float32 else 1e-9
+    assert torch.allclose(kw, kl, rtol=ktol, atol=ktol)
+    same = (aw == al).all(dim=1)
+    assert float(same.float().mean()) > 0.995          # (ties of the arg-max may fall either way)
+    assert np.max(rel_err_rows(yw.cpu().numpy(), yl.cpu().numpy())) <= 2 * tol
+    # wider input rows (only the first n columns are read), a strided output, kappa alone, and the empty batch
+    wide_in = torch.cat((v, torch.full((B, 3), 7.0, dtype=dtype, device="cuda")), dim=1)
+    buf = torch.zeros(B, cs.k + 5, dtype=dtype, device="cuda")
+    y2, _, _ = ops.project_raw(wide_in, dp, want_active=False, want_kappa=False, out=buf)
+    assert torch.equal(buf[:, :cs.k], yw) and float(buf[:, cs.k:].abs().max()) == 0.0
+    _, k3, _ = ops.project_raw(v, dp, want_y=False)
+    assert torch.equal(k3, kw)
+    y0, k0, a0 = ops.project_raw(v[:0], dp)
+    assert y0.shape == (0, cs.k) and k0.shape == (0,)
+    # non-finite rows stay non-finite, raise the flag, and touch nobody else
+    vb = v.clone()
+    vb[7, 3] = float("nan")
+    vb[9, 0] = float("inf")
+    dp.nan_flag.zero_()
+    yb, _, _ = ops.project_raw(vb, dp)
+    assert int(dp.nan_flag.item()) == 1
+    dp.nan_flag.zero_()
+    assert not torch.isfinite(yb[7]).all() and not torch.isfinite(yb[9]).all()
+    keep = torch.ones(B, dtype=torch.bool, device="cuda")
+    keep[[7, 9]] = False
+    assert torch.equal(yb[keep], yw[keep])
