@@ -217,6 +217,17 @@ int rayen_ray_project_from_products_f64(const RayenPack* pack, const double* T, 
                                         int64_t ldv, double* y, int64_t ldy, double* kappa, int32_t* active,
                                         int32_t* nan_flag, void* stream);
 
+/* Backward of the wide route: grad_v = C W_ext (+ gs), with this entry writing the COEFFICIENTS C [B, ldc >= rows] --
+ * row b is zero outside sample b's active segment; s g on the NA_E rows -- and, for sets without equality constraints
+ * (NA_E = I), gs [B, k] = s g; the caller finishes with one vendor GEMM.  T is the forward's product matrix (recomputed
+ * by the caller: one more GEMM), kappa / active the forward's outputs. */
+int rayen_ray_project_bwd_coefficients_f32(const RayenPack* pack, const float* T, int64_t ldt, const float* v, int64_t B,
+                                           int64_t ldv, const float* kappa, const int32_t* active, const float* grad_y,
+                                           int64_t ldg, float* C, int64_t ldc, float* gs, void* stream);
+int rayen_ray_project_bwd_coefficients_f64(const RayenPack* pack, const double* T, int64_t ldt, const double* v, int64_t B,
+                                           int64_t ldv, const double* kappa, const int32_t* active, const double* grad_y,
+                                           int64_t ldg, double* C, int64_t ldc, double* gs, void* stream);
+
 /* Backward of y w.r.t. v (vector-Jacobian product):
  *   grad_v = s N'g - [kappa > 1] s^2 (g . N v) grad kappa(v),   s = 1/max(1,kappa)
  * with grad kappa taken on the active constraint only, which is what autograd

@@ -29,6 +29,7 @@ EXPORTS = (
     "rayen_bwd_workspace_bytes_f64", "rayen_ray_project_bwd_ws_f64", "rayen_last_forward_kernel",
     "rayen_pair_schedule", "rayen_reserve_cus",
     "rayen_products_rows", "rayen_ray_project_from_products_f32", "rayen_ray_project_from_products_f64",
+    "rayen_ray_project_bwd_coefficients_f32", "rayen_ray_project_bwd_coefficients_f64",
 )
 KERNEL_NONE, KERNEL_LANE, KERNEL_MFMA, KERNEL_TRIPLE, KERNEL_PAIR, KERNEL_PAIR_IO, KERNEL_LMI_QUAD, KERNEL_LMI_WAVE, KERNEL_PAIR_WS, KERNEL_PRODUCTS = range(10)
 
@@ -109,6 +110,9 @@ def load():
     for name in ("rayen_ray_project_from_products_f32", "rayen_ray_project_from_products_f64"):
         getattr(lib, name).restype = ctypes.c_int
         getattr(lib, name).argtypes = [p, p, i64, p, i64, i64, p, i64, p, i32p, i32p, p]
+    for name in ("rayen_ray_project_bwd_coefficients_f32", "rayen_ray_project_bwd_coefficients_f64"):
+        getattr(lib, name).restype = ctypes.c_int
+        getattr(lib, name).argtypes = [p, p, i64, p, i64, i64, p, i32p, p, i64, p, i64, p, p]
     lib.rayen_products_rows.restype = ctypes.c_int64
     lib.rayen_products_rows.argtypes = [p]
     bwd = [p, p, i64, i64, p, i32p, p, i64, p, i64, p]

@@ -684,6 +684,23 @@ int rayen_ray_project_from_products_f64(const RayenPack* p, const double* T, int
   return project_from_products<double>(p, T, ldt, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
 }
 
+#define RAYEN_BWD_COEFF(NAME, T)                                                                                      \
+  int NAME(const RayenPack* p, const T* Tm, int64_t ldt, const T* v, int64_t B, int64_t ldv, const T* kappa,             \
+           const int32_t* active, const T* grad_y, int64_t ldg, T* C, int64_t ldc, T* gs, void* stream) {                \
+    if (p == nullptr || B < 0 || ldv < p->n || ldg < p->k || ldt < (int64_t)p->n_rows + (p->out_identity ? 0 : p->k) ||  \
+        ldc < (int64_t)p->n_rows + (p->out_identity ? 0 : p->k) || (p->out_identity && gs == nullptr && B > 0))          \
+      return RAYEN_E_BAD_ARG;                                                                                            \
+    if (B > 0 && (!Tm || !v || !kappa || !active || !grad_y || !C)) return RAYEN_E_BAD_ARG;                              \
+    int dev = -1;                                                                                                        \
+    if (hipGetDevice(&dev) != hipSuccess) return RAYEN_E_NO_DEVICE;                                                      \
+    if (dev != p->device) return RAYEN_E_DEVICE_MISMATCH;                                                                \
+    return wide_bwd_coefficients<T>(p, p->wide, Tm, ldt, v, B, ldv, kappa, active, grad_y, ldg, C, ldc, gs,              \
+                                    static_cast<hipStream_t>(stream));                                                   \
+  }
+RAYEN_BWD_COEFF(rayen_ray_project_bwd_coefficients_f32, float)
+RAYEN_BWD_COEFF(rayen_ray_project_bwd_coefficients_f64, double)
+#undef RAYEN_BWD_COEFF
+
 int64_t rayen_products_rows(const RayenPack* p) {
   if (p == nullptr || p->wide == nullptr) return 0;
   return (int64_t)p->n_rows + (p->out_identity ? 0 : p->k);

@@ -107,6 +107,11 @@ template <typename T>
 int wide_epilogue(const RayenPack* p, const WideImage* img, const T* Tm, int64_t ldt, const T* v, int64_t B, int64_t ldv,
                   T* y, int64_t ldy, T* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream);
 
+template <typename T>
+int wide_bwd_coefficients(const RayenPack* p, const WideImage* img, const T* Tm, int64_t ldt, const T* v, int64_t B,
+                          int64_t ldv, const T* kappa, const int32_t* active, const T* gy, int64_t ldg, T* C, int64_t ldc,
+                          T* gs, hipStream_t stream);
+
 // SIMDs the persistent grids may fill: all of the device's minus rayen_reserve_cus() compute units (a collective that
 // runs beside the projection -- RCCL's all-gather kernels in the multi-GPU step -- needs CUs of its own)
 int launch_simds(int n_simd);

@@ -137,6 +137,72 @@ __global__ __launch_bounds__(256) void wide_epilogue_kernel(
   if (nan_flag && bad) atomicOr(nan_flag, 1);
 }
 
+// Backward of the wide route.  grad_v = s N'g - [kappa > 1] s^2 (g . N v) grad kappa(v), and grad kappa of the ACTIVE
+// constraint is a combination of rows of W (the arg-max row; phi + sum_j (v_j / sqrt(v'Gv)) G_j; phi + sum_j (w_j / |w|) U_j;
+// the implicit derivative of the cone's root in c, M'beta and the rows of M) -- so is N'g in the rows of NA_E.  This
+// kernel writes those COEFFICIENTS, one row of C per sample (zero outside the active segment), and the host finishes
+// with ONE vendor GEMM: grad_v = C W_ext (+ s g when NA_E = I, written to `gs`).
+template <typename T>
+__global__ __launch_bounds__(256) void wide_bwd_coeff_kernel(
+    const typename WSegOf<T>::type* __restrict__ segs, int n_seg, int k, int n, int n_rows, int identity,
+    const T* __restrict__ Tm, int64_t ldt, const T* __restrict__ v, int64_t B, int64_t ldv, const T* __restrict__ kappa,
+    const int32_t* __restrict__ active, const T* __restrict__ gy, int64_t ldg, T* __restrict__ C, int64_t ldc,
+    T* __restrict__ gs) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+  const int rows_ext = n_rows + (identity ? 0 : k);
+  for (int64_t s = wave; s < B; s += n_waves) {
+    const T* __restrict__ tr = Tm + s * ldt;
+    const T* __restrict__ vr = v + s * ldv;
+    const T* __restrict__ gr = gy + s * ldg;
+    T* __restrict__ cr_ = C + s * ldc;
+    const T kap = kappa[s];
+    const T sc = T(1) / fmax(T(1), kap);
+    const T* __restrict__ nv = identity ? vr : tr + n_rows;
+    T tv = T(0);
+    for (int i = lane; i < k; i += 64) tv = fma(gr[i], nv[i], tv);
+    tv = wave_sum(tv);
+    const bool clipped = kap > T(1);
+    const T coef = clipped ? -sc * sc * tv : T(0);
+    for (int j = lane; j < n_rows; j += 64) cr_[j] = T(0);
+    if (identity) {
+      for (int i = lane; i < k; i += 64) gs[s * k + i] = sc * gr[i];
+    } else {
+      for (int i = lane; i < k; i += 64) cr_[n_rows + i] = sc * gr[i];
+    }
+    (void)rows_ext;
+    const int a = active[2 * s];
+    if (!clipped || a < 0 || a >= n_seg) continue;
+    const auto sg = segs[a];
+    if (sg.type == RAYEN_SEG_LIN) {
+      const int row = active[2 * s + 1];
+      if (lane == 0 && row >= sg.row0 && row < sg.row0 + sg.nrows) cr_[row] = coef;
+    } else if (sg.type == RAYEN_SEG_QUAD_SYM || sg.type == RAYEN_SEG_QUAD_FAC) {
+      const bool sym = sg.type == RAYEN_SEG_QUAD_SYM;
+      T acc = T(0);
+      for (int j = lane; j < sg.nrows; j += 64) {
+        const T t = tr[sg.row0 + j];
+        acc = sym ? fma(t, vr[j], acc) : fma(t, t, acc);
+      }
+      acc = wave_sum(acc);
+      const T rad = sqrt(fmax(acc, T(0)));
+      const T inv = rad > T(0) ? coef / rad : T(0);
+      for (int j = lane; j < sg.nrows; j += 64) cr_[sg.row0 + j] = inv * (sym ? vr[j] : tr[sg.row0 + j]);
+      if (lane == 0) cr_[sg.aux_row] = coef;
+    } else if (sg.type == RAYEN_SEG_SOC) {
+      const T cr = tr[sg.aux_row], br = tr[sg.aux_row + 1];
+      const T bp = T(2) * br - T(2) * cr * (T)sg.f0;
+      const T den = T(2) * (T)sg.f1 * kap + bp;
+      const T q = den != T(0) ? coef / den : T(0);
+      for (int j = lane; j < sg.nrows; j += 64) cr_[sg.row0 + j] = T(-2) * q * tr[sg.row0 + j];
+      if (lane == 0) {
+        cr_[sg.aux_row] = q * (T(2) * (T)sg.f0 * kap + T(2) * cr);
+        cr_[sg.aux_row + 1] = T(-2) * q * kap;
+      }
+    }
+  }
+}
+
 template <typename V>
 bool upload_vec(const std::vector<V>& host, void** dev, int64_t* bytes) {
   if (host.empty()) { *dev = nullptr; return true; }
@@ -205,6 +271,28 @@ int wide_epilogue(const RayenPack* p, const WideImage* img, const T* Tm, int64_t
                      p->n_rows, p->out_identity, Tm, ldt, v, B, ldv, y, ldy, kappa, active, nan_flag);
   return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
 }
+
+template <typename T>
+int wide_bwd_coefficients(const RayenPack* p, const WideImage* img, const T* Tm, int64_t ldt, const T* v, int64_t B,
+                          int64_t ldv, const T* kappa, const int32_t* active, const T* gy, int64_t ldg, T* C, int64_t ldc,
+                          T* gs, hipStream_t stream) {
+  if (img == nullptr) return RAYEN_E_UNSUPPORTED;
+  if (B == 0) return RAYEN_OK;
+  const int64_t want = (B + 3) / 4, cap = (int64_t)launch_simds(img->n_simd) * 2;
+  const unsigned grid = (unsigned)(want < cap ? want : cap);
+  typedef typename WSegOf<T>::type S;
+  const S* segs = static_cast<const S*>(sizeof(T) == 4 ? img->segs32 : img->segs64);
+  hipLaunchKernelGGL((wide_bwd_coeff_kernel<T>), dim3(grid), dim3(256), 0, stream, segs, img->n_seg, p->k, p->n, p->n_rows,
+                     p->out_identity, Tm, ldt, v, B, ldv, kappa, active, gy, ldg, C, ldc, gs);
+  return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
+}
+
+template int wide_bwd_coefficients<float>(const RayenPack*, const WideImage*, const float*, int64_t, const float*, int64_t,
+                                          int64_t, const float*, const int32_t*, const float*, int64_t, float*, int64_t,
+                                          float*, hipStream_t);
+template int wide_bwd_coefficients<double>(const RayenPack*, const WideImage*, const double*, int64_t, const double*,
+                                           int64_t, int64_t, const double*, const int32_t*, const double*, int64_t,
+                                           double*, int64_t, double*, hipStream_t);
 
 template int wide_epilogue<float>(const RayenPack*, const WideImage*, const float*, int64_t, const float*, int64_t,
                                   int64_t, float*, int64_t, float*, int32_t*, int32_t*, hipStream_t);

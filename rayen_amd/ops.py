@@ -202,6 +202,25 @@ def backward_raw(v, kappa, active, grad_y, pack, old_head=False, force_generic=F
         if old_head:
             raise RuntimeError("force_generic selects between the two RAYEN backward kernels only")
         name = "rayen_ray_project_bwd_generic_f32" if v.dtype == torch.float32 else "rayen_ray_project_bwd_generic_f64"
+    Wt = _wide_route(v, pack, force_generic, old_head) if B else None
+    if Wt is not None:
+        # wide sets: T = v W_ext' again (one GEMM), the coefficient kernel, grad_v = C W_ext (+ s g): rayen_wide.hip
+        n, k = pack.consts.n, pack.consts.k
+        identity = bool(pack.consts.out_identity)
+        with _on_device(v.device):
+            prods = torch.mm(v if v.shape[1] == n else v[:, :n], Wt)
+            coeff = torch.empty_like(prods)
+            gs = torch.empty((B, k), dtype=v.dtype, device=v.device) if identity else None
+            fn = _entry("rayen_ray_project_bwd_coefficients_f32" if v.dtype == torch.float32
+                        else "rayen_ray_project_bwd_coefficients_f64")
+            code = fn(pack.handle, _ptr(prods), prods.stride(0), _ptr(v), B, v.stride(0), _ptr(kappa), _ptr(active),
+                      _ptr(grad_y), grad_y.stride(0), _ptr(coeff), coeff.stride(0), _ptr(gs), _stream(v.device.index))
+            _lib.check(code, "rayen_ray_project_bwd_coefficients")
+            core = torch.addmm(gs, coeff, Wt.t()) if identity else torch.mm(coeff, Wt.t())
+        if v.shape[1] == n:
+            return core
+        grad_v[:, :n] = core
+        return grad_v
     with _on_device(v.device):
         lib = _lib.load()
         ws_bytes = 0
@@ -225,12 +244,19 @@ def backward_raw(v, kappa, active, grad_y, pack, old_head=False, force_generic=F
 @torch.library.custom_op("rayen_amd::ray_project_bwd", mutates_args=())
 def ray_project_bwd(v: torch.Tensor, kappa: torch.Tensor, active: torch.Tensor,
                     grad_y: torch.Tensor, pack_id: int, old_head: bool = False) -> torch.Tensor:
-    pack = _pack(pack_id)
+    return backward_raw(v, kappa, active, grad_y, _pack(pack_id), old_head)
+
+
+def _bwd_or_detour(v, kappa, active, grad_y, pack_id, old_head):
+    """The HIP backward; where the kernels decline the shape (``RAYEN_E_UNSUPPORTED``), autograd through the packed
+    torch evaluator on the same device -- loudly, once per pack.  Called from the autograd formulas (NOT from inside the
+    custom op: below the dispatcher's autograd key nothing would be recorded)."""
     try:
-        return backward_raw(v, kappa, active, grad_y, pack, old_head)
+        return torch.ops.rayen_amd.ray_project_bwd(v, kappa, active, grad_y, pack_id, old_head)
     except _lib.RayenError as err:
         if err.code != _lib.E_UNSUPPORTED or os.environ.get("RAYEN_STRICT_HIP", "0") == "1":
             raise
+        pack = _pack(pack_id)
         if not pack.__dict__.get("_warned_bwd"):
             warnings.warn(f"rayen_amd: no HIP backward kernel serves this constraint set ({err}); gradients come from "
                           "autograd through the packed torch evaluator (rayen_amd/eager.py) on " + str(v.device),
@@ -272,8 +298,7 @@ def _backward(ctx, grad_y, grad_kappa, grad_active):
     v, kappa, active = ctx.saved_tensors
     if grad_y is None:
         return torch.zeros_like(v), None, None, None
-    return (torch.ops.rayen_amd.ray_project_bwd(v, kappa, active, grad_y, ctx.pack_id, ctx.old_head),
-            None, None, None)
+    return (_bwd_or_detour(v, kappa, active, grad_y, ctx.pack_id, ctx.old_head), None, None, None)
 
 
 ray_project.register_autograd(_backward, setup_context=_setup_context)
@@ -359,7 +384,7 @@ def _mapped_backward(ctx, grad_y, grad_kappa, grad_active, grad_v_out):
     if grad_y is None:
         return None, None, None, None, None
     # d y / d v on the HIP backward kernel; the three mapper products are plain GEMMs (rocBLAS via torch)
-    grad_v = torch.ops.rayen_amd.ray_project_bwd(v, kappa, active, grad_y, ctx.pack_id, False)
+    grad_v = _bwd_or_detour(v, kappa, active, grad_y, ctx.pack_id, False)
     grad_x = grad_v @ weight if ctx.needs_input_grad[0] else None
     grad_w = grad_v.t() @ x if ctx.needs_input_grad[1] else None
     grad_b = grad_v.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None

@@ -65,22 +65,32 @@ def test_lmi_beyond_one_waves_lds_runs_on_the_device_libraries(r):
     assert cs.getMaxViolation(y.cpu().numpy()[:, :, 0]) <= 1e-9
 
 
-def test_backward_of_a_wide_set_detours_loudly_and_matches_autograd():
-    """n = 400 with quadratics and cones: the forward runs on the lane kernels; a backward they do not stage comes
-    from autograd through the packed evaluator, with a warning, and equals autograd through the reference's ops."""
+def test_backward_of_a_wide_set_on_the_wide_route_and_on_the_loud_detour(monkeypatch):
+    """n = 400 with quadratics and cones.  Default: forward and backward on the wide route (vendor GEMMs + the products
+    epilogue / coefficient kernels), silently.  With RAYEN_WIDE_ROUTE=0 the forward is the lane kernel's, whose backward
+    does not stage n = 400: the gradient then comes from autograd through the packed evaluator -- with a warning.
+    Both equal autograd through the reference's op sequence."""
     raw = workloads.random_lin_quad_soc(k=400, m=60, n_quad=2, n_soc=1, r_M=30, seed=9)
     cs, layer = _layer64(raw)
     x = torch.empty(48, cs.n, 1, dtype=torch.float64).uniform_(-1, 1)
     w = torch.empty(48, cs.k, 1, dtype=torch.float64).uniform_(-1, 1)
-    xg = x.cuda().requires_grad_(True)
-    with warnings.catch_warnings(record=True):
-        warnings.simplefilter("always")
-        (layer(xg) * w.cuda()).sum().backward()
     x2 = x.clone().requires_grad_(True)
     (oracle.forward(oracle.precompute(csd_from_cs(cs), torch.float64), x2) * w).sum().backward()
-    err = (xg.grad.cpu() - x2.grad).abs().amax(dim=(1, 2)) / x2.grad.abs().amax(dim=(1, 2)).clamp_min(1e-30)
+
+    def grad_and_warnings():
+        xg = x.cuda().requires_grad_(True)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            (layer(xg) * w.cuda()).sum().backward()
+        err = (xg.grad.cpu() - x2.grad).abs().amax(dim=(1, 2)) / x2.grad.abs().amax(dim=(1, 2)).clamp_min(1e-30)
+        return float(err.max()), [c for c in caught if issubclass(c.category, RuntimeWarning)]
+
     # (kinks -- ties of the arg-max, kappa = 1 -- are measure-zero for these random directions at fp64)
-    assert float(err.max()) <= 1e-7
+    err, warned = grad_and_warnings()
+    assert err <= 1e-7 and not warned and _lib.load().rayen_last_forward_kernel() == _lib.KERNEL_PRODUCTS
+    monkeypatch.setenv("RAYEN_WIDE_ROUTE", "0")
+    err, warned = grad_and_warnings()
+    assert err <= 1e-7 and len(warned) == 1 and _lib.load().rayen_last_forward_kernel() == _lib.KERNEL_LANE
 
 
 # --------------------------------------------------------------------------- the wide route: library GEMM + products epilogue
@@ -133,6 +143,24 @@ def test_wide_route_against_oracle_and_the_lane_kernel(name, dtype, tol):
     same = (aw == al).all(dim=1)
     assert float(same.float().mean()) > 0.995          # (ties of the arg-max may fall either way)
     assert np.max(rel_err_rows(yw.cpu().numpy(), yl.cpu().numpy())) <= 2 * tol
+    # backward on the wide route (coefficient kernel + one GEMM) against autograd through the oracle at fp64 away from
+    # kinks, and against the lane backward where that kernel stages the set
+    from helpers import kink_mask
+    g = torch.empty(B, cs.k, dtype=dtype).uniform_(-1, 1, generator=gen)
+    gw = ops.backward_raw(v, kw, aw, g.cuda(), dp)
+    xo = x.double().clone().requires_grad_(True)
+    (oracle.forward(oracle.precompute(csd_from_cs(cs), torch.float64), xo)[:, :, 0] * g.double()).sum().backward()
+    keep = ~kink_mask(oracle, cs, x.double(), 1e-6 if dtype == torch.float64 else 1e-3)
+    keep[:5] = False
+    gerr = (gw.cpu().double() - xo.grad[:, :, 0]).abs().amax(dim=1) / xo.grad[:, :, 0].abs().amax(dim=1).clamp_min(1e-30)
+    assert keep.sum() > B // 2
+    assert float(gerr[torch.as_tensor(keep)].max()) <= (2e-4 if dtype == torch.float32 else 1e-8)
+    try:
+        gl = ops.backward_raw(v, kl, al, g.cuda(), dp, force_generic=True)
+        lerr = (gw - gl).abs().amax(dim=1) / gl.abs().amax(dim=1).clamp_min(1e-30)
+        assert float(lerr[same & torch.as_tensor(keep, device="cuda")].max()) <= (4e-4 if dtype == torch.float32 else 1e-8)
+    except _lib.RayenError as err:
+        assert err.code == _lib.E_UNSUPPORTED          # (the lane backward does not stage this n)
     # wider input rows (only the first n columns are read), a strided output, kappa alone, and the empty batch
     wide_in = torch.cat((v, torch.full((B, 3), 7.0, dtype=dtype, device="cuda")), dim=1)
     buf = torch.zeros(B, cs.k + 5, dtype=dtype, device="cuda")
