@@ -153,8 +153,10 @@ enum {
 int rayen_last_forward_kernel(void);
 
 /* Tuning / A-B switch (ABI v4, process-wide): which SCHEDULE of the f16-pair forward serves the calls whose shape
- * allows it -- 1 (default): rows of v and y trickled through LDS under the tile walk | 0: the plain kernel | 2 (ABI v6):
- * the W-stationary kernel where it serves, else as 1.  All compute the same values bit for bit.  Initial value from the
+ * allows it -- 1 (default): rows of v and y trickled through LDS under the tile walk for batches that give every
+ * resident wave a group (B >= 131 072 on MI355X), the W-stationary kernel for 32 768 <= B < 131 072 where it serves the
+ * pack (ABI v7), else the plain kernel | 0: always the plain kernel | 2 (ABI v6): the W-stationary kernel wherever it
+ * serves, else as 1.  All compute the same values bit for bit.  Initial value from the
  * environment variable RAYEN_PAIR_IO.  mode outside 0..2 only queries.  Returns the previous setting. */
 int rayen_pair_schedule(int mode);
 

@@ -722,6 +722,14 @@ static int project_f32(const RayenPack* p, const float* v, int64_t B, int64_t ld
       g_last_forward = RAYEN_KERNEL_PAIR_IO;
       return mfma_pair_io_forward(p, p->pr32, v, B, ldv, y, ldy, kappa, active, nan_flag, static_cast<hipStream_t>(stream));
     }
+    // Batches between two groups per CU and one group per resident wave (32 768 <= B < 131 072 on this chip): too small
+    // for the trickled rows to have interior rounds, and the plain kernel leaves SIMDs with one wave or none -- there the
+    // W-stationary kernel is the fastest of the three bit-identical schedules (12.7 against 18.2 us at B = 32 768,
+    // 20.5 / 22.6 at 65 536, 27.2 / 28.4 at 98 304: profiles/bench/r04_midbatch_schedules.txt).
+    if (pair_schedule() == 1 && mfma_pair_ws8_serves(p, p->pr32, p->ws8_32, v, B, ldv, y, ldy)) {
+      g_last_forward = RAYEN_KERNEL_PAIR_WS;
+      return mfma_pair_ws8_forward(p, p->pr32, p->ws8_32, v, B, ldv, y, ldy, kappa, active, nan_flag, static_cast<hipStream_t>(stream));
+    }
     g_last_forward = RAYEN_KERNEL_PAIR;
     return mfma_pair_forward(p, p->pr32, v, B, ldv, y, ldy, kappa, active, nan_flag, static_cast<hipStream_t>(stream));
   }

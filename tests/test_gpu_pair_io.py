@@ -57,7 +57,7 @@ def schedule(request):
 
 
 # group = 64 rows; a full chip holds 2048 waves: B = 131072 is one group per wave, 262144 two, 393216 three
-@pytest.mark.parametrize("B", [64, 1000, 4096 + 37, 131072, 131072 + 64 * 5 + 11, 262144, 393216 + 29, 655360])
+@pytest.mark.parametrize("B", [64, 1000, 4096 + 37, 32768, 65536 + 101, 131072, 131072 + 64 * 5 + 11, 262144, 393216 + 29, 655360])
 @pytest.mark.parametrize("name", ["c3", "n32", "n32_many_aux"])
 @pytest.mark.parametrize("want_active", [False, True])
 def test_trickled_rows_equal_the_plain_pair_kernel_bit_for_bit(name, B, want_active, schedule):
@@ -72,8 +72,17 @@ def test_trickled_rows_equal_the_plain_pair_kernel_bit_for_bit(name, B, want_act
     v[B // 2] *= 1e-3
     y1, k1, a1, fam1 = _run(dp, v, want_active)
     y2, k2, a2, fam2 = _run(dp, _misaligned_copy(v), want_active)
-    # (batches that do not give every resident wave a 64-row group -- 2048 waves: B < 131072 -- stay on the plain kernel)
-    assert fam1 == (schedule if B >= 131072 else _lib.KERNEL_PAIR), "which kernel served the aligned call"
+    # (batches that do not give every resident wave a 64-row group -- 2048 waves: B < 131072 -- are not for the trickled
+    # rows: from two groups per CU on, B >= 32768, the W-stationary schedule takes them where it serves the pack
+    # (round 4, third bit-identical schedule), below that the plain kernel)
+    if B >= 131072:
+        assert fam1 == schedule, "which kernel served the aligned call"
+    elif B >= 32768:
+        assert fam1 in (_lib.KERNEL_PAIR_WS, _lib.KERNEL_PAIR)
+        if name == "c3":
+            assert fam1 == _lib.KERNEL_PAIR_WS
+    else:
+        assert fam1 == _lib.KERNEL_PAIR
     assert fam2 == _lib.KERNEL_PAIR
     assert torch.equal(y1, y2)
     assert torch.equal(k1, k2)
