@@ -487,6 +487,23 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_io_
 // the flat block.  With NA_E != I the rows of y come out of the NA_E tiles at the END of the walk, while the buffer
 // still holds v(next): the next rows are read into registers in front of the first of those tiles.
 // LDS (dynamic): the aux patch (64 KiB) + 8 x (256 max(n, k)) bytes.
+// developer build (scripts/ubench/tu_variant.sh rayen_mfma_pair_io stamps -DRAYEN_IOF_STAMPS; scripts/ubench/iof_stamps.py):
+// s_memtime per tile of the flat-row kernel's SECOND group, waves 0 / 3 / 4 of every 64th workgroup --
+// [tile top | burst + row operations issued | epilogue done], and the group boundary.  Nothing in the library build.
+#ifdef RAYEN_IOF_STAMPS
+__device__ unsigned long long iof_stamp_buf[16 * 3 * 256 * 4];
+extern "C" int rayen_debug_iof_stamps(void* dst, size_t bytes) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(iof_stamp_buf), bytes < sizeof(iof_stamp_buf) ? bytes : sizeof(iof_stamp_buf)) == hipSuccess ? 0 : -1;
+}
+#define RAYEN_IOF_STAMP(tile, slot)                                                                                  \
+  do {                                                                                                               \
+    if (stamp_on && lane == 0 && (tile) < 256)                                                                       \
+      iof_stamp_buf[((stamp_row * 256) + (tile)) * 4 + (slot)] = __builtin_amdgcn_s_memtime();                       \
+  } while (0)
+#else
+#define RAYEN_IOF_STAMP(tile, slot) do { } while (0)
+#endif
+
 template <bool TRACK, bool STAGED>
 __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_iof_kernel(
     const f16x8* __restrict__ Wh, const MItem* __restrict__ items, int n_items,
@@ -498,6 +515,13 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_iof
   extern __shared__ __attribute__((aligned(1024))) char iof_smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef RAYEN_IOF_STAMPS
+  const int stamp_wsel = wave == 0 ? 0 : wave == 3 ? 1 : wave == 4 ? 2 : -1;
+  const int stamp_row = (int)(blockIdx.x >> 6) * 3 + stamp_wsel;           // 16 workgroups x 3 waves at most
+  const bool stamp_wave = (blockIdx.x & 63) == 0 && (blockIdx.x >> 6) < 16 && stamp_wsel >= 0;
+  bool stamp_on = false;
+  int stamp_round = 0;
+#endif
   float (*aux_lds)[AUXR][32] = reinterpret_cast<float (*)[AUXR][32]>(iof_smem) + wave * NT;   // [t][row][sample]
   char* const io_all = iof_smem + kMfmaWaves * NT * AUXR * 32 * 4;
   char* const io = io_all + wave * buf_bytes;
@@ -620,6 +644,11 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_iof
     const bool trickle_ld = has_next && (next + 1) * (NT * 32) <= B;   // whole groups only
     const char* vnext = uniform_ptr(v + (has_next ? next : grp) * (NT * 32) * n);
     char* yprev = const_cast<char*>(uniform_ptr(y + prev_base * k));
+#ifdef RAYEN_IOF_STAMPS
+    stamp_on = stamp_wave && stamp_round == 1;
+    ++stamp_round;
+    RAYEN_IOF_STAMP(255, 0);
+#endif
     if (need_fetch) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -660,6 +689,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_iof
     {
       f32x16 acc[NT];
       for (int it = 0; it < n_items; ++it) {
+        RAYEN_IOF_STAMP(it, 0);
         const MItem item = items[it];
         // (the index, not the descriptor: the scalar loads of `item` then wait behind the MFMA burst instead of in front of it)
         if (STAGED && it == first_out) {
@@ -720,6 +750,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_iof
           __builtin_amdgcn_sched_barrier(0);
           __builtin_amdgcn_s_setprio(1);
         }
+        RAYEN_IOF_STAMP(it, 1);
         if (item.type == MI_LIN) {
           const int lin_code = (item.seg << 20) + item.row0 + 4 * hi;
 #pragma unroll
@@ -769,6 +800,10 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_iof
             for (int g = 0; g < 16; ++g) aux_lds[t][(g & 3) + 8 * (g >> 2) + 4 * hi][col] = acc[t][g];
           __builtin_amdgcn_wave_barrier();
         } else if (item.type == MI_PACK) {
+          // (round 4, measured with scripts/ubench/iof_stamps.py: this epilogue takes 1 550 cycles against 290 for a tile
+          // of linear rows.  Batching its eight half-wave exchanges and aux reads made hipcc copy `pk` to SCRATCH through
+          // vector loads with vmcnt(0) waits -- 5 600 cycles per tile, and the A prefetch drained nine times per walk.
+          // Left as it is.)
           const MPack pk = packs[item.aux];
 #pragma unroll
           for (int a = 0; a < 4; ++a) {
@@ -787,25 +822,53 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_iof
           }
         } else if (STAGED && item.type == MI_OUT) {
           // rows of NA_E: y = y0 + (N v) / max(1, kappa) into the flat block [64][k] (4-byte LDS stores at a stride of k
-          // words: conflict-free for odd k); it leaves as whole lines during the next walk
+          // words: conflict-free for odd k); it leaves as whole lines during the next walk.
+          // Round 4 (stamps: 3 300 cycles per tile): y0 of the tile's sixteen rows in ONE batch of reads -- it was a
+          // ds_read_b32 + lgkmcnt(0) inside every element's predicate, 32 exposed LDS round trips per tile --, and a tile
+          // that lies wholly inside the k rows (wave-uniform) stores without predicates.  Same fma, same values.
+          float y0r[16];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 y4 = *reinterpret_cast<const f32x4*>(&y0_lds[item.row0 + 4 * hi + 8 * q]);   // (padded to a tile multiple)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) y0r[4 * q + c] = y4[c];
+          }
+          const bool full = item.row0 + 32 <= k;
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             float* yrow = io_f + (32 * t + col) * k + item.row0 + 4 * hi;
+            float o[16];
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-              const int r = (g & 3) + 8 * (g >> 2);
-              const float o = fmaf(acc[t][g], scale[t], y0_lds[item.row0 + 4 * hi + r]);  // (padded to a tile multiple)
-              if (item.row0 + 4 * hi + r < k) {
-                bad |= live[t] && (o != o);
-                yrow[r] = o;
+            for (int g = 0; g < 16; ++g) o[g] = fmaf(acc[t][g], scale[t], y0r[g]);
+            if (full) {
+              bool nn = false;
+#pragma unroll
+              for (int g = 0; g < 16; ++g) {
+                nn |= (o[g] != o[g]);
+                yrow[(g & 3) + 8 * (g >> 2)] = o[g];
+              }
+              bad |= live[t] && nn;
+            } else {
+              // (the last, partial tile keeps its predicates: sending the rows beyond k to a dummy LDS word under a select
+              // instead was slower -- 76.6 against 73.6 us on config 5 -- and not bit-identical on the record path)
+#pragma unroll
+              for (int g = 0; g < 16; ++g) {
+                const int r = (g & 3) + 8 * (g >> 2);
+                if (item.row0 + 4 * hi + r < k) {
+                  bad |= live[t] && (o[g] != o[g]);
+                  yrow[r] = o[g];
+                }
               }
             }
           }
         }
+        RAYEN_IOF_STAMP(it, 2);
       }
     }
+    RAYEN_IOF_STAMP(255, 1);
     // every row of v(next) has landed, y(prev) is out, the next group's first tile is in the A buffer
     drain();
+    RAYEN_IOF_STAMP(255, 2);
 
     if (!STAGED) finish_kappa();
     if (hi == 0) {
