@@ -801,9 +801,11 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_iof
           __builtin_amdgcn_wave_barrier();
         } else if (item.type == MI_PACK) {
           // (round 4, measured with scripts/ubench/iof_stamps.py: this epilogue takes 1 550 cycles against 290 for a tile
-          // of linear rows.  Batching its eight half-wave exchanges and aux reads made hipcc copy `pk` to SCRATCH through
-          // vector loads with vmcnt(0) waits -- 5 600 cycles per tile, and the A prefetch drained nine times per walk.
-          // Left as it is.)
+          // of linear rows -- 18 % of config 5's walk.  It is NOT the eight exchanges: batching them and the aux reads
+          // (all in flight at once, the descriptor's words pinned in SGPRs) is bit-identical and takes 1 580-1 630; one
+          // packed tile of the same walk takes 650, so what the others wait for is the dependent scalar load of `pk`
+          // behind `item` when it misses the scalar cache.  Without the pinning hipcc turned `hi ? pk.x[a][1] : pk.x[a][0]`
+          // into an indexed load from a SCRATCH copy of `pk`: 5 600 cycles per tile.  Left as it was.)
           const MPack pk = packs[item.aux];
 #pragma unroll
           for (int a = 0; a < 4; ++a) {
