@@ -803,10 +803,14 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_iof
           // (round 4, measured with scripts/ubench/iof_stamps.py: this epilogue takes 1 550 cycles against 290 for a tile
           // of linear rows -- 18 % of config 5's walk.  It is NOT the eight exchanges: batching them and the aux reads
           // (all in flight at once, the descriptor's words pinned in SGPRs) is bit-identical and takes 1 580-1 630; one
-          // packed tile of the same walk takes 650, so what the others wait for is the dependent scalar load of `pk`
-          // behind `item` when it misses the scalar cache.  Without the pinning hipcc turned `hi ? pk.x[a][1] : pk.x[a][0]`
+          // stamp behind the descriptor load says `pk` -- a scalar load that depends on `item` -- arrives 375 cycles after the
+          // burst; the other ~1 200 are the ~150 vector instructions of the eight candidates and their half-wave selects.  Without the pinning hipcc turned `hi ? pk.x[a][1] : pk.x[a][0]`
           // into an indexed load from a SCRATCH copy of `pk`: 5 600 cycles per tile.  Left as it was.)
           const MPack pk = packs[item.aux];
+#ifdef RAYEN_IOF_STAMPS
+          { int probe = pk.aux[0][0] + pk.seg[3][1]; asm volatile("" : "+s"(probe)); }   // (the descriptor has arrived)
+          RAYEN_IOF_STAMP(it, 3);
+#endif
 #pragma unroll
           for (int a = 0; a < 4; ++a) {
             const int slot = hi ? pk.aux[a][1] : pk.aux[a][0];

@@ -47,3 +47,8 @@ print("tile  burst+io  epilogue  to-next   (mean over the stamped waves, ticks ~
 for it in range(n_items):
     print(f"{it:4d} {burst[:, it].mean():9.0f} {epi[:, it].mean():9.0f} {gap[:, it].mean():8.0f}")
 print(f"sum  {burst.mean(0).sum():9.0f} {epi.mean(0).sum():9.0f} {gap.mean(0).sum():8.0f}")
+desc = np.array([st[r, :n_items, 3] - st[r, :n_items, 1] for r in rows])
+packed = [it for it in range(n_items) if (st[rows[0], it, 3] > 0)]
+if packed:
+    print("packed tiles: cycles from the end of the burst until the tile's descriptor (dependent scalar load) is there")
+    print("  " + "  ".join(f"{it}:{desc[:, it].mean():.0f}" for it in packed))
