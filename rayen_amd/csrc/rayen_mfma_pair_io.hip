@@ -41,6 +41,28 @@ namespace rayen {
 
 namespace {
 
+// issue priority of a wave inside the tile walk (developer A/B: -DRAYEN_IO_PRIO=n)
+//   0  burst at priority 0, epilogue at 1 (rounds 2-4)          1  no priority changes at all
+//   2  STATIC: the first wave of every SIMD (waves 0-3 of the workgroup) at 2, its partner at 0, no per-tile flips
+//   3  burst at 1, epilogue at 0
+#ifndef RAYEN_IO_PRIO
+#define RAYEN_IO_PRIO 0
+#endif
+__device__ __forceinline__ void prio_burst() {
+  if constexpr (RAYEN_IO_PRIO == 0) __builtin_amdgcn_s_setprio(0);
+  else if constexpr (RAYEN_IO_PRIO == 3) __builtin_amdgcn_s_setprio(1);
+}
+__device__ __forceinline__ void prio_epilogue() {
+  if constexpr (RAYEN_IO_PRIO == 0) __builtin_amdgcn_s_setprio(1);
+  else if constexpr (RAYEN_IO_PRIO == 3) __builtin_amdgcn_s_setprio(0);
+}
+__device__ __forceinline__ void prio_static(const int wave) {
+  if constexpr (RAYEN_IO_PRIO == 2) {
+    if (wave < 4) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(0);
+  }
+}
+
 template <int NKK>
 struct IoGeom {
   static constexpr int NT = 2;
@@ -114,6 +136,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_io_
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  prio_static(wave);
   const int col = lane & 31;
   const int hi = lane >> 5;
   const int64_t n_groups = (B + NT * 32 - 1) / (NT * 32);
@@ -281,7 +304,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_io_
         if (slot && has_prev) ytmp = *reinterpret_cast<const f32x4*>(io + it * 1024 + lane * 16);
         {
           const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          __builtin_amdgcn_s_setprio(0);
+          prio_burst();
           auto load_chunk = [&](const int idx) {
             const char* sb = next_tile + idx * 1024;
             uint64_t asm_base;
@@ -325,7 +348,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_io_
             else dma4_dummy(reinterpret_cast<const char*>(Wh), lane_off >> 2, sink_addr);
           }
           __builtin_amdgcn_sched_barrier(0);
-          __builtin_amdgcn_s_setprio(1);
+          prio_epilogue();
         }
         if (item.type == MI_LIN) {
           const int lin_code = (item.seg << 20) + item.row0 + 4 * hi;
@@ -515,6 +538,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_iof
   extern __shared__ __attribute__((aligned(1024))) char iof_smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  prio_static(wave);
 #ifdef RAYEN_IOF_STAMPS
   const int stamp_wsel = wave == 0 ? 0 : wave == 3 ? 1 : wave == 4 ? 2 : -1;
   const int stamp_row = (int)(blockIdx.x >> 6) * 3 + stamp_wsel;           // 16 workgroups x 3 waves at most
@@ -709,7 +733,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_iof
         if (st && it * 64 + lane < pieces_y) ytmp = *reinterpret_cast<const f32x4*>(io + it * 1024 + lane * 16);
         {
           const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          __builtin_amdgcn_s_setprio(0);
+          prio_burst();
           auto load_chunk = [&](const int idx) {
             const char* sb = next_tile + idx * 1024;
             uint64_t asm_base;
@@ -748,7 +772,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_iof
             else dma4_dummy(reinterpret_cast<const char*>(Wh), lane_off >> 2, sink_addr);
           }
           __builtin_amdgcn_sched_barrier(0);
-          __builtin_amdgcn_s_setprio(1);
+          prio_epilogue();
         }
         RAYEN_IOF_STAMP(it, 1);
         if (item.type == MI_LIN) {

@@ -1,13 +1,9 @@
-# round 4, session 5: the flat-row kernel's runs of linear tiles -- bit-equality tests, then timings of three builds on one box
-out=gpurun_out/r04e; mkdir -p $out
-timeout 1500 python -m pytest tests/test_gpu_pair_io.py -m gpu -q -k "flat" --timeout 900 -p no:cacheprovider -x > $out/pytest_flat.log 2>&1
-tail -4 $out/pytest_flat.log
+# round 4, session 5: issue priority of the two waves of a SIMD inside the tile walk (RAYEN_IO_PRIO) -- one box, two passes
+out=gpurun_out/r04h; mkdir -p $out
 V=scripts/ubench/variants
 for rep in 1 2; do
-for lib in $V/librayen_base.so $V/librayen_mfma_pair_io_noruns.so rayen_amd/csrc/librayen_hip.so; do
-  for cfg in c5 c5r; do
-    RAYEN_HIP_LIBRARY=$PWD/$lib timeout 300 python scripts/ubench/io_bench.py --config $cfg --batches 262144,524288 2>&1 | tail -1 | sed "s/^/$cfg /"
-    RAYEN_HIP_LIBRARY=$PWD/$lib timeout 300 python scripts/ubench/io_bench.py --config $cfg --batches 262144 --track 2>&1 | tail -1 | sed "s/^/$cfg track /"
-  done
+for lib in $V/librayen_base.so $V/librayen_mfma_pair_io_prio1.so $V/librayen_mfma_pair_io_prio2.so $V/librayen_mfma_pair_io_prio3.so; do
+  RAYEN_HIP_LIBRARY=$PWD/$lib timeout 300 python scripts/ubench/io_bench.py --config c3 --batches 262144,1048576 2>&1 | tail -1 | sed "s/^/c3 /"
+  RAYEN_HIP_LIBRARY=$PWD/$lib timeout 300 python scripts/ubench/io_bench.py --config c5 --batches 262144,1048576 2>&1 | tail -1 | sed "s/^/c5 /"
 done
-done 2>&1 | tee $out/timing.txt
+done 2>&1 | tee $out/prio.txt
