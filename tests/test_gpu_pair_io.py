@@ -220,3 +220,30 @@ def test_dynamic_lds_promise_survives_a_later_smaller_pack():
     torch.cuda.synchronize()
     assert fam0 == fam1 == _lib.KERNEL_PAIR_IO
     assert torch.equal(y0, y1) and torch.equal(k0, k1) and torch.equal(a0, a1) and torch.equal(gv0, gv1)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# the same launch many times (round 4): 22 of 3 000 launches of the flat-row kernel's TRACK instance on config 5 at
+# B = 655 360 returned y0 itself in 16 rows of one column (a packed fma of the NA_E write-out: rayen_mfma_pair_io.hip),
+# never repeatably -- one launch per shape cannot see that
+# --------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,B,reps", [("c5", 655360, 300), ("c5r", 393216, 150), ("c3", 393216, 100)])
+def test_trickled_rows_equal_the_plain_kernel_on_every_one_of_many_launches(name, B, reps):
+    raw = _flat_sets()[name] if name != "c3" else _sets()["c3"]
+    cs, layer, dp = _pack(raw)
+    if dp.info().mfma_f32 != 3:
+        pytest.skip("the f16-pair family does not serve this pack")
+    gen = torch.Generator(device="cuda").manual_seed(B)
+    buf = torch.empty(B * cs.n + 4, device="cuda")
+    w = buf[1:1 + B * cs.n].view(B, cs.n)
+    assert w.data_ptr() % 16 != 0
+    mismatching = 0
+    for rep in range(reps):
+        v = torch.empty(B, cs.n, device="cuda").uniform_(-1.5, 1.5, generator=gen)
+        y1, k1, a1, fam1 = _run(dp, v, True)                  # (the arg-max record: the instance that failed)
+        assert fam1 == _lib.KERNEL_PAIR_IO
+        w.copy_(v)
+        y2, k2, a2, fam2 = _run(dp, w, True)
+        assert fam2 == _lib.KERNEL_PAIR
+        mismatching += int(not (torch.equal(y1, y2) and torch.equal(k1, k2) and torch.equal(a1, a2)))
+    assert mismatching == 0, f"{mismatching} of {reps} launches differ from the plain kernel"
