@@ -1,4 +1,8 @@
-# round 4, last call: smoke(), then the self-consistency stress at ten times the launches on the sets with an NA_E write-out
-out=gpurun_out/r04v; mkdir -p $out
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -4 | tee $out/smoke.txt
-timeout 2400 python scripts/ubench/determinism_stress.py --reps 3000 --configs c5,c5r 2>&1 | grep "^{" | tee $out/determinism_c5.txt
+# round 4, last session: config 3's walk with its A re-loads kept but the counted waits removed / relaxed (wrong results) -- is it the waits or the loads?
+out=gpurun_out/r04w; mkdir -p $out
+V=scripts/ubench/variants
+for rep in 1 2; do
+for lib in rayen_amd/csrc/librayen_hip.so $V/librayen_mfma_pair_io_nowait.so $V/librayen_mfma_pair_io_latewait.so; do
+  RAYEN_HIP_LIBRARY=$PWD/$lib timeout 300 python scripts/ubench/io_bench.py --config c3 --batches 262144,1048576 2>&1 | tail -1 | sed "s/^/c3 /"
+done
+done 2>&1 | tee $out/waits.txt
