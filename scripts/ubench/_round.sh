@@ -1,6 +1,4 @@
-# round 4, last session: the ten fp32 LMI-backward seeds of the 1000-seed fuzz on variants of the inverse iteration (iterations / shift)
-out=gpurun_out/r04y; mkdir -p $out
-ids=""; for s in 71 74 78 111 133 150 189 216 229 234; do ids="$ids tests/test_gpu_backward.py::test_random_lmi_sets_backward[dtype0-$s]"; done
-for lib in rayen_amd/csrc/librayen_hip.so scripts/ubench/variants/librayen_lmi_it5.so scripts/ubench/variants/librayen_lmi_it5s.so scripts/ubench/variants/librayen_lmi_s1.so; do
-  RAYEN_HIP_LIBRARY=$PWD/$lib RAYEN_FUZZ_SEEDS=1000 timeout 600 python -m pytest $ids -m gpu -q --timeout 300 -p no:cacheprovider 2>&1 | grep -E "AssertionError: \(|passed|failed" | cut -c1-260 | sed "s|^|$(basename $lib) |"
-done 2>&1 | tee $out/lmi_seeds.txt
+# round 4, closing check of the library as it lies in the tree: smoke(), the schedule-equality file (with the many-launch tests), the boundary file
+out=gpurun_out/r04z; mkdir -p $out
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $out/smoke.txt
+timeout 1200 python -m pytest tests/test_gpu_pair_io.py tests/test_gpu_boundary.py -m gpu -q --timeout 600 -p no:cacheprovider 2>&1 | tail -3 | tee $out/pytest.txt
