@@ -1,4 +1,4 @@
-# round 4, closing check of the library as it lies in the tree: smoke(), the schedule-equality file (with the many-launch tests), the boundary file
+# round 4, closing: the failing shape of the repetition fault, 30 000 launches (15 000 with the record) on the library in the tree
 out=gpurun_out/r04z; mkdir -p $out
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $out/smoke.txt
-timeout 1200 python -m pytest tests/test_gpu_pair_io.py tests/test_gpu_boundary.py -m gpu -q --timeout 600 -p no:cacheprovider 2>&1 | tail -3 | tee $out/pytest.txt
+timeout 1500 python scripts/ubench/io_stress.py --reps 30000 --configs c5 --batches 655360 2>&1 | grep "^{" | tee $out/io_stress_30000.txt
+timeout 900 python scripts/ubench/io_stress.py --reps 10000 --configs c5r --batches 655360 2>&1 | grep "^{" | tee -a $out/io_stress_30000.txt
