@@ -349,7 +349,10 @@ def _check_lmi_backward(raw, dtype):
     # measured against the incoming gradient's size there, not against rounding noise)
     # the two terms that cancel are of the size of g; rounding leaves a few ulps of THAT (observed <= 5e-16 |g| in
     # fp64 over 250 sets), so the floor is |g| * 1e-6: an absolute error of 1e-14 |g| still fails
-    floor = g.double().abs().amax(1) * (1e-3 if dtype == torch.float32 else 1e-6)
+    # fp32 (round 4, 1000-seed fuzz): the residue of that cancellation is 3e-7 ... 5e-7 |g| on the n = 1 sets (2 - 4 ulps of
+    # the two terms; the forward's kappa is within 2e-7 of the fp64 oracle's there, scripts/ubench/lmi_kappa_check.py), which
+    # a floor of 1e-3 |g| turned into "errors" of 2.1e-4 ... 4.1e-4 on 10 of 250 seeds; 4e-3 |g| asks for 8e-7 |g| absolute
+    floor = g.double().abs().amax(1) * (4e-3 if dtype == torch.float32 else 1e-6)
     _assert_gradient(got.numpy(), want.numpy(), cs, v.unsqueeze(2), g, dtype, floor=floor.numpy(), what=f"lmi r={r}")
     err = torch.from_numpy(_row_err(got.numpy(), want.numpy(), floor.numpy()))
     assert float(err[:22].max()) <= (1e-5 if dtype == torch.float32 else 1e-12)
