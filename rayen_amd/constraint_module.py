@@ -38,7 +38,29 @@ from . import _lib, eager, ops, pack as _pack, utils
 
 class ConstraintModule(torch.nn.Module):
     _fast = {}                    # (replaced per instance; a pickle written before round 4 has no such attribute)
-    _hip_unsupported = False      # set per instance (with a warning) when no HIP kernel serves the set: eager.py runs instead
+
+    # Which (device index, dtype, old_head) combinations the HIP kernels refused (RAYEN_E_UNSUPPORTED, announced with a
+    # warning): those calls -- and only those -- run rayen_amd/eager.py.  Forgotten whenever the packs are rebuilt
+    # (.to(), load_state_dict) and never pickled.  ``_hip_unsupported`` is the any-of view the tests read.
+    @property
+    def _hip_unsupported(self):
+        return bool(self.__dict__.get("_unsupported"))
+
+    @_hip_unsupported.setter
+    def _hip_unsupported(self, value):
+        if value:
+            self.__dict__.setdefault("_unsupported", set()).add(None)     # (None: every combination)
+        else:
+            self.__dict__["_unsupported"] = set()
+
+    def _refused(self, v, old_head=False):
+        refused = self.__dict__.get("_unsupported")
+        return bool(refused) and (None in refused or (v.device.index, v.dtype, bool(old_head)) in refused)
+
+    def __setattr__(self, name, value):
+        super().__setattr__(name, value)
+        if name == "mapper":
+            self.__dict__["_fast"] = {}       # (the fast path caches "the mapper is the identity" per device and dtype)
 
     def __init__(self, cs, input_dim=None, method='RAYEN', create_map=True, args_DC3=None):
         super().__init__()
@@ -137,6 +159,7 @@ class ConstraintModule(torch.nn.Module):
         self._device_packs = {}
         self._consts = None
         self._fast = {}
+        self.__dict__["_unsupported"] = set()
         self.__dict__.pop("_eager", None)
 
     def _apply(self, fn, *args, **kwargs):
@@ -174,6 +197,7 @@ class ConstraintModule(torch.nn.Module):
         state["_device_packs"] = {}   # device handles are not picklable; rebuilt lazily
         state["_consts"] = None
         state["_fast"] = {}
+        state["_unsupported"] = set()
         state.pop("_eager", None)
         state.pop("forwardForMethod", None)
         return state
@@ -195,7 +219,7 @@ class ConstraintModule(torch.nn.Module):
         if v.dtype not in (torch.float32, torch.float64):
             y, kappa = self._project(v.float(), old_head=old_head)       # 16-bit activations: computed in fp32
             return y.to(v.dtype), (None if kappa is None else kappa.to(v.dtype))
-        if self._hip_unsupported:
+        if self._refused(v, old_head):
             return eager.project(self, v, old_head=old_head)
         try:
             dp, pack_id = self.device_pack(v.device)
@@ -215,13 +239,13 @@ class ConstraintModule(torch.nn.Module):
             # RAYEN_STRICT_HIP=1 turns it back into the error.
             warnings.warn(f"rayen_amd: no HIP kernel serves this constraint set ({err}); this module now runs the "
                           "packed torch evaluator (rayen_amd/eager.py) on " + str(v.device), RuntimeWarning, stacklevel=3)
-            self._hip_unsupported = True
+            self.__dict__.setdefault("_unsupported", set()).add((v.device.index, v.dtype, bool(old_head)))
             return eager.project(self, v, old_head=old_head)
 
     def computeKappa(self, v_bar):
         """``kappa [B,1,1]`` of directions ``v_bar [B,n,1]`` (rayen/constraint_module.py:351-458)."""
         v = torch.flatten(v_bar, 1)
-        if not v.is_cuda or self._hip_unsupported or v.dtype not in (torch.float32, torch.float64):
+        if not v.is_cuda or self._refused(v) or v.dtype not in (torch.float32, torch.float64):
             return eager.evaluator_for(self, v).kappa(v[:, :self.n]).reshape(-1, 1, 1)
         dp, _ = self.device_pack(v.device)
         _, kappa, _ = ops.project_raw(v, dp, want_y=False)
@@ -257,7 +281,7 @@ class ConstraintModule(torch.nn.Module):
         the fused kernel does not serve this layer/input (then the two-op path below runs)."""
         if (self.method != 'RAYEN' or not getattr(self, "fuse_mapper", True)
                 or not isinstance(self.mapper, nn.Linear) or not x2.is_cuda or x2.dtype != torch.float32
-                or self._hip_unsupported):
+                or self._refused(x2)):
             return None
         try:
             dp, pack_id = self.device_pack(x2.device)
@@ -282,7 +306,7 @@ class ConstraintModule(torch.nn.Module):
         if entry is False:
             entry = None
             if (self.method == 'RAYEN' and isinstance(self.mapper, nn.Sequential) and len(self.mapper) == 0
-                    and not self._hip_unsupported and x.dtype in (torch.float32, torch.float64)
+                    and not self._refused(x) and x.dtype in (torch.float32, torch.float64)
                     and self.n < ops._WIDE_MIN_N[x.dtype]):      # (wide sets: GEMM + products epilogue, ops.project_raw)
                 try:
                     dp, _ = self.device_pack(x.device)
@@ -327,7 +351,7 @@ class ConstraintModule(torch.nn.Module):
             y = self.forwardForMethod(q)
 
         if __debug__ and self.check_nan and self.method in ('RAYEN', 'RAYEN_old'):
-            if not y.is_cuda or self._hip_unsupported:
+            if not y.is_cuda or self._refused(y, self.method == 'RAYEN_old'):
                 assert not torch.isnan(y).any(), "the projection produced NaN (NaN in the input?)"     # CM:531
             elif not torch.cuda.is_current_stream_capturing():  # the flag read is a host sync
                 dp, _ = self.device_pack(y.device)

@@ -322,7 +322,11 @@ class ConvexConstraints:
                 return None
             z0 = np.asarray(z.value, dtype=np.float64).reshape(self.n, 1)
             return z0 if float(np.min(self.margins(z0))) > 1e-8 else None
-        except Exception:
+        except Exception as exc:        # said, not swallowed: z0 (hence every y) then comes from the built-in program
+            import warnings
+            warnings.warn(f"rayen_amd: cvxpy is importable but its margin program failed ({type(exc).__name__}: {exc}); "
+                          "the interior point comes from the built-in solvers instead (RAYEN_NO_CVXPY=1 skips cvxpy)",
+                          UserWarning, stacklevel=2)
             return None
 
     # ------------------------------------------------------------------ linear preprocessing

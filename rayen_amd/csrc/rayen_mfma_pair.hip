@@ -22,6 +22,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 namespace rayen {
@@ -290,48 +291,81 @@ __device__ __forceinline__ void mfma_pair_fwd_body(
   };
 
   f32x16 acc[NT];
+  // (which tile an item reads and which K-steps of it come with the PREVIOUS item's record -- MItem::qbegin, mfma_pair_build:
+  // nothing in front of a burst waits for a scalar load)
+  int ts_next = items[0].tile_shape;
+  bool after_half_b = false;   // the previous item was the second half of a shared tile (its loads sit later in the queue)
   for (int it = 0; it < n_items; ++it) {
     const MItem item = items[it];
+    const int ts = ts_next;
+    ts_next = item.qbegin;
     if (item.type == MI_OUT && (item.flags & MF_FIRST)) finish_kappa();
     // the tile after this one; the last tile of a group fetches tile 0 for the next group
-    const char* next_tile = reinterpret_cast<const char*>(Wh) + (size_t)(it + 1 == n_items ? 0 : it + 1) * (NCH * 1024);
+    const char* next_tile = reinterpret_cast<const char*>(Wh) + (size_t)(((ts >> 30) & 1) ? 0 : (ts & 0xFFFFFF) + 1) * (NCH * 1024);
     {
       const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       __builtin_amdgcn_s_setprio(0);
       // Two passes over the K-steps, by product size: the 2^-11 cross products of ALL steps first, the leading
       // products last (the instruction aligns its products and C to the largest and keeps ~26 bits: small products go
       // in while the accumulator is still small, scripts/ubench/mfma_bf16_acc.hip)
-      auto load_chunk = [&](const int idx) {
-        const char* sb = next_tile + idx * 1024;
-        uint64_t asm_base;
-        asm volatile(RAYEN_ASM_BASE_COPY "global_load_dwordx4 %[d], %[off], " RAYEN_ASM_BASE "" : [d] "+v"(abuf[idx]), [b] "=&s"(asm_base) : [off] "v"(lane_off), [base] "s"(sb));
-      };
+      // Which K-steps of the tile an item multiplies (`k_*`) and streams (`s_*`: waits for, re-loads for the next tile):
+      // a full tile all of them; the halves of a shared tile (NS = 4, rayen_tiles.h) K-steps 0,1 or 2,3; a block alone in
+      // its tile multiplies K-steps 2,3 and streams all.  ONE instruction stream: a K-step -- wait, MFMAs, re-load -- is a
+      // single statement with its branches inside (rayen_split_image.h::pair_kstep1 / pair_kstep2).
+      // Counted waits: a chunk's re-load for the NEXT tile follows its last use, so K-step sp of a full tile behind a full
+      // tile has NS - 1 younger loads behind its chunks; the second half of a shared tile has the first half's four
+      // re-loads behind them on top, and so have K-steps 0,1 of the tile after it.
+      if constexpr (NS == 4) {
+        const int shape = (ts >> 24) & 3;
+        const int ctrl = pair_item_ctrl(shape, after_half_b);
+        auto step1 = [&](auto SP) {
+          constexpr int sp = decltype(SP)::value;
+          f16x8 b1[NT], b2[NT];
 #pragma unroll
-      for (int sp = 0; sp < NS; ++sp) {
-        __builtin_amdgcn_sched_barrier(0);
-        // the step's two chunks: the younger (a1, re-loaded in the second pass of the previous tile) has NS - 1 loads behind it
-        if constexpr (NS == 4)
-          asm volatile("s_waitcnt vmcnt(3)" : "+v"(abuf[2 * sp + 0]), "+v"(abuf[2 * sp + 1]));
-        else
+          for (int t = 0; t < NT; ++t) { b1[t] = vb[t][0][sp]; b2[t] = vb[t][1][sp]; }
+          __builtin_amdgcn_sched_barrier(0);
+          pair_kstep1<NT, sp, 3, 5>(abuf[2 * sp + 0], abuf[2 * sp + 1], acc, b1, b2, ctrl, next_tile + (2 * sp + 1) * 1024, lane_off);
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        auto step2 = [&](auto SP) {
+          constexpr int sp = decltype(SP)::value;
+          f16x8 b1[NT];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) b1[t] = vb[t][0][sp];
+          __builtin_amdgcn_sched_barrier(0);
+          pair_kstep2<NT, sp, sp == NS - 1>(abuf[2 * sp + 0], acc, b1, ctrl, next_tile + (2 * sp + 0) * 1024, lane_off);
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        step1(std::integral_constant<int, 0>{}); step1(std::integral_constant<int, 1>{});
+        step1(std::integral_constant<int, 2>{}); step1(std::integral_constant<int, 3>{});
+        step2(std::integral_constant<int, 0>{}); step2(std::integral_constant<int, 1>{});
+        step2(std::integral_constant<int, 2>{}); step2(std::integral_constant<int, 3>{});
+        after_half_b = shape == MS_HALF_B;
+      } else {
+        // n_pad = 32: every item is a full tile; the builtins, scheduled by hipcc (rounds 3-4)
+#pragma unroll
+        for (int sp = 0; sp < NS; ++sp) {
+          __builtin_amdgcn_sched_barrier(0);
           asm volatile("s_waitcnt vmcnt(1)" : "+v"(abuf[2 * sp + 0]), "+v"(abuf[2 * sp + 1]));
-        const f16x8 a1 = __builtin_bit_cast(f16x8, abuf[2 * sp + 0]), a2 = __builtin_bit_cast(f16x8, abuf[2 * sp + 1]);
+          const f16x8 a1 = __builtin_bit_cast(f16x8, abuf[2 * sp + 0]), a2 = __builtin_bit_cast(f16x8, abuf[2 * sp + 1]);
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, vb[t][0][sp], sp == 0 ? zero : acc[t], 0, 0, 0);
+          for (int t = 0; t < NT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, vb[t][0][sp], sp == 0 ? zero : acc[t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, vb[t][1][sp], acc[t], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        load_chunk(2 * sp + 1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, vb[t][1][sp], acc[t], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          pair_reload(abuf[2 * sp + 1], next_tile + (2 * sp + 1) * 1024, lane_off);
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
-      for (int sp = 0; sp < NS; ++sp) {
-        const f16x8 a1 = __builtin_bit_cast(f16x8, abuf[2 * sp + 0]);
+        for (int sp = 0; sp < NS; ++sp) {
+          const f16x8 a1 = __builtin_bit_cast(f16x8, abuf[2 * sp + 0]);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, vb[t][0][sp], acc[t], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        load_chunk(2 * sp + 0);
-        __builtin_amdgcn_sched_barrier(0);
+          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, vb[t][0][sp], acc[t], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          pair_reload(abuf[2 * sp + 0], next_tile + (2 * sp + 0) * 1024, lane_off);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       __builtin_amdgcn_s_setprio(1);
     }
@@ -581,9 +615,15 @@ void mfma_pair_free(PairImage* img) {
 
 int mfma_pair_build(const RayenPack* p, PairImage** out, int64_t* bytes) {
   TileLayout b(p->n);
-  const int rc = layout_tiles(p, b, /*allow_pack=*/true, /*allow_sym=*/false);
+  // (RAYEN_PAIR_TRI=0: dense factors, two tiles each -- the image of rounds 3 and 4, for A/B measurements)
+  const char* tri_env = std::getenv("RAYEN_PAIR_TRI");
+  const bool tri = !(tri_env != nullptr && tri_env[0] == '0');
+  const int rc = layout_tiles(p, b, /*allow_pack=*/true, /*allow_sym=*/false, tri);
   if (rc != RAYEN_OK) return rc;
   if (b.packs.empty()) { MPack none; std::memset(&none, 0, sizeof(none)); b.packs.push_back(none); }
+  // an item also carries the NEXT item's tile and shape (in `qbegin`, which only symmetric-form layouts use): the walks
+  // need them in front of an item's burst, and a scalar load issued there would be waited for there
+  for (size_t i = 0; i < b.items.size(); ++i) b.items[i].qbegin = b.items[i + 1 < b.items.size() ? i + 1 : i].tile_shape;
   // ---- one power of two per quadratic / cone on top of the image's gW (round 3).  f16 has five exponent bits: with ONE
   // scale for the whole image, a constraint whose rows are 2^-15 of the image's largest entry keeps only its leading
   // pieces (config 5's jerk limits next to its corridor rows: 3e-5 -- the creation-time measurement sent the set to the
@@ -593,17 +633,24 @@ int mfma_pair_build(const RayenPack* p, PairImage** out, int64_t* bytes) {
   // Linear rows keep the image's scale (their maximum runs over rows of different segments' worth of scale).
   std::vector<float> seg_inv(p->segs.size(), 1.f);
   {
+    // who owns an entry of the image: [tile row][column half] (a shared tile's rows belong to one segment in columns
+    // 0..31 and to another in columns 32..63, rayen_tiles.h)
     const int n_tiles0 = b.n_tiles();
-    std::vector<int> row_seg((size_t)n_tiles0 * 32, -1);
+    const int half_w = b.n_pad >= 64 ? 32 : b.n_pad;
+    std::vector<int> cell_seg((size_t)n_tiles0 * 32 * 2, -1);
+    auto own_row = [&](int tile, int r, int shape, int seg) {
+      if (shape != MS_HALF_B) cell_seg[((size_t)tile * 32 + r) * 2 + 0] = seg;
+      if (shape != MS_HALF_A) cell_seg[((size_t)tile * 32 + r) * 2 + 1] = seg;
+    };
     int cur_aux = -1;
     for (size_t idx = 0; idx < b.items.size(); ++idx) {
       const MItem& it = b.items[idx];
-      if (it.type == MI_AUX) cur_aux = (int)idx;
+      if (it.type == MI_AUX) cur_aux = it.tile();
       if (it.type == MI_QFAC || it.type == MI_SOC) {
-        for (int r = 0; r < 32; ++r) row_seg[idx * 32 + r] = it.seg;
+        for (int r = 0; r < 32; ++r) own_row(it.tile(), r, it.shape(), it.seg);
         if (cur_aux >= 0) {
-          row_seg[(size_t)cur_aux * 32 + it.aux] = it.seg;
-          if (it.type == MI_SOC) row_seg[(size_t)cur_aux * 32 + it.aux + 1] = it.seg;
+          own_row(cur_aux, it.aux, MS_FULL, it.seg);
+          if (it.type == MI_SOC) own_row(cur_aux, it.aux + 1, MS_FULL, it.seg);
         }
       }
       if (it.type == MI_PACK) {
@@ -611,19 +658,21 @@ int mfma_pair_build(const RayenPack* p, PairImage** out, int64_t* bytes) {
         for (int a = 0; a < 4; ++a)
           for (int h = 0; h < 2; ++h) {
             if (pk.seg[a][h] < 0) continue;
-            for (int c = 0; c < 4; ++c) row_seg[idx * 32 + 8 * a + 4 * h + c] = pk.seg[a][h];
-            if (cur_aux >= 0) row_seg[(size_t)cur_aux * 32 + pk.aux[a][h]] = pk.seg[a][h];
+            for (int c = 0; c < 4; ++c) own_row(it.tile(), 8 * a + 4 * h + c, MS_FULL, pk.seg[a][h]);
+            if (cur_aux >= 0) own_row(cur_aux, pk.aux[a][h], MS_FULL, pk.seg[a][h]);
           }
       }
     }
+    auto cell_of = [&](size_t r, int c) { return cell_seg[r * 2 + (c >= half_w ? 1 : 0)]; };
     double image_big = 0.0;
     std::vector<double> seg_big(p->segs.size(), 0.0);
-    for (size_t r = 0; r < row_seg.size(); ++r)
+    for (size_t r = 0; r < (size_t)n_tiles0 * 32; ++r)
       for (int c = 0; c < b.n_pad; ++c) {
         const double x = std::fabs(b.raw[r * b.n_pad + c]);
         if (!std::isfinite(x)) continue;
         image_big = x > image_big ? x : image_big;
-        if (row_seg[r] >= 0 && x > seg_big[row_seg[r]]) seg_big[row_seg[r]] = x;
+        const int sg = cell_of(r, c);
+        if (sg >= 0 && x > seg_big[sg]) seg_big[sg] = x;
       }
     std::vector<double> boost(p->segs.size(), 1.0);
     for (size_t s = 0; s < p->segs.size(); ++s) {
@@ -636,9 +685,11 @@ int mfma_pair_build(const RayenPack* p, PairImage** out, int64_t* bytes) {
       boost[s] = std::ldexp(1.0, e);
       seg_inv[s] = (float)std::ldexp(1.0, -e);
     }
-    for (size_t r = 0; r < row_seg.size(); ++r)
-      if (row_seg[r] >= 0 && boost[row_seg[r]] != 1.0)
-        for (int c = 0; c < b.n_pad; ++c) b.raw[r * b.n_pad + c] *= boost[row_seg[r]];
+    for (size_t r = 0; r < (size_t)n_tiles0 * 32; ++r)
+      for (int c = 0; c < b.n_pad; ++c) {
+        const int sg = cell_of(r, c);
+        if (sg >= 0 && boost[sg] != 1.0) b.raw[r * b.n_pad + c] *= boost[sg];
+      }
     for (MItem& it : b.items)
       if (it.type == MI_QFAC || it.type == MI_SOC) it.seg_inv = seg_inv[it.seg];
     for (MPack& pk : b.packs)

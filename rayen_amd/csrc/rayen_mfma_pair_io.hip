@@ -295,49 +295,83 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_io_
 
     {
       f32x16 acc[NT];
+      // (which tile an item reads and which K-steps of it -- rayen_tiles.h -- come with the PREVIOUS item's record,
+      // MItem::qbegin: nothing in front of a burst waits for a scalar load)
+      int ts_next = items[0].tile_shape;
+      bool after_half_b = false;   // the previous item was the second half of a shared tile
       for (int it = 0; it < n_items; ++it) {
         const MItem item = items[it];
+        const int ts = ts_next;
+        ts_next = item.qbegin;
         // the tile after this one; the last tile of a group fetches tile 0 for the next group
-        const char* next_tile = reinterpret_cast<const char*>(Wh) + (size_t)(it + 1 == n_items ? 0 : it + 1) * (NCH * 1024);
+        const char* next_tile = reinterpret_cast<const char*>(Wh) + (size_t)(((ts >> 30) & 1) ? 0 : (ts & 0xFFFFFF) + 1) * (NCH * 1024);
         const bool slot = it < NBLK;
         f32x4 ytmp = {0.f, 0.f, 0.f, 0.f};
         if (slot && has_prev) ytmp = *reinterpret_cast<const f32x4*>(io + it * 1024 + lane * 16);
         {
           const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           prio_burst();
-          auto load_chunk = [&](const int idx) {
-            const char* sb = next_tile + idx * 1024;
-            uint64_t asm_base;
-            asm volatile(RAYEN_ASM_BASE_COPY "global_load_dwordx4 %[d], %[off], " RAYEN_ASM_BASE "" : [d] "+v"(abuf[idx]), [b] "=&s"(asm_base) : [off] "v"(lane_off), [base] "s"(sb));
-          };
-          // Two passes over the K-steps, by product size (rayen_mfma_pair.hip).  The counted waits step over the two
-          // I/O operations the previous tile issued behind its last re-load.  (Tile 0: everything it needs landed
-          // before the boundary's vmcnt(0), the count is irrelevant there.)
+          // Two passes over the K-steps, by product size (rayen_mfma_pair.hip).  Which K-steps of the tile an item
+          // multiplies (`k_*`) and streams (`s_*`): a full tile all of them; the halves of a shared tile (NS = 4,
+          // rayen_tiles.h) K-steps 0,1 or 2,3; a block alone in its tile multiplies K-steps 2,3 and streams all.  ONE
+          // instruction stream: a K-step -- wait, MFMAs, re-load -- is a single statement with its branches inside
+          // (rayen_split_image.h::pair_kstep1 / pair_kstep2).  The counted waits step over the two I/O operations the
+          // previous ITEM issued behind its last re-load (tile 0: everything it needs landed before the boundary's
+          // vmcnt(0)): behind the chunks of K-step sp there are -- full behind full NS - 1 re-loads + 2 = 5; a first half
+          // (always behind a full item) the same 5; a second half the first half's 4 + 2 on top of a tile's remaining
+          // 3: 9; K-steps 0,1 of the full item behind a shared tile 9 likewise (their chunks were re-loaded by the FIRST
+          // half), K-steps 2,3 of it 5.
+          if constexpr (NS == 4) {
+            const int shape = (ts >> 24) & 3;
+            const int ctrl = pair_item_ctrl(shape, after_half_b);
+            auto step1 = [&](auto SP) {
+              constexpr int sp = decltype(SP)::value;
+              f16x8 b1[NT], b2[NT];
 #pragma unroll
-          for (int sp = 0; sp < NS; ++sp) {
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (NS == 4)
-              asm volatile("s_waitcnt vmcnt(5)" : "+v"(abuf[2 * sp + 0]), "+v"(abuf[2 * sp + 1]));
-            else
+              for (int t = 0; t < NT; ++t) { b1[t] = vb[t][0][sp]; b2[t] = vb[t][1][sp]; }
+              __builtin_amdgcn_sched_barrier(0);
+              pair_kstep1<NT, sp, 5, 9>(abuf[2 * sp + 0], abuf[2 * sp + 1], acc, b1, b2, ctrl, next_tile + (2 * sp + 1) * 1024, lane_off);
+              __builtin_amdgcn_sched_barrier(0);
+            };
+            auto step2 = [&](auto SP) {
+              constexpr int sp = decltype(SP)::value;
+              f16x8 b1[NT];
+#pragma unroll
+              for (int t = 0; t < NT; ++t) b1[t] = vb[t][0][sp];
+              __builtin_amdgcn_sched_barrier(0);
+              pair_kstep2<NT, sp, sp == NS - 1>(abuf[2 * sp + 0], acc, b1, ctrl, next_tile + (2 * sp + 0) * 1024, lane_off);
+              __builtin_amdgcn_sched_barrier(0);
+            };
+            step1(std::integral_constant<int, 0>{}); step1(std::integral_constant<int, 1>{});
+            step1(std::integral_constant<int, 2>{}); step1(std::integral_constant<int, 3>{});
+            step2(std::integral_constant<int, 0>{}); step2(std::integral_constant<int, 1>{});
+            step2(std::integral_constant<int, 2>{}); step2(std::integral_constant<int, 3>{});
+            after_half_b = shape == MS_HALF_B;
+          } else {
+            // n_pad = 32: every item is a full tile; the builtins, scheduled by hipcc (rounds 3-4)
+#pragma unroll
+            for (int sp = 0; sp < NS; ++sp) {
+              __builtin_amdgcn_sched_barrier(0);
               asm volatile("s_waitcnt vmcnt(3)" : "+v"(abuf[2 * sp + 0]), "+v"(abuf[2 * sp + 1]));
-            const f16x8 a1 = __builtin_bit_cast(f16x8, abuf[2 * sp + 0]), a2 = __builtin_bit_cast(f16x8, abuf[2 * sp + 1]);
+              const f16x8 a1 = __builtin_bit_cast(f16x8, abuf[2 * sp + 0]), a2 = __builtin_bit_cast(f16x8, abuf[2 * sp + 1]);
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, vb[t][0][sp], sp == 0 ? zero : acc[t], 0, 0, 0);
+              for (int t = 0; t < NT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, vb[t][0][sp], sp == 0 ? zero : acc[t], 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, vb[t][1][sp], acc[t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            load_chunk(2 * sp + 1);
-            __builtin_amdgcn_sched_barrier(0);
-          }
+              for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, vb[t][1][sp], acc[t], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              pair_reload(abuf[2 * sp + 1], next_tile + (2 * sp + 1) * 1024, lane_off);
+              __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
-          for (int sp = 0; sp < NS; ++sp) {
-            const f16x8 a1 = __builtin_bit_cast(f16x8, abuf[2 * sp + 0]);
+            for (int sp = 0; sp < NS; ++sp) {
+              const f16x8 a1 = __builtin_bit_cast(f16x8, abuf[2 * sp + 0]);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, vb[t][0][sp], acc[t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            load_chunk(2 * sp + 0);
-            __builtin_amdgcn_sched_barrier(0);
+              for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, vb[t][0][sp], acc[t], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              pair_reload(abuf[2 * sp + 0], next_tile + (2 * sp + 0) * 1024, lane_off);
+              __builtin_amdgcn_sched_barrier(0);
+            }
           }
           // ---- the tile's two I/O operations: 1 KiB of y(prev) out, 1 KiB of v(next) in (or their stand-ins)
           {

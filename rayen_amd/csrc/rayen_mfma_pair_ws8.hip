@@ -84,8 +84,8 @@ __device__ __forceinline__ const char* w8_uniform(const void* p) {
 
 template <int NKK, int TPW, bool TRACK>
 __global__ __launch_bounds__(kW8Waves * 64, 2) void mfma_pair_ws8_kernel(
-    const f16x8* __restrict__ Wh, const W8Item* __restrict__ witems, const int32_t* __restrict__ wtile,
-    const MPack* __restrict__ packs, const float* __restrict__ y0,
+    const f16x8* __restrict__ Wh, const W8Item* __restrict__ witems, const W8Item* __restrict__ witems2,
+    const int32_t* __restrict__ wtile, const MPack* __restrict__ packs, const float* __restrict__ y0,
     const float* __restrict__ v, int64_t B, int64_t ldv, float* __restrict__ y, int64_t ldy,
     float* __restrict__ kappa_out, int32_t* __restrict__ active_out, int32_t* __restrict__ nan_flag,
     const float w_scale, const float w_inv) {
@@ -112,11 +112,14 @@ __global__ __launch_bounds__(kW8Waves * 64, 2) void mfma_pair_ws8_kernel(
   bool bad = false;
 
   // ---- this wave's tiles of W, once.  A[tt][sp][0 | 1] = leading | second piece
+  // (a tile two triangular factors share -- rayen_tiles.h -- is ONE slot: its K-steps 0,1 belong to its[tt], a first half,
+  // its K-steps 2,3 to its2[tt], a second half.  its2[tt].type = MI_NOP: the slot is an ordinary tile.)
   f16x8 A[TPW][NS][2];
-  W8Item its[TPW];
+  W8Item its[TPW], its2[TPW];
 #pragma unroll
   for (int tt = 0; tt < TPW; ++tt) {
     its[tt] = witems[wave * TPW + tt];
+    its2[tt] = witems2[wave * TPW + tt];
     int tile = wtile[wave * TPW + tt];
     tile = tile < 0 ? 0 : tile;     // (a tile without rows: padding of this wave's list, never walked)
     const f16x8* tb = Wh + (size_t)tile * (NS * 2 * 64) + lane;
@@ -275,11 +278,11 @@ __global__ __launch_bounds__(kW8Waves * 64, 2) void mfma_pair_ws8_kernel(
 
   // one tile: its MFMAs (two passes over the K-steps, by product size -- rayen_mfma_pair.hip's instructions in its order on
   // its operands, hence its bits), then its epilogue on this wave's candidates
-  auto tile = [&](const int tt_dyn, auto TT, const int gen, const int par) {
+  auto tile_part = [&](auto TT, auto SHAPE, const W8Item& item, const int gen, const int par) {
     constexpr int tt = decltype(TT)::value;
-    (void)tt_dyn;
-    const W8Item& item = its[tt];
-    if (item.type == MI_NOP) return;
+    constexpr int shape = decltype(SHAPE)::value;
+    constexpr int sp_lo = shape == MS_HALF_B ? NS / 2 : 0, sp_hi = shape == MS_HALF_A ? NS / 2 : NS;
+    constexpr int boff = 0;      // (either half of a shared tile runs against the direction's own K-steps, rayen_tiles.h)
     int lane_ = lane;
     asm volatile("" : "+v"(lane_));
     const int col = lane_ & 31, hi = lane_ >> 5;
@@ -288,17 +291,17 @@ __global__ __launch_bounds__(kW8Waves * 64, 2) void mfma_pair_ws8_kernel(
     if constexpr ((RAYEN_W8_ABL & 4) != 0) { acc[0] = zero; acc[1] = zero; acc[0][0] = kap[0]; acc[1][3] = part[1]; }
     else {
 #pragma unroll
-    for (int sp = 0; sp < NS; ++sp) {
+    for (int sp = sp_lo; sp < sp_hi; ++sp) {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[tt][sp][1], vb[t][0][sp], sp == 0 ? zero : acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[tt][sp][1], vb[t][0][sp + boff], sp == sp_lo ? zero : acc[t], 0, 0, 0);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[tt][sp][0], vb[t][1][sp], acc[t], 0, 0, 0);
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[tt][sp][0], vb[t][1][sp + boff], acc[t], 0, 0, 0);
     }
 #pragma unroll
-    for (int sp = 0; sp < NS; ++sp)
+    for (int sp = sp_lo; sp < sp_hi; ++sp)
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[tt][sp][0], vb[t][0][sp], acc[t], 0, 0, 0);
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[tt][sp][0], vb[t][0][sp + boff], acc[t], 0, 0, 0);
     }
     if constexpr ((RAYEN_W8_ABL & 8) != 0) { kap[0] = fmaxf(kap[0], acc[0][5] + acc[1][7]); return; }
 
@@ -335,8 +338,11 @@ __global__ __launch_bounds__(kW8Waves * 64, 2) void mfma_pair_ws8_kernel(
         // (the item's constants are made opaque where they are used: hipcc otherwise hoists what it derives from them --
         // LDS addresses of the aux rows, 1 / (2 a'), 4 a', w_inv / f_s of EVERY tile of the wave -- out of the loop into
         // VGPRs this kernel does not have)
-        int aux = item.aux();
-        float seg_inv = item.seg_inv, f0 = item.f0, f1 = item.f1;
+        // (read through readfirstlane: where two call sites of this body share code, hipcc selects between the two items'
+        // fields in VGPRs, and an "s" operand does not move them back)
+        auto uni = [](const float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); };
+        int aux = __builtin_amdgcn_readfirstlane(item.aux());
+        float seg_inv = uni(item.seg_inv), f0 = uni(item.f0), f1 = uni(item.f1);
         asm volatile("" : "+s"(aux), "+s"(seg_inv), "+s"(f0), "+s"(f1));
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -379,6 +385,19 @@ __global__ __launch_bounds__(kW8Waves * 64, 2) void mfma_pair_ws8_kernel(
         }
       }
     }
+  };
+  auto tile = [&](const int tt_dyn, auto TT, const int gen, const int par) {
+    constexpr int tt = decltype(TT)::value;
+    (void)tt_dyn;
+    if (its[tt].type == MI_NOP) return;
+    if constexpr (NS == 4) {
+      if (its2[tt].type != MI_NOP) {     // (wave-uniform: a shared tile, first half then second half)
+        tile_part(TT, std::integral_constant<int, MS_HALF_A>{}, its[tt], gen, par);
+        tile_part(TT, std::integral_constant<int, MS_HALF_B>{}, its2[tt], gen, par);
+        return;
+      }
+    }
+    tile_part(TT, std::integral_constant<int, MS_FULL>{}, its[tt], gen, par);
   };
 
   // the wave's candidates of a finished group -> LDS
@@ -471,6 +490,7 @@ __global__ __launch_bounds__(kW8Waves * 64, 2) void mfma_pair_ws8_kernel(
 // ---------------------------------------------------------------------------------------------
 struct Ws8Image {
   W8Item* items = nullptr;     // [8][tpw]
+  W8Item* items2 = nullptr;    // [8][tpw]: the second half of a slot that holds a shared tile (type MI_NOP: none)
   int32_t* tiles = nullptr;    // [8][tpw]: tile of the f16-pair image, -1 = none
   int tpw = 0;                 // compiled instance that serves the pack
   int64_t bytes = 0;
@@ -479,6 +499,7 @@ struct Ws8Image {
 void mfma_pair_ws8_free(Ws8Image* ws) {
   if (ws == nullptr) return;
   if (ws->items) (void)hipFree(ws->items);
+  if (ws->items2) (void)hipFree(ws->items2);
   if (ws->tiles) (void)hipFree(ws->tiles);
   delete ws;
 }
@@ -497,16 +518,28 @@ int mfma_pair_ws8_build(const RayenPack* p, const PairImage* img, Ws8Image** out
   if (img == nullptr || !img->identity || img->host_items.empty()) return RAYEN_OK;
   if (p->n != img->nkk * 32 || p->k != p->n) return RAYEN_OK;
   const std::vector<MItem>& items = img->host_items;
-  struct Unit { int first, count; bool aux; };
+  // a slot = one tile of the image in a wave's registers: an ordinary item, or the two halves of a shared tile
+  // (rayen_tiles.h: item `a` its K-steps 0,1, item `b` its K-steps 2,3); a unit = the slots one wave must own together
+  // (a segment's running sum lives in one wave; two segments that share a tile go together: three slots)
+  struct Slot { int a, b; };
+  struct Unit { std::vector<Slot> slots; bool aux; int first; int count() const { return (int)slots.size(); } };
   std::vector<Unit> units;
   int n_aux = 0;
   for (int i = 0; i < (int)items.size(); ++i) {
     const MItem& it = items[i];
-    if (it.type == MI_AUX) { units.push_back({i, 1, true}); ++n_aux; }
-    else if (it.type == MI_LIN || it.type == MI_PACK) units.push_back({i, 1, false});
+    if (it.type == MI_AUX) { units.push_back({{{i, -1}}, true, i}); ++n_aux; }
+    else if (it.type == MI_LIN || it.type == MI_PACK) units.push_back({{{i, -1}}, false, i});
     else if (it.type == MI_QFAC || it.type == MI_SOC) {
-      if (it.flags & MF_FIRST) units.push_back({i, 1, false});
-      else if (!units.empty()) ++units.back().count;
+      if (it.shape() == MS_HALF_B) {
+        if (units.empty() || units.back().slots.back().b >= 0 || items[units.back().slots.back().a].shape() != MS_HALF_A) return RAYEN_OK;
+        units.back().slots.back().b = i;
+      } else if (it.shape() != MS_HALF_A && (it.flags & MF_FIRST)) {
+        units.push_back({{{i, -1}}, false, i});
+      } else if (!units.empty()) {
+        units.back().slots.push_back({i, -1});
+      } else {
+        return RAYEN_OK;
+      }
     } else return RAYEN_OK;        // (NA_E tiles: not this kernel's)
   }
   if (n_aux > 1) return RAYEN_OK;
@@ -514,7 +547,7 @@ int mfma_pair_ws8_build(const RayenPack* p, const PairImage* img, Ws8Image** out
   for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
     if (units[a].aux != units[b].aux) return units[a].aux;       // the aux tile is placed first
-    return units[a].count > units[b].count;
+    return units[a].count() > units[b].count();
   });
   std::vector<std::vector<int>> mine(kW8Waves);
   int load[kW8Waves] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -522,7 +555,7 @@ int mfma_pair_ws8_build(const RayenPack* p, const PairImage* img, Ws8Image** out
     int w = 0;
     for (int c = 1; c < kW8Waves; ++c) if (load[c] < load[w]) w = c;
     mine[w].push_back(u);
-    load[w] += units[u].count;
+    load[w] += units[u].count();
   }
   // the SIMD of wave w is not ours to choose, but waves s and s + 4 are the likeliest pair: heavy beside light, and the
   // wave with the aux tile in the leading team (waves 0..3: the kernel's closers count on it)
@@ -541,7 +574,8 @@ int mfma_pair_ws8_build(const RayenPack* p, const PairImage* img, Ws8Image** out
     }
     mine = paired;
   }
-  std::vector<std::vector<int>> seq(kW8Waves);     // item indices per wave, -1 = empty tile
+  const Slot empty_slot = {-1, -1};
+  std::vector<std::vector<Slot>> seq(kW8Waves);     // slots per wave, a = -1: an empty one
   int tpw = 0;
   for (int w = 0; w < kW8Waves; ++w) {
     std::vector<int>& us = mine[w];
@@ -551,43 +585,49 @@ int mfma_pair_ws8_build(const RayenPack* p, const PairImage* img, Ws8Image** out
     });
     auto closes_at_once = [&](int u) {
       const MItem& it = items[units[u].first];
-      return it.type == MI_PACK || ((it.type == MI_QFAC || it.type == MI_SOC) && units[u].count == 1);
+      return it.type == MI_PACK || ((it.type == MI_QFAC || it.type == MI_SOC) && units[u].count() == 1);
     };
     if (!us.empty() && closes_at_once(us[0])) {
       size_t alt = 0;
       for (size_t i = 1; i < us.size(); ++i) if (!closes_at_once(us[i])) { alt = i; break; }
       if (alt) std::rotate(us.begin(), us.begin() + alt, us.begin() + alt + 1);
-      else seq[w].push_back(-1);
+      else seq[w].push_back(empty_slot);
     }
     for (const int u : us)
-      for (int c = 0; c < units[u].count; ++c) seq[w].push_back(units[u].first + c);
+      for (const Slot& sl : units[u].slots) seq[w].push_back(sl);
     tpw = std::max(tpw, (int)seq[w].size());
   }
   const int inst = ws8_instance_for(img->nkk, tpw);
   if (inst == 0) return RAYEN_OK;
-  std::vector<W8Item> wi((size_t)kW8Waves * inst);
+  std::vector<W8Item> wi((size_t)kW8Waves * inst), wi2((size_t)kW8Waves * inst);
   std::vector<int32_t> wt((size_t)kW8Waves * inst, -1);
+  auto fill = [&](W8Item& o, int idx) {
+    std::memset(&o, 0, sizeof(o));
+    o.type = MI_NOP;
+    o.seg_inv = 1.f;
+    if (idx < 0) return;
+    const MItem& it = items[idx];
+    o.type = it.type; o.flags = it.flags; o.seg = it.seg; o.row0 = it.row0;
+    o.aux_order = (it.aux & 255) | (idx << 8);
+    o.seg_inv = it.seg_inv; o.f0 = it.f0; o.f1 = it.f1;
+  };
   for (int w = 0; w < kW8Waves; ++w)
     for (int t = 0; t < inst; ++t) {
-      W8Item& o = wi[(size_t)w * inst + t];
-      std::memset(&o, 0, sizeof(o));
-      o.type = MI_NOP;
-      o.seg_inv = 1.f;
-      const int idx = t < (int)seq[w].size() ? seq[w][t] : -1;
-      if (idx < 0) continue;
-      const MItem& it = items[idx];
-      o.type = it.type; o.flags = it.flags; o.seg = it.seg; o.row0 = it.row0; o.aux_order = (it.aux & 255) | (idx << 8);
-      o.seg_inv = it.seg_inv; o.f0 = it.f0; o.f1 = it.f1;
-      wt[(size_t)w * inst + t] = idx;       // item i of the list is tile i of the image
+      const Slot sl = t < (int)seq[w].size() ? seq[w][t] : empty_slot;
+      fill(wi[(size_t)w * inst + t], sl.a);
+      fill(wi2[(size_t)w * inst + t], sl.b);
+      if (sl.a >= 0) wt[(size_t)w * inst + t] = items[sl.a].tile();
     }
   Ws8Image* ws = new Ws8Image();
   ws->tpw = inst;
   const bool ok = hipMalloc(&ws->items, wi.size() * sizeof(W8Item)) == hipSuccess &&
                   hipMemcpy(ws->items, wi.data(), wi.size() * sizeof(W8Item), hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMalloc(&ws->items2, wi2.size() * sizeof(W8Item)) == hipSuccess &&
+                  hipMemcpy(ws->items2, wi2.data(), wi2.size() * sizeof(W8Item), hipMemcpyHostToDevice) == hipSuccess &&
                   hipMalloc(&ws->tiles, wt.size() * sizeof(int32_t)) == hipSuccess &&
                   hipMemcpy(ws->tiles, wt.data(), wt.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess;
   if (!ok) { mfma_pair_ws8_free(ws); return RAYEN_E_ALLOC; }
-  ws->bytes = (int64_t)(wi.size() * sizeof(W8Item) + wt.size() * sizeof(int32_t));
+  ws->bytes = (int64_t)(2 * wi.size() * sizeof(W8Item) + wt.size() * sizeof(int32_t));
   *out = ws;
   return RAYEN_OK;
 }
@@ -610,7 +650,7 @@ static int launch_ws8(const RayenPack* p, const PairImage* img, const Ws8Image* 
   const unsigned grid = (unsigned)((n_groups + rounds - 1) / rounds);
   auto go = [&](auto kern) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kW8Waves * 64), 0, stream, static_cast<const f16x8*>(img->Wh), ws->items,
-                       ws->tiles, img->packs, img->y0, v, B, ldv, y, ldy, kappa, active, nan_flag, img->w_scale, img->w_inv);
+                       ws->items2, ws->tiles, img->packs, img->y0, v, B, ldv, y, ldy, kappa, active, nan_flag, img->w_scale, img->w_inv);
   };
   if (active != nullptr) go(mfma_pair_ws8_kernel<NKK, TPW, true>);
   else go(mfma_pair_ws8_kernel<NKK, TPW, false>);

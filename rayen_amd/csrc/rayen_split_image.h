@@ -28,6 +28,129 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #endif
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+// One K-step of the f16-pair walks' tile burst (n_pad = 64 instances of rayen_mfma_pair.hip / rayen_mfma_pair_io.hip) as
+// ONE statement with its control flow INSIDE: items that use only half of a tile (rayen_tiles.h) skip the other half's
+// K-steps and wait with other counts.  To the compiler each statement is a single definition of the chunk registers and
+// of the accumulators whatever path runs inside.  Written as C++ branches around plain statements and MFMA builtins,
+// hipcc (a) gave a chunk different registers on different paths and copied chunks that were still in flight
+// (scripts/check_split_asm.py), and (b) gave the accumulators a second register set, 32 v_mov and an exposed s_nop 10
+// behind every guarded pair of MFMAs (0.082 ms on config 3 where the unguarded stream takes 0.058).
+// `ctrl` (wave-uniform, one SGPR per item, pair_item_ctrl below): bit sp = K-step sp belongs to the item; bit 4 + sp = its
+// chunks have only the tight count of younger operations behind them; bit 8 = the item's first K-step is 2 (the accumulators
+// start afresh there).  A full tile behind a full tile takes no branch at all:
+//   pair_kstep1<NT, SP, T, R>: [not the item's: nothing] vmcnt(R) [tight: vmcnt(T)]
+//                              [first K-step: acc = a2 b1 | else acc += a2 b1] acc += a1 b2;  a2 <- 1 KiB at base
+//   pair_kstep2<NT, SP, LAST>: [not the item's: nothing] acc += a1 b1; a1 <- 1 KiB at base
+//                              [LAST: the 12 wait states between an 8-pass MFMA's result and its first reader that is not
+//                              an accumulating MFMA -- hipcc pads nothing for instructions inside a statement]
+// (Two sample tiles: the chains of acc[0] and acc[1] alternate, as hipcc schedules the builtins.)
+#define RAYEN_MFMA16 "v_mfma_f32_32x32x16_f16 "
+#define RAYEN_PAIR_RELOAD_TEXT(reg) RAYEN_ASM_BASE_COPY "global_load_dwordx4 " reg ", %[off], " RAYEN_ASM_BASE "\n"
+__device__ __forceinline__ int pair_item_ctrl(const int shape, const bool after_half_b) {
+  // MS_FULL: K-steps 0..3, tight unless it follows a second half (then K-steps 0,1 are relaxed: their chunks were re-loaded
+  // by the FIRST half, a whole item earlier); MS_HALF_A: K-steps 0,1, tight; MS_HALF_B: K-steps 2,3, relaxed, fresh start
+  int ctrl = shape == 1 ? 0x33 : (shape == 2 ? 0x10C : (after_half_b ? 0xCF : 0xFF));
+  return __builtin_amdgcn_readfirstlane(ctrl);
+}
+// (the plain re-load of a chunk: n_pad = 32 instances, where every item is a full tile)
+__device__ __forceinline__ void pair_reload(u32x4& chunk, const char* base, const unsigned off) {
+  uint64_t asm_base;
+  asm volatile(RAYEN_ASM_BASE_COPY "global_load_dwordx4 %[d], %[off], " RAYEN_ASM_BASE "" : [d] "+v"(chunk), [b] "=&s"(asm_base) : [off] "v"(off), [base] "s"(base));
+}
+template <int NT, int SP, int T, int R>
+__device__ __forceinline__ void pair_kstep1(u32x4& a1, u32x4& a2, f32x16 (&acc)[NT], const f16x8 (&b1)[NT], const f16x8 (&b2)[NT],
+                                            const int ctrl, const char* base, const unsigned off) {
+  uint64_t asm_base;
+  // SP = 0: always a first K-step (C = 0); SP = 2: first iff bit 8; SP = 1, 3: never
+#define RAYEN_K1_HEAD "s_bitcmp1_b32 %[ctrl], %[sp]\n\ts_cbranch_scc0 9f\n\ts_waitcnt vmcnt(%[R])\n\ts_bitcmp1_b32 %[ctrl], %[tb]\n\ts_cbranch_scc0 1f\n\ts_waitcnt vmcnt(%[T])\n1:\n\t"
+  if constexpr (NT == 2) {
+    if constexpr (SP == 0) {
+      // (the accumulators are OUTPUTS here: an item's first statement.  As read-write operands they would be live from one
+      // item into the next and across the group boundary -- 32 registers hipcc then spills, and the reload's vmcnt(0),
+      // which it places inside the item loop, drains the A stream and the trickled rows on every item.  A second half
+      // skips this statement and starts them at K-step 2.)
+      asm volatile(RAYEN_K1_HEAD
+                   RAYEN_MFMA16 "%[c0], %[a2], %[b10], 0\n\t" RAYEN_MFMA16 "%[c1], %[a2], %[b11], 0\n\t"
+                   RAYEN_MFMA16 "%[c0], %[a1], %[b20], %[c0]\n\t" RAYEN_MFMA16 "%[c1], %[a1], %[b21], %[c1]\n\t"
+                   RAYEN_PAIR_RELOAD_TEXT("%[a2]") "9:"
+                   : [a1] "+v"(a1), [a2] "+v"(a2), [c0] "=&v"(acc[0]), [c1] "=&v"(acc[1]), [b] "=&s"(asm_base)
+                   : [b10] "v"(b1[0]), [b11] "v"(b1[1]), [b20] "v"(b2[0]), [b21] "v"(b2[1]), [ctrl] "s"(ctrl), [base] "s"(base),
+                     [off] "v"(off), [T] "n"(T), [R] "n"(R), [sp] "n"(SP), [tb] "n"(4 + SP)
+                   : "scc");
+    } else if constexpr (SP == 2) {
+      asm volatile(RAYEN_K1_HEAD
+                   "s_bitcmp1_b32 %[ctrl], 8\n\ts_cbranch_scc1 3f\n\t"
+                   RAYEN_MFMA16 "%[c0], %[a2], %[b10], %[c0]\n\t" RAYEN_MFMA16 "%[c1], %[a2], %[b11], %[c1]\n4:\n\t"
+                   RAYEN_MFMA16 "%[c0], %[a1], %[b20], %[c0]\n\t" RAYEN_MFMA16 "%[c1], %[a1], %[b21], %[c1]\n\t"
+                   RAYEN_PAIR_RELOAD_TEXT("%[a2]") "\ts_branch 9f\n3:\n\t"
+                   RAYEN_MFMA16 "%[c0], %[a2], %[b10], 0\n\t" RAYEN_MFMA16 "%[c1], %[a2], %[b11], 0\n\ts_branch 4b\n9:"
+                   : [a1] "+v"(a1), [a2] "+v"(a2), [c0] "+v"(acc[0]), [c1] "+v"(acc[1]), [b] "=&s"(asm_base)
+                   : [b10] "v"(b1[0]), [b11] "v"(b1[1]), [b20] "v"(b2[0]), [b21] "v"(b2[1]), [ctrl] "s"(ctrl), [base] "s"(base),
+                     [off] "v"(off), [T] "n"(T), [R] "n"(R), [sp] "n"(SP), [tb] "n"(4 + SP)
+                   : "scc");
+    } else {
+      asm volatile(RAYEN_K1_HEAD
+                   RAYEN_MFMA16 "%[c0], %[a2], %[b10], %[c0]\n\t" RAYEN_MFMA16 "%[c1], %[a2], %[b11], %[c1]\n\t"
+                   RAYEN_MFMA16 "%[c0], %[a1], %[b20], %[c0]\n\t" RAYEN_MFMA16 "%[c1], %[a1], %[b21], %[c1]\n\t"
+                   RAYEN_PAIR_RELOAD_TEXT("%[a2]") "9:"
+                   : [a1] "+v"(a1), [a2] "+v"(a2), [c0] "+v"(acc[0]), [c1] "+v"(acc[1]), [b] "=&s"(asm_base)
+                   : [b10] "v"(b1[0]), [b11] "v"(b1[1]), [b20] "v"(b2[0]), [b21] "v"(b2[1]), [ctrl] "s"(ctrl), [base] "s"(base),
+                     [off] "v"(off), [T] "n"(T), [R] "n"(R), [sp] "n"(SP), [tb] "n"(4 + SP)
+                   : "scc");
+    }
+  } else {
+    if constexpr (SP == 0) {
+      asm volatile(RAYEN_K1_HEAD
+                   RAYEN_MFMA16 "%[c0], %[a2], %[b10], 0\n\t" RAYEN_MFMA16 "%[c0], %[a1], %[b20], %[c0]\n\t"
+                   RAYEN_PAIR_RELOAD_TEXT("%[a2]") "9:"
+                   : [a1] "+v"(a1), [a2] "+v"(a2), [c0] "=&v"(acc[0]), [b] "=&s"(asm_base)
+                   : [b10] "v"(b1[0]), [b20] "v"(b2[0]), [ctrl] "s"(ctrl), [base] "s"(base), [off] "v"(off), [T] "n"(T), [R] "n"(R),
+                     [sp] "n"(SP), [tb] "n"(4 + SP)
+                   : "scc");
+    } else if constexpr (SP == 2) {
+      asm volatile(RAYEN_K1_HEAD
+                   "s_bitcmp1_b32 %[ctrl], 8\n\ts_cbranch_scc1 3f\n\t"
+                   RAYEN_MFMA16 "%[c0], %[a2], %[b10], %[c0]\n4:\n\t" RAYEN_MFMA16 "%[c0], %[a1], %[b20], %[c0]\n\t"
+                   RAYEN_PAIR_RELOAD_TEXT("%[a2]") "\ts_branch 9f\n3:\n\t"
+                   RAYEN_MFMA16 "%[c0], %[a2], %[b10], 0\n\ts_branch 4b\n9:"
+                   : [a1] "+v"(a1), [a2] "+v"(a2), [c0] "+v"(acc[0]), [b] "=&s"(asm_base)
+                   : [b10] "v"(b1[0]), [b20] "v"(b2[0]), [ctrl] "s"(ctrl), [base] "s"(base), [off] "v"(off), [T] "n"(T), [R] "n"(R),
+                     [sp] "n"(SP), [tb] "n"(4 + SP)
+                   : "scc");
+    } else {
+      asm volatile(RAYEN_K1_HEAD
+                   RAYEN_MFMA16 "%[c0], %[a2], %[b10], %[c0]\n\t" RAYEN_MFMA16 "%[c0], %[a1], %[b20], %[c0]\n\t"
+                   RAYEN_PAIR_RELOAD_TEXT("%[a2]") "9:"
+                   : [a1] "+v"(a1), [a2] "+v"(a2), [c0] "+v"(acc[0]), [b] "=&s"(asm_base)
+                   : [b10] "v"(b1[0]), [b20] "v"(b2[0]), [ctrl] "s"(ctrl), [base] "s"(base), [off] "v"(off), [T] "n"(T), [R] "n"(R),
+                     [sp] "n"(SP), [tb] "n"(4 + SP)
+                   : "scc");
+    }
+  }
+#undef RAYEN_K1_HEAD
+}
+template <int NT, int SP, bool LAST>
+__device__ __forceinline__ void pair_kstep2(u32x4& a1, f32x16 (&acc)[NT], const f16x8 (&b1)[NT], const int ctrl, const char* base,
+                                            const unsigned off) {
+  uint64_t asm_base;
+  if constexpr (NT == 2) {
+    asm volatile("s_bitcmp1_b32 %[ctrl], %[sp]\n\ts_cbranch_scc0 9f\n\t"
+                 RAYEN_MFMA16 "%[c0], %[a1], %[b10], %[c0]\n\t" RAYEN_MFMA16 "%[c1], %[a1], %[b11], %[c1]\n\t"
+                 RAYEN_PAIR_RELOAD_TEXT("%[a1]") "9:\n\ts_nop %[pad]"
+                 : [a1] "+v"(a1), [c0] "+v"(acc[0]), [c1] "+v"(acc[1]), [b] "=&s"(asm_base)
+                 : [b10] "v"(b1[0]), [b11] "v"(b1[1]), [ctrl] "s"(ctrl), [base] "s"(base), [off] "v"(off), [sp] "n"(SP),
+                   [pad] "n"(LAST ? 11 : 0)
+                 : "scc");
+  } else {
+    asm volatile("s_bitcmp1_b32 %[ctrl], %[sp]\n\ts_cbranch_scc0 9f\n\t"
+                 RAYEN_MFMA16 "%[c0], %[a1], %[b10], %[c0]\n\t"
+                 RAYEN_PAIR_RELOAD_TEXT("%[a1]") "9:\n\ts_nop %[pad]"
+                 : [a1] "+v"(a1), [c0] "+v"(acc[0]), [b] "=&s"(asm_base)
+                 : [b10] "v"(b1[0]), [ctrl] "s"(ctrl), [base] "s"(base), [off] "v"(off), [sp] "n"(SP), [pad] "n"(LAST ? 11 : 0)
+                 : "scc");
+  }
+}
+
 // 2^13 / 2^floor(log2 m) as a float and its inverse, from the biased exponent of m (clamped to [14, 254])
 __device__ __forceinline__ void pow2_scale(const float m, float& scale, float& inv, int& exp_scale) {
   unsigned e = __builtin_bit_cast(unsigned, m) >> 23;

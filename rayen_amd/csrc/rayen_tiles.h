@@ -26,9 +26,23 @@ struct MItem {
   int32_t qbegin;  // first k-group this tile needs (QSYM: the block-lower-triangular part is folded away)
   float f0, f1;    // SOC: tau, a'
   float seg_inv;   // f16-pair image: 1 / (the power of two the segment's rows were boosted by), see rayen_mfma_pair.hip
-  float pad_;
+  int32_t tile_shape;  // image tile this item reads | MS_* << 24 (which K-steps of that tile are the item's: f16-pair image)
   double f0d, f1d; // the same in full precision (fp64 kernel)
+  __host__ __device__ int tile() const { return tile_shape & 0xFFFFFF; }
+  __host__ __device__ int shape() const { return (tile_shape >> 24) & 3; }
+  __host__ __device__ bool last_tile() const { return (tile_shape >> 30) & 1; }   // the walk wraps to tile 0 behind it
 };
+
+// An item reads a whole tile, or -- f16-pair image, n_pad = 64 -- the half of a tile that two triangular factors share.
+// A factor U of more than 32 rows only ever enters through ||U v|| (rayen/constraint_module.py:360-399), so it is
+// replaced by a triangular R with R'R = U'U (upper_triangular_factor): 32 of its rows are dense (a full tile), the
+// others are zero over one 32-column half of the direction and keep a block of at most 32 x 32.  Two neighbouring
+// factors X, Y are eliminated in opposite column orders, so that X's block sits over columns 0..31 and Y's over columns
+// 32..63, and the two blocks share ONE tile: K-steps 0,1 of it are X's (MS_HALF_A), K-steps 2,3 are Y's (MS_HALF_B),
+// each against the direction's own K-steps -- the operand pairing of a full tile, only the accumulator starts afresh at
+// K-step 2.  The walk is [X dense][shared: X's block][shared: Y's block][Y dense]: four items on three tiles.
+// A triangular factor without such a neighbour keeps two full tiles (the zero block of its second one is multiplied).
+enum : int32_t { MS_FULL = 0, MS_HALF_A = 1, MS_HALF_B = 2 };
 
 // A packed tile holds up to eight small factor segments (rank <= 4: one quad of rows = the four
 // registers 4a..4a+3 of one half-wave; rank 5..8: the same quad in both halves).  One record per
@@ -157,12 +171,92 @@ inline std::vector<std::vector<double>> psd_factor_rows(const double* G, int n) 
   return rows;
 }
 
+// Upper-triangular factor of a set of rows: R (min(m, n) x n, zero below the diagonal) with R'R = U'U, by Householder
+// reflections in fp64 -- ||R v|| = ||U v|| for every v (rayen/constraint_module.py:360-399 only ever asks for that norm).
+// Rows that come out all zero (rank-deficient U) are dropped from the end.
+// `order`: the column elimination order (order[j] = original column eliminated j-th; empty = 0, 1, 2, ...): row i of the
+// result is zero in the columns order[0..i-1].  Rows come back in ORIGINAL column positions.
+inline std::vector<std::vector<double>> upper_triangular_factor(const std::vector<const double*>& rows, int n,
+                                                                const std::vector<int>& order = std::vector<int>()) {
+  const int m = (int)rows.size();
+  std::vector<double> A((size_t)m * n);
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < n; ++j) A[(size_t)i * n + j] = rows[i][order.empty() ? j : order[j]];
+  const int steps = m < n ? m : n;
+  std::vector<double> w(m);
+  for (int j = 0; j < steps; ++j) {
+    double norm = 0.0;
+    for (int i = j; i < m; ++i) norm += A[(size_t)i * n + j] * A[(size_t)i * n + j];
+    norm = std::sqrt(norm);
+    if (!(norm > 0.0)) continue;
+    const double alpha = A[(size_t)j * n + j] > 0.0 ? -norm : norm;
+    for (int i = j; i < m; ++i) w[i] = A[(size_t)i * n + j];
+    w[j] -= alpha;
+    double wn = 0.0;
+    for (int i = j; i < m; ++i) wn += w[i] * w[i];
+    if (!(wn > 0.0)) continue;
+    for (int c = j; c < n; ++c) {
+      double dot = 0.0;
+      for (int i = j; i < m; ++i) dot += w[i] * A[(size_t)i * n + c];
+      const double f = 2.0 * dot / wn;
+      for (int i = j; i < m; ++i) A[(size_t)i * n + c] -= f * w[i];
+    }
+    A[(size_t)j * n + j] = alpha;
+    for (int i = j + 1; i < m; ++i) A[(size_t)i * n + j] = 0.0;
+  }
+  std::vector<std::vector<double>> R;
+  for (int i = 0; i < steps; ++i) {
+    std::vector<double> r(n, 0.0);
+    for (int c = i; c < n; ++c) r[order.empty() ? c : order[c]] = A[(size_t)i * n + c];
+    R.push_back(r);
+  }
+  while (!R.empty()) {
+    bool zero = true;
+    for (const double x : R.back()) zero = zero && x == 0.0;
+    if (!zero) break;
+    R.pop_back();
+  }
+  return R;
+}
+
 // allow_sym = false: every quadratic / cone is laid out through a factor (rows u with ||U v||^2 = v'Gv), so
 // that no epilogue needs the direction itself (the split-operand kernel keeps v only as bf16 pieces).
-inline int layout_tiles(const RayenPack* p, TileLayout& b, bool allow_pack, bool allow_sym = true) {
+// tri (f16-pair image, with allow_sym = false, n_pad = 64): factors of more than 32 rows are made upper triangular
+// (above) and two neighbours share ONE tile for their second halves: [X rows 0..31] [X rows 32.. | Y rows 32..] [Y rows
+// 0..31] -- three tiles of matrix work and of A stream where four were (config 3: 14 tiles instead of 17).
+inline int layout_tiles(const RayenPack* p, TileLayout& b, bool allow_pack, bool allow_sym = true, bool tri = false) {
   const double* W = p->W.data();
   auto wrow = [&](int r) { return W + (size_t)r * p->n; };
   auto blank = [](int type) { MItem it; std::memset(&it, 0, sizeof(it)); it.type = type; it.seg_inv = 1.f; return it; };
+  tri = tri && !allow_sym && b.n_pad == 64;
+  // the factor rows a segment is laid out through when `tri` applies to it (empty: not triangular)
+  // swapped: columns 32.. are eliminated first, so the rows from n - 32 on keep columns 0..31 only (the X of a pair);
+  // otherwise the rows from 32 on keep columns 32.. only (the Y of a pair, or a factor on its own)
+  auto tri_rows = [&](const RayenSegment& g, bool swapped) {
+    std::vector<std::vector<double>> none;
+    if (!tri || (allow_pack && is_small_factor(g))) return none;
+    std::vector<const double*> src;
+    std::vector<std::vector<double>> eig;
+    if (g.type == RAYEN_SEG_QUAD_SYM) {
+      eig = psd_factor_rows(wrow(g.row0), p->n);
+      for (const auto& u : eig) src.push_back(u.data());
+    } else if (g.type == RAYEN_SEG_QUAD_FAC || g.type == RAYEN_SEG_SOC) {
+      for (int r = 0; r < g.nrows; ++r) src.push_back(wrow(g.row0 + r));
+    } else {
+      return none;
+    }
+    if ((int)src.size() <= 32) return none;
+    for (const double* r : src)
+      for (int c = 0; c < p->n; ++c) if (!std::isfinite(r[c])) return none;
+    std::vector<int> order;
+    if (swapped) {
+      for (int c = 32; c < p->n; ++c) order.push_back(c);
+      for (int c = 0; c < 32; ++c) order.push_back(c);
+    }
+    std::vector<std::vector<double>> R = upper_triangular_factor(src, p->n, order);
+    if ((int)R.size() <= 32) return none;
+    return R;
+  };
   const size_t nseg = p->segs.size();
   size_t s0 = 0;
   while (s0 < nseg) {
@@ -181,12 +275,77 @@ inline int layout_tiles(const RayenPack* p, TileLayout& b, bool allow_pack, bool
         for (int r = 0; r < aux_rows_of(g); ++r) rows.push_back(wrow(g.aux_row + r));
       }
       b.items.push_back(blank(MI_AUX));
+      b.items.back().tile_shape = b.n_tiles();
       b.add_tile(rows, p->n);
     }
     // ---- large segments: their own tiles
     for (size_t s = s0; s < s1; ++s) {
       const RayenSegment& g = p->segs[s];
       if (allow_pack && is_small_factor(g)) continue;
+      if (tri) {
+        // the next large segment of the batch, if it is triangular too: the two share a tile
+        size_t sy = s + 1;
+        while (sy < s1 && allow_pack && is_small_factor(p->segs[sy])) ++sy;
+        std::vector<std::vector<double>> RY;
+        if (sy < s1) RY = tri_rows(p->segs[sy], /*swapped=*/false);
+        std::vector<std::vector<double>> RX = tri_rows(g, /*swapped=*/!RY.empty());
+        if (RX.empty()) RY.clear();
+        if (!RX.empty()) {
+          auto seg_item = [&](size_t sg, int flags, int shape) {
+            const RayenSegment& gg = p->segs[sg];
+            MItem it = blank(gg.type == RAYEN_SEG_SOC ? MI_SOC : MI_QFAC);
+            it.seg = (int32_t)sg;
+            it.aux = aux_slot[sg];
+            it.f0 = (float)gg.f0;
+            it.f1 = (float)gg.f1;
+            it.flags = flags;
+            it.tile_shape = b.n_tiles() | (shape << 24);
+            return it;
+          };
+          auto own = [&](std::vector<std::vector<double>>& R) {
+            const size_t first = b.owned.size();
+            for (auto& r : R) b.owned.push_back(std::move(r));
+            return first;
+          };
+          const int nx = (int)RX.size();
+          const size_t x0 = own(RX);
+          std::vector<const double*> rows;
+          if (!RY.empty()) {
+            // X, columns 32.. eliminated first: rows 0 .. n-33 dense, rows n-32 .. keep columns 0..31
+            const int ny = (int)RY.size(), xh = p->n - 32;
+            const size_t y0 = own(RY);
+            for (int r = 0; r < xh; ++r) rows.push_back(b.owned[x0 + r].data());
+            b.items.push_back(seg_item(s, MF_FIRST, MS_FULL));
+            b.add_tile(rows, p->n);
+            // the shared tile: columns 0..31 <- X's rows n-32 .., columns 32.. <- Y's rows 32 ..
+            std::vector<std::vector<double>> shared(32, std::vector<double>(p->n, 0.0));
+            for (int r = xh; r < nx; ++r)
+              for (int c = 0; c < 32; ++c) shared[r - xh][c] = b.owned[x0 + r][c];
+            for (int r = 32; r < ny; ++r)
+              for (int c = 32; c < p->n; ++c) shared[r - 32][c] = b.owned[y0 + r][c];
+            rows.clear();
+            for (auto& r : shared) rows.push_back(r.data());
+            b.items.push_back(seg_item(s, MF_LAST, MS_HALF_A));
+            b.items.push_back(seg_item(sy, MF_FIRST, MS_HALF_B));
+            b.add_tile(rows, p->n);
+            rows.clear();
+            for (int r = 0; r < 32; ++r) rows.push_back(b.owned[y0 + r].data());
+            b.items.push_back(seg_item(sy, MF_LAST, MS_FULL));
+            b.add_tile(rows, p->n);
+            s = sy;       // (the small factor segments in between are laid out below, like all of them)
+            continue;
+          }
+          // no partner (natural order: rows 32.. keep columns 32.. only): two ordinary tiles
+          for (int r = 0; r < 32; ++r) rows.push_back(b.owned[x0 + r].data());
+          b.items.push_back(seg_item(s, MF_FIRST, MS_FULL));
+          b.add_tile(rows, p->n);
+          rows.clear();
+          for (int r = 32; r < nx; ++r) rows.push_back(b.owned[x0 + r].data());
+          b.items.push_back(seg_item(s, MF_LAST, MS_FULL));
+          b.add_tile(rows, p->n);
+          continue;
+        }
+      }
       // a symmetric form v'Gv costs (NKK+1)/2 tiles per 32 rows thanks to the block-triangular fold;
       // an SOC block M (rows x n) is turned into G = M'M when that is cheaper than its own rows
       const int sym_cost = (b.n_pad / 32) * (b.n_pad / 32 + 1) / 2;        // both in 32 x 32 blocks of MFMA work
@@ -229,8 +388,9 @@ inline int layout_tiles(const RayenPack* p, TileLayout& b, bool allow_pack, bool
           for (int r = 32 * t; r < 32 * t + 32 && r < fac_rows; ++r)
             rows.push_back(refactor ? b.owned[fac0 + r].data() : wrow(g.row0 + r));
         }
-        b.add_tile(rows, p->n);
         MItem it = blank(0);
+        it.tile_shape = b.n_tiles();
+        b.add_tile(rows, p->n);
         it.seg = (int32_t)s;
         it.aux = aux_slot[s];
         it.f0 = (float)g.f0;
@@ -263,6 +423,7 @@ inline int layout_tiles(const RayenPack* p, TileLayout& b, bool allow_pack, bool
         MItem it = blank(MI_PACK);
         it.aux = (int32_t)b.packs.size();
         it.row0 = pair_bits;
+        it.tile_shape = b.n_tiles();
         b.packs.push_back(pk);
         b.items.push_back(it);
         b.add_tile(rows, p->n);
@@ -291,13 +452,17 @@ inline int layout_tiles(const RayenPack* p, TileLayout& b, bool allow_pack, bool
     for (int t = 0; t < k_tiles; ++t) {
       std::vector<const double*> rows;
       for (int r = 32 * t; r < 32 * t + 32 && r < p->k; ++r) rows.push_back(p->NA_E.data() + (size_t)r * p->n);
-      b.add_tile(rows, p->n);
       MItem it = blank(MI_OUT);
+      it.tile_shape = b.n_tiles();
+      b.add_tile(rows, p->n);
       it.row0 = 32 * t;
       it.flags = (t == 0 ? MF_FIRST : 0) | (t == k_tiles - 1 ? MF_LAST : 0);
       b.items.push_back(it);
     }
   }
+  const int last = b.n_tiles() - 1;
+  for (MItem& it : b.items)
+    if (it.tile() == last) it.tile_shape |= 1 << 30;
   return RAYEN_OK;
 }
 

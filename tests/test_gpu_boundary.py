@@ -218,6 +218,7 @@ def test_reserved_compute_units_change_the_launch_not_the_values():
     assert lib.rayen_reserve_cus(-1) == 0
 
 
+@pytest.mark.eager_detour
 def test_a_set_no_kernel_serves_is_evaluated_by_the_packed_torch_evaluator_loudly(monkeypatch):
     """an LMI above 30 x 30 mixed with a quadratic has no HIP kernel.  The module says so once
     (RuntimeWarning) and evaluates the packed form with torch ops ON THE DEVICE (rayen_amd/eager.py);

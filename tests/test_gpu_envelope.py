@@ -51,6 +51,7 @@ def test_ten_thousand_linear_rows_on_the_kernels():
     assert np.max(rel_err_rows(y32.cpu().numpy()[:, :, 0], want.numpy()[:, :, 0])) <= 1e-5
 
 
+@pytest.mark.eager_detour
 @pytest.mark.parametrize("r", [250, 300])
 def test_lmi_beyond_one_waves_lds_runs_on_the_device_libraries(r):
     """time_analysis.py:159-160 ends at 300 x 300: no kernel holds that matrix; the module says so once and evaluates
@@ -65,6 +66,7 @@ def test_lmi_beyond_one_waves_lds_runs_on_the_device_libraries(r):
     assert cs.getMaxViolation(y.cpu().numpy()[:, :, 0]) <= 1e-9
 
 
+@pytest.mark.eager_detour
 def test_backward_of_a_wide_set_on_the_wide_route_and_on_the_loud_detour(monkeypatch):
     """n = 400 with quadratics and cones.  Default: forward and backward on the wide route (vendor GEMMs + the products
     epilogue / coefficient kernels), silently.  With RAYEN_WIDE_ROUTE=0 the forward is the lane kernel's, whose backward

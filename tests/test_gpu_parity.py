@@ -24,9 +24,45 @@ def _layer(raw_or_cs, dtype=torch.float32, **kw):
     try:
         cs = raw_or_cs if isinstance(raw_or_cs, constraints.ConvexConstraints) \
             else workloads.build_constraints(raw_or_cs)
-        return cs, ConstraintModule(cs, method="RAYEN", create_map=False, **kw).to("cuda")
+        layer = ConstraintModule(cs, method="RAYEN", create_map=False, **kw).to("cuda")
+        layer.register_forward_hook(_served_by_a_kernel)
+        return cs, layer
     finally:
         torch.set_default_dtype(prev)
+
+
+def _served_by_a_kernel(module, args, output):
+    """Every forward of a parity test ran on a hand-written kernel: the module never switched to the packed torch
+    evaluator on the device libraries (rayen_amd/eager.py).  tests/conftest.py already makes that switch an error
+    (RAYEN_STRICT_HIP=1, the announcement a raised warning); this is the belt to those braces."""
+    assert not module._hip_unsupported, "the HIP kernels refused this set; the answer came from the device-library detour"
+
+
+def test_a_kernel_that_refuses_a_baseline_shape_fails_this_suite(monkeypatch):
+    """The guard itself: make the C ABI refuse config 3 (RAYEN_E_UNSUPPORTED from every forward entry point).  Under
+    this suite's environment the module raises; with the environment lifted the detour answers (correctly, loudly) and
+    the forward hook of ``_layer`` fails the test."""
+    import warnings
+    from rayen_amd import _lib
+    cs, layer = _layer(workloads.make_raw("c3", seed=0))
+    x = torch.empty(256, cs.n, 1).uniform_(-1, 1).cuda()
+    good = layer(x)
+    assert _lib.load().rayen_last_forward_kernel() != _lib.KERNEL_NONE
+    for name in list(ops._FWD.values()) + list(ops._FWD_OLD.values()):
+        monkeypatch.setitem(ops._ENTRY, name, lambda *a, **k: _lib.E_UNSUPPORTED)
+    layer._fast.clear()
+    with pytest.raises(_lib.RayenError):
+        layer(x)
+    assert not layer._hip_unsupported
+    monkeypatch.delenv("RAYEN_STRICT_HIP")
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        with pytest.raises(AssertionError, match="device-library detour"):
+            layer(x)
+        layer._forward_hooks.clear()
+        detour = layer(x)
+    assert any("no HIP kernel serves" in str(w.message) for w in caught)
+    assert float((detour - good).abs().max()) <= 1e-5      # (the detour's answer is right: that is why it must be loud)
 
 
 def _to_my_basis(cs, csd_ref, x, dtype):
