@@ -14,6 +14,13 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 INCLUDE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
 SOURCES = ["rayen_abi.hip", "rayen_generic.hip", "rayen_mfma.hip", "rayen_mfma_split.hip", "rayen_mfma_pair.hip", "rayen_mfma_pair_io.hip", "rayen_mfma_pair_ws8.hip", "rayen_wide.hip", "rayen_mfma_mapped.hip", "rayen_mfma_bwd.hip", "rayen_mfma_bwdg.hip", "rayen_mfma_bwdp.hip", "rayen_lmi_wave32.hip", "rayen_lmi_wave64.hip", "rayen_mfma_bwdg64.hip", "rayen_mfma_bwd64.hip", "rayen_mfma_f64.hip",
            "rayen_lmi_quad32.hip", "rayen_lmi_quad64.hip"]
+# Every translation unit is built WITHOUT hipcc's SLP vectoriser.  On gfx950 a packed-fp32 instruction whose low result
+# reads the HIGH half of its second source (op_sel:[0,1,..]: how the vectoriser broadcasts the second element of a register
+# pair) reads that operand as 0 in lanes 48-63 now and then while an MFMA is executing on the SIMD -- the fault behind the
+# flat-row kernel's intermittent y == y0 of round 4 (scripts/ubench/pkfma_hazard.hip reproduces it in
+# 60 lines).  Packed arithmetic the kernels ask for themselves (ext_vector_type(2) operands in their natural halves) is
+# unaffected; scripts/check_packed_opsel.py (tests/test_kernel_isa_hazards.py) audits the ISA of every kernel for the form.
+COMMON_FLAGS = ["-fno-slp-vectorize"]
 EXTRA_FLAGS = {}      # per-source compiler flags
 LIBRARY = os.environ.get("RAYEN_HIP_LIBRARY") or os.path.join(CSRC, "librayen_hip.so")
 
@@ -43,7 +50,7 @@ def build(force=False, verbose=False):
     from concurrent.futures import ThreadPoolExecutor
     objdir = os.path.join(CSRC, "_obj")
     os.makedirs(objdir, exist_ok=True)
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC, *COMMON_FLAGS]
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")

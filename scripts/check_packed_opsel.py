@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+"""ISA audit for the gfx950 packed-fp32 operand-selection fault ("Repetition"; reproducers
+scripts/ubench/pkfma_hazard.hip, pkfma_opsel_sweep.hip): while an MFMA is executing on the SIMD -- the wave's own or its
+partner's, any kernel's -- a VOP3P fp32 instruction with op_sel[src0] = 0 and op_sel[src1] = 1 (the LOW result multiplies
+src0's low dword by src1's HIGH dword: what hipcc emits to broadcast the second element of a register pair) now and then
+reads that src1 operand as 0 in lanes 48-63.  Every other (op_sel, op_sel_hi) combination is clean.  This script compiles
+every translation unit of librayen_hip.so to gfx950 assembly (with the flags rayen_amd/_build.py uses) and lists each
+instruction of the faulty form; exit code 1 if there is any.
+    python scripts/check_packed_opsel.py [tu ...]"""
+import os
+import re
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from rayen_amd import _build  # noqa: E402
+
+PACKED = re.compile(r"^\s*(v_pk_(?:fma|mul|add)_f32)\b")
+SEL = re.compile(r"\bop_sel:\[([01]),([01])(?:,([01]))?\]")
+
+
+def faulty(line):
+    if not PACKED.match(line):
+        return False
+    m = SEL.search(line)
+    return bool(m) and m.group(1) == "0" and m.group(2) == "1"
+
+
+def audit(src):
+    asm = f"/tmp/opsel_{os.path.splitext(src)[0]}.s"
+    cmd = [_build.hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", _build.INCLUDE, "-I", _build.CSRC,
+           *_build.COMMON_FLAGS, *_build.EXTRA_FLAGS.get(src, []), "-S", "--cuda-device-only", os.path.join(_build.CSRC, src), "-o", asm]
+    subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+    found, kernel, packed = [], "?", 0
+    for n, line in enumerate(open(asm), 1):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            kernel = m.group(1)
+        packed += bool(PACKED.match(line))
+        if faulty(line):
+            found.append((kernel, n, line.strip()))
+    return src, packed, found
+
+
+if __name__ == "__main__":
+    sources = [a if a.endswith(".hip") else a + ".hip" for a in sys.argv[1:]] or _build.SOURCES
+    total = 0
+    with ThreadPoolExecutor(max_workers=min(len(sources), os.cpu_count() or 1)) as pool:
+        for src, packed, found in pool.map(audit, sources):
+            kernels = sorted({k for k, _, _ in found})
+            print(f"{src}: {packed} packed fp32 instructions, {len(found)} of the faulty form in {len(kernels)} kernels")
+            for k, n, text in found[:4]:
+                print(f"      {k[:60]} line {n}: {text}")
+            total += len(found)
+    sys.exit(1 if total else 0)

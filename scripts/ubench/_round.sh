@@ -1,23 +1,22 @@
 #!/bin/bash
-# scratch script of the current gpurun call (rewritten per call)
-out=gpurun_out/r05e; mkdir -p $out
+out=gpurun_out/r05k; mkdir -p $out
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_pair_io.py tests/test_gpu_pair_ws.py -m gpu -x -q --timeout 600 -p no:cacheprovider > $out/pytest_pair.log 2>&1; echo "rc=$?" >> $out/pytest_pair.log
-tail -3 $out/pytest_pair.log
-run() {  # tag, env...
-  tag=$1; shift
-  env "$@" timeout 300 python bench.py --config c3 --no-cpu-baseline --no-families > $out/bench_$tag.json 2> $out/bench_$tag.err
-  python - <<P
-import json
+U=$PWD/scripts/ubench/variants
+line() { python - "$1" "$2" <<'P'
+import json,sys
 try:
-    d=json.loads(open("$out/bench_$tag.json").read().strip().splitlines()[-1])
-    print("$tag", round(d["ms_per_step"],5), round(d.get("kernel_ms",0),5), d["config"]["kernel"][:30])
+    d=json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
+    ts=d.get("training_step",{})
+    print(sys.argv[1], round(d["ms_per_step"],5), d["config"].get("kernel","")[:36], "| viol", d.get("max_violation"), "| train fwd/bwd", ts.get("forward_with_record_ms"), ts.get("backward_ms"), "| exact", (d.get("families") or {}).get("exact_fp32_ms"))
 except Exception as e:
-    print("$tag failed", e)
+    print(sys.argv[1], "failed", e)
 P
 }
-for rep in 1 2; do
-  run r04_$rep RAYEN_HIP_LIBRARY=$PWD/scripts/ubench/variants/librayen_r04.so
-  run tri1_$rep RAYEN_PAIR_TRI=1
-  run tri0_$rep RAYEN_PAIR_TRI=0
+for cfg in c3 c1 c2 c4 c5 c5r; do
+  RAYEN_HIP_LIBRARY=$U/librayen_r04.so timeout 400 python bench.py --config $cfg --no-cpu-baseline > $out/bench_${cfg}_r04.json 2> $out/bench_${cfg}_r04.err; line r04_$cfg $out/bench_${cfg}_r04.json
+  timeout 400 python bench.py --config $cfg --no-cpu-baseline > $out/bench_${cfg}_new.json 2> $out/bench_${cfg}_new.err; line new_$cfg $out/bench_${cfg}_new.json
 done
+RAYEN_HIP_LIBRARY=$U/librayen_r04.so timeout 400 python bench.py --mapper 64 --no-cpu-baseline > $out/bench_map_r04.json 2>/dev/null; line r04_map64 $out/bench_map_r04.json
+timeout 400 python bench.py --mapper 64 --no-cpu-baseline > $out/bench_map_new.json 2>/dev/null; line new_map64 $out/bench_map_new.json
+timeout 2400 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider -x > $out/pytest_full.log 2>&1; echo "rc=$?" >> $out/pytest_full.log
+tail -4 $out/pytest_full.log

@@ -180,3 +180,54 @@ def lmi_gradient_bound(oracle, cs, x, eps, factor=4.0):
     gap = (lam[:, -1] - lam[:, -2]).clamp_min(1e-300)
     bound = factor * r * eps * lam.abs().amax(dim=1) / gap
     return torch.where(on_top, bound, torch.zeros_like(bound)).numpy()
+
+
+def residuals_device(raw, y):
+    """``oracle.residuals`` and the relative form of ``test_gpu_parity._relative_violation`` for a FULL batch on the
+    device: per-sample worst signed residual per family, and per-sample worst residual / (sum of |terms|), in fp64 torch
+    ops on ``y``'s device (262 144 rows x 72 quadratics are minutes of numpy on the host, seconds here).  Test
+    infrastructure: the callers cross-check a slice against the numpy forms of the oracle."""
+    import torch
+    y = y.double()
+    ay = y.abs()
+    dev = y.device
+    t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64), device=dev)  # noqa: E731
+    res, rel = {}, []
+    if raw.get("A1") is not None:
+        A, b = t(raw["A1"]), t(raw["b1"])[:, 0]
+        r = y @ A.T - b
+        res["lin_ineq"] = r.amax(dim=1)
+        rel.append((r / (ay @ A.abs().T + b.abs())).amax(dim=1))
+    if raw.get("A2") is not None:
+        A, b = t(raw["A2"]), t(raw["b2"])[:, 0]
+        r = (y @ A.T - b).abs()
+        res["lin_eq"] = r.amax(dim=1)
+        rel.append((r / (ay @ A.abs().T + b.abs() + 1e-300)).amax(dim=1))
+    if len(raw.get("P", [])):
+        vals, rels = [], []
+        for P, q, r0 in zip(raw["P"], raw["q"], raw["r"]):
+            P, q = t(P), t(q)[:, 0]
+            r = 0.5 * ((y @ P) * y).sum(dim=1) + y @ q + float(r0[0, 0])
+            mag = 0.5 * ((ay @ P.abs()) * ay).sum(dim=1) + ay @ q.abs() + abs(float(r0[0, 0]))
+            vals.append(r)
+            rels.append(r / mag)
+        res["quad"] = torch.stack(vals, dim=1).amax(dim=1)
+        rel.append(torch.stack(rels, dim=1).amax(dim=1))
+    if len(raw.get("M", [])):
+        vals, rels = [], []
+        for M, s_, c, d in zip(raw["M"], raw["s"], raw["c"], raw["d"]):
+            M, s_, c = t(M), t(s_)[:, 0], t(c)[:, 0]
+            r = torch.linalg.norm(y @ M.T + s_, dim=1) - (y @ c + float(d[0, 0]))
+            mag = torch.linalg.norm(ay @ M.abs().T + s_.abs(), dim=1) + ay @ c.abs() + abs(float(d[0, 0]))
+            vals.append(r)
+            rels.append(r / mag)
+        res["soc"] = torch.stack(vals, dim=1).amax(dim=1)
+        rel.append(torch.stack(rels, dim=1).amax(dim=1))
+    if len(raw.get("F", [])):
+        F = t(np.stack(raw["F"][:-1], axis=0))
+        H = torch.einsum("ba,ajk->bjk", y, F) + t(raw["F"][-1])[None]
+        lam = torch.linalg.eigvalsh(H)[:, 0]
+        res["lmi"] = -lam
+        norms = t(np.array([np.linalg.norm(Fi, 2) for Fi in raw["F"][:-1]]))
+        rel.append(-lam / (ay @ norms + float(np.linalg.norm(raw["F"][-1], 2))))
+    return res, torch.stack(rel, dim=1).amax(dim=1)

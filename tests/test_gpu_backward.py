@@ -290,7 +290,7 @@ def _random_lmi_set(seed):
     return raw
 
 
-@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("RAYEN_FUZZ_SEEDS", "100")) // 4)))
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("RAYEN_FUZZ_SEEDS", "100")) // 8)))
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_random_lmi_sets_backward(seed, dtype):
     _check_lmi_backward(_random_lmi_set(seed), dtype)
@@ -349,10 +349,21 @@ def _check_lmi_backward(raw, dtype):
     # measured against the incoming gradient's size there, not against rounding noise)
     # the two terms that cancel are of the size of g; rounding leaves a few ulps of THAT (observed <= 5e-16 |g| in
     # fp64 over 250 sets), so the floor is |g| * 1e-6: an absolute error of 1e-14 |g| still fails
-    # fp32 (round 4, 1000-seed fuzz): the residue of that cancellation is 3e-7 ... 5e-7 |g| on the n = 1 sets (2 - 4 ulps of
-    # the two terms; the forward's kappa is within 2e-7 of the fp64 oracle's there, scripts/ubench/lmi_kappa_check.py), which
-    # a floor of 1e-3 |g| turned into "errors" of 2.1e-4 ... 4.1e-4 on 10 of 250 seeds; 4e-3 |g| asks for 8e-7 |g| absolute
-    floor = g.double().abs().amax(1) * (4e-3 if dtype == torch.float32 else 1e-6)
+    # fp32 (round 4, 1000-seed fuzz; round 5: the floor is 1e-3 |g| again for every set): on ONE- and TWO-dimensional
+    # feasible sets a clipped sample's true gradient is (nearly) zero, and what the kernel returns there is the residue of
+    # that cancellation, 3e-7 ... 5e-7 |g| (2 - 4 ulps of the two terms; the forward's kappa is within 2e-7 of the fp64
+    # oracle's, scripts/ubench/lmi_kappa_check.py).  Those rows -- n <= 2 and |true gradient| < 1e-3 |g| -- are held to an
+    # explicit ABSOLUTE bound, 1e-6 |g|, instead of a relative one against a number that is zero; every other row of
+    # every set keeps the relative bar with the 1e-3 |g| floor.
+    gmag = g.double().abs().amax(1)
+    floor = gmag * (1e-3 if dtype == torch.float32 else 1e-6)
+    if dtype == torch.float32 and cs.n <= 2:
+        tiny = want.abs().amax(1) < 1e-3 * gmag
+        if bool(tiny.any()):
+            resid = (got[tiny].double() - want[tiny]).abs().amax(1)
+            assert bool((resid <= 1e-6 * gmag[tiny]).all()), (float((resid / gmag[tiny]).max()), r, cs.n)
+            got = got.clone()
+            got[tiny] = want[tiny].to(got.dtype)
     _assert_gradient(got.numpy(), want.numpy(), cs, v.unsqueeze(2), g, dtype, floor=floor.numpy(), what=f"lmi r={r}")
     err = torch.from_numpy(_row_err(got.numpy(), want.numpy(), floor.numpy()))
     assert float(err[:22].max()) <= (1e-5 if dtype == torch.float32 else 1e-12)
