@@ -14,14 +14,17 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 INCLUDE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
 SOURCES = ["rayen_abi.hip", "rayen_generic.hip", "rayen_mfma.hip", "rayen_mfma_split.hip", "rayen_mfma_pair.hip", "rayen_mfma_pair_io.hip", "rayen_mfma_pair_ws8.hip", "rayen_wide.hip", "rayen_mfma_mapped.hip", "rayen_mfma_bwd.hip", "rayen_mfma_bwdg.hip", "rayen_mfma_bwdp.hip", "rayen_lmi_wave32.hip", "rayen_lmi_wave64.hip", "rayen_mfma_bwdg64.hip", "rayen_mfma_bwd64.hip", "rayen_mfma_f64.hip",
            "rayen_lmi_quad32.hip", "rayen_lmi_quad64.hip"]
-# Every translation unit is built WITHOUT hipcc's SLP vectoriser.  On gfx950 a packed-fp32 instruction whose low result
-# reads the HIGH half of its second source (op_sel:[0,1,..]: how the vectoriser broadcasts the second element of a register
-# pair) reads that operand as 0 in lanes 48-63 now and then while an MFMA is executing on the SIMD -- the fault behind the
-# flat-row kernel's intermittent y == y0 of round 4 (scripts/ubench/pkfma_hazard.hip reproduces it in
-# 60 lines).  Packed arithmetic the kernels ask for themselves (ext_vector_type(2) operands in their natural halves) is
-# unaffected; scripts/check_packed_opsel.py (tests/test_kernel_isa_hazards.py) audits the ISA of every kernel for the form.
-COMMON_FLAGS = ["-fno-slp-vectorize"]
-EXTRA_FLAGS = {}      # per-source compiler flags
+# On gfx950 a packed-fp32 instruction whose low result reads the HIGH half of its second source (op_sel:[0,1,..]: how hipcc's
+# SLP vectoriser broadcasts the second element of a register pair) reads that operand as 0 in lanes 48-63 now and then while
+# an MFMA is executing on the SIMD -- the fault behind the flat-row kernel's intermittent y == y0 of round 4 (DESIGN.md
+# section 3; scripts/ubench/pkfma_hazard.hip reproduces it in 60 lines).  scripts/check_packed_opsel.py
+# (tests/test_kernel_isa_hazards.py, no GPU needed) audits the ISA of EVERY kernel of the library for that form with the
+# flags below; the translation units in which the vectoriser produced it are built without the vectoriser (packed arithmetic
+# the kernels ask for themselves -- ext_vector_type(2) operands in their natural halves -- is unaffected), the others keep it
+# (without it the fused-mapper instances of rayen_mfma_pair.hip spill 2.5 x as many registers: 0.101 against 0.086 ms).
+COMMON_FLAGS = []     # extra compiler flags of every translation unit
+EXTRA_FLAGS = {"rayen_generic.hip": ["-fno-slp-vectorize"],          # per-source compiler flags
+               "rayen_mfma_pair_io.hip": ["-fno-slp-vectorize"]}
 LIBRARY = os.environ.get("RAYEN_HIP_LIBRARY") or os.path.join(CSRC, "librayen_hip.so")
 
 

@@ -131,6 +131,8 @@ int build_images(RayenPack* p, int prepare) {
       if ((rc = build_one(p, split_ok && (mode == 0 || mode == 3), &p->pr32, mfma_pair_build))) return rc;
       if (p->pr32 != nullptr && (rc = mfma_pair_io_prepare(p, p->pr32))) return rc;
       if (p->pr32 != nullptr && (rc = mfma_pair_ws8_build(p, p->pr32, &p->ws8_32))) return rc;
+      // (the instances behind the fused mapper walk an image without shared tiles, rayen_mfma_pair.hip)
+      if (p->pr32 != nullptr && mfma_pair_has_halves(p->pr32) && (rc = build_one(p, true, &p->pr32m, mfma_pair_build_dense))) return rc;
     }
     if ((rc = build_one(p, lmi_quad_eligible_f32(p), &p->q32, lmi_quad_build_f32))) return rc;
     // (the wave-per-sample LMI kernels take what neither the quad kernel nor the lane kernels hold: matrices beyond ~30 x 30)
@@ -620,6 +622,7 @@ void rayen_pack_destroy(RayenPack* p) {
   if (p->mbg64) mfma64_bwdg_free(p->mbg64);
   if (p->sp32) mfma_split_free(p->sp32);
   if (p->pr32) mfma_pair_free(p->pr32);
+  if (p->pr32m) mfma_pair_free(p->pr32m);
   if (p->ws8_32) mfma_pair_ws8_free(p->ws8_32);
   if (p->wide) wide_free(p->wide);
   if (p->q32) lmi_quad_free(p->q32);
@@ -805,8 +808,8 @@ int rayen_ray_project_mapped_image_f32(const RayenPack* p, const float* x, int64
   const int rc = check_ready<float>(p, false);
   if (rc) return rc;
   if (p->pr32 != nullptr && p->pr32_state == 1)
-    return mfma_pair_forward_mapped(p, p->pr32, x, B, ldx, in_dim, image, v_out, ldvo, y, ldy, kappa, active, nan_flag,
-                                    static_cast<hipStream_t>(stream));
+    return mfma_pair_forward_mapped(p, p->pr32m != nullptr ? p->pr32m : p->pr32, x, B, ldx, in_dim, image, v_out, ldvo, y, ldy,
+                                    kappa, active, nan_flag, static_cast<hipStream_t>(stream));
   if (p->sp32 == nullptr || p->sp32_state != 1) return RAYEN_E_UNSUPPORTED;
   return mfma_split_forward_mapped(p, p->sp32, x, B, ldx, in_dim, image, v_out, ldvo, y, ldy, kappa, active, nan_flag,
                                    static_cast<hipStream_t>(stream));

@@ -91,6 +91,8 @@ struct RayenPack {
   rayen::SplitImage* sp32 = nullptr;
   int sp32_state = 0;            // 1: the bf16-triple kernel may serve this pack | 2: rejected by fp32_selfcheck
   rayen::PairImage* pr32 = nullptr;
+  rayen::PairImage* pr32m = nullptr;   // the f16-pair image without shared tiles, for the instances behind the fused mapper
+                                       // (null: pr32 has none either and serves them)
   rayen::Ws8Image* ws8_32 = nullptr;   // the same image dealt out to eight W-stationary waves (null: not served)
   int pr32_state = 0;            // the same for the f16-pair kernel (which is preferred when both are accepted)
   rayen::WideImage* wide = nullptr;    // segment tables of the products epilogue (any n; packs without an LMI)
@@ -152,6 +154,8 @@ int mfma_split_forward(const RayenPack* p, const SplitImage* img, const float* v
 
 // fp32 results on pairs of f16 operands (rayen_mfma_pair.hip); eligibility is mfma_split_eligible's
 int mfma_pair_build(const RayenPack* p, PairImage** out, int64_t* bytes);
+int mfma_pair_build_dense(const RayenPack* p, PairImage** out, int64_t* bytes);   // without shared tiles (fused mapper)
+bool mfma_pair_has_halves(const PairImage* img);
 void mfma_pair_free(PairImage* img);
 int mfma_pair_forward(const RayenPack* p, const PairImage* img, const float* v, int64_t B, int64_t ldv,
                       float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,

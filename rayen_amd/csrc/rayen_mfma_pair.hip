@@ -315,7 +315,7 @@ __device__ __forceinline__ void mfma_pair_fwd_body(
       // Counted waits: a chunk's re-load for the NEXT tile follows its last use, so K-step sp of a full tile behind a full
       // tile has NS - 1 younger loads behind its chunks; the second half of a shared tile has the first half's four
       // re-loads behind them on top, and so have K-steps 0,1 of the tile after it.
-      if constexpr (NS == 4) {
+      if constexpr (NS == 4 && NKX == 0) {
         const int shape = (ts >> 24) & 3;
         const int ctrl = pair_item_ctrl(shape, after_half_b);
         auto step1 = [&](auto SP) {
@@ -342,11 +342,14 @@ __device__ __forceinline__ void mfma_pair_fwd_body(
         step2(std::integral_constant<int, 2>{}); step2(std::integral_constant<int, 3>{});
         after_half_b = shape == MS_HALF_B;
       } else {
-        // n_pad = 32: every item is a full tile; the builtins, scheduled by hipcc (rounds 3-4)
+        // n_pad = 32, and the instances behind the fused mapper (their image is laid out without shared tiles,
+        // mfma_pair_build_dense: as statements the burst cost them 20 more spilled registers, 0.101 against 0.088 ms on
+        // config 3 behind a 64-column mapper): every item is a full tile; the builtins, scheduled by hipcc (rounds 3-4)
 #pragma unroll
         for (int sp = 0; sp < NS; ++sp) {
           __builtin_amdgcn_sched_barrier(0);
-          asm volatile("s_waitcnt vmcnt(1)" : "+v"(abuf[2 * sp + 0]), "+v"(abuf[2 * sp + 1]));
+          if constexpr (NS == 4) asm volatile("s_waitcnt vmcnt(3)" : "+v"(abuf[2 * sp + 0]), "+v"(abuf[2 * sp + 1]));
+          else asm volatile("s_waitcnt vmcnt(1)" : "+v"(abuf[2 * sp + 0]), "+v"(abuf[2 * sp + 1]));
           const f16x8 a1 = __builtin_bit_cast(f16x8, abuf[2 * sp + 0]), a2 = __builtin_bit_cast(f16x8, abuf[2 * sp + 1]);
 #pragma unroll
           for (int t = 0; t < NT; ++t)
@@ -613,11 +616,18 @@ void mfma_pair_free(PairImage* img) {
   delete img;
 }
 
+static int pair_build(const RayenPack* p, PairImage** out, int64_t* bytes, bool tri);
 int mfma_pair_build(const RayenPack* p, PairImage** out, int64_t* bytes) {
-  TileLayout b(p->n);
   // (RAYEN_PAIR_TRI=0: dense factors, two tiles each -- the image of rounds 3 and 4, for A/B measurements)
   const char* tri_env = std::getenv("RAYEN_PAIR_TRI");
-  const bool tri = !(tri_env != nullptr && tri_env[0] == '0');
+  return pair_build(p, out, bytes, !(tri_env != nullptr && tri_env[0] == '0'));
+}
+bool mfma_pair_has_halves(const PairImage* img) { return img != nullptr && img->has_halves; }
+// the image of the instances behind the fused mapper: every item a full tile
+int mfma_pair_build_dense(const RayenPack* p, PairImage** out, int64_t* bytes) { return pair_build(p, out, bytes, false); }
+
+static int pair_build(const RayenPack* p, PairImage** out, int64_t* bytes, const bool tri) {
+  TileLayout b(p->n);
   const int rc = layout_tiles(p, b, /*allow_pack=*/true, /*allow_sym=*/false, tri);
   if (rc != RAYEN_OK) return rc;
   if (b.packs.empty()) { MPack none; std::memset(&none, 0, sizeof(none)); b.packs.push_back(none); }
@@ -703,6 +713,7 @@ int mfma_pair_build(const RayenPack* p, PairImage** out, int64_t* bytes) {
   img->identity = p->out_identity;
   img->n_items = (int)b.items.size();
   img->host_items = b.items;
+  for (const MItem& it : b.items) img->has_halves = img->has_halves || it.shape() != MS_FULL;
   for (const RayenSegment& g : p->segs) img->aux_rows += aux_rows_of(g);
   img->first_out = img->n_items;
   for (int i = img->n_items - 1; i >= 0; --i)
@@ -836,7 +847,7 @@ static int launch_pair_map(const RayenPack* p, const PairImage* img, const float
 int mfma_pair_forward_mapped(const RayenPack* p, const PairImage* img, const float* x, int64_t B, int64_t ldx,
                              int in_dim, const void* image, float* v_out, int64_t ldvo, float* y, int64_t ldy,
                              float* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream) {
-  if (mfma_pair_mapper_image_bytes(p, img, in_dim) == 0 || image == nullptr) return RAYEN_E_UNSUPPORTED;
+  if (mfma_pair_mapper_image_bytes(p, img, in_dim) == 0 || image == nullptr || img->has_halves) return RAYEN_E_UNSUPPORTED;
   if (B == 0) return RAYEN_OK;
   PairMapper mp;
   mp.img = static_cast<const f16x8*>(image);

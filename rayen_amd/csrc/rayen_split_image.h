@@ -210,6 +210,7 @@ struct PairImage {
   float w_scale = 1.f, w_inv = 1.f;
   int aux_rows = 0;        // aux rows (phi | c, M'beta) of the whole set
   int first_out = 0;       // index of the first NA_E tile in the item list (n_items when NA_E = I)
+  bool has_halves = false; // some items read half of a shared tile (rayen_tiles.h): not for the mapped instances
   int64_t bytes = 0;
   std::vector<MItem> host_items;   // the item list as uploaded (rayen_mfma_pair_ws8.hip deals it out to eight waves)
 };
