@@ -148,7 +148,8 @@ enum {
   RAYEN_KERNEL_LMI_WAVE = 7,  /* one wave per sample, the matrix in LDS (one LMI beyond ~30 x 30 + linear rows) */
   RAYEN_KERNEL_PAIR_WS = 8,   /* f16 pairs, W-stationary (ABI v6): the tiles of W resident in the registers of a workgroup's eight
                                  waves, the batch streamed through a shared B-operand image in LDS */
-  RAYEN_KERNEL_PRODUCTS = 9   /* wide sets (ABI v7): the epilogue over products T = v W_ext' of a library GEMM */
+  RAYEN_KERNEL_PRODUCTS = 9,  /* wide sets (ABI v7): the epilogue over products T = v W_ext' of a library GEMM */
+  RAYEN_KERNEL_LMI_BLOCK = 10 /* one workgroup per sample, the packed lower triangle in LDS (one LMI to ~280 x 280 + linear rows; round 5) */
 };
 int rayen_last_forward_kernel(void);
 

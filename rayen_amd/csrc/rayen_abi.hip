@@ -106,6 +106,16 @@ int build_one(RayenPack* p, bool eligible, Image** slot, Build build) {
   return RAYEN_OK;
 }
 
+// Which LMI kernel takes a matrix neither the quad nor the lane kernels hold: the workgroup-per-sample forward
+// (rayen_lmi_block.h) beyond 64 x 64 and wherever the wave kernel's full storage does not fit.
+bool lmi_block_preferred(bool block_serves, bool wave_serves, int r) {
+  if (!block_serves) return false;
+  if (!wave_serves) return true;
+  const char* env = std::getenv("RAYEN_LMI_BLOCK");       // 0 / 1 pin a kernel (developer A/B, tests)
+  if (env != nullptr && (env[0] == '0' || env[0] == '1')) return env[0] == '1';
+  return r > 64;      // (measured, B = 2 000: r = 64 0.33 against 0.30 ms for the wave kernel, r = 100 1.26 against 2.53)
+}
+
 int lmi_dim(const RayenPack* p) {
   int r = 0;
   for (const RayenSegment& g : p->segs)
@@ -136,7 +146,8 @@ int build_images(RayenPack* p, int prepare) {
     }
     if ((rc = build_one(p, lmi_quad_eligible_f32(p), &p->q32, lmi_quad_build_f32))) return rc;
     // (the wave-per-sample LMI kernels take what neither the quad kernel nor the lane kernels hold: matrices beyond ~30 x 30)
-    if ((rc = build_one(p, lmi_wave_eligible_f32(p) && (p->q32 == nullptr || lmi_dim(p) > 28), &p->w32, lmi_wave_build_f32))) return rc;
+    if ((rc = build_one(p, (lmi_wave_eligible_f32(p) || lmi_block_eligible_f32(p)) && (p->q32 == nullptr || lmi_dim(p) > 28), &p->w32, lmi_wave_build_f32))) return rc;
+    if (p->w32 != nullptr && (rc = lmi_block_prepare_f32(p->w32))) return rc;
     if (bwd) {
       if ((rc = build_one(p, mfma_bwd_eligible(p), &p->mb32, mfma_bwd_build))) return rc;
       if (p->mb32 == nullptr && (rc = build_one(p, mfma_bwdg_eligible(p), &p->mbg32, mfma_bwdg_build))) return rc;
@@ -151,7 +162,8 @@ int build_images(RayenPack* p, int prepare) {
     if ((rc = build_generic<double>(p))) return rc;
     if ((rc = build_one(p, mfma64_eligible(p), &p->m64, mfma64_build))) return rc;
     if ((rc = build_one(p, lmi_quad_eligible_f64(p), &p->q64, lmi_quad_build_f64))) return rc;
-    if ((rc = build_one(p, lmi_wave_eligible_f64(p) && (p->q64 == nullptr || lmi_dim(p) > 20), &p->w64, lmi_wave_build_f64))) return rc;
+    if ((rc = build_one(p, (lmi_wave_eligible_f64(p) || lmi_block_eligible_f64(p)) && (p->q64 == nullptr || lmi_dim(p) > 20), &p->w64, lmi_wave_build_f64))) return rc;
+    if (p->w64 != nullptr && (rc = lmi_block_prepare_f64(p->w64))) return rc;
     if (bwd) {
       if ((rc = build_one(p, mfma64_bwd_eligible(p), &p->mb64, mfma64_bwd_build))) return rc;
       if (p->mb64 == nullptr && (rc = build_one(p, mfma64_bwdg_eligible(p), &p->mbg64, mfma64_bwdg_build))) return rc;
@@ -653,7 +665,7 @@ int rayen_pack_info(const RayenPack* p, RayenPackInfo* info) {
                   : p->mb32 != nullptr ? 1
                   : (p->mbp32 != nullptr && p->mbp32_state == 1) ? 3
                   : p->mbg32 != nullptr ? 2
-                  : (p->w32 != nullptr && !generic_backward_serves<float>(p, image_of<float>(p))) ? 5 : 0;
+                  : (p->w32 != nullptr && lmi_wave_serves_f32(p->w32) && !generic_backward_serves<float>(p, image_of<float>(p))) ? 5 : 0;
   info->bwd32_check_pair = p->check_bwd_pair;
   info->bwd32_check_exact = p->check_bwd_exact;
   int lmi_words = 0;
@@ -756,6 +768,10 @@ static int project_f32(const RayenPack* p, const float* v, int64_t B, int64_t ld
   g_last_forward = RAYEN_KERNEL_LANE;
   const int rcg = project_generic<float>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, old_mode);
   if (rcg == RAYEN_E_UNSUPPORTED && p->w32 != nullptr && y != nullptr && !old_mode) {   // (nothing was launched)
+    if (lmi_block_preferred(lmi_block_serves_f32(p->w32), lmi_wave_serves_f32(p->w32), lmi_dim(p))) {
+      g_last_forward = RAYEN_KERNEL_LMI_BLOCK;
+      return lmi_block_forward_f32(p, p->w32, v, B, ldv, y, ldy, kappa, active, nan_flag, static_cast<hipStream_t>(stream));
+    }
     g_last_forward = RAYEN_KERNEL_LMI_WAVE;
     return lmi_wave_forward_f32(p, p->w32, v, B, ldv, y, ldy, kappa, active, nan_flag, static_cast<hipStream_t>(stream));
   }
@@ -855,6 +871,11 @@ static int project_f64(const RayenPack* p, const double* v, int64_t B, int64_t l
   }
   g_last_forward = RAYEN_KERNEL_LANE;
   const int rcg = project_generic<double>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, old_mode);
+  if (rcg == RAYEN_E_UNSUPPORTED && p->w64 != nullptr && y != nullptr && !old_mode &&
+      lmi_block_preferred(lmi_block_serves_f64(p->w64), lmi_wave_serves_f64(p->w64), lmi_dim(p))) {
+    g_last_forward = RAYEN_KERNEL_LMI_BLOCK;
+    return lmi_block_forward_f64(p, p->w64, v, B, ldv, y, ldy, kappa, active, nan_flag, static_cast<hipStream_t>(stream));
+  }
   if (rcg == RAYEN_E_UNSUPPORTED && p->w64 != nullptr && y != nullptr && !old_mode) {
     g_last_forward = RAYEN_KERNEL_LMI_WAVE;
     return lmi_wave_forward_f64(p, p->w64, v, B, ldv, y, ldy, kappa, active, nan_flag, static_cast<hipStream_t>(stream));

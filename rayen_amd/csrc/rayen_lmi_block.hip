@@ -1,0 +1,31 @@
+// Instances of the workgroup-per-sample LMI forward (see rayen_lmi_block.h).
+#include "rayen_lmi_block.h"
+
+namespace rayen {
+
+// [linear rows] + one LMI whose packed triangle fits the LDS
+template <typename T>
+static bool eligible(const RayenPack* p) {
+  int n_lmi = 0, r = 0;
+  for (const RayenSegment& g : p->segs) {
+    if (g.type == RAYEN_SEG_LMI) { ++n_lmi; r = g.dim; }
+    else if (g.type != RAYEN_SEG_LIN) return false;
+  }
+  return n_lmi == 1 && r >= 2 && lb::lds_elems(r, p->n) * sizeof(T) <= lb::kLdsMax;
+}
+bool lmi_block_eligible_f32(const RayenPack* p) { return eligible<float>(p); }
+bool lmi_block_eligible_f64(const RayenPack* p) { return eligible<double>(p); }
+bool lmi_block_serves_f32(const LmiWaveImage* img) { return lb::lmi_block_serves_t<float>(img); }
+bool lmi_block_serves_f64(const LmiWaveImage* img) { return lb::lmi_block_serves_t<double>(img); }
+int lmi_block_prepare_f32(const LmiWaveImage* img) { return lb::lmi_block_prepare_t<float>(img); }
+int lmi_block_prepare_f64(const LmiWaveImage* img) { return lb::lmi_block_prepare_t<double>(img); }
+int lmi_block_forward_f32(const RayenPack* p, const LmiWaveImage* img, const float* v, int64_t B, int64_t ldv, float* y,
+                          int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream) {
+  return lb::lmi_block_forward_t<float>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+}
+int lmi_block_forward_f64(const RayenPack* p, const LmiWaveImage* img, const double* v, int64_t B, int64_t ldv, double* y,
+                          int64_t ldy, double* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream) {
+  return lb::lmi_block_forward_t<double>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+}
+
+}  // namespace rayen

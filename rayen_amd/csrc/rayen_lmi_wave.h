@@ -463,7 +463,7 @@ int lmi_wave_build_t(const RayenPack* p, LmiWaveImage** out, int64_t* bytes) {
   if (!ok) { lmi_wave_free_image(img); return RAYEN_E_ALLOC; }
   // (pack creation is the one place that may touch function attributes: large matrices need more than 64 KiB of LDS)
   const size_t lds = lds_elems(r, n, k) * sizeof(T);
-  if (lds > 48 * 1024) {
+  if (lds > 48 * 1024 && lds <= kWaveLdsMax) {
     const void* fwd = reinterpret_cast<const void*>(&lmi_wave_kernel<T>);
     const void* bwd = reinterpret_cast<const void*>(&lmi_wave_bwd_kernel<T>);
     if (hipFuncSetAttribute(fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWaveLdsMax) != hipSuccess ||
@@ -478,10 +478,17 @@ int lmi_wave_build_t(const RayenPack* p, LmiWaveImage** out, int64_t* bytes) {
   return RAYEN_OK;
 }
 
+// (the image is also built for packs only the workgroup-per-sample forward of rayen_lmi_block.h holds)
+template <typename T>
+bool lmi_wave_serves_t(const LmiWaveImage* img) {
+  return img != nullptr && lds_elems(img->r, img->n, img->k) * sizeof(T) <= kWaveLdsMax;
+}
+
 template <typename T>
 int lmi_wave_forward_t(const RayenPack* p, const LmiWaveImage* img, const T* v, int64_t B, int64_t ldv, T* y, int64_t ldy,
                        T* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream) {
   (void)p;
+  if (!lmi_wave_serves_t<T>(img)) return RAYEN_E_UNSUPPORTED;
   if (B == 0) return RAYEN_OK;
   if (B > 0x7fffffffLL) return RAYEN_E_UNSUPPORTED;
   const size_t lds = lds_elems(img->r, img->n, img->k) * sizeof(T);
@@ -496,6 +503,7 @@ template <typename T>
 int lmi_wave_backward_t(const RayenPack* p, const LmiWaveImage* img, const T* v, int64_t B, int64_t ldv, const T* kappa,
                         const int32_t* active, const T* gy, int64_t ldg, T* gv, int64_t ldgv, hipStream_t stream) {
   (void)p;
+  if (!lmi_wave_serves_t<T>(img)) return RAYEN_E_UNSUPPORTED;
   if (B == 0) return RAYEN_OK;
   if (B > 0x7fffffffLL) return RAYEN_E_UNSUPPORTED;
   const size_t lds = lds_elems(img->r, img->n, img->k) * sizeof(T);

@@ -5,6 +5,7 @@ namespace rayen {
 
 bool lmi_wave_eligible_f32(const RayenPack* p) { return lw::lmi_wave_eligible_t<float>(p); }
 int lmi_wave_build_f32(const RayenPack* p, LmiWaveImage** out, int64_t* bytes) { return lw::lmi_wave_build_t<float>(p, out, bytes); }
+bool lmi_wave_serves_f32(const LmiWaveImage* img) { return lw::lmi_wave_serves_t<float>(img); }
 void lmi_wave_free(LmiWaveImage* img) { lw::lmi_wave_free_image(img); }
 int lmi_wave_forward_f32(const RayenPack* p, const LmiWaveImage* img, const float* v, int64_t B, int64_t ldv, float* y,
                          int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream) {

@@ -58,7 +58,11 @@ def _layer(raw, dtype):
 
 @pytest.mark.parametrize("name", list(CASES))
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
-def test_large_lmi_forward_and_backward(name, dtype):
+@pytest.mark.parametrize("kernel", ["block", "wave"])
+def test_large_lmi_forward_and_backward(name, dtype, kernel, monkeypatch):
+    """``kernel``: the forward on the workgroup-per-sample kernel (rayen_lmi_block.h, round 5: the default wherever it
+    serves) or, pinned with RAYEN_LMI_BLOCK=0, on the wave-per-sample kernel; the backward is the wave kernel's either way."""
+    monkeypatch.setenv("RAYEN_LMI_BLOCK", "1" if kernel == "block" else "0")
     raw = _case(**CASES[name])
     r = CASES[name]["r"]
     cs, layer = _layer(raw, dtype)
@@ -74,7 +78,7 @@ def test_large_lmi_forward_and_backward(name, dtype):
     if name == "r30_eq" and dtype == torch.float32:
         assert fam == _lib.KERNEL_LMI_QUAD                    # (the small kernels keep what they can hold)
     else:
-        assert fam == _lib.KERNEL_LMI_WAVE, (name, fam)
+        assert fam == (_lib.KERNEL_LMI_BLOCK if kernel == "block" else _lib.KERNEL_LMI_WAVE), (name, fam)
     buf64 = oracle.precompute(csd_from_cs(cs), torch.float64)
     xr = x.double().unsqueeze(2).requires_grad_(True)
     y_true_t = oracle.forward(buf64, xr)
@@ -117,14 +121,53 @@ def test_large_lmi_forward_and_backward(name, dtype):
     assert kink.sum() <= max(3, 0.05 * B)
 
 
-def test_wave_kernel_small_and_ragged_batches_and_nan_rows():
+BIG = {
+    "r200_lin": dict(k=8, r=200, m=40, n_eq=0, seed=11),     # beyond the wave kernel's LDS in fp32 (r <= ~190) and at the
+    "r196_eq": dict(k=9, r=196, m=0, n_eq=2, seed=12),       # block kernel's limit in fp64 (r <= 197)
+    "r250": dict(k=6, r=250, m=0, n_eq=0, seed=13),
+    "r280_lin": dict(k=5, r=280, m=10, n_eq=0, seed=14),     # the largest packed triangle a workgroup's LDS holds in fp32 (281)
+}
+
+
+@pytest.mark.parametrize("name,dtype", [("r200_lin", torch.float32), ("r196_eq", torch.float64), ("r196_eq", torch.float32),
+                                         ("r250", torch.float32), ("r280_lin", torch.float32)])
+def test_matrices_only_the_block_kernel_holds(name, dtype):
+    """Forward of LMIs up to 281 x 281 (fp32) / 197 x 197 (fp64) on a hand-written kernel -- the reference's own sweep ends
+    at 300 x 300 (time_analysis.py:157-160); rounds 3-4 sent everything beyond ~190 / ~135 to rocSOLVER through the packed
+    torch evaluator.  This suite runs with RAYEN_STRICT_HIP=1 (conftest): a detour would raise."""
+    raw = _case(**BIG[name])
+    cs, layer = _layer(raw, dtype)
+    gen = torch.Generator().manual_seed(2)
+    B = 40
+    x = torch.empty(B, cs.n, 1).uniform_(-2.0, 2.0, generator=gen)
+    x[:2] *= 1e-4
+    x[2] = 0.0
+    y = layer(x.to(dtype).cuda())
+    assert _lib.load().rayen_last_forward_kernel() == _lib.KERNEL_LMI_BLOCK and not layer._hip_unsupported
+    y_true = oracle.forward(oracle.precompute(csd_from_cs(cs), torch.float64), x.double()).numpy()[:, :, 0]
+    err = rel_err_rows(y.cpu().double().numpy()[:, :, 0], y_true)
+    if dtype == torch.float64:
+        assert err.max() <= 1e-9, (name, err.max())
+    else:
+        y32 = oracle.forward(oracle.precompute(csd_from_cs(cs), torch.float32), x).numpy()[:, :, 0]
+        theirs = rel_err_rows(y32.astype(np.float64), y_true).max()
+        assert err.max() <= max(1e-5, 2.0 * theirs), (name, err.max(), theirs)
+    assert cs.getMaxViolation(y.cpu().double().numpy()[:, :, 0]) <= (1e-9 if dtype == torch.float64 else 2e-4)
+    # the batch does not matter (persistent workgroups, one sample after the other), nor does a second launch
+    y2 = layer(x[:7].to(dtype).cuda())
+    assert torch.equal(y2, y[:7]) and torch.equal(layer(x.to(dtype).cuda()), y)
+
+
+@pytest.mark.parametrize("kernel", ["block", "wave"])
+def test_wave_kernel_small_and_ragged_batches_and_nan_rows(kernel, monkeypatch):
+    monkeypatch.setenv("RAYEN_LMI_BLOCK", "1" if kernel == "block" else "0")
     raw = _case(**CASES["r48_lin"])
     cs, layer = _layer(raw, torch.float32)
     dp, _ = layer.device_pack(torch.device("cuda", 0))
     gen = torch.Generator().manual_seed(9)
     x = torch.empty(67, cs.n).uniform_(-2, 2, generator=gen).cuda()
     y_all, k_all, _ = ops.project_raw(x, dp)
-    assert _lib.load().rayen_last_forward_kernel() == _lib.KERNEL_LMI_WAVE
+    assert _lib.load().rayen_last_forward_kernel() == (_lib.KERNEL_LMI_BLOCK if kernel == "block" else _lib.KERNEL_LMI_WAVE)
     for B in (1, 5, 64):
         y, kap, _ = ops.project_raw(x[:B].contiguous(), dp)
         assert torch.equal(y, y_all[:B]) and torch.equal(kap, k_all[:B])
