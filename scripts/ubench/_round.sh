@@ -1,6 +1,7 @@
 #!/bin/bash
-out=gpurun_out/r05n; mkdir -p $out
+out=gpurun_out/r05p; mkdir -p $out
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests/test_gpu_lmi_wave.py -m gpu -x -q --timeout 900 -p no:cacheprovider > $out/pytest_lmi.log 2>&1; echo "rc=$?" >> $out/pytest_lmi.log
-tail -15 $out/pytest_lmi.log
-timeout 900 python scripts/ubench/lmi_block_bench.py > $out/lmi_block_bench.txt 2>&1; cat $out/lmi_block_bench.txt | cut -c1-250
+timeout 2400 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider > $out/pytest_full.log 2>&1; echo "rc=$?" >> $out/pytest_full.log
+tail -6 $out/pytest_full.log
+python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1; tail -2 $out/smoke.log
+timeout 600 python scripts/ubench/lmi_sweep.py 2>&1 | grep "^{" > $out/lmi_sweep.txt; cat $out/lmi_sweep.txt | cut -c1-220

@@ -14,7 +14,7 @@ sys.path.insert(0, os.getcwd())
 from rayen_amd import _lib, constraints, ops              # noqa: E402
 from rayen_amd.constraint_module import ConstraintModule   # noqa: E402
 
-NAMES = {1: "lane", 6: "lmi_quad", 7: "lmi_wave"}
+NAMES = {1: "lane", 6: "lmi_quad", 7: "lmi_wave", 10: "lmi_block"}
 
 
 def t(fn, reps=10):
