@@ -231,13 +231,21 @@ int project_bwd(const RayenPack* p, const T* v, int64_t B, int64_t ldv, const T*
                                       old_mode, static_cast<hipStream_t>(stream));
   if (rcg == RAYEN_E_UNSUPPORTED && !old_mode) {   // (nothing was launched)
     if constexpr (sizeof(T) == 4) {
-      if (p->w32 != nullptr)
+      if (p->w32 != nullptr) {
+        if (lmi_block_preferred(lmi_block_bwd_serves_f32(p->w32), lmi_wave_serves_f32(p->w32), lmi_dim(p)))
+          return lmi_block_backward_f32(p, p->w32, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv,
+                                        static_cast<hipStream_t>(stream));
         return lmi_wave_backward_f32(p, p->w32, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv,
                                      static_cast<hipStream_t>(stream));
+      }
     } else {
-      if (p->w64 != nullptr)
+      if (p->w64 != nullptr) {
+        if (lmi_block_preferred(lmi_block_bwd_serves_f64(p->w64), lmi_wave_serves_f64(p->w64), lmi_dim(p)))
+          return lmi_block_backward_f64(p, p->w64, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv,
+                                        static_cast<hipStream_t>(stream));
         return lmi_wave_backward_f64(p, p->w64, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv,
                                      static_cast<hipStream_t>(stream));
+      }
     }
   }
   return rcg;
@@ -665,7 +673,8 @@ int rayen_pack_info(const RayenPack* p, RayenPackInfo* info) {
                   : p->mb32 != nullptr ? 1
                   : (p->mbp32 != nullptr && p->mbp32_state == 1) ? 3
                   : p->mbg32 != nullptr ? 2
-                  : (p->w32 != nullptr && lmi_wave_serves_f32(p->w32) && !generic_backward_serves<float>(p, image_of<float>(p))) ? 5 : 0;
+                  : (p->w32 != nullptr && (lmi_wave_serves_f32(p->w32) || lmi_block_bwd_serves_f32(p->w32)) &&
+                     !generic_backward_serves<float>(p, image_of<float>(p))) ? 5 : 0;
   info->bwd32_check_pair = p->check_bwd_pair;
   info->bwd32_check_exact = p->check_bwd_exact;
   int lmi_words = 0;

@@ -265,7 +265,7 @@ int lmi_wave_backward_f64(const RayenPack* p, const LmiWaveImage* img, const dou
                           const double* kappa, const int32_t* active, const double* grad_y, int64_t ldg, double* grad_v,
                           int64_t ldgv, hipStream_t stream);
 
-// one workgroup per sample, the packed lower triangle in LDS (rayen_lmi_block.h): forward for r up to ~280 (fp32) / ~199 (fp64)
+// one workgroup per sample, the packed lower triangle in LDS (rayen_lmi_block.h): forward and backward for r up to ~280 (fp32) / ~197 (fp64)
 // on the wave kernel's image
 bool lmi_block_eligible_f32(const RayenPack* p);
 bool lmi_block_eligible_f64(const RayenPack* p);
@@ -277,6 +277,14 @@ int lmi_block_forward_f32(const RayenPack* p, const LmiWaveImage* img, const flo
                           int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream);
 int lmi_block_forward_f64(const RayenPack* p, const LmiWaveImage* img, const double* v, int64_t B, int64_t ldv, double* y,
                           int64_t ldy, double* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream);
+bool lmi_block_bwd_serves_f32(const LmiWaveImage* img);
+bool lmi_block_bwd_serves_f64(const LmiWaveImage* img);
+int lmi_block_backward_f32(const RayenPack* p, const LmiWaveImage* img, const float* v, int64_t B, int64_t ldv,
+                           const float* kappa, const int32_t* active, const float* grad_y, int64_t ldg, float* grad_v,
+                           int64_t ldgv, hipStream_t stream);
+int lmi_block_backward_f64(const RayenPack* p, const LmiWaveImage* img, const double* v, int64_t B, int64_t ldv,
+                           const double* kappa, const int32_t* active, const double* grad_y, int64_t ldg, double* grad_v,
+                           int64_t ldgv, hipStream_t stream);
 bool lmi_wave_serves_f32(const LmiWaveImage* img);      // (the image may exist for the block kernel alone)
 bool lmi_wave_serves_f64(const LmiWaveImage* img);
 

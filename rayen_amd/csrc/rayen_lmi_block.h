@@ -22,6 +22,18 @@
 namespace rayen {
 namespace lb {
 
+#ifdef RAYEN_LB_PROFILE
+// developer build (scripts/ubench/tu_variant.sh rayen_lmi_block prof -DRAYEN_LB_PROFILE): cycles of workgroup 0's thread 0
+// between the barriers of the reduction -- [0] column + sigma, [1] matvec, [2] w, [3] update, [4] S(v), [5] Sturm, [6] all
+__device__ unsigned long long g_lb_prof[8];
+#define LB_TICK(slot) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long now_ = clock64(); \
+    g_lb_prof[slot] += now_ - lb_t_; lb_t_ = now_; } } while (0)
+#define LB_TICK_DECL unsigned long long lb_t_ = clock64()
+#else
+#define LB_TICK(slot) do { } while (0)
+#define LB_TICK_DECL do { } while (0)
+#endif
+
 constexpr int kWaves = 16;                   // slots of the reduction scratch (the largest workgroup's waves)
 constexpr size_t kLdsMax = 160 * 1024;
 // threads that share a row of the matrix, and threads of the workgroup: every row has its threads
@@ -44,6 +56,192 @@ __device__ __forceinline__ T bsum(T x, T* red, const int tid) {
 #pragma unroll
   for (int w = 1; w < NW; ++w) s += red[w];
   return s;
+}
+
+// S(v) = sum_a v_a G_a, lower triangle packed (no barrier: the caller synchronises)
+template <typename T, int NTH>
+__device__ __forceinline__ void form_S(T* A, const T* __restrict__ gt, const T* vs, int n, int P, int Pp, const int tid) {
+  // ---- S(v), lower triangle packed
+  for (int idx = tid; idx < P; idx += NTH) {
+    T p0 = T(0), p1 = T(0), p2 = T(0), p3 = T(0);
+    const T* col = gt + idx;
+    int a = 0;
+    for (; a + 3 < n; a += 4) {
+      p0 = fma(vs[a + 0], col[(size_t)(a + 0) * Pp], p0);
+      p1 = fma(vs[a + 1], col[(size_t)(a + 1) * Pp], p1);
+      p2 = fma(vs[a + 2], col[(size_t)(a + 2) * Pp], p2);
+      p3 = fma(vs[a + 3], col[(size_t)(a + 3) * Pp], p3);
+    }
+    for (; a < n; ++a) p0 = fma(vs[a], col[(size_t)a * Pp], p0);
+    A[idx] = (p0 + p1) + (p2 + p3);
+  }
+}
+
+// Lane layout of a wave in the reduction: W = 64 / SPLIT consecutive rows, row `lane % W`; the SPLIT lanes `lane / W` of a
+// row take its columns i0 + part, + SPLIT, ...  (a half-wave reads 32 consecutive words, or 32 row starts, at once).
+//
+// q_i = sum_{j = i0}^{r-1} A(i, j) x_j for row ic of the live block (the part of it this lane's columns hold).  The column
+// index runs for the whole wave at once, in three stretches that need no per-lane address arithmetic beyond an add:
+//   j below the wave's first row: every lane reads its own row, A[T(ic) + j]: one pointer, immediate offsets;
+//   j among the wave's rows (W columns): own row or the mirrored entry A[T(j) + ic], by comparison;
+//   j beyond the wave's last row: every lane reads the mirrored entry; T(j + SPLIT) - T(j) = SPLIT j + SPLIT (SPLIT + 1) / 2
+//   grows by SPLIT^2 per step, so the offsets are running sums.
+// (The first version computed T(j) and the comparison for every element: ~12 vector instructions and a 32-bit multiply per
+// element made the reduction instruction-bound at a seventh of what LDS delivers.)
+template <typename T, int SPLIT>
+__device__ __forceinline__ T matvec_row(const T* A, const T* vv, int r, int i0, int wave, int ic, int part) {
+  constexpr int W = 64 / SPLIT, UA = W / SPLIT, S2 = SPLIT * SPLIT * (int)sizeof(T);
+  const char* Ab = reinterpret_cast<const char*>(A);
+  auto at = [&](int byte_off) { return *reinterpret_cast<const T*>(Ab + byte_off); };
+  T q0 = T(0), q1 = T(0), q2 = T(0), q3 = T(0);
+  const int Tc = ic * (ic + 1) / 2;
+  const int nA = UA * wave;                          // steps with j below the wave's first row
+  const int nU = (r - i0) / SPLIT;                   // steps every part has a column for
+  const T* pv = vv + i0 + part;
+  const T* pa = A + Tc + i0 + part;
+  for (int t = 0; t < nA; t += UA) {
+#pragma unroll
+    for (int u = 0; u < UA; u += 4) {
+      q0 = fma(pa[SPLIT * (u + 0)], pv[SPLIT * (u + 0)], q0);
+      q1 = fma(pa[SPLIT * (u + 1)], pv[SPLIT * (u + 1)], q1);
+      q2 = fma(pa[SPLIT * (u + 2)], pv[SPLIT * (u + 2)], q2);
+      q3 = fma(pa[SPLIT * (u + 3)], pv[SPLIT * (u + 3)], q3);
+    }
+    pa += SPLIT * UA;
+    pv += SPLIT * UA;
+  }
+  int j = i0 + part + SPLIT * nA;                    // the wave's first row + part
+  int offM = (j * (j + 1) / 2 + ic) * (int)sizeof(T);                             // (bytes) the mirrored entry (j, ic)
+  int dj = (SPLIT * j + SPLIT * (SPLIT + 1) / 2) * (int)sizeof(T);
+  int t = nA;
+  const int nB = nA + UA < nU ? nA + UA : nU;
+#pragma unroll 4
+  for (; t < nB; ++t) {
+    const T a = at(j <= ic ? (Tc + j) * (int)sizeof(T) : offM);
+    q0 = fma(a, *pv, q0);
+    offM += dj;
+    dj += S2;
+    j += SPLIT;
+    pv += SPLIT;
+  }
+  for (; t + 4 <= nU; t += 4) {
+    const int o1 = offM + dj, o2 = o1 + dj + S2, o3 = o2 + dj + 2 * S2;
+    q0 = fma(at(offM), pv[0], q0);
+    q1 = fma(at(o1), pv[SPLIT], q1);
+    q2 = fma(at(o2), pv[2 * SPLIT], q2);
+    q3 = fma(at(o3), pv[3 * SPLIT], q3);
+    offM = o3 + dj + 3 * S2;
+    dj += 4 * S2;
+    pv += 4 * SPLIT;
+    j += 4 * SPLIT;
+  }
+  for (; t < nU; ++t) {
+    q0 = fma(at(offM), *pv, q0);
+    offM += dj;
+    dj += S2;
+    pv += SPLIT;
+    j += SPLIT;
+  }
+  if (j < r) q0 = fma(at(j <= ic ? (Tc + j) * (int)sizeof(T) : offM), *pv, q0);     // (the parts that have one more column)
+  T q = (q0 + q1) + (q2 + q3);
+  if constexpr (SPLIT >= 4) q += __shfl_xor(q, 16);
+  if constexpr (SPLIT >= 2) q += __shfl_xor(q, 32);
+  return q;
+}
+
+// A(i, j) -= v_i w_j + w_i v_j for j = i0 .. i, this lane's columns of row i (row = A + T(i))
+template <typename T, int SPLIT>
+__device__ __forceinline__ void update_row(T* row, const T* vv, const T* ww, int i0, int wave, int i, int part, T vi, T w) {
+  constexpr int W = 64 / SPLIT, UA = W / SPLIT;
+  const int nA = UA * wave;
+  T* pr = row + i0 + part;
+  const T* pw = ww + i0 + part;
+  const T* pu = vv + i0 + part;
+  // (every load of a group before its first store: the compiler cannot know that the row does not overlap vv / ww, and one
+  // LDS round trip per element is what it would schedule otherwise)
+  for (int t = 0; t < nA; t += UA) {
+    T a[UA], b[UA], c[UA];
+#pragma unroll
+    for (int u = 0; u < UA; ++u) { a[u] = pr[SPLIT * u]; b[u] = pw[SPLIT * u]; c[u] = pu[SPLIT * u]; }
+#pragma unroll
+    for (int u = 0; u < UA; ++u) pr[SPLIT * u] = a[u] - (vi * b[u] + w * c[u]);
+    pr += SPLIT * UA;
+    pw += SPLIT * UA;
+    pu += SPLIT * UA;
+  }
+  const int j0 = i0 + part + SPLIT * nA;
+  T a[UA], b[UA], c[UA];
+#pragma unroll
+  for (int u = 0; u < UA; ++u)
+    if (j0 + SPLIT * u <= i) { a[u] = pr[SPLIT * u]; b[u] = pw[SPLIT * u]; c[u] = pu[SPLIT * u]; }
+#pragma unroll
+  for (int u = 0; u < UA; ++u)
+    if (j0 + SPLIT * u <= i) pr[SPLIT * u] = a[u] - (vi * b[u] + w * c[u]);
+}
+
+// Householder reduction of the packed matrix to tridiagonal form: dd (diagonal), ee (signed sub-diagonal).  The raw column
+// x of step kc stays in A(i > kc, kc); KEEP also leaves tau_kc = 1 / (sigma - x0 alpha) in tt[kc] (0: H = I), so that
+// H_kc = I - tau v v' with v = x - alpha e_{kc+1}, alpha = ee[kc], can be applied again (the backward maps the eigenvector back).
+// Wave w works on rows i0 + W w .. of the live block: SPLIT lanes per row keep all waves busy on matrices of fewer rows than
+// the workgroup has threads (one wave per SIMD reads LDS at a fraction of its rate).  Four workgroup barriers per column.
+template <typename T, int SPLIT, int NTH, bool KEEP>
+__device__ __forceinline__ void tridiagonalise(T* A, int r, T* dd, T* ee, T* tt, T* vv, T* ww, T* red, const int tid) {
+  constexpr int NW = NTH / 64, W = 64 / SPLIT;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (loop bounds in scalar registers)
+  const int rw = lane % W, part = lane / W;
+  LB_TICK_DECL;
+  for (int kc = 0; kc + 2 < r; ++kc) {
+    const int i0 = kc + 1, rlo = i0 + W * wave, i = rlo + rw;
+    const bool has = i < r;
+    const int Ti = i * (i + 1) / 2;
+    T* rd = red + (kc & 1) * 2 * kWaves;
+    const T x = has ? A[Ti + kc] : T(0);
+    if (has && part == 0) vv[i] = x;
+    const T sigma = bsum<T, NW>(part == 0 ? x * x : T(0), rd, tid);   // barrier 1 (vv = the raw column is visible too)
+    LB_TICK(0);
+    const T x0 = vv[i0];
+    const T below = sigma - x0 * x0;                               // what the reflector has to annihilate
+    if (!(below > lw::Eps<T>::tiny * lw::Eps<T>::tiny)) {          // nothing to do: H = I  (the same for every thread)
+      if (tid == 0) { dd[kc] = A[kc * (kc + 1) / 2 + kc]; ee[kc] = x0; if constexpr (KEEP) tt[kc] = T(0); }
+      __syncthreads();
+      continue;
+    }
+    const T alpha = (x0 >= T(0) ? T(-1) : T(1)) * sqrt(sigma);
+    const T taup = T(1) / (sigma - x0 * alpha);
+    // p = tau A v with v = x - alpha e_i0 (the raw column x is in vv; the correction is one extra term)
+    T p = T(0), vi = T(0);
+    if (rlo < r) {                            // (a wave without a live row has nothing to sum)
+      const T q = matvec_row<T, SPLIT>(A, vv, r, i0, wave, has ? i : r - 1, part);   // (idle lanes read a valid row)
+      if (has) {
+        p = taup * (q - alpha * A[Ti + i0]);
+        vi = i == i0 ? x - alpha : x;
+      }
+    }
+    const T pv = bsum<T, NW>(part == 0 ? p * vi : T(0), rd + kWaves, tid);                // barrier 2
+    LB_TICK(1);
+    const T K = T(0.5) * taup * pv;
+    const T w = fma(-K, vi, p);
+    if (has && part == 0) {
+      ww[i] = w;
+      if (i == i0) vv[i0] = vi;
+    }
+    __syncthreads();                                               // barrier 3
+    LB_TICK(2);
+    // A -= v w' + w v' on the lower triangle of the live block
+    if (has) update_row<T, SPLIT>(A + Ti, vv, ww, i0, wave, i, part, vi, w);
+    if (tid == 0) { dd[kc] = A[kc * (kc + 1) / 2 + kc]; ee[kc] = alpha; if constexpr (KEEP) tt[kc] = taup; }
+    __syncthreads();                                               // barrier 4
+    LB_TICK(3);
+  }
+  if (tid == 0) {
+    if (r >= 2) {
+      dd[r - 2] = A[(r - 2) * (r - 1) / 2 + (r - 2)];
+      ee[r - 2] = A[(r - 1) * r / 2 + (r - 2)];
+    }
+    dd[r - 1] = A[(r - 1) * r / 2 + (r - 1)];
+    ee[r - 1] = T(0);
+  }
+  __syncthreads();
 }
 
 template <typename T, int SPLIT, int NTH>
@@ -87,21 +285,13 @@ __global__ __launch_bounds__(NTH) void lmi_block_kernel(
     int* redi = reinterpret_cast<int*>(red + 5 * kWaves);     // (slot set 2, second half: the indices)
     if (lane == 0) { red[2 * 2 * kWaves + wave] = kap; redi[wave] = who; }
 
-    // ---- S(v), lower triangle packed
-    for (int idx = tid; idx < P; idx += kThreads) {
-      T p0 = T(0), p1 = T(0), p2 = T(0), p3 = T(0);
-      const T* col = gt + idx;
-      int a = 0;
-      for (; a + 3 < n; a += 4) {
-        p0 = fma(vs[a + 0], col[(size_t)(a + 0) * Pp], p0);
-        p1 = fma(vs[a + 1], col[(size_t)(a + 1) * Pp], p1);
-        p2 = fma(vs[a + 2], col[(size_t)(a + 2) * Pp], p2);
-        p3 = fma(vs[a + 3], col[(size_t)(a + 3) * Pp], p3);
-      }
-      for (; a < n; ++a) p0 = fma(vs[a], col[(size_t)a * Pp], p0);
-      A[idx] = (p0 + p1) + (p2 + p3);
-    }
+#ifdef RAYEN_LB_PROFILE
+    unsigned long long lb_t_ = clock64();
+    const unsigned long long lb_start = lb_t_;
+#endif
+    form_S<T, NTH>(A, gt, vs, n, P, Pp, tid);
     __syncthreads();
+    LB_TICK(4);
     {
       kap = red[2 * 2 * kWaves];
       who = redi[0];
@@ -114,92 +304,10 @@ __global__ __launch_bounds__(NTH) void lmi_block_kernel(
     }
     int aseg = who >= 0 ? lin_id[2 * who] : -1, arow = who >= 0 ? lin_id[2 * who + 1] : 0;
 
-    // ---- Householder reduction to tridiagonal form: dd (diagonal), ee (signed sub-diagonal)
-    // Thread tid works on row i0 + tid / SPLIT, columns i0 + tid % SPLIT, + SPLIT, ...: SPLIT threads per row keep all eight
-    // waves busy on matrices of fewer than 512 rows (one wave per SIMD reads LDS at a fraction of its rate).
-    for (int kc = 0; kc + 2 < r; ++kc) {
-      const int i0 = kc + 1, i = i0 + tid / SPLIT, part = tid % SPLIT;
-      const bool has = i < r;
-      const int Ti = i * (i + 1) / 2;
-      T* rd = red + (kc & 1) * 2 * kWaves;
-      const T x = has ? A[Ti + kc] : T(0);
-      if (has && part == 0) vv[i] = x;
-      const T sigma = bsum<T, NW>(part == 0 ? x * x : T(0), rd, tid);   // barrier 1 (vv = the raw column is visible too)
-      const T x0 = vv[i0];
-      const T below = sigma - x0 * x0;                               // what the reflector has to annihilate
-      if (!(below > lw::Eps<T>::tiny * lw::Eps<T>::tiny)) {          // nothing to do: H = I  (the same for every thread)
-        if (tid == 0) { dd[kc] = A[kc * (kc + 1) / 2 + kc]; ee[kc] = x0; }
-        __syncthreads();
-        continue;
-      }
-      const T alpha = (x0 >= T(0) ? T(-1) : T(1)) * sqrt(sigma);
-      const T taup = T(1) / (sigma - x0 * alpha);
-      // p = tau A v with v = x - alpha e_i0 (the raw column x is in vv; the correction is one extra term)
-      T p = T(0), vi = T(0);
-      if (i0 + (64 / SPLIT) * wave < r) {     // (a wave without a live row has nothing to sum)
-        // the column index runs for the whole wave at once: lanes read A(i, j) = A[Ti + j] (j <= i: the row starts Ti are
-        // distinct modulo 32 for 32 consecutive i) or A(j, i) = A[Tj + i] (j > i: consecutive words); v_j is a broadcast
-        T q0 = T(0), q1 = T(0), q2 = T(0), q3 = T(0);
-        const int ic = has ? i : r - 1;                      // (idle threads read a valid row; their sum is dropped)
-        const int Tc = ic * (ic + 1) / 2;
-        int j = i0 + part;
-        int Tj = j * (j + 1) / 2;
-        for (; j + 3 * SPLIT < r; j += 4 * SPLIT) {
-          const int j1 = j + SPLIT, j2 = j + 2 * SPLIT, j3 = j + 3 * SPLIT;
-          const int T1 = j1 * (j1 + 1) / 2, T2 = j2 * (j2 + 1) / 2, T3 = j3 * (j3 + 1) / 2;
-          const T a0 = A[j <= ic ? Tc + j : Tj + ic];
-          const T a1 = A[j1 <= ic ? Tc + j1 : T1 + ic];
-          const T a2 = A[j2 <= ic ? Tc + j2 : T2 + ic];
-          const T a3 = A[j3 <= ic ? Tc + j3 : T3 + ic];
-          const T v0 = vv[j], v1 = vv[j1], v2 = vv[j2], v3 = vv[j3];
-          q0 = fma(a0, v0, q0);
-          q1 = fma(a1, v1, q1);
-          q2 = fma(a2, v2, q2);
-          q3 = fma(a3, v3, q3);
-          const int j4 = j + 4 * SPLIT;
-          Tj = j4 * (j4 + 1) / 2;
-        }
-        for (; j < r; j += SPLIT) q0 = fma(A[j <= ic ? Tc + j : j * (j + 1) / 2 + ic], vv[j], q0);
-        T q = (q0 + q1) + (q2 + q3);
-        if constexpr (SPLIT >= 2) q += __shfl_xor(q, 1);
-        if constexpr (SPLIT >= 4) q += __shfl_xor(q, 2);
-        if (has) {
-          p = taup * (q - alpha * A[Ti + i0]);
-          vi = i == i0 ? x - alpha : x;
-        }
-      }
-      const T pv = bsum<T, NW>(part == 0 ? p * vi : T(0), rd + kWaves, tid);                // barrier 2
-      const T K = T(0.5) * taup * pv;
-      const T w = fma(-K, vi, p);
-      if (has && part == 0) {
-        ww[i] = w;
-        if (i == i0) vv[i0] = vi;
-      }
-      __syncthreads();                                               // barrier 3
-      // A -= v w' + w v' on the lower triangle of the live block
-      if (has) {
-        T* row = A + Ti;
-        int j = i0 + part;
-        for (; j + SPLIT <= i; j += 2 * SPLIT) {
-          const T r0 = row[j], r1 = row[j + SPLIT];
-          const T w0 = ww[j], w1 = ww[j + SPLIT], u0 = vv[j], u1 = vv[j + SPLIT];
-          row[j] = r0 - (vi * w0 + w * u0);
-          row[j + SPLIT] = r1 - (vi * w1 + w * u1);
-        }
-        if (j <= i) row[j] = row[j] - (vi * ww[j] + w * vv[j]);
-      }
-      if (tid == 0) { dd[kc] = A[kc * (kc + 1) / 2 + kc]; ee[kc] = alpha; }
-      __syncthreads();                                               // barrier 4
-    }
-    if (tid == 0) {
-      if (r >= 2) {
-        dd[r - 2] = A[(r - 2) * (r - 1) / 2 + (r - 2)];
-        ee[r - 2] = A[(r - 1) * r / 2 + (r - 2)];
-      }
-      dd[r - 1] = A[(r - 1) * r / 2 + (r - 1)];
-      ee[r - 1] = T(0);
-    }
-    __syncthreads();
+    tridiagonalise<T, SPLIT, NTH, false>(A, r, dd, ee, nullptr, vv, ww, red, tid);
+#ifdef RAYEN_LB_PROFILE
+    lb_t_ = clock64();
+#endif
 
     // ---- lambda_max of the tridiagonal: Gershgorin bracket, then Sturm counts at 512 shifts per round
     T lo, hi, scale;
@@ -259,6 +367,10 @@ __global__ __launch_bounds__(NTH) void lmi_block_kernel(
       hi = new_hi;
     }
     const T lam = T(0.5) * (lo + hi);
+    LB_TICK(5);
+#ifdef RAYEN_LB_PROFILE
+    if (threadIdx.x == 0 && blockIdx.x == 0) { g_lb_prof[6] += clock64() - lb_start; g_lb_prof[7] += 1; }
+#endif
     if (lam > kap) { kap = lam; aseg = lmi_seg; arow = 0; }
 
     const T scl = T(1) / fmax(T(1), kap);
@@ -284,12 +396,197 @@ __global__ __launch_bounds__(NTH) void lmi_block_kernel(
   if (nan_flag && bad) atomicOr(nan_flag, 1);
 }
 
+// LDS of the backward's workgroup: A[P] | dd[r] (later the eigenvector) | ee[r] | vv[r] | ww[r] | tt[r] | red | vs[n] | ts[n]
+__host__ __device__ inline size_t lds_bwd_elems(int r, int n) {
+  return (size_t)r * (r + 1) / 2 + 5 * (size_t)r + 6 * kWaves + 2 * (size_t)n + 8;
+}
+
+// grad_v for one sample per workgroup.  y = y0 + NA_E v / max(1, kappa):
+//   grad_v = NA_E' g / max(1, kappa) - [kappa > 1] (g' NA_E v) / kappa^2 * d kappa / d v,
+// and d kappa / d v_a = x' G_a x for the unit eigenvector x of lambda_max(S(v)) when the LMI is the active row (a row of D
+// otherwise).  The reduction is repeated keeping the reflectors; x = H_0 ... H_{r-3} z, z the eigenvector of the tridiagonal
+// matrix (inverse iteration at the forward's kappa, the same factorisation with the same guards as rayen_lmi_wave.h:323-354);
+// then x x' (off-diagonal entries twice) replaces the matrix in packed order and every generator is ONE dot product with it,
+// a wave each -- the same n P words of G the forward reads.
+template <typename T, int SPLIT, int NTH>
+__global__ __launch_bounds__(NTH) void lmi_block_bwd_kernel(
+    const T* __restrict__ gt, const T* __restrict__ dt, const T* __restrict__ nrm, const int32_t* __restrict__ rho_of, int r,
+    int n, int k, int P, int Pp, int Mp, int identity, int lmi_seg, const T* __restrict__ v, int64_t B, int64_t ldv,
+    const T* __restrict__ kappa, const int32_t* __restrict__ active, const T* __restrict__ gy, int64_t ldg,
+    T* __restrict__ gv, int64_t ldgv) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lb_smem[];
+  T* A = reinterpret_cast<T*>(lb_smem);
+  T* dd = A + P;
+  T* ee = dd + r;
+  T* vv = ee + r;
+  T* ww = vv + r;
+  T* tt = ww + r;
+  T* red = tt + r;            // [3][2 * kWaves]
+  T* vs = red + 6 * kWaves;
+  T* ts = vs + n;
+  T* zz = dd;                 // (the diagonal is dead once (kappa + shift) I - T is factorised)
+  constexpr int NW = NTH / 64;
+  constexpr int kMaxChunks = 5;             // rows of the eigenvector a lane of the mapping-back wave holds: r <= 320
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();          // (the previous sample's last readers)
+    for (int a = tid; a < n; a += NTH) vs[a] = v[b * ldv + a];
+    const T* grow = gy + b * ldg;
+    T tv = T(0);
+    for (int a = tid; a < n; a += NTH) {
+      T acc;
+      if (identity) {
+        acc = grow[a];
+      } else {
+        T a0 = T(0), a1 = T(0), a2 = T(0), a3 = T(0);
+        const T* col = nrm + a;
+        int i = 0;
+        for (; i + 3 < k; i += 4) {
+          a0 = fma(col[(size_t)(i + 0) * n], grow[i + 0], a0);
+          a1 = fma(col[(size_t)(i + 1) * n], grow[i + 1], a1);
+          a2 = fma(col[(size_t)(i + 2) * n], grow[i + 2], a2);
+          a3 = fma(col[(size_t)(i + 3) * n], grow[i + 3], a3);
+        }
+        for (; i < k; ++i) a0 = fma(col[(size_t)i * n], grow[i], a0);
+        acc = (a0 + a1) + (a2 + a3);
+      }
+      ts[a] = acc;
+      tv = fma(acc, v[b * ldv + a], tv);
+    }
+    tv = bsum<T, NW>(tv, red + 2 * 2 * kWaves, tid);         // (vs and ts are visible after this barrier)
+    const T kap = kappa[b];
+    const int aseg = active[2 * b], arow = active[2 * b + 1];
+    const bool clipped = kap > T(1) && aseg >= 0;
+    const T sc = T(1) / fmax(T(1), kap);
+    const T coef = clipped ? sc * sc * tv : T(0);
+
+    if (!(clipped && aseg == lmi_seg)) {                     // (the same for the whole workgroup)
+      const int rho = clipped ? rho_of[arow] : -1;
+      for (int a = tid; a < n; a += NTH) {
+        const T u = rho >= 0 ? dt[(size_t)a * Mp + rho] : T(0);
+        gv[b * ldgv + a] = fma(sc, ts[a], -coef * u);
+      }
+      continue;
+    }
+
+    form_S<T, NTH>(A, gt, vs, n, P, Pp, tid);
+    __syncthreads();
+    tridiagonalise<T, SPLIT, NTH, true>(A, r, dd, ee, tt, vv, ww, red, tid);
+
+    // ---- z: inverse iteration on M = (kappa + shift) I - T = L D L'.  ww: D, vv: the sub-diagonal of L.
+    if (wave == 0) {
+      T scale = fabs(kap);
+      for (int i = lane; i < r; i += 64) scale = fmax(scale, fabs(dd[i]));
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) scale = fmax(scale, __shfl_xor(scale, o));
+      const T shift = lw::Eps<T>::shift * fmax(scale, lw::Eps<T>::tiny);
+      if (lane == 0) {
+        T dprev = fmax(kap + shift - dd[0], shift * T(1e-3));
+        ww[0] = dprev;
+        vv[0] = T(0);
+        for (int i = 1; i < r; ++i) {
+          const T li = ee[i - 1] / dprev;              // M's off-diagonal is -ee: l = -ee / D, kept with the sign folded
+          const T di = fmax(kap + shift - dd[i] - li * ee[i - 1], shift * T(1e-3));
+          vv[i] = -li;
+          ww[i] = T(1) / di;                           // (the solves multiply)
+          dprev = di;
+        }
+        ww[0] = T(1) / ww[0];
+        for (int i = 0; i < r; ++i) zz[i] = T(1) + T(0.01) * (T)i;   // not orthogonal to anything special
+        for (int it = 0; it < 3; ++it) {
+          T prev = zz[0];
+          for (int i = 1; i < r; ++i) { prev = fma(-vv[i], prev, zz[i]); zz[i] = prev; }     // L y = b
+          prev = prev * ww[r - 1];
+          zz[r - 1] = prev;
+          T nrm2 = prev * prev;
+          for (int i = r - 2; i >= 0; --i) {                                                   // D L' z = y
+            prev = fma(-vv[i + 1], prev, zz[i] * ww[i]);
+            zz[i] = prev;
+            nrm2 = fma(prev, prev, nrm2);
+          }
+          const T inv = T(1) / sqrt(fmax(nrm2, lw::Eps<T>::tiny));
+          for (int i = 0; i < r; ++i) zz[i] *= inv;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      // ---- x = H_0 H_1 ... H_{r-3} z, the vector in this wave's registers (row lane + 64 q)
+      T xq[kMaxChunks];
+#pragma unroll
+      for (int q = 0; q < kMaxChunks; ++q) xq[q] = lane + 64 * q < r ? zz[lane + 64 * q] : T(0);
+      for (int c = r - 3; c >= 0; --c) {
+        const T tc = tt[c];
+        if (tc == T(0)) continue;                      // (wave-uniform)
+        const T alpha = ee[c];
+        T hv[kMaxChunks];
+        T dot = T(0);
+#pragma unroll
+        for (int q = 0; q < kMaxChunks; ++q) {
+          const int i = lane + 64 * q;
+          T h = T(0);
+          if (i > c && i < r) {
+            h = A[i * (i + 1) / 2 + c];
+            if (i == c + 1) h -= alpha;
+          }
+          hv[q] = h;
+          dot = fma(h, xq[q], dot);
+        }
+        dot = lw::wsum(dot) * tc;
+#pragma unroll
+        for (int q = 0; q < kMaxChunks; ++q) xq[q] = fma(-dot, hv[q], xq[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < kMaxChunks; ++q)
+        if (lane + 64 * q < r) zz[lane + 64 * q] = xq[q];
+    }
+    __syncthreads();
+    // ---- x_i x_j (twice off the diagonal) in packed order over the matrix storage
+    for (int idx = tid; idx < P; idx += NTH) {
+      int i = (int)((sqrtf(8.f * (float)idx + 1.f) - 1.f) * 0.5f);
+      while ((i + 1) * (i + 2) / 2 <= idx) ++i;
+      while (i * (i + 1) / 2 > idx) --i;
+      const int j = idx - i * (i + 1) / 2;
+      A[idx] = (i == j ? T(1) : T(2)) * zz[i] * zz[j];
+    }
+    __syncthreads();
+    // ---- one contraction per generator, a wave each
+    for (int a = wave; a < n; a += NW) {
+      const T* col = gt + (size_t)a * Pp;
+      T p0 = T(0), p1 = T(0), p2 = T(0), p3 = T(0);
+      int idx = lane;
+      for (; idx + 192 < P; idx += 256) {
+        p0 = fma(col[idx], A[idx], p0);
+        p1 = fma(col[idx + 64], A[idx + 64], p1);
+        p2 = fma(col[idx + 128], A[idx + 128], p2);
+        p3 = fma(col[idx + 192], A[idx + 192], p3);
+      }
+      for (; idx < P; idx += 64) p0 = fma(col[idx], A[idx], p0);
+      const T part = lw::wsum((p0 + p1) + (p2 + p3));
+      if (lane == 0) gv[b * ldgv + a] = fma(sc, ts[a], -coef * part);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 bool lmi_block_serves_t(const LmiWaveImage* img) {
   return img != nullptr && img->r >= 2 && lds_elems(img->r, img->n) * sizeof(T) <= kLdsMax;
+}
+
+template <typename T>
+bool lmi_block_bwd_serves_t(const LmiWaveImage* img) {
+  return img != nullptr && img->r >= 2 && img->r <= 320 && lds_bwd_elems(img->r, img->n) * sizeof(T) <= kLdsMax;
+}
+
+template <typename T, typename F>
+void with_bwd_instance(int r, F f) {
+  if (r <= 128) f(lmi_block_bwd_kernel<T, 4, 512>, 512);
+  else if (r <= 256) f(lmi_block_bwd_kernel<T, 2, 512>, 512);
+  else f(lmi_block_bwd_kernel<T, 2, 1024>, 1024);
 }
 
 template <typename T, typename F>
@@ -307,6 +604,10 @@ int lmi_block_prepare_t(const LmiWaveImage* img) {
   with_instance<T>(img->r, [&](auto kern, int) {
     ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax) == hipSuccess;
   });
+  if (ok && lmi_block_bwd_serves_t<T>(img))
+    with_bwd_instance<T>(img->r, [&](auto kern, int) {
+      ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax) == hipSuccess;
+    });
   if (!ok) { (void)hipGetLastError(); return RAYEN_E_LAUNCH; }
   return RAYEN_OK;
 }
@@ -332,6 +633,29 @@ int lmi_block_forward_t(const RayenPack* p, const LmiWaveImage* img, const T* v,
                        static_cast<const T*>(img->dt), static_cast<const T*>(img->nat), static_cast<const T*>(img->y0),
                        img->lin_id, img->r, img->n, img->k, img->m, img->P, img->Pp, img->Mp, img->Kp, img->identity,
                        img->lmi_seg, v, B, ldv, y, ldy, kappa, active, nan_flag);
+  });
+  return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
+}
+
+template <typename T>
+int lmi_block_backward_t(const RayenPack* p, const LmiWaveImage* img, const T* v, int64_t B, int64_t ldv, const T* kappa,
+                         const int32_t* active, const T* gy, int64_t ldg, T* gv, int64_t ldgv, hipStream_t stream) {
+  if (!lmi_block_bwd_serves_t<T>(img)) return RAYEN_E_UNSUPPORTED;
+  if (B == 0) return RAYEN_OK;
+  const size_t lds = lds_bwd_elems(img->r, img->n) * sizeof(T);
+  int cus = 256;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  }
+  with_bwd_instance<T>(img->r, [&](auto kern, int nth) {
+    int per_cu = (int)(kLdsMax / lds);
+    const int by_threads = 2048 / nth;
+    per_cu = per_cu < 1 ? 1 : (per_cu > by_threads ? by_threads : per_cu);
+    const int64_t grid = B < (int64_t)cus * per_cu ? B : (int64_t)cus * per_cu;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(nth), lds, stream, static_cast<const T*>(img->gt),
+                       static_cast<const T*>(img->dt), static_cast<const T*>(img->nrm), img->rho_of, img->r, img->n, img->k,
+                       img->P, img->Pp, img->Mp, img->identity, img->lmi_seg, v, B, ldv, kappa, active, gy, ldg, gv, ldgv);
   });
   return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
 }

@@ -28,4 +28,25 @@ int lmi_block_forward_f64(const RayenPack* p, const LmiWaveImage* img, const dou
   return lb::lmi_block_forward_t<double>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
 }
 
+bool lmi_block_bwd_serves_f32(const LmiWaveImage* img) { return lb::lmi_block_bwd_serves_t<float>(img); }
+bool lmi_block_bwd_serves_f64(const LmiWaveImage* img) { return lb::lmi_block_bwd_serves_t<double>(img); }
+int lmi_block_backward_f32(const RayenPack* p, const LmiWaveImage* img, const float* v, int64_t B, int64_t ldv,
+                           const float* kappa, const int32_t* active, const float* grad_y, int64_t ldg, float* grad_v,
+                           int64_t ldgv, hipStream_t stream) {
+  return lb::lmi_block_backward_t<float>(p, img, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, stream);
+}
+int lmi_block_backward_f64(const RayenPack* p, const LmiWaveImage* img, const double* v, int64_t B, int64_t ldv,
+                           const double* kappa, const int32_t* active, const double* grad_y, int64_t ldg, double* grad_v,
+                           int64_t ldgv, hipStream_t stream) {
+  return lb::lmi_block_backward_t<double>(p, img, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, stream);
+}
 }  // namespace rayen
+
+#ifdef RAYEN_LB_PROFILE
+extern "C" void rayen_debug_lb_prof(unsigned long long* out8) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(rayen::lb::g_lb_prof), 8 * sizeof(unsigned long long));
+  unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(rayen::lb::g_lb_prof), zero, sizeof(zero));
+}
+#endif

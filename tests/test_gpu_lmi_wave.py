@@ -46,6 +46,36 @@ CASES = {
 }
 
 
+def _check_backward(cs, buf64, x, xd, xr, y_true_t, kappa, active, dp, dtype, r, gen, name):
+    """grad_v of the kernels against autograd through the fp64 oracle (eigvalsh), kinks set aside."""
+    B = x.shape[0]
+    g = torch.empty(B, cs.k).uniform_(-1, 1, generator=gen)
+    (y_true_t[:, :, 0] * g.double()).sum().backward()
+    want = xr.grad[:, :, 0].numpy()
+    got = ops.backward_raw(xd, kappa, active, g.to(dtype).cuda(), dp).cpu().double().numpy()
+    assert np.all(np.isfinite(got))
+    size = np.maximum(np.abs(want).max(axis=1), 1e-30)
+    gerr = np.abs(got - want).max(axis=1) / size
+    gerr[2] = 0.0                                             # v = 0: eigvalsh of the zero matrix has no derivative worth comparing
+    # kinks: the two largest eigenvalues (nearly) tie, or kappa within rounding of 1 / of the linear rows' maximum
+    terms = oracle.compute_kappa(buf64, torch.nn.functional.normalize(x.double().unsqueeze(2), dim=1), terms=True).numpy()
+    lam_gap = np.abs(terms[:, -1] - terms[:, -2]) / np.maximum(np.abs(terms[:, -1]), 1e-30)
+    kap = kappa.cpu().double().numpy()
+    kink = (lam_gap < (1e-3 if dtype == torch.float32 else 1e-7)) | (np.abs(kap - 1.0) < 1e-4)
+    if terms.shape[1] > 2:
+        top_lin = terms[:, :-2].max(axis=1)
+        kink |= np.abs(top_lin - np.maximum(terms[:, -1], 0.0)) < 1e-4 * np.maximum(np.abs(top_lin), 1e-30)
+    tol = 2e-3 if dtype == torch.float32 else 1e-7
+    # (nearly repeated top eigenvalues that are no kink yet: what a backward-stable eigen-solver delivers,
+    # eps r ||S|| / gap, next to the flat tolerance)
+    eps = 6e-8 if dtype == torch.float32 else 1.1e-16
+    bound = np.maximum(tol, 8.0 * r * eps / np.maximum(lam_gap, 1e-30))
+    bad = (~kink) & ~(gerr <= bound)
+    assert not bad.any(), (name, int(bad.sum()), np.flatnonzero(bad)[:5], gerr[bad][:5], bound[bad][:5])
+    assert kink.sum() <= max(3, 0.05 * B)
+    return got
+
+
 def _layer(raw, dtype):
     prev = torch.get_default_dtype()
     torch.set_default_dtype(dtype)
@@ -61,7 +91,7 @@ def _layer(raw, dtype):
 @pytest.mark.parametrize("kernel", ["block", "wave"])
 def test_large_lmi_forward_and_backward(name, dtype, kernel, monkeypatch):
     """``kernel``: the forward on the workgroup-per-sample kernel (rayen_lmi_block.h, round 5: the default wherever it
-    serves) or, pinned with RAYEN_LMI_BLOCK=0, on the wave-per-sample kernel; the backward is the wave kernel's either way."""
+    serves) or, pinned with RAYEN_LMI_BLOCK=0, on the wave-per-sample kernel; the same switch moves the backward."""
     monkeypatch.setenv("RAYEN_LMI_BLOCK", "1" if kernel == "block" else "0")
     raw = _case(**CASES[name])
     r = CASES[name]["r"]
@@ -94,31 +124,7 @@ def test_large_lmi_forward_and_backward(name, dtype, kernel, monkeypatch):
     assert cs.getMaxViolation(y.cpu().double().numpy()) <= (1e-9 if dtype == torch.float64 else 2e-4)
     assert np.allclose(y[2].cpu().double().numpy(), cs.y0[:, 0], atol=1e-12 if dtype == torch.float64 else 1e-6)
 
-    # ---- backward against autograd through the fp64 oracle
-    g = torch.empty(B, cs.k).uniform_(-1, 1, generator=gen)
-    (y_true_t[:, :, 0] * g.double()).sum().backward()
-    want = xr.grad[:, :, 0].numpy()
-    got = ops.backward_raw(xd, kappa, active, g.to(dtype).cuda(), dp).cpu().double().numpy()
-    assert np.all(np.isfinite(got))
-    size = np.maximum(np.abs(want).max(axis=1), 1e-30)
-    gerr = np.abs(got - want).max(axis=1) / size
-    gerr[2] = 0.0                                             # v = 0: eigvalsh of the zero matrix has no derivative worth comparing
-    # kinks: the two largest eigenvalues (nearly) tie, or kappa within rounding of 1 / of the linear rows' maximum
-    terms = oracle.compute_kappa(buf64, torch.nn.functional.normalize(x.double().unsqueeze(2), dim=1), terms=True).numpy()
-    lam_gap = np.abs(terms[:, -1] - terms[:, -2]) / np.maximum(np.abs(terms[:, -1]), 1e-30)
-    kap = kappa.cpu().double().numpy()
-    kink = (lam_gap < (1e-3 if dtype == torch.float32 else 1e-7)) | (np.abs(kap - 1.0) < 1e-4)
-    if terms.shape[1] > 2:
-        top_lin = terms[:, :-2].max(axis=1)
-        kink |= np.abs(top_lin - np.maximum(terms[:, -1], 0.0)) < 1e-4 * np.maximum(np.abs(top_lin), 1e-30)
-    tol = 2e-3 if dtype == torch.float32 else 1e-7
-    # (nearly repeated top eigenvalues that are no kink yet: what a backward-stable eigen-solver delivers,
-    # eps r ||S|| / gap, next to the flat tolerance)
-    eps = 6e-8 if dtype == torch.float32 else 1.1e-16
-    bound = np.maximum(tol, 8.0 * r * eps / np.maximum(lam_gap, 1e-30))
-    bad = (~kink) & ~(gerr <= bound)
-    assert not bad.any(), (name, int(bad.sum()), np.flatnonzero(bad)[:5], gerr[bad][:5], bound[bad][:5])
-    assert kink.sum() <= max(3, 0.05 * B)
+    _check_backward(cs, buf64, x, xd, xr, y_true_t, kappa, active, dp, dtype, r, gen, name)
 
 
 BIG = {
@@ -132,11 +138,14 @@ BIG = {
 @pytest.mark.parametrize("name,dtype", [("r200_lin", torch.float32), ("r196_eq", torch.float64), ("r196_eq", torch.float32),
                                          ("r250", torch.float32), ("r280_lin", torch.float32)])
 def test_matrices_only_the_block_kernel_holds(name, dtype):
-    """Forward of LMIs up to 281 x 281 (fp32) / 197 x 197 (fp64) on a hand-written kernel -- the reference's own sweep ends
-    at 300 x 300 (time_analysis.py:157-160); rounds 3-4 sent everything beyond ~190 / ~135 to rocSOLVER through the packed
-    torch evaluator.  This suite runs with RAYEN_STRICT_HIP=1 (conftest): a detour would raise."""
+    """Forward AND backward of LMIs up to 280 x 280 (fp32) / 196 x 196 (fp64) on hand-written kernels -- the reference's own
+    sweep ends at 300 x 300 (time_analysis.py:157-160); rounds 3-4 sent everything beyond ~190 / ~135 to rocSOLVER through
+    the packed torch evaluator.  This suite runs with RAYEN_STRICT_HIP=1 (conftest): a detour would raise, and the
+    wave-per-sample kernels refuse these sizes (their full r x r storage does not fit)."""
     raw = _case(**BIG[name])
+    r = BIG[name]["r"]
     cs, layer = _layer(raw, dtype)
+    dp, _ = layer.device_pack(torch.device("cuda", 0))
     gen = torch.Generator().manual_seed(2)
     B = 40
     x = torch.empty(B, cs.n, 1).uniform_(-2.0, 2.0, generator=gen)
@@ -144,7 +153,10 @@ def test_matrices_only_the_block_kernel_holds(name, dtype):
     x[2] = 0.0
     y = layer(x.to(dtype).cuda())
     assert _lib.load().rayen_last_forward_kernel() == _lib.KERNEL_LMI_BLOCK and not layer._hip_unsupported
-    y_true = oracle.forward(oracle.precompute(csd_from_cs(cs), torch.float64), x.double()).numpy()[:, :, 0]
+    buf64 = oracle.precompute(csd_from_cs(cs), torch.float64)
+    xr = x.double().clone().requires_grad_(True)
+    y_true_t = oracle.forward(buf64, xr)
+    y_true = y_true_t.detach().numpy()[:, :, 0]
     err = rel_err_rows(y.cpu().double().numpy()[:, :, 0], y_true)
     if dtype == torch.float64:
         assert err.max() <= 1e-9, (name, err.max())
@@ -156,6 +168,17 @@ def test_matrices_only_the_block_kernel_holds(name, dtype):
     # the batch does not matter (persistent workgroups, one sample after the other), nor does a second launch
     y2 = layer(x[:7].to(dtype).cuda())
     assert torch.equal(y2, y[:7]) and torch.equal(layer(x.to(dtype).cuda()), y)
+    # ---- backward: the kernel's grad_v against autograd through the fp64 oracle, and through the module's autograd
+    xd = x[:, :, 0].to(dtype).cuda().contiguous()
+    yk, kappa, active = ops.project_raw(xd, dp, want_active=True)
+    assert torch.equal(yk, y[:, :, 0])
+    got = _check_backward(cs, buf64, x[:, :, 0], xd, xr, y_true_t, kappa, active, dp, dtype, r, gen, name)
+    assert torch.equal(ops.backward_raw(xd[:7].contiguous(), kappa[:7].contiguous(), active[:7].contiguous(),
+                                        torch.ones(7, cs.k, dtype=dtype, device="cuda"), dp),
+                       ops.backward_raw(xd, kappa, active, torch.ones(B, cs.k, dtype=dtype, device="cuda"), dp)[:7])
+    xg = x.to(dtype).cuda().requires_grad_(True)
+    layer(xg).sum().backward()
+    assert not layer._hip_unsupported and torch.isfinite(xg.grad).all() and got.shape == (B, cs.n)
 
 
 @pytest.mark.parametrize("kernel", ["block", "wave"])
