@@ -36,13 +36,23 @@ __device__ unsigned long long g_lb_prof[8];
 
 constexpr int kWaves = 16;                   // slots of the reduction scratch (the largest workgroup's waves)
 constexpr size_t kLdsMax = 160 * 1024;
-// threads that share a row of the matrix, and threads of the workgroup: every row has its threads
-__host__ __device__ inline int split_for(int r) { return r <= 128 ? 4 : 2; }
-__host__ __device__ inline int threads_for(int r) { return r <= 256 ? 512 : 1024; }
+// threads of the workgroup (at least two per row of the matrix)
+__host__ __device__ inline int threads_for(int r) { return r <= 128 ? 512 : 1024; }
 
 // LDS of a workgroup (units of T): A[P] | dd[r] | ee[r] | vv[r] | ww[r] | red[3][2 kWaves] | vs[n]
 __host__ __device__ inline size_t lds_elems(int r, int n) {
   return (size_t)r * (r + 1) / 2 + 4 * (size_t)r + 6 * kWaves + (size_t)n + 8;
+}
+
+// e^2 / q of the Sturm recurrence: the count needs the SIGN of the next pivot, and the bracket is padded by 1e-6 of the
+// matrix scale -- the hardware reciprocal (1 ulp) does in fp32 (two instructions in the dependent chain instead of ten)
+__device__ __forceinline__ float quot(float e2, float q) { return e2 * __builtin_amdgcn_rcpf(q); }
+__device__ __forceinline__ double quot(double e2, double q) { return e2 / q; }
+
+// ... with the first hc columns in registers (head_phase): the packed triangle of the other r - hc rows / columns
+__host__ __device__ inline size_t lds_elems_head(int r, int n, int hc, bool bwd) {
+  const size_t rp = (size_t)(r - hc);
+  return rp * (rp + 1) / 2 + (bwd ? 5 : 4) * (size_t)r + 6 * kWaves + (bwd ? 2 : 1) * (size_t)n + 8;
 }
 
 // sum over the workgroup, returned to every thread; ONE barrier.  `red` (kWaves slots) must not be written again before the
@@ -61,11 +71,23 @@ __device__ __forceinline__ T bsum(T x, T* red, const int tid) {
 // S(v) = sum_a v_a G_a, lower triangle packed (no barrier: the caller synchronises)
 template <typename T, int NTH>
 __device__ __forceinline__ void form_S(T* A, const T* __restrict__ gt, const T* vs, int n, int P, int Pp, const int tid) {
-  // ---- S(v), lower triangle packed
+  // sixteen generators' words in flight per thread (four were latency-bound: 0.57 of 3.56 M cycles per sample at r = 250, k = 100)
   for (int idx = tid; idx < P; idx += NTH) {
     T p0 = T(0), p1 = T(0), p2 = T(0), p3 = T(0);
     const T* col = gt + idx;
     int a = 0;
+    for (; a + 15 < n; a += 16) {
+      T g[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) g[u] = col[(size_t)(a + u) * Pp];
+#pragma unroll
+      for (int u = 0; u < 16; u += 4) {
+        p0 = fma(vs[a + u + 0], g[u + 0], p0);
+        p1 = fma(vs[a + u + 1], g[u + 1], p1);
+        p2 = fma(vs[a + u + 2], g[u + 2], p2);
+        p3 = fma(vs[a + u + 3], g[u + 3], p3);
+      }
+    }
     for (; a + 3 < n; a += 4) {
       p0 = fma(vs[a + 0], col[(size_t)(a + 0) * Pp], p0);
       p1 = fma(vs[a + 1], col[(size_t)(a + 1) * Pp], p1);
@@ -77,161 +99,209 @@ __device__ __forceinline__ void form_S(T* A, const T* __restrict__ gt, const T* 
   }
 }
 
-// Lane layout of a wave in the reduction: W = 64 / SPLIT consecutive rows, row `lane % W`; the SPLIT lanes `lane / W` of a
-// row take its columns i0 + part, + SPLIT, ...  (a half-wave reads 32 consecutive words, or 32 row starts, at once).
+// Lane layout of a wave in one column step of the reduction: W = 64 / SPLIT consecutive rows, row `lane % W`; the SPLIT lanes
+// `lane / W` of a row take its columns i0 + part, + SPLIT, ...  (with two lanes per row a half-wave reads 32 consecutive
+// words, or 32 row starts, at once).  SPLIT is chosen PER COLUMN: as the live block shrinks, more lanes share a row
+// (tridiagonalise), so a lane's share of the row -- the length of the dependent chain between two barriers -- stays short.
 //
 // q_i = sum_{j = i0}^{r-1} A(i, j) x_j for row ic of the live block (the part of it this lane's columns hold).  The column
 // index runs for the whole wave at once, in three stretches that need no per-lane address arithmetic beyond an add:
 //   j below the wave's first row: every lane reads its own row, A[T(ic) + j]: one pointer, immediate offsets;
-//   j among the wave's rows (W columns): own row or the mirrored entry A[T(j) + ic], by comparison;
+//   j among the wave's rows: own row or the mirrored entry A[T(j) + ic], by comparison;
 //   j beyond the wave's last row: every lane reads the mirrored entry; T(j + SPLIT) - T(j) = SPLIT j + SPLIT (SPLIT + 1) / 2
 //   grows by SPLIT^2 per step, so the offsets are running sums.
 // (The first version computed T(j) and the comparison for every element: ~12 vector instructions and a 32-bit multiply per
-// element made the reduction instruction-bound at a seventh of what LDS delivers.)
-template <typename T, int SPLIT>
+// element; profiles/r05_lmi_block_phases.txt.)
+template <typename T, int SPLIT, bool SUM = true>
 __device__ __forceinline__ T matvec_row(const T* A, const T* vv, int r, int i0, int wave, int ic, int part) {
-  constexpr int W = 64 / SPLIT, UA = W / SPLIT, S2 = SPLIT * SPLIT * (int)sizeof(T);
+  constexpr int W = 64 / SPLIT, S2 = SPLIT * SPLIT * (int)sizeof(T), SZ = (int)sizeof(T);
   const char* Ab = reinterpret_cast<const char*>(A);
   auto at = [&](int byte_off) { return *reinterpret_cast<const T*>(Ab + byte_off); };
   T q0 = T(0), q1 = T(0), q2 = T(0), q3 = T(0);
   const int Tc = ic * (ic + 1) / 2;
-  const int nA = UA * wave;                          // steps with j below the wave's first row
   const int nU = (r - i0) / SPLIT;                   // steps every part has a column for
+  const int nA = (W * wave) / SPLIT;                 // steps with j below the wave's first row, whatever the part
+  int nB = (W * wave + W - 1) / SPLIT + 1;           // first step with j beyond the wave's last row, whatever the part
+  nB = nB < nU ? nB : nU;
   const T* pv = vv + i0 + part;
   const T* pa = A + Tc + i0 + part;
-  for (int t = 0; t < nA; t += UA) {
+  constexpr int UC = sizeof(T) == 4 ? 8 : 4;        // (elements in flight per lane; the fp64 instances have no registers for 8)
+  int t = 0;
+  for (; t + UC <= nA; t += UC) {
 #pragma unroll
-    for (int u = 0; u < UA; u += 4) {
+    for (int u = 0; u < UC; u += 4) {
       q0 = fma(pa[SPLIT * (u + 0)], pv[SPLIT * (u + 0)], q0);
       q1 = fma(pa[SPLIT * (u + 1)], pv[SPLIT * (u + 1)], q1);
       q2 = fma(pa[SPLIT * (u + 2)], pv[SPLIT * (u + 2)], q2);
       q3 = fma(pa[SPLIT * (u + 3)], pv[SPLIT * (u + 3)], q3);
     }
-    pa += SPLIT * UA;
-    pv += SPLIT * UA;
+    pa += SPLIT * UC;
+    pv += SPLIT * UC;
   }
-  int j = i0 + part + SPLIT * nA;                    // the wave's first row + part
-  int offM = (j * (j + 1) / 2 + ic) * (int)sizeof(T);                             // (bytes) the mirrored entry (j, ic)
-  int dj = (SPLIT * j + SPLIT * (SPLIT + 1) / 2) * (int)sizeof(T);
-  int t = nA;
-  const int nB = nA + UA < nU ? nA + UA : nU;
+  for (; t < nA; ++t) {
+    q0 = fma(pa[0], pv[0], q0);
+    pa += SPLIT;
+    pv += SPLIT;
+  }
+  int j = i0 + part + SPLIT * nA;
+  int offM = (j * (j + 1) / 2 + ic) * SZ;                             // (bytes) the mirrored entry (j, ic)
+  int dj = (SPLIT * j + SPLIT * (SPLIT + 1) / 2) * SZ;
 #pragma unroll 4
   for (; t < nB; ++t) {
-    const T a = at(j <= ic ? (Tc + j) * (int)sizeof(T) : offM);
+    const T a = at(j <= ic ? (Tc + j) * SZ : offM);
     q0 = fma(a, *pv, q0);
     offM += dj;
     dj += S2;
     j += SPLIT;
     pv += SPLIT;
   }
-  for (; t + 4 <= nU; t += 4) {
-    const int o1 = offM + dj, o2 = o1 + dj + S2, o3 = o2 + dj + 2 * S2;
-    q0 = fma(at(offM), pv[0], q0);
-    q1 = fma(at(o1), pv[SPLIT], q1);
-    q2 = fma(at(o2), pv[2 * SPLIT], q2);
-    q3 = fma(at(o3), pv[3 * SPLIT], q3);
-    offM = o3 + dj + 3 * S2;
-    dj += 4 * S2;
-    pv += 4 * SPLIT;
-    j += 4 * SPLIT;
+  for (; t + UC <= nU; t += UC) {
+    int o[UC];
+    o[0] = offM;
+#pragma unroll
+    for (int u = 1; u < UC; ++u) o[u] = o[u - 1] + dj + (u - 1) * S2;
+    T a[UC];
+#pragma unroll
+    for (int u = 0; u < UC; ++u) a[u] = at(o[u]);
+#pragma unroll
+    for (int u = 0; u < UC; u += 4) {
+      q0 = fma(a[u + 0], pv[(u + 0) * SPLIT], q0);
+      q1 = fma(a[u + 1], pv[(u + 1) * SPLIT], q1);
+      q2 = fma(a[u + 2], pv[(u + 2) * SPLIT], q2);
+      q3 = fma(a[u + 3], pv[(u + 3) * SPLIT], q3);
+    }
+    offM = o[UC - 1] + dj + (UC - 1) * S2;
+    dj += UC * S2;
+    pv += UC * SPLIT;
+    j += UC * SPLIT;
   }
   for (; t < nU; ++t) {
-    q0 = fma(at(offM), *pv, q0);
+    q1 = fma(at(offM), *pv, q1);
     offM += dj;
     dj += S2;
     pv += SPLIT;
     j += SPLIT;
   }
-  if (j < r) q0 = fma(at(j <= ic ? (Tc + j) * (int)sizeof(T) : offM), *pv, q0);     // (the parts that have one more column)
+  if (j < r) q2 = fma(at(j <= ic ? (Tc + j) * SZ : offM), *pv, q2);     // (the parts that have one more column)
   T q = (q0 + q1) + (q2 + q3);
-  if constexpr (SPLIT >= 4) q += __shfl_xor(q, 16);
-  if constexpr (SPLIT >= 2) q += __shfl_xor(q, 32);
+  if constexpr (SUM) {
+    if constexpr (SPLIT >= 8) q += __shfl_xor(q, 8);
+    if constexpr (SPLIT >= 4) q += __shfl_xor(q, 16);
+    if constexpr (SPLIT >= 2) q += __shfl_xor(q, 32);
+  }
   return q;
 }
 
 // A(i, j) -= v_i w_j + w_i v_j for j = i0 .. i, this lane's columns of row i (row = A + T(i))
 template <typename T, int SPLIT>
 __device__ __forceinline__ void update_row(T* row, const T* vv, const T* ww, int i0, int wave, int i, int part, T vi, T w) {
-  constexpr int W = 64 / SPLIT, UA = W / SPLIT;
-  const int nA = UA * wave;
+  constexpr int W = 64 / SPLIT, NB = W / SPLIT + 1;
+  const int nA = (W * wave) / SPLIT;
   T* pr = row + i0 + part;
   const T* pw = ww + i0 + part;
   const T* pu = vv + i0 + part;
   // (every load of a group before its first store: the compiler cannot know that the row does not overlap vv / ww, and one
   // LDS round trip per element is what it would schedule otherwise)
-  for (int t = 0; t < nA; t += UA) {
-    T a[UA], b[UA], c[UA];
+  constexpr int UU = sizeof(T) == 4 ? 8 : 4;
+  int t = 0;
+  for (; t + UU <= nA; t += UU) {
+    T a[UU], b[UU], c[UU];
 #pragma unroll
-    for (int u = 0; u < UA; ++u) { a[u] = pr[SPLIT * u]; b[u] = pw[SPLIT * u]; c[u] = pu[SPLIT * u]; }
+    for (int u = 0; u < UU; ++u) { a[u] = pr[SPLIT * u]; b[u] = pw[SPLIT * u]; c[u] = pu[SPLIT * u]; }
 #pragma unroll
-    for (int u = 0; u < UA; ++u) pr[SPLIT * u] = a[u] - (vi * b[u] + w * c[u]);
-    pr += SPLIT * UA;
-    pw += SPLIT * UA;
-    pu += SPLIT * UA;
+    for (int u = 0; u < UU; ++u) pr[SPLIT * u] = a[u] - (vi * b[u] + w * c[u]);
+    pr += SPLIT * UU;
+    pw += SPLIT * UU;
+    pu += SPLIT * UU;
   }
-  const int j0 = i0 + part + SPLIT * nA;
-  T a[UA], b[UA], c[UA];
+  {                                             // the rest of the stretch below the wave's rows (fewer than UU steps) ...
+    T a[UU - 1], b[UU - 1], c[UU - 1];
 #pragma unroll
-  for (int u = 0; u < UA; ++u)
-    if (j0 + SPLIT * u <= i) { a[u] = pr[SPLIT * u]; b[u] = pw[SPLIT * u]; c[u] = pu[SPLIT * u]; }
+    for (int u = 0; u < UU - 1; ++u)
+      if (t + u < nA) { a[u] = pr[SPLIT * u]; b[u] = pw[SPLIT * u]; c[u] = pu[SPLIT * u]; }
 #pragma unroll
-  for (int u = 0; u < UA; ++u)
-    if (j0 + SPLIT * u <= i) pr[SPLIT * u] = a[u] - (vi * b[u] + w * c[u]);
+    for (int u = 0; u < UU - 1; ++u)
+      if (t + u < nA) pr[SPLIT * u] = a[u] - (vi * b[u] + w * c[u]);
+    const int left = nA - t;
+    pr += SPLIT * left;
+    pw += SPLIT * left;
+    pu += SPLIT * left;
+  }
+  const int j0 = i0 + part + SPLIT * nA;        // ... and the columns among the wave's rows, up to the diagonal
+#pragma unroll
+  for (int g = 0; g < NB; g += UU) {
+    T a[UU], b[UU], c[UU];
+#pragma unroll
+    for (int u = 0; u < UU; ++u)
+      if (g + u < NB && j0 + SPLIT * (g + u) <= i) { a[u] = pr[SPLIT * (g + u)]; b[u] = pw[SPLIT * (g + u)]; c[u] = pu[SPLIT * (g + u)]; }
+#pragma unroll
+    for (int u = 0; u < UU; ++u)
+      if (g + u < NB && j0 + SPLIT * (g + u) <= i) pr[SPLIT * (g + u)] = a[u] - (vi * b[u] + w * c[u]);
+  }
+}
+
+// One column of the Householder reduction with SPLIT lanes per row (four workgroup barriers).
+template <typename T, int SPLIT, int NTH, bool KEEP>
+__device__ __forceinline__ void reduce_column(T* A, int r, int kc, T* dd, T* ee, T* tt, T* vv, T* ww, T* red, const int tid) {
+  constexpr int NW = NTH / 64, W = 64 / SPLIT;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (loop bounds in scalar registers)
+  const int rw = lane % W, part = lane / W;
+  LB_TICK_DECL;
+  const int i0 = kc + 1, rlo = i0 + W * wave, i = rlo + rw;
+  const bool has = i < r;
+  const int Ti = i * (i + 1) / 2;
+  T* rd = red + (kc & 1) * 2 * kWaves;
+  const T x = has ? A[Ti + kc] : T(0);
+  if (has && part == 0) vv[i] = x;
+  const T sigma = bsum<T, NW>(part == 0 ? x * x : T(0), rd, tid);   // barrier 1 (vv = the raw column is visible too)
+  LB_TICK(0);
+  const T x0 = vv[i0];
+  const T below = sigma - x0 * x0;                               // what the reflector has to annihilate
+  if (!(below > lw::Eps<T>::tiny * lw::Eps<T>::tiny)) {          // nothing to do: H = I  (the same for every thread)
+    if (tid == 0) { dd[kc] = A[kc * (kc + 1) / 2 + kc]; ee[kc] = x0; if constexpr (KEEP) tt[kc] = T(0); }
+    __syncthreads();
+    return;
+  }
+  const T alpha = (x0 >= T(0) ? T(-1) : T(1)) * sqrt(sigma);
+  const T taup = T(1) / (sigma - x0 * alpha);
+  // p = tau A v with v = x - alpha e_i0 (the raw column x is in vv; the correction is one extra term)
+  T p = T(0), vi = T(0);
+  if (rlo < r) {                            // (a wave without a live row has nothing to sum)
+    const T q = matvec_row<T, SPLIT>(A, vv, r, i0, wave, has ? i : r - 1, part);   // (idle lanes read a valid row)
+    if (has) {
+      p = taup * (q - alpha * A[Ti + i0]);
+      vi = i == i0 ? x - alpha : x;
+    }
+  }
+  const T pv = bsum<T, NW>(part == 0 ? p * vi : T(0), rd + kWaves, tid);                // barrier 2
+  LB_TICK(1);
+  const T K = T(0.5) * taup * pv;
+  const T w = fma(-K, vi, p);
+  if (has && part == 0) {
+    ww[i] = w;
+    if (i == i0) vv[i0] = vi;
+  }
+  __syncthreads();                                               // barrier 3
+  LB_TICK(2);
+  // A -= v w' + w v' on the lower triangle of the live block
+  if (has) update_row<T, SPLIT>(A + Ti, vv, ww, i0, wave, i, part, vi, w);
+  if (tid == 0) { dd[kc] = A[kc * (kc + 1) / 2 + kc]; ee[kc] = alpha; if constexpr (KEEP) tt[kc] = taup; }
+  __syncthreads();                                               // barrier 4
+  LB_TICK(3);
 }
 
 // Householder reduction of the packed matrix to tridiagonal form: dd (diagonal), ee (signed sub-diagonal).  The raw column
 // x of step kc stays in A(i > kc, kc); KEEP also leaves tau_kc = 1 / (sigma - x0 alpha) in tt[kc] (0: H = I), so that
 // H_kc = I - tau v v' with v = x - alpha e_{kc+1}, alpha = ee[kc], can be applied again (the backward maps the eigenvector back).
-// Wave w works on rows i0 + W w .. of the live block: SPLIT lanes per row keep all waves busy on matrices of fewer rows than
-// the workgroup has threads (one wave per SIMD reads LDS at a fraction of its rate).  Four workgroup barriers per column.
-template <typename T, int SPLIT, int NTH, bool KEEP>
+// Wave w works on rows i0 + W w .. of the live block, SPLIT = 64 / W lanes per row: as many as the workgroup has for the rows
+// that are left (two at 257 .. 512 rows of 1024 threads, eight at 128 and fewer).
+template <typename T, int NTH, bool KEEP>
 __device__ __forceinline__ void tridiagonalise(T* A, int r, T* dd, T* ee, T* tt, T* vv, T* ww, T* red, const int tid) {
-  constexpr int NW = NTH / 64, W = 64 / SPLIT;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (loop bounds in scalar registers)
-  const int rw = lane % W, part = lane / W;
-  LB_TICK_DECL;
   for (int kc = 0; kc + 2 < r; ++kc) {
-    const int i0 = kc + 1, rlo = i0 + W * wave, i = rlo + rw;
-    const bool has = i < r;
-    const int Ti = i * (i + 1) / 2;
-    T* rd = red + (kc & 1) * 2 * kWaves;
-    const T x = has ? A[Ti + kc] : T(0);
-    if (has && part == 0) vv[i] = x;
-    const T sigma = bsum<T, NW>(part == 0 ? x * x : T(0), rd, tid);   // barrier 1 (vv = the raw column is visible too)
-    LB_TICK(0);
-    const T x0 = vv[i0];
-    const T below = sigma - x0 * x0;                               // what the reflector has to annihilate
-    if (!(below > lw::Eps<T>::tiny * lw::Eps<T>::tiny)) {          // nothing to do: H = I  (the same for every thread)
-      if (tid == 0) { dd[kc] = A[kc * (kc + 1) / 2 + kc]; ee[kc] = x0; if constexpr (KEEP) tt[kc] = T(0); }
-      __syncthreads();
-      continue;
-    }
-    const T alpha = (x0 >= T(0) ? T(-1) : T(1)) * sqrt(sigma);
-    const T taup = T(1) / (sigma - x0 * alpha);
-    // p = tau A v with v = x - alpha e_i0 (the raw column x is in vv; the correction is one extra term)
-    T p = T(0), vi = T(0);
-    if (rlo < r) {                            // (a wave without a live row has nothing to sum)
-      const T q = matvec_row<T, SPLIT>(A, vv, r, i0, wave, has ? i : r - 1, part);   // (idle lanes read a valid row)
-      if (has) {
-        p = taup * (q - alpha * A[Ti + i0]);
-        vi = i == i0 ? x - alpha : x;
-      }
-    }
-    const T pv = bsum<T, NW>(part == 0 ? p * vi : T(0), rd + kWaves, tid);                // barrier 2
-    LB_TICK(1);
-    const T K = T(0.5) * taup * pv;
-    const T w = fma(-K, vi, p);
-    if (has && part == 0) {
-      ww[i] = w;
-      if (i == i0) vv[i0] = vi;
-    }
-    __syncthreads();                                               // barrier 3
-    LB_TICK(2);
-    // A -= v w' + w v' on the lower triangle of the live block
-    if (has) update_row<T, SPLIT>(A + Ti, vv, ww, i0, wave, i, part, vi, w);
-    if (tid == 0) { dd[kc] = A[kc * (kc + 1) / 2 + kc]; ee[kc] = alpha; if constexpr (KEEP) tt[kc] = taup; }
-    __syncthreads();                                               // barrier 4
-    LB_TICK(3);
+    const int m = r - kc - 1;                       // rows of the live block
+    if (8 * m <= NTH) reduce_column<T, 8, NTH, KEEP>(A, r, kc, dd, ee, tt, vv, ww, red, tid);
+    else if (4 * m <= NTH) reduce_column<T, 4, NTH, KEEP>(A, r, kc, dd, ee, tt, vv, ww, red, tid);
+    else reduce_column<T, 2, NTH, KEEP>(A, r, kc, dd, ee, tt, vv, ww, red, tid);
   }
   if (tid == 0) {
     if (r >= 2) {
@@ -244,7 +314,161 @@ __device__ __forceinline__ void tridiagonalise(T* A, int r, T* dd, T* ee, T* tt,
   __syncthreads();
 }
 
-template <typename T, int SPLIT, int NTH>
+// ---------------------------------------------------------------------------------------------
+// Matrices whose packed triangle does not fit the LDS (r = 282 .. 304 in fp32, 198 .. 212 in fp64): the first HC COLUMNS stay in
+// registers.  Entry (i, c < HC) lives in slot c / 2 of the lane with part c % 2 of row i; the LDS holds the packed triangle of
+// rows and columns HC .. r - 1.  The first HC columns are reduced with fixed owners -- the rows HC + 32 w + (lane % 32) in wave
+// w, the rows 0 .. HC - 1 in the LAST wave (idle otherwise: HC <= 32, at most nine waves of rows in the LDS) --, after which
+// what is left IS the LDS matrix and tridiagonalise() runs on it with every pointer shifted by HC.
+//   q_i = sum_j A(i, j) x_j splits into: this lane's slots (columns i0 .. min(i, HC - 1));  for a row >= HC the LDS columns
+//   (matvec_row from column 0 of the LDS matrix);  for a row < HC the entries (j > i, i) that sit in OTHER rows' slots -- every
+//   lane multiplies its slots by its own x, the 32 lanes of a part add up per slot (shuffles), one lane per wave leaves the
+//   sum in ww[column][wave] before the barrier of sigma, the row's lane adds the waves' sums in a fixed order.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct HeadCols { static constexpr int value = sizeof(T) == 4 ? 24 : 16; };
+
+template <typename T, int HS>
+__device__ __forceinline__ T slot_of(const T (&head)[HS], int s) {
+  T x = T(0);
+#pragma unroll
+  for (int u = 0; u < HS; ++u) x = u == s ? head[u] : x;
+  return x;
+}
+
+// S(v): columns < HC into the slots, the rest into the LDS triangle (no barrier)
+template <typename T, int NTH, int HC>
+__device__ __forceinline__ void form_S_head(T* A, T (&head)[HC / 2], const T* __restrict__ gt, const T* vs, int n, int r, int Pp,
+                                            const int tid) {
+  constexpr int HS = HC / 2, NW = NTH / 64;
+  const int lane = tid & 63, wave = tid >> 6, rw = lane & 31, part = lane >> 5;
+  const int i = wave == NW - 1 ? rw : HC + 32 * wave + rw;
+  const bool has = wave == NW - 1 ? rw < HC : i < r;
+#pragma unroll
+  for (int s = 0; s < HS; ++s) head[s] = T(0);
+  if (has) {
+    const T* row = gt + (size_t)i * (i + 1) / 2 + part;
+    for (int a = 0; a < n; ++a) {
+      const T va = vs[a];
+      const T* g = row + (size_t)a * Pp;
+#pragma unroll
+      for (int s = 0; s < HS; ++s)
+        if (2 * s + part <= i) head[s] = fma(va, g[2 * s], head[s]);
+    }
+  }
+  const int rp = r - HC, Pl = rp * (rp + 1) / 2;
+  for (int idx = tid; idx < Pl; idx += NTH) {
+    int ip = (int)((sqrtf(8.f * (float)idx + 1.f) - 1.f) * 0.5f);
+    while ((ip + 1) * (ip + 2) / 2 <= idx) ++ip;
+    while (ip * (ip + 1) / 2 > idx) --ip;
+    const int jp = idx - ip * (ip + 1) / 2;
+    const T* col = gt + (size_t)(ip + HC) * (ip + HC + 1) / 2 + jp + HC;
+    T p0 = T(0), p1 = T(0), p2 = T(0), p3 = T(0);
+    int a = 0;
+    for (; a + 15 < n; a += 16) {
+      T g[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) g[u] = col[(size_t)(a + u) * Pp];
+#pragma unroll
+      for (int u = 0; u < 16; u += 4) {
+        p0 = fma(vs[a + u + 0], g[u + 0], p0);
+        p1 = fma(vs[a + u + 1], g[u + 1], p1);
+        p2 = fma(vs[a + u + 2], g[u + 2], p2);
+        p3 = fma(vs[a + u + 3], g[u + 3], p3);
+      }
+    }
+    for (; a < n; ++a) p0 = fma(vs[a], col[(size_t)a * Pp], p0);
+    A[idx] = (p0 + p1) + (p2 + p3);
+  }
+}
+
+// the first HC columns of the reduction (A: the LDS triangle of rows / columns >= HC); four barriers per column
+template <typename T, int NTH, int HC, bool KEEP>
+__device__ __forceinline__ void head_phase(T* A, int r, T (&head)[HC / 2], T* dd, T* ee, T* tt, T* vv, T* ww, T* red, const int tid) {
+  constexpr int HS = HC / 2, NW = NTH / 64;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), rw = lane & 31, part = lane >> 5;
+  const bool head_wave = wave == NW - 1;
+  const int i = head_wave ? rw : HC + 32 * wave + rw;
+  const bool has = head_wave ? rw < HC : i < r;
+  const int rp = r - HC;
+  const int nbw = (rp + 31) / 32;                   // waves that hold rows of the LDS matrix
+  const int ncontrib = nbw + 1, contributor = head_wave ? nbw : wave;
+  const int ip = i - HC, Tp = ip * (ip + 1) / 2;    // (rows of the LDS matrix)
+  for (int kc = 0; kc < HC; ++kc) {
+    const int i0 = kc + 1, pk = kc & 1, sk = kc >> 1;
+    const bool live = has && i >= i0;
+    T* rd = red + (kc & 1) * 2 * kWaves;
+    const T xown = live && part == pk ? slot_of<T, HS>(head, sk) : T(0);
+    const T xi = xown + __shfl_xor(xown, 32);       // (both lanes of the row)
+    if (live && part == pk) vv[i] = xi;
+    if (has && i == kc && part == pk) dd[kc] = slot_of<T, HS>(head, sk);          // A(kc, kc) is final
+    // what the rows above HC need from the other rows' slots: sum_{j > c} A(j, c) x_j for the columns c = i0 .. HC - 1
+    if (head_wave || wave < nbw) {
+#pragma unroll
+      for (int s = 0; s < HS; ++s) {
+        if (2 * s + 1 < i0) continue;               // (both parts' columns are behind the reduction)
+        const int c = 2 * s + part;
+        T val = live && i > c && c >= i0 ? head[s] * xi : T(0);
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) val += __shfl_xor(val, o);
+        if (rw == 0 && c >= i0) ww[c * ncontrib + contributor] = val;
+      }
+    }
+    const T sigma = bsum<T, NW>(part == pk ? xown * xown : T(0), rd, tid);        // barrier 1
+    const T x0 = vv[i0];
+    const T below = sigma - x0 * x0;
+    if (!(below > lw::Eps<T>::tiny * lw::Eps<T>::tiny)) {          // H = I
+      if (tid == 0) { ee[kc] = x0; if constexpr (KEEP) tt[kc] = T(0); }
+      __syncthreads();
+      continue;
+    }
+    const T alpha = (x0 >= T(0) ? T(-1) : T(1)) * sqrt(sigma);
+    const T taup = T(1) / (sigma - x0 * alpha);
+    T q = T(0);
+    if (live) {
+#pragma unroll
+      for (int s = 0; s < HS; ++s) {
+        const int c = 2 * s + part;
+        if (c >= i0 && c <= i) q = fma(head[s], vv[c], q);
+      }
+      if (i0 < HC) {
+        if (part == (i0 & 1)) q = fma(-alpha, slot_of<T, HS>(head, i0 >> 1), q);      // - alpha A(i, i0)
+      } else if (part == 0) {
+        q = fma(-alpha, A[Tp], q);                                                   // i0 = HC: column 0 of the LDS matrix
+      }
+      if (head_wave && part == 0) {
+        T cs = T(0);
+        for (int w = 0; w < ncontrib; ++w) cs += ww[i * ncontrib + w];
+        q += cs;
+      }
+    }
+    if (!head_wave && wave < nbw) q += matvec_row<T, 2, false>(A, vv + HC, rp, 0, wave, has ? ip : rp - 1, part);
+    q += __shfl_xor(q, 32);
+    const T p = live ? taup * q : T(0);
+    const T vi = live ? (i == i0 ? xi - alpha : xi) : T(0);
+    const T pv = bsum<T, NW>(part == 0 ? p * vi : T(0), rd + kWaves, tid);        // barrier 2
+    const T K = T(0.5) * taup * pv;
+    const T w = fma(-K, vi, p);
+    if (live && part == 0) {
+      ww[i] = w;
+      if (i == i0) vv[i0] = vi;
+    }
+    __syncthreads();                                               // barrier 3
+    if (live) {
+#pragma unroll
+      for (int s = 0; s < HS; ++s) {
+        const int c = 2 * s + part;
+        if (c >= i0 && c <= i) head[s] = head[s] - (vi * ww[c] + w * vv[c]);
+      }
+      if (!head_wave) update_row<T, 2>(A + Tp, vv + HC, ww + HC, 0, wave, ip, part, vi, w);
+    }
+    if (tid == 0) { ee[kc] = alpha; if constexpr (KEEP) tt[kc] = taup; }
+    __syncthreads();                                               // barrier 4
+  }
+}
+
+
+template <typename T, int NTH, int HC>
 __global__ __launch_bounds__(NTH) void lmi_block_kernel(
     const T* __restrict__ gt, const T* __restrict__ dt, const T* __restrict__ nat, const T* __restrict__ y0,
     const int32_t* __restrict__ lin_id, int r, int n, int k, int m, int P, int Pp, int Mp, int Kp, int identity,
@@ -252,7 +476,7 @@ __global__ __launch_bounds__(NTH) void lmi_block_kernel(
     T* __restrict__ kappa_out, int32_t* __restrict__ active_out, int32_t* __restrict__ nan_flag) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lb_smem[];
   T* A = reinterpret_cast<T*>(lb_smem);
-  T* dd = A + P;
+  T* dd = A + (HC > 0 ? (r - HC) * (r - HC + 1) / 2 : P);
   T* ee = dd + r;
   T* vv = ee + r;
   T* ww = vv + r;
@@ -261,6 +485,7 @@ __global__ __launch_bounds__(NTH) void lmi_block_kernel(
   constexpr int kThreads = NTH, NW = NTH / 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   bool bad = false;
+  T head[HC > 0 ? HC / 2 : 1];
 
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
     __syncthreads();          // (the previous sample's last readers of vs / dd / ee)
@@ -289,7 +514,8 @@ __global__ __launch_bounds__(NTH) void lmi_block_kernel(
     unsigned long long lb_t_ = clock64();
     const unsigned long long lb_start = lb_t_;
 #endif
-    form_S<T, NTH>(A, gt, vs, n, P, Pp, tid);
+    if constexpr (HC > 0) form_S_head<T, NTH, HC>(A, head, gt, vs, n, r, Pp, tid);
+    else form_S<T, NTH>(A, gt, vs, n, P, Pp, tid);
     __syncthreads();
     LB_TICK(4);
     {
@@ -304,10 +530,12 @@ __global__ __launch_bounds__(NTH) void lmi_block_kernel(
     }
     int aseg = who >= 0 ? lin_id[2 * who] : -1, arow = who >= 0 ? lin_id[2 * who + 1] : 0;
 
-    tridiagonalise<T, SPLIT, NTH, false>(A, r, dd, ee, nullptr, vv, ww, red, tid);
+    if constexpr (HC > 0) head_phase<T, NTH, HC, false>(A, r, head, dd, ee, nullptr, vv, ww, red, tid);
+    tridiagonalise<T, NTH, false>(A, r - HC, dd + HC, ee + HC, nullptr, vv + HC, ww + HC, red, tid);
 #ifdef RAYEN_LB_PROFILE
     lb_t_ = clock64();
 #endif
+    for (int i = 1 + tid; i < r; i += kThreads) ww[i] = ee[i - 1] * ee[i - 1];     // (visible after the bracket's barrier)
 
     // ---- lambda_max of the tridiagonal: Gershgorin bracket, then Sturm counts at 512 shifts per round
     T lo, hi, scale;
@@ -348,10 +576,22 @@ __global__ __launch_bounds__(NTH) void lmi_block_kernel(
       int cnt = 0;                                               // eigenvalues below sig = negative pivots of T - sig I
       T q = dd[0] - sig;
       cnt += q < T(0);
-      for (int i = 1; i < r; ++i) {
+      // (eight rows' d and e^2 fetched ahead of the eight dependent steps that use them; ww holds e_{i-1}^2)
+      int i = 1;
+      for (; i + 8 <= r; i += 8) {
+        T d8[8], e8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { d8[u] = dd[i + u]; e8[u] = ww[i + u]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (fabs(q) < floor_q) q = q < T(0) ? -floor_q : floor_q;
+          q = d8[u] - sig - quot(e8[u], q);
+          cnt += q < T(0);
+        }
+      }
+      for (; i < r; ++i) {
         if (fabs(q) < floor_q) q = q < T(0) ? -floor_q : floor_q;
-        const T e = ee[i - 1];
-        q = dd[i] - sig - e * e / q;
+        q = dd[i] - sig - quot(ww[i], q);
         cnt += q < T(0);
       }
       const unsigned long long above = __ballot(cnt >= r);       // sig beyond the largest eigenvalue
@@ -408,7 +648,7 @@ __host__ __device__ inline size_t lds_bwd_elems(int r, int n) {
 // matrix (inverse iteration at the forward's kappa, the same factorisation with the same guards as rayen_lmi_wave.h:323-354);
 // then x x' (off-diagonal entries twice) replaces the matrix in packed order and every generator is ONE dot product with it,
 // a wave each -- the same n P words of G the forward reads.
-template <typename T, int SPLIT, int NTH>
+template <typename T, int NTH, int HC>
 __global__ __launch_bounds__(NTH) void lmi_block_bwd_kernel(
     const T* __restrict__ gt, const T* __restrict__ dt, const T* __restrict__ nrm, const int32_t* __restrict__ rho_of, int r,
     int n, int k, int P, int Pp, int Mp, int identity, int lmi_seg, const T* __restrict__ v, int64_t B, int64_t ldv,
@@ -416,7 +656,7 @@ __global__ __launch_bounds__(NTH) void lmi_block_bwd_kernel(
     T* __restrict__ gv, int64_t ldgv) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lb_smem[];
   T* A = reinterpret_cast<T*>(lb_smem);
-  T* dd = A + P;
+  T* dd = A + (HC > 0 ? (r - HC) * (r - HC + 1) / 2 : P);
   T* ee = dd + r;
   T* vv = ee + r;
   T* ww = vv + r;
@@ -428,6 +668,7 @@ __global__ __launch_bounds__(NTH) void lmi_block_bwd_kernel(
   constexpr int NW = NTH / 64;
   constexpr int kMaxChunks = 5;             // rows of the eigenvector a lane of the mapping-back wave holds: r <= 320
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  T head[HC > 0 ? HC / 2 : 1];
 
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
     __syncthreads();          // (the previous sample's last readers)
@@ -470,9 +711,11 @@ __global__ __launch_bounds__(NTH) void lmi_block_bwd_kernel(
       continue;
     }
 
-    form_S<T, NTH>(A, gt, vs, n, P, Pp, tid);
+    if constexpr (HC > 0) form_S_head<T, NTH, HC>(A, head, gt, vs, n, r, Pp, tid);
+    else form_S<T, NTH>(A, gt, vs, n, P, Pp, tid);
     __syncthreads();
-    tridiagonalise<T, SPLIT, NTH, true>(A, r, dd, ee, tt, vv, ww, red, tid);
+    if constexpr (HC > 0) head_phase<T, NTH, HC, true>(A, r, head, dd, ee, tt, vv, ww, red, tid);
+    tridiagonalise<T, NTH, true>(A, r - HC, dd + HC, ee + HC, tt + HC, vv + HC, ww + HC, red, tid);
 
     // ---- z: inverse iteration on M = (kappa + shift) I - T = L D L'.  ww: D, vv: the sub-diagonal of L.
     if (wave == 0) {
@@ -516,7 +759,7 @@ __global__ __launch_bounds__(NTH) void lmi_block_bwd_kernel(
       T xq[kMaxChunks];
 #pragma unroll
       for (int q = 0; q < kMaxChunks; ++q) xq[q] = lane + 64 * q < r ? zz[lane + 64 * q] : T(0);
-      for (int c = r - 3; c >= 0; --c) {
+      for (int c = r - 3; c >= HC; --c) {                // (the reflectors whose columns are in the LDS)
         const T tc = tt[c];
         if (tc == T(0)) continue;                      // (wave-uniform)
         const T alpha = ee[c];
@@ -527,7 +770,7 @@ __global__ __launch_bounds__(NTH) void lmi_block_bwd_kernel(
           const int i = lane + 64 * q;
           T h = T(0);
           if (i > c && i < r) {
-            h = A[i * (i + 1) / 2 + c];
+            h = A[(i - HC) * (i - HC + 1) / 2 + (c - HC)];
             if (i == c + 1) h -= alpha;
           }
           hv[q] = h;
@@ -542,6 +785,59 @@ __global__ __launch_bounds__(NTH) void lmi_block_bwd_kernel(
         if (lane + 64 * q < r) zz[lane + 64 * q] = xq[q];
     }
     __syncthreads();
+    if constexpr (HC > 0) {
+      // ---- the reflectors of the columns in the slots, HC - 1 .. 0: their entries sit with the rows' lanes (head_phase)
+      const int rw = lane & 31, part = lane >> 5;
+      const bool head_wave = wave == NW - 1;
+      const int i = head_wave ? rw : HC + 32 * wave + rw;
+      const bool has = head_wave ? rw < HC : i < r;
+      for (int c = HC - 1; c >= 0; --c) {
+        const T tc = tt[c];
+        if (tc == T(0)) continue;                      // (the same for every thread)
+        T h = T(0);
+        if (has && i > c && part == (c & 1)) {
+          h = slot_of<T, HC / 2>(head, c >> 1);
+          if (i == c + 1) h -= ee[c];
+        }
+        const T dot = bsum<T, NW>(h != T(0) ? h * zz[i] : T(0), red + (c & 1) * 2 * kWaves, tid) * tc;
+        if (h != T(0)) zz[i] = fma(-dot, h, zz[i]);
+        __syncthreads();
+      }
+      // ---- d kappa / d v_a = x' G_a x, a wave per generator: lane l takes the columns l, l + 64, ... and walks down the rows
+      // (the packed outer product of the plain kernel would not fit the LDS either)
+      for (int a = wave; a < n; a += NW) {
+        const T* ga = gt + (size_t)a * Pp;
+        T acc = T(0);
+        for (int j0 = 0; j0 < r; j0 += 64) {
+          const int j = j0 + lane;
+          const T xj = j < r ? zz[j] : T(0);
+          T s0 = T(0), s1 = T(0), s2 = T(0), s3 = T(0);
+          int i = j0;
+          int Ti = i * (i + 1) / 2;
+          for (; i + 3 < r; i += 4) {
+            const int T1 = Ti + i + 1, T2 = T1 + i + 2, T3 = T2 + i + 3;
+            const T g0 = j <= i ? ga[Ti + j] : T(0);
+            const T g1 = j <= i + 1 ? ga[T1 + j] : T(0);
+            const T g2 = j <= i + 2 ? ga[T2 + j] : T(0);
+            const T g3 = j <= i + 3 ? ga[T3 + j] : T(0);
+            s0 = fma(g0, (j == i ? T(1) : T(2)) * zz[i], s0);
+            s1 = fma(g1, (j == i + 1 ? T(1) : T(2)) * zz[i + 1], s1);
+            s2 = fma(g2, (j == i + 2 ? T(1) : T(2)) * zz[i + 2], s2);
+            s3 = fma(g3, (j == i + 3 ? T(1) : T(2)) * zz[i + 3], s3);
+            Ti = T3 + i + 4;
+          }
+          for (; i < r; ++i) {
+            const T g0 = j <= i ? ga[Ti + j] : T(0);
+            s0 = fma(g0, (j == i ? T(1) : T(2)) * zz[i], s0);
+            Ti += i + 1;
+          }
+          acc = fma((s0 + s1) + (s2 + s3), xj, acc);
+        }
+        const T part_a = lw::wsum(acc);
+        if (lane == 0) gv[b * ldgv + a] = fma(sc, ts[a], -coef * part_a);
+      }
+      continue;
+    }
     // ---- x_i x_j (twice off the diagonal) in packed order over the matrix storage
     for (int idx = tid; idx < P; idx += NTH) {
       int i = (int)((sqrtf(8.f * (float)idx + 1.f) - 1.f) * 0.5f);
@@ -572,28 +868,42 @@ __global__ __launch_bounds__(NTH) void lmi_block_bwd_kernel(
 // ---------------------------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------------------------
+// columns kept in registers (0: the whole packed triangle fits the LDS)
+template <typename T>
+int head_cols_fwd(int r, int n) {
+  if (lds_elems(r, n) * sizeof(T) <= kLdsMax) return 0;
+  constexpr int HC = HeadCols<T>::value;
+  return r > HC + 2 && lds_elems_head(r, n, HC, false) * sizeof(T) <= kLdsMax ? HC : -1;
+}
+template <typename T>
+int head_cols_bwd(int r, int n) {
+  if (lds_bwd_elems(r, n) * sizeof(T) <= kLdsMax) return 0;
+  constexpr int HC = HeadCols<T>::value;
+  return r > HC + 2 && lds_elems_head(r, n, HC, true) * sizeof(T) <= kLdsMax ? HC : -1;
+}
+
 template <typename T>
 bool lmi_block_serves_t(const LmiWaveImage* img) {
-  return img != nullptr && img->r >= 2 && lds_elems(img->r, img->n) * sizeof(T) <= kLdsMax;
+  return img != nullptr && img->r >= 2 && head_cols_fwd<T>(img->r, img->n) >= 0;
 }
 
 template <typename T>
 bool lmi_block_bwd_serves_t(const LmiWaveImage* img) {
-  return img != nullptr && img->r >= 2 && img->r <= 320 && lds_bwd_elems(img->r, img->n) * sizeof(T) <= kLdsMax;
+  return img != nullptr && img->r >= 2 && img->r <= 320 && head_cols_bwd<T>(img->r, img->n) >= 0;
 }
 
 template <typename T, typename F>
-void with_bwd_instance(int r, F f) {
-  if (r <= 128) f(lmi_block_bwd_kernel<T, 4, 512>, 512);
-  else if (r <= 256) f(lmi_block_bwd_kernel<T, 2, 512>, 512);
-  else f(lmi_block_bwd_kernel<T, 2, 1024>, 1024);
+void with_bwd_instance(int r, int hc, F f) {
+  if (hc > 0) f(lmi_block_bwd_kernel<T, 1024, HeadCols<T>::value>, 1024);
+  else if (r <= 128) f(lmi_block_bwd_kernel<T, 512, 0>, 512);
+  else f(lmi_block_bwd_kernel<T, 1024, 0>, 1024);
 }
 
 template <typename T, typename F>
-void with_instance(int r, F f) {
-  if (r <= 128) f(lmi_block_kernel<T, 4, 512>, 512);
-  else if (r <= 256) f(lmi_block_kernel<T, 2, 512>, 512);
-  else f(lmi_block_kernel<T, 2, 1024>, 1024);
+void with_instance(int r, int hc, F f) {
+  if (hc > 0) f(lmi_block_kernel<T, 1024, HeadCols<T>::value>, 1024);
+  else if (r <= 128) f(lmi_block_kernel<T, 512, 0>, 512);
+  else f(lmi_block_kernel<T, 1024, 0>, 1024);
 }
 
 // called by rayen_pack_create (the only place that may touch function attributes)
@@ -601,11 +911,11 @@ template <typename T>
 int lmi_block_prepare_t(const LmiWaveImage* img) {
   if (!lmi_block_serves_t<T>(img)) return RAYEN_OK;
   bool ok = true;
-  with_instance<T>(img->r, [&](auto kern, int) {
+  with_instance<T>(img->r, head_cols_fwd<T>(img->r, img->n), [&](auto kern, int) {
     ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax) == hipSuccess;
   });
   if (ok && lmi_block_bwd_serves_t<T>(img))
-    with_bwd_instance<T>(img->r, [&](auto kern, int) {
+    with_bwd_instance<T>(img->r, head_cols_bwd<T>(img->r, img->n), [&](auto kern, int) {
       ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax) == hipSuccess;
     });
   if (!ok) { (void)hipGetLastError(); return RAYEN_E_LAUNCH; }
@@ -617,17 +927,20 @@ int lmi_block_forward_t(const RayenPack* p, const LmiWaveImage* img, const T* v,
                         T* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream) {
   if (!lmi_block_serves_t<T>(img)) return RAYEN_E_UNSUPPORTED;
   if (B == 0) return RAYEN_OK;
-  const size_t lds = lds_elems(img->r, img->n) * sizeof(T);
+  const int hc = head_cols_fwd<T>(img->r, img->n);
+  const size_t lds = (hc > 0 ? lds_elems_head(img->r, img->n, hc, false) : lds_elems(img->r, img->n)) * sizeof(T);
   int cus = 256;
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
   }
-  with_instance<T>(img->r, [&](auto kern, int nth) {
-    // persistent: as many workgroups as the chip holds at once (LDS; 2048 threads per compute unit)
-    int per_cu = (int)(kLdsMax / lds);
-    const int by_threads = 2048 / nth;
-    per_cu = per_cu < 1 ? 1 : (per_cu > by_threads ? by_threads : per_cu);
+  with_instance<T>(img->r, hc, [&](auto kern, int nth) {
+    // persistent: as many workgroups as the chip holds at once (LDS, registers, threads)
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, nth, lds) != hipSuccess || per_cu < 1) {
+      (void)hipGetLastError();
+      per_cu = 1;
+    }
     const int64_t grid = B < (int64_t)cus * per_cu ? B : (int64_t)cus * per_cu;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(nth), lds, stream, static_cast<const T*>(img->gt),
                        static_cast<const T*>(img->dt), static_cast<const T*>(img->nat), static_cast<const T*>(img->y0),
@@ -642,16 +955,19 @@ int lmi_block_backward_t(const RayenPack* p, const LmiWaveImage* img, const T* v
                          const int32_t* active, const T* gy, int64_t ldg, T* gv, int64_t ldgv, hipStream_t stream) {
   if (!lmi_block_bwd_serves_t<T>(img)) return RAYEN_E_UNSUPPORTED;
   if (B == 0) return RAYEN_OK;
-  const size_t lds = lds_bwd_elems(img->r, img->n) * sizeof(T);
+  const int hc = head_cols_bwd<T>(img->r, img->n);
+  const size_t lds = (hc > 0 ? lds_elems_head(img->r, img->n, hc, true) : lds_bwd_elems(img->r, img->n)) * sizeof(T);
   int cus = 256;
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
   }
-  with_bwd_instance<T>(img->r, [&](auto kern, int nth) {
-    int per_cu = (int)(kLdsMax / lds);
-    const int by_threads = 2048 / nth;
-    per_cu = per_cu < 1 ? 1 : (per_cu > by_threads ? by_threads : per_cu);
+  with_bwd_instance<T>(img->r, hc, [&](auto kern, int nth) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, nth, lds) != hipSuccess || per_cu < 1) {
+      (void)hipGetLastError();
+      per_cu = 1;
+    }
     const int64_t grid = B < (int64_t)cus * per_cu ? B : (int64_t)cus * per_cu;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(nth), lds, stream, static_cast<const T*>(img->gt),
                        static_cast<const T*>(img->dt), static_cast<const T*>(img->nrm), img->rho_of, img->r, img->n, img->k,

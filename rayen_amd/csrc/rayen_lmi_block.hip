@@ -11,7 +11,7 @@ static bool eligible(const RayenPack* p) {
     if (g.type == RAYEN_SEG_LMI) { ++n_lmi; r = g.dim; }
     else if (g.type != RAYEN_SEG_LIN) return false;
   }
-  return n_lmi == 1 && r >= 2 && lb::lds_elems(r, p->n) * sizeof(T) <= lb::kLdsMax;
+  return n_lmi == 1 && r >= 2 && lb::head_cols_fwd<T>(r, p->n) >= 0;
 }
 bool lmi_block_eligible_f32(const RayenPack* p) { return eligible<float>(p); }
 bool lmi_block_eligible_f64(const RayenPack* p) { return eligible<double>(p); }

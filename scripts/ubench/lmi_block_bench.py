@@ -30,7 +30,7 @@ def t(fn, reps=5):
 
 B = 2000
 for dtype in (torch.float32, torch.float64):
-    for r_F, k in ((40, 10), (64, 10), (100, 10), (100, 100), (150, 10), (180, 10), (196, 10), (250, 10), (280, 10)):
+    for r_F, k in ((40, 10), (64, 10), (100, 10), (100, 100), (150, 10), (180, 10), (196, 10), (250, 10), (280, 10), (300, 10), (304, 10)):
         rng = np.random.default_rng(r_F * 7 + k)
         F = []
         for _ in range(k):

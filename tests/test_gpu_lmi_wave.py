@@ -129,16 +129,22 @@ def test_large_lmi_forward_and_backward(name, dtype, kernel, monkeypatch):
 
 BIG = {
     "r200_lin": dict(k=8, r=200, m=40, n_eq=0, seed=11),     # beyond the wave kernel's LDS in fp32 (r <= ~190) and at the
-    "r196_eq": dict(k=9, r=196, m=0, n_eq=2, seed=12),       # block kernel's limit in fp64 (r <= 197)
+    "r196_eq": dict(k=9, r=196, m=0, n_eq=2, seed=12),       # block kernel's limit in fp64 with the whole triangle in LDS
     "r250": dict(k=6, r=250, m=0, n_eq=0, seed=13),
     "r280_lin": dict(k=5, r=280, m=10, n_eq=0, seed=14),     # the largest packed triangle a workgroup's LDS holds in fp32 (281)
+    # beyond the LDS: the first 24 (fp32) / 16 (fp64) columns in registers (rayen_lmi_block.h, head_phase)
+    "r282": dict(k=5, r=282, m=0, n_eq=0, seed=15),          # the first size that needs them
+    "r300": dict(k=6, r=300, m=0, n_eq=0, seed=16),          # the end of the reference's sweep (time_analysis.py:157-160)
+    "r303_lin": dict(k=4, r=303, m=10, n_eq=0, seed=17),     # the largest the backward holds in fp32
+    "r210_eq": dict(k=9, r=210, m=0, n_eq=2, seed=18),       # fp64 with 16 columns in registers
 }
 
 
 @pytest.mark.parametrize("name,dtype", [("r200_lin", torch.float32), ("r196_eq", torch.float64), ("r196_eq", torch.float32),
-                                         ("r250", torch.float32), ("r280_lin", torch.float32)])
+                                         ("r250", torch.float32), ("r280_lin", torch.float32), ("r282", torch.float32),
+                                         ("r300", torch.float32), ("r303_lin", torch.float32), ("r210_eq", torch.float64)])
 def test_matrices_only_the_block_kernel_holds(name, dtype):
-    """Forward AND backward of LMIs up to 280 x 280 (fp32) / 196 x 196 (fp64) on hand-written kernels -- the reference's own
+    """Forward AND backward of LMIs up to 303 x 303 (fp32) / 210 x 210 (fp64) on hand-written kernels -- the reference's own
     sweep ends at 300 x 300 (time_analysis.py:157-160); rounds 3-4 sent everything beyond ~190 / ~135 to rocSOLVER through
     the packed torch evaluator.  This suite runs with RAYEN_STRICT_HIP=1 (conftest): a detour would raise, and the
     wave-per-sample kernels refuse these sizes (their full r x r storage does not fit)."""
