@@ -132,6 +132,8 @@ int build_images(RayenPack* p, int prepare) {
   if ((rc = build_one(p, true, &p->wide, wide_build))) return rc;
   if (f32) {
     p->prepared |= RAYEN_PREPARE_F32;
+    p->mixed32 = lmi_block_eligible_mixed_f32(p) && !generic_holds_lmis<float>(p);
+    p->g32.skip_lmi = p->mixed32;
     if ((rc = build_generic<float>(p))) return rc;
     if ((rc = build_one(p, mfma_eligible(p), &p->m32, mfma_build))) return rc;
     {
@@ -146,7 +148,7 @@ int build_images(RayenPack* p, int prepare) {
     }
     if ((rc = build_one(p, lmi_quad_eligible_f32(p), &p->q32, lmi_quad_build_f32))) return rc;
     // (the wave-per-sample LMI kernels take what neither the quad kernel nor the lane kernels hold: matrices beyond ~30 x 30)
-    if ((rc = build_one(p, (lmi_wave_eligible_f32(p) || lmi_block_eligible_f32(p)) && (p->q32 == nullptr || lmi_dim(p) > 28), &p->w32, lmi_wave_build_f32))) return rc;
+    if ((rc = build_one(p, (lmi_wave_eligible_f32(p) || lmi_block_eligible_f32(p) || p->mixed32) && (p->q32 == nullptr || lmi_dim(p) > 28), &p->w32, lmi_wave_build_f32))) return rc;
     if (p->w32 != nullptr && (rc = lmi_block_prepare_f32(p->w32))) return rc;
     if (bwd) {
       if ((rc = build_one(p, mfma_bwd_eligible(p), &p->mb32, mfma_bwd_build))) return rc;
@@ -159,10 +161,12 @@ int build_images(RayenPack* p, int prepare) {
   }
   if (f64) {
     p->prepared |= RAYEN_PREPARE_F64;
+    p->mixed64 = lmi_block_eligible_mixed_f64(p) && !generic_holds_lmis<double>(p);
+    p->g64.skip_lmi = p->mixed64;
     if ((rc = build_generic<double>(p))) return rc;
     if ((rc = build_one(p, mfma64_eligible(p), &p->m64, mfma64_build))) return rc;
     if ((rc = build_one(p, lmi_quad_eligible_f64(p), &p->q64, lmi_quad_build_f64))) return rc;
-    if ((rc = build_one(p, (lmi_wave_eligible_f64(p) || lmi_block_eligible_f64(p)) && (p->q64 == nullptr || lmi_dim(p) > 20), &p->w64, lmi_wave_build_f64))) return rc;
+    if ((rc = build_one(p, (lmi_wave_eligible_f64(p) || lmi_block_eligible_f64(p) || p->mixed64) && (p->q64 == nullptr || lmi_dim(p) > 20), &p->w64, lmi_wave_build_f64))) return rc;
     if (p->w64 != nullptr && (rc = lmi_block_prepare_f64(p->w64))) return rc;
     if (bwd) {
       if ((rc = build_one(p, mfma64_bwd_eligible(p), &p->mb64, mfma64_bwd_build))) return rc;
@@ -173,6 +177,31 @@ int build_images(RayenPack* p, int prepare) {
   return RAYEN_OK;
 }
 
+// Sets with quadratics / cones NEXT TO an LMI the lane kernels do not hold (beyond ~30 x 30; until round 5 these left the C
+// ABI for the device's libraries): two launches.  The lane-per-sample kernel walks an image whose LMI segment is empty
+// (GenericImage::skip_lmi) and leaves, per sample, the maximum over everything else -- in `kappa`, or in column 0 of `y`
+// when the caller wants no kappa -- and its row in `active`; the workgroup-per-sample kernel (rayen_lmi_block.h) evaluates
+// the LMI (and the linear rows once more), takes the larger of the two and writes y.  The backward is the lane kernel's for
+// every sample (a sample whose active row is the LMI gets s N'g from it) followed by the workgroup kernel on the samples
+// the LMI clipped.
+template <typename T> bool is_mixed(const RayenPack* p) { return sizeof(T) == 4 ? p->mixed32 : p->mixed64; }
+
+template <typename T>
+int mixed_forward(const RayenPack* p, const T* v, int64_t B, int64_t ldv, T* y, int64_t ldy, T* kappa, int32_t* active,
+                  int32_t* nan_flag, int old_mode, hipStream_t stream) {
+  if (old_mode || y == nullptr) return RAYEN_E_UNSUPPORTED;
+  T* between = kappa != nullptr ? kappa : y;
+  const int64_t ldk = kappa != nullptr ? 1 : ldy;
+  const int rc = generic_forward<T>(p, image_of<T>(p), v, B, ldv, static_cast<T*>(nullptr), 0, between, active, nullptr, 0,
+                                    stream, ldk);
+  if (rc) return rc;
+  g_last_forward = RAYEN_KERNEL_LMI_BLOCK;
+  if constexpr (sizeof(T) == 4)
+    return lmi_block_forward_f32(p, p->w32, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, between, ldk);
+  else
+    return lmi_block_forward_f64(p, p->w64, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, between, ldk);
+}
+
 template <typename T>
 int project_generic(const RayenPack* p, const T* v, int64_t B, int64_t ldv, T* y, int64_t ldy, T* kappa,
                     int32_t* active, int32_t* nan_flag, void* stream, int old_mode = 0) {
@@ -181,6 +210,7 @@ int project_generic(const RayenPack* p, const T* v, int64_t B, int64_t ldv, T* y
     return RAYEN_E_BAD_ARG;
   int rc = check_ready<T>(p, false);
   if (rc) return rc;
+  if (is_mixed<T>(p)) return mixed_forward<T>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, static_cast<hipStream_t>(stream));
   return generic_forward<T>(p, image_of<T>(p), v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode,
                             static_cast<hipStream_t>(stream));
 }
@@ -227,8 +257,17 @@ int project_bwd(const RayenPack* p, const T* v, int64_t B, int64_t ldv, const T*
                                     static_cast<hipStream_t>(stream));
     }
   }
+  if (is_mixed<T>(p) && old_mode) return RAYEN_E_UNSUPPORTED;
   const int rcg = generic_backward<T>(p, image_of<T>(p), v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv,
                                       old_mode, static_cast<hipStream_t>(stream));
+  if (rcg == RAYEN_OK && is_mixed<T>(p)) {        // (the lane kernel has left out the LMI's term: see mixed_forward)
+    if constexpr (sizeof(T) == 4)
+      return lmi_block_backward_f32(p, p->w32, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv,
+                                    static_cast<hipStream_t>(stream), 1);
+    else
+      return lmi_block_backward_f64(p, p->w64, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv,
+                                    static_cast<hipStream_t>(stream), 1);
+  }
   if (rcg == RAYEN_E_UNSUPPORTED && !old_mode) {   // (nothing was launched)
     if constexpr (sizeof(T) == 4) {
       if (p->w32 != nullptr) {

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(BLOCK) void generic_fwd_kernel(
     const GSeg* __restrict__ segs, int n_gseg, int out_nrb, int k, int n, int lmi_words,
     const T* __restrict__ v, int64_t B, int64_t ldv, T* __restrict__ y, int64_t ldy,
     T* __restrict__ kappa_out, int32_t* __restrict__ active_out, int32_t* __restrict__ nan_flag,
-    int old_mode) {
+    int old_mode, int64_t ldk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int LD = VG ? 1 : BLOCK + 1;
   const int n_pad = (n + kRowBlock - 1) / kRowBlock * kRowBlock;
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(BLOCK) void generic_fwd_kernel(
     scale = nrm > T(0) ? T(1) / (nrm * exp(beta) + kap) : T(0);
   }
   if (live) {
-    if (kappa_out) kappa_out[b0 + tid] = kap;
+    if (kappa_out) kappa_out[(b0 + tid) * ldk] = kap;       // (ldk = 1 but for the sets of rayen_abi.hip::mixed_forward)
     if (active_out) { active_out[2 * (b0 + tid)] = aseg; active_out[2 * (b0 + tid) + 1] = arow; }
   }
   if (y == nullptr) return;
@@ -465,6 +465,13 @@ int generic_build(const RayenPack* p, GenericImage<T>* img) {
     g.f0 = sg.f0;
     g.f1 = sg.f1;
     g.aux_rb = -1;
+    if (sg.type == RAYEN_SEG_LMI && img->skip_lmi) {      // (rayen_abi.hip::mixed_forward: the LMI is another kernel's)
+      g.type = -1;
+      g.rb0 = rb;
+      g.nrb = 0;
+      gs.push_back(g);
+      continue;
+    }
     if (sg.type == RAYEN_SEG_QUAD_SYM || sg.type == RAYEN_SEG_QUAD_FAC) {
       g.aux_rb = rb;
       rb += append_rowblocks(Wg, p->W.data(), sg.aux_row, 1, p->n);
@@ -543,6 +550,17 @@ static size_t generic_lds_bytes(int n, int lmi_words, int block) {
 constexpr size_t kLdsSoft = 64 * 1024;    // keep >= 2 workgroups per CU when possible
 constexpr size_t kLdsHard = 160 * 1024;   // gfx950 LDS per CU
 
+// does the lane-per-sample forward hold the pack's largest LMI (its packed matrix + four vectors per lane)?
+template <typename T>
+bool generic_holds_lmis(const RayenPack* p) {
+  int words = 0;
+  for (const RayenSegment& g : p->segs)
+    if (g.type == RAYEN_SEG_LMI && g.nrows + 4 * g.dim > words) words = g.nrows + 4 * g.dim;
+  return generic_lds_bytes<T>(p->n, words, 64) <= kLdsHard || generic_lds_bytes<T>(0, words, 64) + sizeof(T) * 64 <= kLdsHard;
+}
+template bool generic_holds_lmis<float>(const RayenPack*);
+template bool generic_holds_lmis<double>(const RayenPack*);
+
 template <typename T>
 int generic_block_for(const RayenPack* p, const GenericImage<T>& img) {
   for (int block : {256, 128, 64})
@@ -554,7 +572,7 @@ int generic_block_for(const RayenPack* p, const GenericImage<T>& img) {
 template <typename T, int BLOCK, int RREG, bool VG = false>
 static int launch_fwd(const RayenPack* p, const GenericImage<T>& img, const T* v, int64_t B,
                       int64_t ldv, T* y, int64_t ldy, T* kappa, int32_t* active, int32_t* nan_flag,
-                      int old_mode, hipStream_t stream) {
+                      int old_mode, hipStream_t stream, int64_t ldk) {
   const int lmi_words = RREG > 0 ? 0 : img.lmi_words;  // the register path needs no LDS scratch
   const size_t lds = VG ? sizeof(T) * ((size_t)BLOCK + (size_t)lmi_words * BLOCK)
                         : generic_lds_bytes<T>(p->n, lmi_words, BLOCK);
@@ -568,7 +586,7 @@ static int launch_fwd(const RayenPack* p, const GenericImage<T>& img, const T* v
   const int64_t grid = (B + BLOCK - 1) / BLOCK;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), lds, stream, img.Wg, img.Ng, img.y0,
                      img.segs, img.n_gseg, img.out_nrb, p->k, p->n, lmi_words, v, B, ldv, y, ldy,
-                     kappa, active, nan_flag, old_mode);
+                     kappa, active, nan_flag, old_mode, ldk);
   return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
 }
 
@@ -586,27 +604,27 @@ static int lmi_reg_class(const RayenPack* p) {
 template <typename T>
 int generic_forward(const RayenPack* p, const GenericImage<T>& img, const T* v, int64_t B,
                     int64_t ldv, T* y, int64_t ldy, T* kappa, int32_t* active, int32_t* nan_flag,
-                    int old_mode, hipStream_t stream) {
+                    int old_mode, hipStream_t stream, int64_t ldk) {
   if (B == 0) return RAYEN_OK;
   if constexpr (std::is_same<T, float>::value) {
-    if (generic_lds_bytes<T>(p->n, 0, 64) <= kLdsHard) {
+    if (!img.skip_lmi && generic_lds_bytes<T>(p->n, 0, 64) <= kLdsHard) {
       switch (lmi_reg_class<T>(p)) {
-        case 4: return launch_fwd<T, 64, 4>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream);
-        case 8: return launch_fwd<T, 64, 8>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream);
-        case 12: return launch_fwd<T, 64, 12>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream);
-        case 16: return launch_fwd<T, 64, 16>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream);
-        case 20: return launch_fwd<T, 64, 20>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream);
-        case 24: return launch_fwd<T, 64, 24>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream);
+        case 4: return launch_fwd<T, 64, 4>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream, ldk);
+        case 8: return launch_fwd<T, 64, 8>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream, ldk);
+        case 12: return launch_fwd<T, 64, 12>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream, ldk);
+        case 16: return launch_fwd<T, 64, 16>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream, ldk);
+        case 20: return launch_fwd<T, 64, 20>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream, ldk);
+        case 24: return launch_fwd<T, 64, 24>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream, ldk);
         default: break;
       }
     }
   }
   switch (generic_block_for<T>(p, img)) {
-    case 256: return launch_fwd<T, 256, 0>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream);
-    case 128: return launch_fwd<T, 128, 0>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream);
-    case 64: return launch_fwd<T, 64, 0>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream);
+    case 256: return launch_fwd<T, 256, 0>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream, ldk);
+    case 128: return launch_fwd<T, 128, 0>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream, ldk);
+    case 64: return launch_fwd<T, 64, 0>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream, ldk);
     default:  // n too large for an LDS tile: directions straight from global memory
-      return launch_fwd<T, 64, 0, true>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream);
+      return launch_fwd<T, 64, 0, true>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, old_mode, stream, ldk);
   }
 }
 
@@ -880,9 +898,8 @@ static void bwd_shape(const RayenPack* p, const GenericImage<T>& img, int* w_row
       const int rows = (g.nrows + kRowBlock - 1) / kRowBlock * kRowBlock;
       if (rows > *w_rows) *w_rows = rows;
     }
-    if (g.type == RAYEN_SEG_LMI && g.nrows + 2 * g.dim > *lmi_words) *lmi_words = g.nrows + 2 * g.dim;
+    if (g.type == RAYEN_SEG_LMI && !img.skip_lmi && g.nrows + 2 * g.dim > *lmi_words) *lmi_words = g.nrows + 2 * g.dim;
   }
-  (void)img;
 }
 
 template <typename T>
@@ -945,7 +962,8 @@ template bool generic_backward_serves<double>(const RayenPack*, const GenericIma
   template void generic_free<T>(GenericImage<T>*);                                                  \
   template int generic_block_for<T>(const RayenPack*, const GenericImage<T>&);                      \
   template int generic_forward<T>(const RayenPack*, const GenericImage<T>&, const T*, int64_t,      \
-                                  int64_t, T*, int64_t, T*, int32_t*, int32_t*, int, hipStream_t);  \
+                                  int64_t, T*, int64_t, T*, int32_t*, int32_t*, int, hipStream_t,   \
+                                  int64_t);                                                         \
   template int generic_backward<T>(const RayenPack*, const GenericImage<T>&, const T*, int64_t,     \
                                    int64_t, const T*, const int32_t*, const T*, int64_t, T*,        \
                                    int64_t, int, hipStream_t);

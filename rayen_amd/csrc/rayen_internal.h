@@ -42,6 +42,8 @@ struct GenericImage {
   int n_rb = 0;
   int out_nrb = 0;
   int lmi_words = 0;      // per-sample LDS words the largest LMI needs
+  bool skip_lmi = false;  // set BEFORE generic_build: LMI segments keep their index but have no rows and no type
+                          // (rayen_abi.hip::mixed_forward: the workgroup-per-sample kernel evaluates the LMI)
   int64_t bytes = 0;
 };
 
@@ -97,6 +99,9 @@ struct RayenPack {
   int pr32_state = 0;            // the same for the f16-pair kernel (which is preferred when both are accepted)
   rayen::WideImage* wide = nullptr;    // segment tables of the products epilogue (any n; packs without an LMI)
   double check_split = -1.0, check_exact = -1.0, check_pair = -1.0;  // worst row errors against fp64 (fp32_selfcheck)
+  // [linear rows, quadratics, cones] + ONE LMI the lane kernels do not hold: the lane kernel evaluates everything but the
+  // LMI (generic image built with skip_lmi), the workgroup-per-sample kernel the LMI on top of that (rayen_abi.hip)
+  bool mixed32 = false, mixed64 = false;
   int64_t device_bytes = 0;
 };
 
@@ -128,7 +133,9 @@ int generic_block_for(const RayenPack* p, const GenericImage<T>& img);
 template <typename T>
 int generic_forward(const RayenPack* p, const GenericImage<T>& img, const T* v, int64_t B,
                     int64_t ldv, T* y, int64_t ldy, T* kappa, int32_t* active, int32_t* nan_flag,
-                    int old_mode, hipStream_t stream);
+                    int old_mode, hipStream_t stream, int64_t ldk = 1);
+template <typename T>
+bool generic_holds_lmis(const RayenPack* p);
 template <typename T>
 bool generic_backward_serves(const RayenPack* p, const GenericImage<T>& img);
 template <typename T>
@@ -273,18 +280,22 @@ bool lmi_block_serves_f32(const LmiWaveImage* img);
 bool lmi_block_serves_f64(const LmiWaveImage* img);
 int lmi_block_prepare_f32(const LmiWaveImage* img);
 int lmi_block_prepare_f64(const LmiWaveImage* img);
+bool lmi_block_eligible_mixed_f32(const RayenPack* p);     // ... with quadratics / cones next to the LMI
+bool lmi_block_eligible_mixed_f64(const RayenPack* p);
 int lmi_block_forward_f32(const RayenPack* p, const LmiWaveImage* img, const float* v, int64_t B, int64_t ldv, float* y,
-                          int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream);
+                          int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream,
+                          const float* kappa_in = nullptr, int64_t ldk_in = 1);
 int lmi_block_forward_f64(const RayenPack* p, const LmiWaveImage* img, const double* v, int64_t B, int64_t ldv, double* y,
-                          int64_t ldy, double* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream);
+                          int64_t ldy, double* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream,
+                          const double* kappa_in = nullptr, int64_t ldk_in = 1);
 bool lmi_block_bwd_serves_f32(const LmiWaveImage* img);
 bool lmi_block_bwd_serves_f64(const LmiWaveImage* img);
 int lmi_block_backward_f32(const RayenPack* p, const LmiWaveImage* img, const float* v, int64_t B, int64_t ldv,
                            const float* kappa, const int32_t* active, const float* grad_y, int64_t ldg, float* grad_v,
-                           int64_t ldgv, hipStream_t stream);
+                           int64_t ldgv, hipStream_t stream, int only_lmi = 0);
 int lmi_block_backward_f64(const RayenPack* p, const LmiWaveImage* img, const double* v, int64_t B, int64_t ldv,
                            const double* kappa, const int32_t* active, const double* grad_y, int64_t ldg, double* grad_v,
-                           int64_t ldgv, hipStream_t stream);
+                           int64_t ldgv, hipStream_t stream, int only_lmi = 0);
 bool lmi_wave_serves_f32(const LmiWaveImage* img);      // (the image may exist for the block kernel alone)
 bool lmi_wave_serves_f64(const LmiWaveImage* img);
 

@@ -17,6 +17,8 @@
 // rayen_lmi_wave.h where it fits.  Uses that kernel's device image (LmiWaveImage).
 #pragma once
 
+#include <cstdlib>
+
 #include "rayen_lmi_wave.h"
 
 namespace rayen {
@@ -37,7 +39,7 @@ __device__ unsigned long long g_lb_prof[8];
 constexpr int kWaves = 16;                   // slots of the reduction scratch (the largest workgroup's waves)
 constexpr size_t kLdsMax = 160 * 1024;
 // threads of the workgroup (at least two per row of the matrix)
-__host__ __device__ inline int threads_for(int r) { return r <= 128 ? 512 : 1024; }
+__host__ __device__ inline int threads_for(int r) { return r <= 257 ? 512 : 1024; }
 
 // LDS of a workgroup (units of T): A[P] | dd[r] | ee[r] | vv[r] | ww[r] | red[3][2 kWaves] | vs[n]
 __host__ __device__ inline size_t lds_elems(int r, int n) {
@@ -299,9 +301,17 @@ template <typename T, int NTH, bool KEEP>
 __device__ __forceinline__ void tridiagonalise(T* A, int r, T* dd, T* ee, T* tt, T* vv, T* ww, T* red, const int tid) {
   for (int kc = 0; kc + 2 < r; ++kc) {
     const int m = r - kc - 1;                       // rows of the live block
-    if (8 * m <= NTH) reduce_column<T, 8, NTH, KEEP>(A, r, kc, dd, ee, tt, vv, ww, red, tid);
+#if defined(RAYEN_LB_MAX_SPLIT) && RAYEN_LB_MAX_SPLIT == 2
+    reduce_column<T, 2, NTH, KEEP>(A, r, kc, dd, ee, tt, vv, ww, red, tid);
+#elif defined(RAYEN_LB_MAX_SPLIT) && RAYEN_LB_MAX_SPLIT == 4
+    if (4 * m <= NTH) reduce_column<T, 4, NTH, KEEP>(A, r, kc, dd, ee, tt, vv, ww, red, tid);
+    else reduce_column<T, 2, NTH, KEEP>(A, r, kc, dd, ee, tt, vv, ww, red, tid);
+#else
+    // (eight lanes per row pay in fp64: 2.70 against 2.07 ms at r = 100 -- profiles/bench/r05_lmi_block_ab.txt)
+    if (sizeof(T) == 4 && 8 * m <= NTH) reduce_column<T, sizeof(T) == 4 ? 8 : 4, NTH, KEEP>(A, r, kc, dd, ee, tt, vv, ww, red, tid);
     else if (4 * m <= NTH) reduce_column<T, 4, NTH, KEEP>(A, r, kc, dd, ee, tt, vv, ww, red, tid);
     else reduce_column<T, 2, NTH, KEEP>(A, r, kc, dd, ee, tt, vv, ww, red, tid);
+#endif
   }
   if (tid == 0) {
     if (r >= 2) {
@@ -472,8 +482,8 @@ template <typename T, int NTH, int HC>
 __global__ __launch_bounds__(NTH) void lmi_block_kernel(
     const T* __restrict__ gt, const T* __restrict__ dt, const T* __restrict__ nat, const T* __restrict__ y0,
     const int32_t* __restrict__ lin_id, int r, int n, int k, int m, int P, int Pp, int Mp, int Kp, int identity,
-    int lmi_seg, const T* __restrict__ v, int64_t B, int64_t ldv, T* __restrict__ y, int64_t ldy,
-    T* __restrict__ kappa_out, int32_t* __restrict__ active_out, int32_t* __restrict__ nan_flag) {
+    int lmi_seg, const T* __restrict__ v, int64_t B, int64_t ldv, T* y, int64_t ldy,
+    T* kappa_out, int32_t* active_out, int32_t* __restrict__ nan_flag, const T* kappa_in, int64_t ldk_in) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lb_smem[];
   T* A = reinterpret_cast<T*>(lb_smem);
   T* dd = A + (HC > 0 ? (r - HC) * (r - HC + 1) / 2 : P);
@@ -612,6 +622,15 @@ __global__ __launch_bounds__(NTH) void lmi_block_kernel(
     if (threadIdx.x == 0 && blockIdx.x == 0) { g_lb_prof[6] += clock64() - lb_start; g_lb_prof[7] += 1; }
 #endif
     if (lam > kap) { kap = lam; aseg = lmi_seg; arow = 0; }
+    if (kappa_in != nullptr) {
+      // sets with quadratics / cones next to the LMI: the lane kernel has left the maximum over everything else (and its
+      // row, in active_out) where this sample's outputs go -- kappa_in may be kappa_out or column 0 of y
+      const T other = kappa_in[b * ldk_in];
+      if (other >= kap) {
+        kap = other;
+        if (active_out) { aseg = active_out[2 * b]; arow = active_out[2 * b + 1]; }
+      }
+    }
 
     const T scl = T(1) / fmax(T(1), kap);
     if (tid == 0) {
@@ -653,7 +672,7 @@ __global__ __launch_bounds__(NTH) void lmi_block_bwd_kernel(
     const T* __restrict__ gt, const T* __restrict__ dt, const T* __restrict__ nrm, const int32_t* __restrict__ rho_of, int r,
     int n, int k, int P, int Pp, int Mp, int identity, int lmi_seg, const T* __restrict__ v, int64_t B, int64_t ldv,
     const T* __restrict__ kappa, const int32_t* __restrict__ active, const T* __restrict__ gy, int64_t ldg,
-    T* __restrict__ gv, int64_t ldgv) {
+    T* __restrict__ gv, int64_t ldgv, int only_lmi) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lb_smem[];
   T* A = reinterpret_cast<T*>(lb_smem);
   T* dd = A + (HC > 0 ? (r - HC) * (r - HC + 1) / 2 : P);
@@ -671,6 +690,8 @@ __global__ __launch_bounds__(NTH) void lmi_block_bwd_kernel(
   T head[HC > 0 ? HC / 2 : 1];
 
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    // (sets with quadratics / cones: the lane kernel has written every sample's gradient but for the LMI's term)
+    if (only_lmi && !(kappa[b] > T(1) && active[2 * b] == lmi_seg)) continue;
     __syncthreads();          // (the previous sample's last readers)
     for (int a = tid; a < n; a += NTH) vs[a] = v[b * ldv + a];
     const T* grow = gy + b * ldg;
@@ -892,17 +913,28 @@ bool lmi_block_bwd_serves_t(const LmiWaveImage* img) {
   return img != nullptr && img->r >= 2 && img->r <= 320 && head_cols_bwd<T>(img->r, img->n) >= 0;
 }
 
+// rows of the matrix up to which the workgroup has 512 threads (two lanes per row at least: 257; measured against 1024
+// threads, B = 2 000: r = 150 2.44 against 4.10 ms, 196 4.15 against 6.30, 250 9.60 against 9.75; RAYEN_LB_512_UPTO moves it)
+inline int small_group_upto() {
+  static const int v = [] {
+    const char* env = std::getenv("RAYEN_LB_512_UPTO");
+    const int x = env != nullptr ? std::atoi(env) : 257;
+    return x < 2 ? 2 : (x > 257 ? 257 : x);
+  }();
+  return v;
+}
+
 template <typename T, typename F>
 void with_bwd_instance(int r, int hc, F f) {
   if (hc > 0) f(lmi_block_bwd_kernel<T, 1024, HeadCols<T>::value>, 1024);
-  else if (r <= 128) f(lmi_block_bwd_kernel<T, 512, 0>, 512);
+  else if (r <= small_group_upto()) f(lmi_block_bwd_kernel<T, 512, 0>, 512);
   else f(lmi_block_bwd_kernel<T, 1024, 0>, 1024);
 }
 
 template <typename T, typename F>
 void with_instance(int r, int hc, F f) {
   if (hc > 0) f(lmi_block_kernel<T, 1024, HeadCols<T>::value>, 1024);
-  else if (r <= 128) f(lmi_block_kernel<T, 512, 0>, 512);
+  else if (r <= small_group_upto()) f(lmi_block_kernel<T, 512, 0>, 512);
   else f(lmi_block_kernel<T, 1024, 0>, 1024);
 }
 
@@ -924,7 +956,8 @@ int lmi_block_prepare_t(const LmiWaveImage* img) {
 
 template <typename T>
 int lmi_block_forward_t(const RayenPack* p, const LmiWaveImage* img, const T* v, int64_t B, int64_t ldv, T* y, int64_t ldy,
-                        T* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream) {
+                        T* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream, const T* kappa_in = nullptr,
+                        int64_t ldk_in = 1) {
   if (!lmi_block_serves_t<T>(img)) return RAYEN_E_UNSUPPORTED;
   if (B == 0) return RAYEN_OK;
   const int hc = head_cols_fwd<T>(img->r, img->n);
@@ -945,14 +978,15 @@ int lmi_block_forward_t(const RayenPack* p, const LmiWaveImage* img, const T* v,
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(nth), lds, stream, static_cast<const T*>(img->gt),
                        static_cast<const T*>(img->dt), static_cast<const T*>(img->nat), static_cast<const T*>(img->y0),
                        img->lin_id, img->r, img->n, img->k, img->m, img->P, img->Pp, img->Mp, img->Kp, img->identity,
-                       img->lmi_seg, v, B, ldv, y, ldy, kappa, active, nan_flag);
+                       img->lmi_seg, v, B, ldv, y, ldy, kappa, active, nan_flag, kappa_in, ldk_in);
   });
   return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
 }
 
 template <typename T>
 int lmi_block_backward_t(const RayenPack* p, const LmiWaveImage* img, const T* v, int64_t B, int64_t ldv, const T* kappa,
-                         const int32_t* active, const T* gy, int64_t ldg, T* gv, int64_t ldgv, hipStream_t stream) {
+                         const int32_t* active, const T* gy, int64_t ldg, T* gv, int64_t ldgv, hipStream_t stream,
+                         int only_lmi = 0) {
   if (!lmi_block_bwd_serves_t<T>(img)) return RAYEN_E_UNSUPPORTED;
   if (B == 0) return RAYEN_OK;
   const int hc = head_cols_bwd<T>(img->r, img->n);
@@ -971,7 +1005,7 @@ int lmi_block_backward_t(const RayenPack* p, const LmiWaveImage* img, const T* v
     const int64_t grid = B < (int64_t)cus * per_cu ? B : (int64_t)cus * per_cu;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(nth), lds, stream, static_cast<const T*>(img->gt),
                        static_cast<const T*>(img->dt), static_cast<const T*>(img->nrm), img->rho_of, img->r, img->n, img->k,
-                       img->P, img->Pp, img->Mp, img->identity, img->lmi_seg, v, B, ldv, kappa, active, gy, ldg, gv, ldgv);
+                       img->P, img->Pp, img->Mp, img->identity, img->lmi_seg, v, B, ldv, kappa, active, gy, ldg, gv, ldgv, only_lmi);
   });
   return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
 }

@@ -13,6 +13,18 @@ static bool eligible(const RayenPack* p) {
   }
   return n_lmi == 1 && r >= 2 && lb::head_cols_fwd<T>(r, p->n) >= 0;
 }
+// the same with quadratics / cones next to the LMI (another kernel's: rayen_abi.hip::mixed_forward)
+template <typename T>
+static bool eligible_mixed(const RayenPack* p) {
+  int n_lmi = 0, n_other = 0, r = 0;
+  for (const RayenSegment& g : p->segs) {
+    if (g.type == RAYEN_SEG_LMI) { ++n_lmi; r = g.dim; }
+    else if (g.type != RAYEN_SEG_LIN) ++n_other;
+  }
+  return n_lmi == 1 && n_other > 0 && r >= 2 && lb::head_cols_fwd<T>(r, p->n) >= 0 && lb::head_cols_bwd<T>(r, p->n) >= 0;
+}
+bool lmi_block_eligible_mixed_f32(const RayenPack* p) { return eligible_mixed<float>(p); }
+bool lmi_block_eligible_mixed_f64(const RayenPack* p) { return eligible_mixed<double>(p); }
 bool lmi_block_eligible_f32(const RayenPack* p) { return eligible<float>(p); }
 bool lmi_block_eligible_f64(const RayenPack* p) { return eligible<double>(p); }
 bool lmi_block_serves_f32(const LmiWaveImage* img) { return lb::lmi_block_serves_t<float>(img); }
@@ -20,25 +32,27 @@ bool lmi_block_serves_f64(const LmiWaveImage* img) { return lb::lmi_block_serves
 int lmi_block_prepare_f32(const LmiWaveImage* img) { return lb::lmi_block_prepare_t<float>(img); }
 int lmi_block_prepare_f64(const LmiWaveImage* img) { return lb::lmi_block_prepare_t<double>(img); }
 int lmi_block_forward_f32(const RayenPack* p, const LmiWaveImage* img, const float* v, int64_t B, int64_t ldv, float* y,
-                          int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream) {
-  return lb::lmi_block_forward_t<float>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+                          int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream,
+                          const float* kappa_in, int64_t ldk_in) {
+  return lb::lmi_block_forward_t<float>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, kappa_in, ldk_in);
 }
 int lmi_block_forward_f64(const RayenPack* p, const LmiWaveImage* img, const double* v, int64_t B, int64_t ldv, double* y,
-                          int64_t ldy, double* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream) {
-  return lb::lmi_block_forward_t<double>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream);
+                          int64_t ldy, double* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream,
+                          const double* kappa_in, int64_t ldk_in) {
+  return lb::lmi_block_forward_t<double>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, kappa_in, ldk_in);
 }
 
 bool lmi_block_bwd_serves_f32(const LmiWaveImage* img) { return lb::lmi_block_bwd_serves_t<float>(img); }
 bool lmi_block_bwd_serves_f64(const LmiWaveImage* img) { return lb::lmi_block_bwd_serves_t<double>(img); }
 int lmi_block_backward_f32(const RayenPack* p, const LmiWaveImage* img, const float* v, int64_t B, int64_t ldv,
                            const float* kappa, const int32_t* active, const float* grad_y, int64_t ldg, float* grad_v,
-                           int64_t ldgv, hipStream_t stream) {
-  return lb::lmi_block_backward_t<float>(p, img, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, stream);
+                           int64_t ldgv, hipStream_t stream, int only_lmi) {
+  return lb::lmi_block_backward_t<float>(p, img, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, stream, only_lmi);
 }
 int lmi_block_backward_f64(const RayenPack* p, const LmiWaveImage* img, const double* v, int64_t B, int64_t ldv,
                            const double* kappa, const int32_t* active, const double* grad_y, int64_t ldg, double* grad_v,
-                           int64_t ldgv, hipStream_t stream) {
-  return lb::lmi_block_backward_t<double>(p, img, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, stream);
+                           int64_t ldgv, hipStream_t stream, int only_lmi) {
+  return lb::lmi_block_backward_t<double>(p, img, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, stream, only_lmi);
 }
 }  // namespace rayen
 

@@ -1,0 +1,89 @@
+"""Quadratics / cones NEXT TO an LMI beyond what the lane kernels hold (~30 x 30): until round 5 these sets left the C ABI for
+the device's libraries.  Now two launches (rayen_abi.hip::mixed_forward): the lane-per-sample kernel evaluates everything but
+the LMI, the workgroup-per-sample kernel (rayen_lmi_block.h) the LMI on top of it -- forward and backward.  This suite runs
+with RAYEN_STRICT_HIP=1 (conftest): a detour would raise.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import csd_from_cs, rel_err_rows
+from oracle import rayen_oracle as oracle
+from rayen_amd import _lib, ops, workloads
+from test_gpu_lmi_wave import _check_backward, _layer
+
+pytestmark = pytest.mark.gpu
+
+
+def _mixed(k, r, m, n_quad, n_soc, scale, seed, n_eq=0):
+    """random_lin_quad_soc + an r x r LMI whose generators are scaled so that every family clips some samples"""
+    rng = np.random.default_rng(seed)
+    raw = workloads.random_lin_quad_soc(k, m, n_quad, n_soc, r_M=min(k, 6), seed=seed)
+    F = []
+    for _ in range(k):
+        T = rng.uniform(-1, 1, size=(r, r))
+        F.append(scale * (T + T.T) / 2)
+    T = rng.uniform(-1, 1, size=(r, r))
+    F.append(T @ T.T + 0.5 * np.eye(r))
+    raw["F"] = F
+    if n_eq:
+        raw["A2"] = rng.uniform(-1, 1, size=(n_eq, k))
+        raw["b2"] = np.zeros((n_eq, 1))
+    return raw
+
+
+CASES = {
+    "r60_all": dict(k=10, r=60, m=12, n_quad=2, n_soc=2, scale=0.7, seed=1),
+    "r100_quad_soc": dict(k=8, r=100, m=0, n_quad=1, n_soc=1, scale=0.6, seed=2),
+    "r40_lin_quad_eq": dict(k=12, r=40, m=20, n_quad=3, n_soc=0, scale=1.5, seed=3, n_eq=2),
+    "r150": dict(k=6, r=150, m=5, n_quad=1, n_soc=1, scale=0.6, seed=4),
+    "r290_head_columns": dict(k=5, r=290, m=4, n_quad=1, n_soc=1, scale=0.35, seed=5),     # fp32 only (r <= 212 in fp64)
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_lmi_next_to_quadratics_and_cones(name, dtype):
+    if dtype == torch.float64 and CASES[name]["r"] > 212:
+        pytest.skip("fp64: the workgroup kernel holds r <= 212")
+    raw = _mixed(**CASES[name])
+    r = CASES[name]["r"]
+    cs, layer = _layer(raw, dtype)
+    dp, _ = layer.device_pack(torch.device("cuda", 0))
+    gen = torch.Generator().manual_seed(8)
+    B = 96 if r <= 100 else 40
+    x = torch.empty(B, cs.n).uniform_(-2.0, 2.0, generator=gen)
+    x[:2] *= 1e-4                                             # interior
+    x[2] = 0.0
+    xd = x.to(dtype).cuda()
+    y, kappa, active = ops.project_raw(xd, dp, want_active=True)
+    assert _lib.load().rayen_last_forward_kernel() == _lib.KERNEL_LMI_BLOCK
+    buf64 = oracle.precompute(csd_from_cs(cs), torch.float64)
+    xr = x.double().unsqueeze(2).requires_grad_(True)
+    y_true_t = oracle.forward(buf64, xr)
+    y_true = y_true_t.detach().numpy()[:, :, 0]
+    err = rel_err_rows(y.cpu().double().numpy(), y_true)
+    if dtype == torch.float64:
+        assert err.max() <= 1e-9, (name, err.max())
+    else:
+        y32 = oracle.forward(oracle.precompute(csd_from_cs(cs), torch.float32), x.unsqueeze(2)).numpy()[:, :, 0]
+        theirs = rel_err_rows(y32.astype(np.float64), y_true).max()
+        assert err.max() <= max(1e-5, 2.0 * theirs), (name, err.max(), theirs)
+    assert cs.getMaxViolation(y.cpu().double().numpy()) <= (1e-9 if dtype == torch.float64 else 2e-4)
+    assert np.allclose(y[2].cpu().double().numpy(), cs.y0[:, 0], atol=1e-12 if dtype == torch.float64 else 1e-6)
+    # every family sets kappa somewhere: the LMI (the last segment) and something else, and both clip
+    seg = active[:, 0].cpu().numpy()
+    clipped = kappa.cpu().numpy() > 1.0
+    lmi_seg = int(seg.max())
+    assert (seg[clipped] == lmi_seg).sum() >= 3 and ((seg[clipped] != lmi_seg) & (seg[clipped] >= 0)).sum() >= 3, np.bincount(seg[seg >= 0])
+    # the module's path (no kappa wanted: the maximum over the other families travels in column 0 of y) gives the same rows
+    y_mod = layer(xd.unsqueeze(2))
+    assert not layer._hip_unsupported and torch.equal(y_mod[:, :, 0], y)
+    y_nok, _, _ = ops.project_raw(xd, dp, want_active=False, want_kappa=False)
+    assert torch.equal(y_nok, y)
+    for b in (1, 7):
+        assert torch.equal(ops.project_raw(xd[:b].contiguous(), dp)[0], y[:b])
+    # ---- backward: lane kernel for every sample, then the workgroup kernel on the samples the LMI clipped
+    _check_backward(cs, buf64, x, xd, xr, y_true_t, kappa, active, dp, dtype, r, gen, name)
+    xg = xd.unsqueeze(2).clone().requires_grad_(True)
+    layer(xg).sum().backward()
+    assert not layer._hip_unsupported and torch.isfinite(xg.grad).all()
