@@ -38,8 +38,6 @@ __device__ unsigned long long g_lb_prof[8];
 
 constexpr int kWaves = 16;                   // slots of the reduction scratch (the largest workgroup's waves)
 constexpr size_t kLdsMax = 160 * 1024;
-// threads of the workgroup (at least two per row of the matrix)
-__host__ __device__ inline int threads_for(int r) { return r <= 257 ? 512 : 1024; }
 
 // LDS of a workgroup (units of T): A[P] | dd[r] | ee[r] | vv[r] | ww[r] | red[3][2 kWaves] | vs[n]
 __host__ __device__ inline size_t lds_elems(int r, int n) {
@@ -194,14 +192,20 @@ __device__ __forceinline__ T matvec_row(const T* A, const T* vv, int r, int i0, 
   return q;
 }
 
-// A(i, j) -= v_i w_j + w_i v_j for j = i0 .. i, this lane's columns of row i (row = A + T(i))
-template <typename T, int SPLIT>
-__device__ __forceinline__ void update_row(T* row, const T* vv, const T* ww, int i0, int wave, int i, int part, T vi, T w) {
+// A(i, j) -= v_i w_j + w_i v_j for j = i0 .. i, this lane's columns of row i (row = A + T(i)).
+// FLY: `ww` holds p = tau A v instead of w = p - K v (K needs a sum over the workgroup: reduce_column writes p BEFORE that
+// sum's barrier and saves the barrier between w and the update) and `vv` the raw column (v_{i0} = vi0 is not in it):
+// w_j = p_j - K v_j is formed here, one more multiply-add per element.
+template <typename T, int SPLIT, bool FLY = false>
+__device__ __forceinline__ void update_row(T* row, const T* vv, const T* ww, int i0, int wave, int i, int part, T vi, T w,
+                                           T K = T(0), T vi0 = T(0)) {
   constexpr int W = 64 / SPLIT, NB = W / SPLIT + 1;
   const int nA = (W * wave) / SPLIT;
   T* pr = row + i0 + part;
   const T* pw = ww + i0 + part;
   const T* pu = vv + i0 + part;
+  bool first = FLY && part == 0;                // (this lane's first element is column i0)
+  auto neww = [&](T a, T b, T c) { return FLY ? a - (vi * fma(-K, c, b) + w * c) : a - (vi * b + w * c); };
   // (every load of a group before its first store: the compiler cannot know that the row does not overlap vv / ww, and one
   // LDS round trip per element is what it would schedule otherwise)
   constexpr int UU = sizeof(T) == 4 ? 8 : 4;
@@ -210,8 +214,9 @@ __device__ __forceinline__ void update_row(T* row, const T* vv, const T* ww, int
     T a[UU], b[UU], c[UU];
 #pragma unroll
     for (int u = 0; u < UU; ++u) { a[u] = pr[SPLIT * u]; b[u] = pw[SPLIT * u]; c[u] = pu[SPLIT * u]; }
+    if (first) { c[0] = vi0; first = false; }
 #pragma unroll
-    for (int u = 0; u < UU; ++u) pr[SPLIT * u] = a[u] - (vi * b[u] + w * c[u]);
+    for (int u = 0; u < UU; ++u) pr[SPLIT * u] = neww(a[u], b[u], c[u]);
     pr += SPLIT * UU;
     pw += SPLIT * UU;
     pu += SPLIT * UU;
@@ -221,9 +226,10 @@ __device__ __forceinline__ void update_row(T* row, const T* vv, const T* ww, int
 #pragma unroll
     for (int u = 0; u < UU - 1; ++u)
       if (t + u < nA) { a[u] = pr[SPLIT * u]; b[u] = pw[SPLIT * u]; c[u] = pu[SPLIT * u]; }
+    if (first && t < nA) { c[0] = vi0; first = false; }
 #pragma unroll
     for (int u = 0; u < UU - 1; ++u)
-      if (t + u < nA) pr[SPLIT * u] = a[u] - (vi * b[u] + w * c[u]);
+      if (t + u < nA) pr[SPLIT * u] = neww(a[u], b[u], c[u]);
     const int left = nA - t;
     pr += SPLIT * left;
     pw += SPLIT * left;
@@ -236,13 +242,14 @@ __device__ __forceinline__ void update_row(T* row, const T* vv, const T* ww, int
 #pragma unroll
     for (int u = 0; u < UU; ++u)
       if (g + u < NB && j0 + SPLIT * (g + u) <= i) { a[u] = pr[SPLIT * (g + u)]; b[u] = pw[SPLIT * (g + u)]; c[u] = pu[SPLIT * (g + u)]; }
+    if (g == 0 && first) { c[0] = vi0; first = false; }
 #pragma unroll
     for (int u = 0; u < UU; ++u)
-      if (g + u < NB && j0 + SPLIT * (g + u) <= i) pr[SPLIT * (g + u)] = a[u] - (vi * b[u] + w * c[u]);
+      if (g + u < NB && j0 + SPLIT * (g + u) <= i) pr[SPLIT * (g + u)] = neww(a[u], b[u], c[u]);
   }
 }
 
-// One column of the Householder reduction with SPLIT lanes per row (four workgroup barriers).
+// One column of the Householder reduction with SPLIT lanes per row (three workgroup barriers).
 template <typename T, int SPLIT, int NTH, bool KEEP>
 __device__ __forceinline__ void reduce_column(T* A, int r, int kc, T* dd, T* ee, T* tt, T* vv, T* ww, T* red, const int tid) {
   constexpr int NW = NTH / 64, W = 64 / SPLIT;
@@ -275,20 +282,16 @@ __device__ __forceinline__ void reduce_column(T* A, int r, int kc, T* dd, T* ee,
       vi = i == i0 ? x - alpha : x;
     }
   }
-  const T pv = bsum<T, NW>(part == 0 ? p * vi : T(0), rd + kWaves, tid);                // barrier 2
+  if (has && part == 0) ww[i] = p;                                // (p, not w: update_row<FLY> forms w_j = p_j - K v_j)
+  const T pv = bsum<T, NW>(part == 0 ? p * vi : T(0), rd + kWaves, tid);                // barrier 2 (ww is visible too)
   LB_TICK(1);
   const T K = T(0.5) * taup * pv;
   const T w = fma(-K, vi, p);
-  if (has && part == 0) {
-    ww[i] = w;
-    if (i == i0) vv[i0] = vi;
-  }
-  __syncthreads();                                               // barrier 3
   LB_TICK(2);
-  // A -= v w' + w v' on the lower triangle of the live block
-  if (has) update_row<T, SPLIT>(A + Ti, vv, ww, i0, wave, i, part, vi, w);
+  // A -= v w' + w v' on the lower triangle of the live block (vv keeps the raw column: v_{i0} = x0 - alpha goes by value)
+  if (has) update_row<T, SPLIT, true>(A + Ti, vv, ww, i0, wave, i, part, vi, w, K, x0 - alpha);
   if (tid == 0) { dd[kc] = A[kc * (kc + 1) / 2 + kc]; ee[kc] = alpha; if constexpr (KEEP) tt[kc] = taup; }
-  __syncthreads();                                               // barrier 4
+  __syncthreads();                                               // barrier 3
   LB_TICK(3);
 }
 
@@ -478,8 +481,9 @@ __device__ __forceinline__ void head_phase(T* A, int r, T (&head)[HC / 2], T* dd
 }
 
 
+// (four waves per SIMD = two 512-thread workgroups per compute unit: one register more and it is one)
 template <typename T, int NTH, int HC>
-__global__ __launch_bounds__(NTH) void lmi_block_kernel(
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4))) void lmi_block_kernel(
     const T* __restrict__ gt, const T* __restrict__ dt, const T* __restrict__ nat, const T* __restrict__ y0,
     const int32_t* __restrict__ lin_id, int r, int n, int k, int m, int P, int Pp, int Mp, int Kp, int identity,
     int lmi_seg, const T* __restrict__ v, int64_t B, int64_t ldv, T* y, int64_t ldy,
@@ -668,7 +672,7 @@ __host__ __device__ inline size_t lds_bwd_elems(int r, int n) {
 // then x x' (off-diagonal entries twice) replaces the matrix in packed order and every generator is ONE dot product with it,
 // a wave each -- the same n P words of G the forward reads.
 template <typename T, int NTH, int HC>
-__global__ __launch_bounds__(NTH) void lmi_block_bwd_kernel(
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4))) void lmi_block_bwd_kernel(
     const T* __restrict__ gt, const T* __restrict__ dt, const T* __restrict__ nrm, const int32_t* __restrict__ rho_of, int r,
     int n, int k, int P, int Pp, int Mp, int identity, int lmi_seg, const T* __restrict__ v, int64_t B, int64_t ldv,
     const T* __restrict__ kappa, const int32_t* __restrict__ active, const T* __restrict__ gy, int64_t ldg,
@@ -889,53 +893,76 @@ __global__ __launch_bounds__(NTH) void lmi_block_bwd_kernel(
 // ---------------------------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------------------------
-// columns kept in registers (0: the whole packed triangle fits the LDS)
-template <typename T>
-int head_cols_fwd(int r, int n) {
-  if (lds_elems(r, n) * sizeof(T) <= kLdsMax) return 0;
-  constexpr int HC = HeadCols<T>::value;
-  return r > HC + 2 && lds_elems_head(r, n, HC, false) * sizeof(T) <= kLdsMax ? HC : -1;
-}
-template <typename T>
-int head_cols_bwd(int r, int n) {
-  if (lds_bwd_elems(r, n) * sizeof(T) <= kLdsMax) return 0;
-  constexpr int HC = HeadCols<T>::value;
-  return r > HC + 2 && lds_elems_head(r, n, HC, true) * sizeof(T) <= kLdsMax ? HC : -1;
-}
-
-template <typename T>
-bool lmi_block_serves_t(const LmiWaveImage* img) {
-  return img != nullptr && img->r >= 2 && head_cols_fwd<T>(img->r, img->n) >= 0;
-}
-
-template <typename T>
-bool lmi_block_bwd_serves_t(const LmiWaveImage* img) {
-  return img != nullptr && img->r >= 2 && img->r <= 320 && head_cols_bwd<T>(img->r, img->n) >= 0;
-}
-
-// rows of the matrix up to which the workgroup has 512 threads (two lanes per row at least: 257; measured against 1024
-// threads, B = 2 000: r = 150 2.44 against 4.10 ms, 196 4.15 against 6.30, 250 9.60 against 9.75; RAYEN_LB_512_UPTO moves it)
-inline int small_group_upto() {
+// developer: workgroups per compute unit of the persistent grids, as a multiple of what fits at once (RAYEN_LB_GRID_MULT)
+inline int grid_mult() {
   static const int v = [] {
-    const char* env = std::getenv("RAYEN_LB_512_UPTO");
-    const int x = env != nullptr ? std::atoi(env) : 257;
-    return x < 2 ? 2 : (x > 257 ? 257 : x);
+    const char* env = std::getenv("RAYEN_LB_GRID_MULT");
+    const int x = env != nullptr ? std::atoi(env) : 1;
+    return x < 1 ? 1 : (x > 8 ? 8 : x);
   }();
   return v;
 }
 
-template <typename T, typename F>
-void with_bwd_instance(int r, int hc, F f) {
-  if (hc > 0) f(lmi_block_bwd_kernel<T, 1024, HeadCols<T>::value>, 1024);
-  else if (r <= small_group_upto()) f(lmi_block_bwd_kernel<T, 512, 0>, 512);
-  else f(lmi_block_bwd_kernel<T, 1024, 0>, 1024);
+// The launch shape of a matrix: threads, columns kept in registers (0: the whole packed triangle in LDS), LDS bytes; nth = 0:
+// no instance holds it.  512 threads while TWO workgroups fit a compute unit's LDS -- this kernel waits on barriers, and a
+// second workgroup fills the gaps -- which the register columns stretch by HC rows (r <= 220 in fp32); 1024 threads beyond.
+// Measured, B = 2 000, k = 100, 512 against 1024 threads without register columns (profiles/bench/r05_lmi_block_ab.txt):
+// forward r = 150 2.7 against 4.5 ms, 196 4.5 against 7.0 (two workgroups of 80.8 KB), 220 9.3 against 8.4, 250 11.7 against
+// 10.7; backward 150 4.0 against 6.2, 196 12.4 against 10.1 (82.4 KB: one workgroup), 250 19.5 against 15.6.
+// RAYEN_LB_512_UPTO (developer) caps the 512-thread range.
+struct Plan { int nth = 0, hc = 0; size_t lds = 0; };
+
+template <typename T>
+Plan plan_for(int r, int n, bool bwd) {
+  static const int upto = [] {
+    const char* env = std::getenv("RAYEN_LB_512_UPTO");
+    const int x = env != nullptr ? std::atoi(env) : 257;
+    return x < 2 ? 2 : (x > 257 ? 257 : x);
+  }();
+  constexpr int HC = HeadCols<T>::value;
+  const size_t plain = (bwd ? lds_bwd_elems(r, n) : lds_elems(r, n)) * sizeof(T);
+  const size_t head = r > HC + 2 ? lds_elems_head(r, n, HC, bwd) * sizeof(T) : kLdsMax + 1;
+  Plan p;
+  if (r < 2 || (bwd && r > 320)) return p;
+  if (r <= upto && (r <= 128 || 2 * plain <= kLdsMax)) { p.nth = 512; p.hc = 0; p.lds = plain; }
+  else if (r <= upto && r - HC <= 224 && 2 * head <= kLdsMax) { p.nth = 512; p.hc = HC; p.lds = head; }   // (7 waves of rows + 1)
+  else if (plain <= kLdsMax) { p.nth = 1024; p.hc = 0; p.lds = plain; }
+  else if (head <= kLdsMax) { p.nth = 1024; p.hc = HC; p.lds = head; }
+  return p;
+}
+
+// (eligibility of a shape, rayen_lmi_block.hip)
+template <typename T>
+int head_cols_fwd(int r, int n) { const Plan p = plan_for<T>(r, n, false); return p.nth == 0 ? -1 : p.hc; }
+template <typename T>
+int head_cols_bwd(int r, int n) { const Plan p = plan_for<T>(r, n, true); return p.nth == 0 ? -1 : p.hc; }
+
+template <typename T>
+bool lmi_block_serves_t(const LmiWaveImage* img) {
+  return img != nullptr && plan_for<T>(img->r, img->n, false).nth != 0;
+}
+
+template <typename T>
+bool lmi_block_bwd_serves_t(const LmiWaveImage* img) {
+  return img != nullptr && plan_for<T>(img->r, img->n, true).nth != 0;
 }
 
 template <typename T, typename F>
-void with_instance(int r, int hc, F f) {
-  if (hc > 0) f(lmi_block_kernel<T, 1024, HeadCols<T>::value>, 1024);
-  else if (r <= small_group_upto()) f(lmi_block_kernel<T, 512, 0>, 512);
-  else f(lmi_block_kernel<T, 1024, 0>, 1024);
+void with_bwd_instance(const Plan& p, F f) {
+  constexpr int HC = HeadCols<T>::value;
+  if (p.hc > 0 && p.nth == 512) f(lmi_block_bwd_kernel<T, 512, HC>);
+  else if (p.hc > 0) f(lmi_block_bwd_kernel<T, 1024, HC>);
+  else if (p.nth == 512) f(lmi_block_bwd_kernel<T, 512, 0>);
+  else f(lmi_block_bwd_kernel<T, 1024, 0>);
+}
+
+template <typename T, typename F>
+void with_instance(const Plan& p, F f) {
+  constexpr int HC = HeadCols<T>::value;
+  if (p.hc > 0 && p.nth == 512) f(lmi_block_kernel<T, 512, HC>);
+  else if (p.hc > 0) f(lmi_block_kernel<T, 1024, HC>);
+  else if (p.nth == 512) f(lmi_block_kernel<T, 512, 0>);
+  else f(lmi_block_kernel<T, 1024, 0>);
 }
 
 // called by rayen_pack_create (the only place that may touch function attributes)
@@ -943,13 +970,11 @@ template <typename T>
 int lmi_block_prepare_t(const LmiWaveImage* img) {
   if (!lmi_block_serves_t<T>(img)) return RAYEN_OK;
   bool ok = true;
-  with_instance<T>(img->r, head_cols_fwd<T>(img->r, img->n), [&](auto kern, int) {
-    ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax) == hipSuccess;
-  });
-  if (ok && lmi_block_bwd_serves_t<T>(img))
-    with_bwd_instance<T>(img->r, head_cols_bwd<T>(img->r, img->n), [&](auto kern, int) {
-      ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax) == hipSuccess;
-    });
+  auto raise = [&](auto kern) {
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax) == hipSuccess;
+  };
+  with_instance<T>(plan_for<T>(img->r, img->n, false), raise);
+  if (lmi_block_bwd_serves_t<T>(img)) with_bwd_instance<T>(plan_for<T>(img->r, img->n, true), raise);
   if (!ok) { (void)hipGetLastError(); return RAYEN_E_LAUNCH; }
   return RAYEN_OK;
 }
@@ -960,20 +985,22 @@ int lmi_block_forward_t(const RayenPack* p, const LmiWaveImage* img, const T* v,
                         int64_t ldk_in = 1) {
   if (!lmi_block_serves_t<T>(img)) return RAYEN_E_UNSUPPORTED;
   if (B == 0) return RAYEN_OK;
-  const int hc = head_cols_fwd<T>(img->r, img->n);
-  const size_t lds = (hc > 0 ? lds_elems_head(img->r, img->n, hc, false) : lds_elems(img->r, img->n)) * sizeof(T);
+  const Plan plan = plan_for<T>(img->r, img->n, false);
+  const size_t lds = plan.lds;
+  const int nth = plan.nth;
   int cus = 256;
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
   }
-  with_instance<T>(img->r, hc, [&](auto kern, int nth) {
+  with_instance<T>(plan, [&](auto kern) {
     // persistent: as many workgroups as the chip holds at once (LDS, registers, threads)
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, nth, lds) != hipSuccess || per_cu < 1) {
       (void)hipGetLastError();
       per_cu = 1;
     }
+    per_cu *= grid_mult();
     const int64_t grid = B < (int64_t)cus * per_cu ? B : (int64_t)cus * per_cu;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(nth), lds, stream, static_cast<const T*>(img->gt),
                        static_cast<const T*>(img->dt), static_cast<const T*>(img->nat), static_cast<const T*>(img->y0),
@@ -989,19 +1016,21 @@ int lmi_block_backward_t(const RayenPack* p, const LmiWaveImage* img, const T* v
                          int only_lmi = 0) {
   if (!lmi_block_bwd_serves_t<T>(img)) return RAYEN_E_UNSUPPORTED;
   if (B == 0) return RAYEN_OK;
-  const int hc = head_cols_bwd<T>(img->r, img->n);
-  const size_t lds = (hc > 0 ? lds_elems_head(img->r, img->n, hc, true) : lds_bwd_elems(img->r, img->n)) * sizeof(T);
+  const Plan plan = plan_for<T>(img->r, img->n, true);
+  const size_t lds = plan.lds;
+  const int nth = plan.nth;
   int cus = 256;
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
   }
-  with_bwd_instance<T>(img->r, hc, [&](auto kern, int nth) {
+  with_bwd_instance<T>(plan, [&](auto kern) {
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, nth, lds) != hipSuccess || per_cu < 1) {
       (void)hipGetLastError();
       per_cu = 1;
     }
+    per_cu *= grid_mult();
     const int64_t grid = B < (int64_t)cus * per_cu ? B : (int64_t)cus * per_cu;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(nth), lds, stream, static_cast<const T*>(img->gt),
                        static_cast<const T*>(img->dt), static_cast<const T*>(img->nrm), img->rho_of, img->r, img->n, img->k,

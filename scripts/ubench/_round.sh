@@ -1,5 +1,6 @@
 #!/bin/bash
-# scratch: one gpurun call
-mkdir -p gpurun_out/r05y
-timeout 1500 python -m pytest tests/test_gpu_lmi_mixed.py -m gpu -q 2>&1 | tail -60 > gpurun_out/r05y/pytest_mixed.log
-cat gpurun_out/r05y/pytest_mixed.log | cut -c1-250
+mkdir -p gpurun_out/r05zd
+timeout 1500 python -m pytest tests/test_gpu_lmi_wave.py tests/test_gpu_lmi_mixed.py -m gpu -x -q 2>&1 | tail -5
+o=gpurun_out/r05zd/lmi_bwd_ab.txt; : > $o
+timeout 300 python scripts/ubench/lmi_bwd_ab.py 2>&1 | grep -v amdgpu.ids >> $o
+cat $o

@@ -1,0 +1,30 @@
+#!/usr/bin/env python
+"""Developer: forward / backward of LMI-only sets at the sweep's shapes (RAYEN_LB_GRID_MULT A/B)."""
+import json, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.getcwd())
+from rayen_amd import constraints, ops                    # noqa: E402
+from rayen_amd.constraint_module import ConstraintModule   # noqa: E402
+B = 2000
+out = {"512_upto": os.environ.get("RAYEN_LB_512_UPTO", "257")}
+for r_F, k in ((100, 100), (150, 100), (196, 100), (220, 100), (250, 100), (300, 100)):
+    rng = np.random.default_rng(r_F * 7 + k)
+    F = []
+    for _ in range(k):
+        tmp = rng.uniform(-1, 1, size=(r_F, r_F)); F.append((tmp + tmp.T) / 2)
+    tmp = rng.uniform(-1, 1, size=(r_F, r_F)); F.append(tmp @ tmp.T + 0.5 * np.eye(r_F))
+    cs = constraints.ConvexConstraints(lc=None, qcs=[], socs=[], lmic=constraints.LMIConstraint(F), y0=np.zeros((k, 1)))
+    layer = ConstraintModule(cs, create_map=False).cuda()
+    v = torch.empty(B, cs.n, device="cuda").uniform_(-1, 1)
+    dp, _ = layer.device_pack(torch.device("cuda", 0))
+    y, kappa, active = ops.project_raw(v, dp, want_active=True)
+    g = torch.ones(B, cs.k, device="cuda")
+    def t(fn, reps=4):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps): fn()
+        e1.record(); torch.cuda.synchronize()
+        return round(e0.elapsed_time(e1) / reps, 3)
+    out[f"r{r_F}_k{k}"] = [t(lambda: ops.project_raw(v, dp, want_active=False, want_kappa=False)), t(lambda: ops.backward_raw(v, kappa, active, g, dp))]
+print(json.dumps(out), flush=True)

@@ -92,6 +92,8 @@ def _layer(raw, dtype):
 def test_large_lmi_forward_and_backward(name, dtype, kernel, monkeypatch):
     """``kernel``: the forward on the workgroup-per-sample kernel (rayen_lmi_block.h, round 5: the default wherever it
     serves) or, pinned with RAYEN_LMI_BLOCK=0, on the wave-per-sample kernel; the same switch moves the backward."""
+    if kernel == "wave" and name == "r128_k70":
+        pytest.skip("the wave kernel is no default beyond 64 x 64 any more: r100 stands for its large matrices")
     monkeypatch.setenv("RAYEN_LMI_BLOCK", "1" if kernel == "block" else "0")
     raw = _case(**CASES[name])
     r = CASES[name]["r"]
@@ -137,12 +139,16 @@ BIG = {
     "r300": dict(k=6, r=300, m=0, n_eq=0, seed=16),          # the end of the reference's sweep (time_analysis.py:157-160)
     "r303_lin": dict(k=4, r=303, m=10, n_eq=0, seed=17),     # the largest the backward holds in fp32
     "r210_eq": dict(k=9, r=210, m=0, n_eq=2, seed=18),       # fp64 with 16 columns in registers
+    # register columns so that TWO 512-thread workgroups share a compute unit's LDS (fp32 198 .. 220, fp64 139 .. ~152)
+    "r212_lin": dict(k=7, r=212, m=6, n_eq=0, seed=19),
+    "r150": dict(k=6, r=150, m=0, n_eq=0, seed=20),
 }
 
 
 @pytest.mark.parametrize("name,dtype", [("r200_lin", torch.float32), ("r196_eq", torch.float64), ("r196_eq", torch.float32),
                                          ("r250", torch.float32), ("r280_lin", torch.float32), ("r282", torch.float32),
-                                         ("r300", torch.float32), ("r303_lin", torch.float32), ("r210_eq", torch.float64)])
+                                         ("r300", torch.float32), ("r303_lin", torch.float32), ("r210_eq", torch.float64),
+                                         ("r212_lin", torch.float32), ("r150", torch.float64)])
 def test_matrices_only_the_block_kernel_holds(name, dtype):
     """Forward AND backward of LMIs up to 303 x 303 (fp32) / 210 x 210 (fp64) on hand-written kernels -- the reference's own
     sweep ends at 300 x 300 (time_analysis.py:157-160); rounds 3-4 sent everything beyond ~190 / ~135 to rocSOLVER through
@@ -153,7 +159,7 @@ def test_matrices_only_the_block_kernel_holds(name, dtype):
     cs, layer = _layer(raw, dtype)
     dp, _ = layer.device_pack(torch.device("cuda", 0))
     gen = torch.Generator().manual_seed(2)
-    B = 40
+    B = 28                                                    # (the fp64 oracle's eigvalsh + autograd on the CPU sets the pace)
     x = torch.empty(B, cs.n, 1).uniform_(-2.0, 2.0, generator=gen)
     x[:2] *= 1e-4
     x[2] = 0.0
