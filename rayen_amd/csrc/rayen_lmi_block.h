@@ -583,7 +583,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4))) void l
     const T floor_q = fmax(scale * (sizeof(T) == 4 ? T(1e-30) : T(1e-200)), lw::Eps<T>::tiny);
     int* firsts = reinterpret_cast<int*>(red + 3 * kWaves);      // [2][kWaves]: the rounds alternate
     // (NTH + 1)^rounds >= 2^27 in fp32, 2^60 in fp64
-    constexpr int kRounds = sizeof(T) == 4 ? (NTH == 1024 ? 3 : 4) : (NTH == 1024 ? 6 : 7);
+    constexpr int kRounds = sizeof(T) == 4 ? (NTH == 1024 ? 3 : 4) : (NTH == 1024 ? 6 : (NTH == 512 ? 7 : 8));
     for (int round = 0; round < kRounds; ++round) {
       const T step = (hi - lo) * (T(1) / T(kThreads + 1));
       const T sig = lo + step * (T)(tid + 1);
@@ -919,12 +919,18 @@ Plan plan_for(int r, int n, bool bwd) {
     const int x = env != nullptr ? std::atoi(env) : 257;
     return x < 2 ? 2 : (x > 257 ? 257 : x);
   }();
+  static const int upto256 = [] {          // 256 threads: four workgroups per compute unit (at most 129 rows)
+    const char* env = std::getenv("RAYEN_LB_256_UPTO");
+    const int x = env != nullptr ? std::atoi(env) : 0;
+    return x < 0 ? 0 : (x > 129 ? 129 : x);
+  }();
   constexpr int HC = HeadCols<T>::value;
   const size_t plain = (bwd ? lds_bwd_elems(r, n) : lds_elems(r, n)) * sizeof(T);
   const size_t head = r > HC + 2 ? lds_elems_head(r, n, HC, bwd) * sizeof(T) : kLdsMax + 1;
   Plan p;
   if (r < 2 || (bwd && r > 320)) return p;
-  if (r <= upto && (r <= 128 || 2 * plain <= kLdsMax)) { p.nth = 512; p.hc = 0; p.lds = plain; }
+  if (r <= upto256) { p.nth = 256; p.hc = 0; p.lds = plain; }
+  else if (r <= upto && (r <= 128 || 2 * plain <= kLdsMax)) { p.nth = 512; p.hc = 0; p.lds = plain; }
   else if (r <= upto && r - HC <= 224 && 2 * head <= kLdsMax) { p.nth = 512; p.hc = HC; p.lds = head; }   // (7 waves of rows + 1)
   else if (plain <= kLdsMax) { p.nth = 1024; p.hc = 0; p.lds = plain; }
   else if (head <= kLdsMax) { p.nth = 1024; p.hc = HC; p.lds = head; }
@@ -952,6 +958,7 @@ void with_bwd_instance(const Plan& p, F f) {
   constexpr int HC = HeadCols<T>::value;
   if (p.hc > 0 && p.nth == 512) f(lmi_block_bwd_kernel<T, 512, HC>);
   else if (p.hc > 0) f(lmi_block_bwd_kernel<T, 1024, HC>);
+  else if (p.nth == 256) f(lmi_block_bwd_kernel<T, 256, 0>);
   else if (p.nth == 512) f(lmi_block_bwd_kernel<T, 512, 0>);
   else f(lmi_block_bwd_kernel<T, 1024, 0>);
 }
@@ -961,6 +968,7 @@ void with_instance(const Plan& p, F f) {
   constexpr int HC = HeadCols<T>::value;
   if (p.hc > 0 && p.nth == 512) f(lmi_block_kernel<T, 512, HC>);
   else if (p.hc > 0) f(lmi_block_kernel<T, 1024, HC>);
+  else if (p.nth == 256) f(lmi_block_kernel<T, 256, 0>);
   else if (p.nth == 512) f(lmi_block_kernel<T, 512, 0>);
   else f(lmi_block_kernel<T, 1024, 0>);
 }

@@ -6,8 +6,9 @@ sys.path.insert(0, os.getcwd())
 from rayen_amd import constraints, ops                    # noqa: E402
 from rayen_amd.constraint_module import ConstraintModule   # noqa: E402
 B = 2000
-out = {"512_upto": os.environ.get("RAYEN_LB_512_UPTO", "257")}
-for r_F, k in ((100, 100), (150, 100), (196, 100), (220, 100), (250, 100), (300, 100)):
+out = {"512_upto": os.environ.get("RAYEN_LB_512_UPTO", "257"), "256_upto": os.environ.get("RAYEN_LB_256_UPTO", "-")}
+SHAPES = ((70, 10), (100, 10), (100, 100), (128, 100)) if os.environ.get("RAYEN_LB_256_UPTO") is not None else ((100, 100), (150, 100), (196, 100), (220, 100), (250, 100), (300, 100))
+for r_F, k in SHAPES:
     rng = np.random.default_rng(r_F * 7 + k)
     F = []
     for _ in range(k):
