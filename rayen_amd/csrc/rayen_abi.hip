@@ -106,14 +106,17 @@ int build_one(RayenPack* p, bool eligible, Image** slot, Build build) {
   return RAYEN_OK;
 }
 
-// Which LMI kernel takes a matrix neither the quad nor the lane kernels hold: the workgroup-per-sample forward
-// (rayen_lmi_block.h) beyond 64 x 64 and wherever the wave kernel's full storage does not fit.
-bool lmi_block_preferred(bool block_serves, bool wave_serves, int r) {
+// Which LMI kernel takes a matrix neither the quad nor the lane kernels hold: the workgroup-per-sample kernels
+// (rayen_lmi_block.h) wherever they serve in fp32, beyond 44 x 44 in fp64, and wherever the wave kernel's full storage does
+// not fit.  Measured with warm clocks, B = 2 000, forward / backward ms, block against wave (profiles/bench/r05_lmi_cross.txt):
+// fp32 r = 33 0.086 / 0.114 against 0.105 / 0.129, 64 0.24 / 0.30 against 0.29 / 0.35, 80 0.43 / 0.51 against 1.01 / 1.21;
+// fp64 r = 40 0.193 / 0.190 against 0.178 / 0.196, 50 0.27 / 0.27 against 0.45 / 0.50.
+bool lmi_block_preferred(bool block_serves, bool wave_serves, int r, bool f64) {
   if (!block_serves) return false;
   if (!wave_serves) return true;
   const char* env = std::getenv("RAYEN_LMI_BLOCK");       // 0 / 1 pin a kernel (developer A/B, tests)
   if (env != nullptr && (env[0] == '0' || env[0] == '1')) return env[0] == '1';
-  return r > 64;      // (measured, B = 2 000: r = 64 0.33 against 0.30 ms for the wave kernel, r = 100 1.26 against 2.53)
+  return f64 ? r > 44 : true;
 }
 
 int lmi_dim(const RayenPack* p) {
@@ -271,7 +274,7 @@ int project_bwd(const RayenPack* p, const T* v, int64_t B, int64_t ldv, const T*
   if (rcg == RAYEN_E_UNSUPPORTED && !old_mode) {   // (nothing was launched)
     if constexpr (sizeof(T) == 4) {
       if (p->w32 != nullptr) {
-        if (lmi_block_preferred(lmi_block_bwd_serves_f32(p->w32), lmi_wave_serves_f32(p->w32), lmi_dim(p)))
+        if (lmi_block_preferred(lmi_block_bwd_serves_f32(p->w32), lmi_wave_serves_f32(p->w32), lmi_dim(p), false))
           return lmi_block_backward_f32(p, p->w32, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv,
                                         static_cast<hipStream_t>(stream));
         return lmi_wave_backward_f32(p, p->w32, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv,
@@ -279,7 +282,7 @@ int project_bwd(const RayenPack* p, const T* v, int64_t B, int64_t ldv, const T*
       }
     } else {
       if (p->w64 != nullptr) {
-        if (lmi_block_preferred(lmi_block_bwd_serves_f64(p->w64), lmi_wave_serves_f64(p->w64), lmi_dim(p)))
+        if (lmi_block_preferred(lmi_block_bwd_serves_f64(p->w64), lmi_wave_serves_f64(p->w64), lmi_dim(p), true))
           return lmi_block_backward_f64(p, p->w64, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv,
                                         static_cast<hipStream_t>(stream));
         return lmi_wave_backward_f64(p, p->w64, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv,
@@ -816,7 +819,7 @@ static int project_f32(const RayenPack* p, const float* v, int64_t B, int64_t ld
   g_last_forward = RAYEN_KERNEL_LANE;
   const int rcg = project_generic<float>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, old_mode);
   if (rcg == RAYEN_E_UNSUPPORTED && p->w32 != nullptr && y != nullptr && !old_mode) {   // (nothing was launched)
-    if (lmi_block_preferred(lmi_block_serves_f32(p->w32), lmi_wave_serves_f32(p->w32), lmi_dim(p))) {
+    if (lmi_block_preferred(lmi_block_serves_f32(p->w32), lmi_wave_serves_f32(p->w32), lmi_dim(p), false)) {
       g_last_forward = RAYEN_KERNEL_LMI_BLOCK;
       return lmi_block_forward_f32(p, p->w32, v, B, ldv, y, ldy, kappa, active, nan_flag, static_cast<hipStream_t>(stream));
     }
@@ -920,7 +923,7 @@ static int project_f64(const RayenPack* p, const double* v, int64_t B, int64_t l
   g_last_forward = RAYEN_KERNEL_LANE;
   const int rcg = project_generic<double>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, old_mode);
   if (rcg == RAYEN_E_UNSUPPORTED && p->w64 != nullptr && y != nullptr && !old_mode &&
-      lmi_block_preferred(lmi_block_serves_f64(p->w64), lmi_wave_serves_f64(p->w64), lmi_dim(p))) {
+      lmi_block_preferred(lmi_block_serves_f64(p->w64), lmi_wave_serves_f64(p->w64), lmi_dim(p), true)) {
     g_last_forward = RAYEN_KERNEL_LMI_BLOCK;
     return lmi_block_forward_f64(p, p->w64, v, B, ldv, y, ldy, kappa, active, nan_flag, static_cast<hipStream_t>(stream));
   }

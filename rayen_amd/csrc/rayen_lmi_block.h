@@ -37,11 +37,24 @@ __device__ unsigned long long g_lb_prof[8];
 #endif
 
 constexpr int kWaves = 16;                   // slots of the reduction scratch (the largest workgroup's waves)
+#ifndef RAYEN_LB_SMALL_WPE
+#define RAYEN_LB_SMALL_WPE 4
+#endif
+constexpr int kSmallWavesPerEu = RAYEN_LB_SMALL_WPE;    // waves per SIMD the 128- / 256-thread instances are compiled for
 constexpr size_t kLdsMax = 160 * 1024;
 
 // LDS of a workgroup (units of T): A[P] | dd[r] | ee[r] | vv[r] | ww[r] | red[3][2 kWaves] | vs[n]
 __host__ __device__ inline size_t lds_elems(int r, int n) {
   return (size_t)r * (r + 1) / 2 + 4 * (size_t)r + 6 * kWaves + (size_t)n + 8;
+}
+
+// rounds of multi-section with one shift per thread: (threads + 1)^rounds >= 2^bits
+constexpr int sturm_rounds(int threads, int bits) {
+  int rounds = 0;
+  double span = 1.0, want = 1.0;
+  for (int b = 0; b < bits; ++b) want *= 2.0;
+  while (span < want) { span *= (double)(threads + 1); ++rounds; }
+  return rounds;
 }
 
 // e^2 / q of the Sturm recurrence: the count needs the SIGN of the next pivot, and the bracket is padded by 1e-6 of the
@@ -313,7 +326,8 @@ __device__ __forceinline__ void tridiagonalise(T* A, int r, T* dd, T* ee, T* tt,
     // (eight lanes per row pay in fp64: 2.70 against 2.07 ms at r = 100 -- profiles/bench/r05_lmi_block_ab.txt)
     if (sizeof(T) == 4 && 8 * m <= NTH) reduce_column<T, sizeof(T) == 4 ? 8 : 4, NTH, KEEP>(A, r, kc, dd, ee, tt, vv, ww, red, tid);
     else if (4 * m <= NTH) reduce_column<T, 4, NTH, KEEP>(A, r, kc, dd, ee, tt, vv, ww, red, tid);
-    else reduce_column<T, 2, NTH, KEEP>(A, r, kc, dd, ee, tt, vv, ww, red, tid);
+    else if (2 * m <= NTH || NTH >= 512) reduce_column<T, 2, NTH, KEEP>(A, r, kc, dd, ee, tt, vv, ww, red, tid);
+    else if constexpr (NTH < 512) reduce_column<T, 1, NTH, KEEP>(A, r, kc, dd, ee, tt, vv, ww, red, tid);   // (a lane per row)
 #endif
   }
   if (tid == 0) {
@@ -483,7 +497,7 @@ __device__ __forceinline__ void head_phase(T* A, int r, T (&head)[HC / 2], T* dd
 
 // (four waves per SIMD = two 512-thread workgroups per compute unit: one register more and it is one)
 template <typename T, int NTH, int HC>
-__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4))) void lmi_block_kernel(
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(NTH <= 256 ? kSmallWavesPerEu : 4))) void lmi_block_kernel(
     const T* __restrict__ gt, const T* __restrict__ dt, const T* __restrict__ nat, const T* __restrict__ y0,
     const int32_t* __restrict__ lin_id, int r, int n, int k, int m, int P, int Pp, int Mp, int Kp, int identity,
     int lmi_seg, const T* __restrict__ v, int64_t B, int64_t ldv, T* y, int64_t ldy,
@@ -583,7 +597,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4))) void l
     const T floor_q = fmax(scale * (sizeof(T) == 4 ? T(1e-30) : T(1e-200)), lw::Eps<T>::tiny);
     int* firsts = reinterpret_cast<int*>(red + 3 * kWaves);      // [2][kWaves]: the rounds alternate
     // (NTH + 1)^rounds >= 2^27 in fp32, 2^60 in fp64
-    constexpr int kRounds = sizeof(T) == 4 ? (NTH == 1024 ? 3 : 4) : (NTH == 1024 ? 6 : (NTH == 512 ? 7 : 8));
+    constexpr int kRounds = sturm_rounds(NTH, sizeof(T) == 4 ? 27 : 60);
     for (int round = 0; round < kRounds; ++round) {
       const T step = (hi - lo) * (T(1) / T(kThreads + 1));
       const T sig = lo + step * (T)(tid + 1);
@@ -672,7 +686,7 @@ __host__ __device__ inline size_t lds_bwd_elems(int r, int n) {
 // then x x' (off-diagonal entries twice) replaces the matrix in packed order and every generator is ONE dot product with it,
 // a wave each -- the same n P words of G the forward reads.
 template <typename T, int NTH, int HC>
-__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4))) void lmi_block_bwd_kernel(
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(NTH <= 256 ? kSmallWavesPerEu : 4))) void lmi_block_bwd_kernel(
     const T* __restrict__ gt, const T* __restrict__ dt, const T* __restrict__ nrm, const int32_t* __restrict__ rho_of, int r,
     int n, int k, int P, int Pp, int Mp, int identity, int lmi_seg, const T* __restrict__ v, int64_t B, int64_t ldv,
     const T* __restrict__ kappa, const int32_t* __restrict__ active, const T* __restrict__ gy, int64_t ldg,
@@ -904,12 +918,15 @@ inline int grid_mult() {
 }
 
 // The launch shape of a matrix: threads, columns kept in registers (0: the whole packed triangle in LDS), LDS bytes; nth = 0:
-// no instance holds it.  512 threads while TWO workgroups fit a compute unit's LDS -- this kernel waits on barriers, and a
-// second workgroup fills the gaps -- which the register columns stretch by HC rows (r <= 220 in fp32); 1024 threads beyond.
-// Measured, B = 2 000, k = 100, 512 against 1024 threads without register columns (profiles/bench/r05_lmi_block_ab.txt):
-// forward r = 150 2.7 against 4.5 ms, 196 4.5 against 7.0 (two workgroups of 80.8 KB), 220 9.3 against 8.4, 250 11.7 against
-// 10.7; backward 150 4.0 against 6.2, 196 12.4 against 10.1 (82.4 KB: one workgroup), 250 19.5 against 15.6.
-// RAYEN_LB_512_UPTO (developer) caps the 512-thread range.
+// no instance holds it.  This kernel waits -- on its barriers and on dependent LDS round trips -- and what fills the gaps
+// is ANOTHER workgroup on the same compute unit: the smaller the workgroup, the more of them (16 waves per unit at these
+// register counts), as long as every wave still has rows.  Measured, B = 2 000, forward ms with 128 / 256 / 512 threads
+// (profiles/bench/r05_lmi_block_ab.txt; the wave-per-sample kernel takes 0.145 at r = 40 and 0.30 at r = 64):
+//   r = 40 0.13 / 0.21 / 0.41, 64 0.26 / 0.38 / 0.68, 70 0.33 / 0.45 / 0.76, 100 1.18 / 0.82 / 1.26, 128 2.21 / 1.47 / 1.99,
+//   150 - / 2.85 / 2.71, 180 - / 5.7 / 3.8, 196 - / 7.0 / 4.5;   512 against 1024 threads: 196 4.5 against 7.0 (two workgroups of
+//   80.8 KB), 220 9.3 against 8.4 (7.3 with 24 columns in registers: two workgroups again), 250 11.7 against 10.7.
+// Hence: 128 threads to r = 80, 256 to r = 140, 512 while TWO workgroups fit the LDS (the register columns stretch that to
+// r = 220 in fp32), 1024 beyond.  RAYEN_LB_NTH / RAYEN_LB_512_UPTO (developer) override.
 struct Plan { int nth = 0, hc = 0; size_t lds = 0; };
 
 template <typename T>
@@ -919,17 +936,18 @@ Plan plan_for(int r, int n, bool bwd) {
     const int x = env != nullptr ? std::atoi(env) : 257;
     return x < 2 ? 2 : (x > 257 ? 257 : x);
   }();
-  static const int upto256 = [] {          // 256 threads: four workgroups per compute unit (at most 129 rows)
-    const char* env = std::getenv("RAYEN_LB_256_UPTO");
-    const int x = env != nullptr ? std::atoi(env) : 0;
-    return x < 0 ? 0 : (x > 129 ? 129 : x);
-  }();
   constexpr int HC = HeadCols<T>::value;
   const size_t plain = (bwd ? lds_bwd_elems(r, n) : lds_elems(r, n)) * sizeof(T);
   const size_t head = r > HC + 2 ? lds_elems_head(r, n, HC, bwd) * sizeof(T) : kLdsMax + 1;
   Plan p;
   if (r < 2 || (bwd && r > 320)) return p;
-  if (r <= upto256) { p.nth = 256; p.hc = 0; p.lds = plain; }
+  static const int forced = [] {           // developer: RAYEN_LB_NTH=128 / 256 / 512 / 1024 wherever the rows fit
+    const char* env = std::getenv("RAYEN_LB_NTH");
+    return env != nullptr ? std::atoi(env) : 0;
+  }();
+  if ((forced == 128 || forced == 256) && r - 1 <= forced && plain <= kLdsMax) { p.nth = forced; p.hc = 0; p.lds = plain; return p; }
+  if (forced == 0 && r <= 80) { p.nth = 128; p.hc = 0; p.lds = plain; }
+  else if (forced == 0 && r <= 140) { p.nth = 256; p.hc = 0; p.lds = plain; }
   else if (r <= upto && (r <= 128 || 2 * plain <= kLdsMax)) { p.nth = 512; p.hc = 0; p.lds = plain; }
   else if (r <= upto && r - HC <= 224 && 2 * head <= kLdsMax) { p.nth = 512; p.hc = HC; p.lds = head; }   // (7 waves of rows + 1)
   else if (plain <= kLdsMax) { p.nth = 1024; p.hc = 0; p.lds = plain; }
@@ -958,6 +976,7 @@ void with_bwd_instance(const Plan& p, F f) {
   constexpr int HC = HeadCols<T>::value;
   if (p.hc > 0 && p.nth == 512) f(lmi_block_bwd_kernel<T, 512, HC>);
   else if (p.hc > 0) f(lmi_block_bwd_kernel<T, 1024, HC>);
+  else if (p.nth == 128) f(lmi_block_bwd_kernel<T, 128, 0>);
   else if (p.nth == 256) f(lmi_block_bwd_kernel<T, 256, 0>);
   else if (p.nth == 512) f(lmi_block_bwd_kernel<T, 512, 0>);
   else f(lmi_block_bwd_kernel<T, 1024, 0>);
@@ -968,6 +987,7 @@ void with_instance(const Plan& p, F f) {
   constexpr int HC = HeadCols<T>::value;
   if (p.hc > 0 && p.nth == 512) f(lmi_block_kernel<T, 512, HC>);
   else if (p.hc > 0) f(lmi_block_kernel<T, 1024, HC>);
+  else if (p.nth == 128) f(lmi_block_kernel<T, 128, 0>);
   else if (p.nth == 256) f(lmi_block_kernel<T, 256, 0>);
   else if (p.nth == 512) f(lmi_block_kernel<T, 512, 0>);
   else f(lmi_block_kernel<T, 1024, 0>);
