@@ -1,7 +1,7 @@
 #!/bin/bash
-mkdir -p gpurun_out/r05zj
-o=gpurun_out/r05zj/lmi_wpe_ab.txt; : > $o
-S="40x10 64x10 80x10 100x10 100x100 128x100 140x100"
-timeout 400 python scripts/ubench/lmi_bwd_ab.py $S 2>&1 | grep -v amdgpu.ids >> $o
-for v in wpe6 wpe8; do RAYEN_HIP_LIBRARY=scripts/ubench/variants/librayen_lmi_block_$v.so timeout 400 python scripts/ubench/lmi_bwd_ab.py $S 2>&1 | grep -v amdgpu.ids | sed "s/^{/{\"lib\": \"$v\", /" >> $o; done
-cat $o
+# scratch: one gpurun call
+mkdir -p gpurun_out/r05zk
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > gpurun_out/r05zk/pytest_full.log
+cat gpurun_out/r05zk/pytest_full.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | cut -c1-330
