@@ -1,7 +1,6 @@
 #!/bin/bash
-# scratch: one gpurun call
-mkdir -p gpurun_out/r05zk
-timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > gpurun_out/r05zk/pytest_full.log
-cat gpurun_out/r05zk/pytest_full.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | cut -c1-330
+mkdir -p gpurun_out/r05zl
+timeout 1500 python -m pytest tests/test_gpu_lmi_wave.py tests/test_gpu_lmi_mixed.py -m gpu -x -q 2>&1 | tail -8
+timeout 400 python scripts/ubench/lmi_bwd_ab.py 150x100 180x100 196x100 220x100 250x100 280x10 300x100 2>&1 | grep -v amdgpu.ids > gpurun_out/r05zl/wp.txt
+LMI_DTYPE=f64 timeout 400 python scripts/ubench/lmi_bwd_ab.py 150x10 196x10 210x10 2>&1 | grep -v amdgpu.ids >> gpurun_out/r05zl/wp.txt
+cat gpurun_out/r05zl/wp.txt
