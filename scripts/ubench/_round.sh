@@ -1,15 +1,2 @@
 #!/bin/bash
-out=gpurun_out/r05zo
-mkdir -p $out
-export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $out/stats -o s -- python scripts/ubench/lmi_sweep.py > $out/sweep_under_profiler.txt 2> $out/stats.err
-python - <<'PY'
-import sqlite3, json
-con = sqlite3.connect("gpurun_out/r05zo/stats/s_results.db")
-rows = []
-for r in con.execute("select name,total_calls,total_duration,average,percentage from top_kernels limit 14"):
-    rows.append({"name": r[0][:110], "calls": r[1], "total_us": r[2], "avg_us": r[3], "pct": r[4]})
-json.dump({"command": "rocprofv3 --kernel-trace --stats -- python scripts/ubench/lmi_sweep.py", "top_kernels": rows}, open("gpurun_out/r05zo/lmi_sweep_rocprofv3.json", "w"), indent=1)
-for r in rows: print(r)
-PY
-rm -rf $out/stats
+timeout 900 python -m pytest tests/test_gpu_lmi_mixed.py -m gpu -x -q -k "old_head" 2>&1 | tail -25 | cut -c1-220

@@ -87,3 +87,28 @@ def test_lmi_next_to_quadratics_and_cones(name, dtype):
     xg = xd.unsqueeze(2).clone().requires_grad_(True)
     layer(xg).sum().backward()
     assert not layer._hip_unsupported and torch.isfinite(xg.grad).all()
+
+
+@pytest.mark.eager_detour
+def test_the_old_head_on_such_a_set_is_refused_by_the_abi_and_answered_loudly(monkeypatch):
+    """RAYEN_old (CM:460-466) on a set with quadratics next to a large LMI: neither of the two kernels of the mixed route has
+    that head for it, the C ABI says RAYEN_E_UNSUPPORTED (strict mode raises) and the module announces the detour once --
+    the lane kernel's image without the LMI must never answer such a call by itself."""
+    import warnings
+    from rayen_amd.constraint_module import ConstraintModule
+    raw = _mixed(**CASES["r60_all"])
+    cs = workloads.build_constraints(raw)
+    layer = ConstraintModule(cs, method="RAYEN_old", create_map=False).cuda()
+    gen = torch.Generator().manual_seed(3)
+    x = torch.empty(32, cs.n + 1, 1).uniform_(-1.0, 1.0, generator=gen)
+    monkeypatch.setenv("RAYEN_STRICT_HIP", "1")
+    with pytest.raises(_lib.RayenError):
+        layer(x.cuda())
+    monkeypatch.delenv("RAYEN_STRICT_HIP")
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        y = layer(x.cuda())
+    assert sum(issubclass(w.category, RuntimeWarning) for w in caught) == 1 and layer._hip_unsupported
+    want = oracle.forward(oracle.precompute(csd_from_cs(cs), torch.float32), x, method="RAYEN_old").numpy()[:, :, 0]
+    assert np.max(rel_err_rows(y.cpu().numpy()[:, :, 0].astype(np.float64), want.astype(np.float64))) <= 1e-4
+    assert cs.getMaxViolation(y.cpu().double().numpy()[:, :, 0]) <= 2e-4
