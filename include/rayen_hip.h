@@ -211,7 +211,9 @@ int rayen_ray_project_generic_f64(const RayenPack* pack, const double* v, int64_
  *   W_ext = [W ; NA_E]   (rayen_products_rows() rows: n_rows, + k when the set has equality constraints; the caller
  *                         builds it from the RayenPackDesc it created the pack with)
  *   T [B, ldt] row-major with ldt >= rayen_products_rows(); v, y, kappa, active, nan_flag as in rayen_ray_project_*.
- * Packs with an LMI segment are not served (RAYEN_E_UNSUPPORTED; rayen_products_rows() == 0). */
+ * Packs with an LMI segment: [linear rows] + ONE LMI that the workgroup-per-sample kernels hold are served (round 5: S(v) is
+ * read from the LMI's rows of T, and the backward leaves (2 - [i = j]) x_i x_j there for the caller's second GEMM); any other
+ * pack with an LMI is not (RAYEN_E_UNSUPPORTED; rayen_products_rows() == 0). */
 int64_t rayen_products_rows(const RayenPack* pack);
 int rayen_ray_project_from_products_f32(const RayenPack* pack, const float* T, int64_t ldt, const float* v, int64_t B,
                                         int64_t ldv, float* y, int64_t ldy, float* kappa, int32_t* active,

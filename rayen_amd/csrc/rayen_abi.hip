@@ -293,6 +293,15 @@ int project_bwd(const RayenPack* p, const T* v, int64_t B, int64_t ldv, const T*
   return rcg;
 }
 
+// [linear rows] + ONE LMI on the workgroup-per-sample kernels, with nothing else in the set: such a pack also takes the
+// products route (the GEMM forms S(v) for the whole batch; the kernels then read / write rows of T and C)
+bool lmi_products_pack(const RayenPack* p) {
+  if (p->mixed32 || p->mixed64 || p->q32 != nullptr || p->q64 != nullptr) return false;   // (the four-lane kernel's sizes stay with it)
+  for (const RayenSegment& g : p->segs)
+    if (g.type != RAYEN_SEG_LIN && g.type != RAYEN_SEG_LMI) return false;
+  return (p->w32 != nullptr && lmi_block_products_serves_f32(p->w32)) || (p->w64 != nullptr && lmi_block_products_serves_f64(p->w64));
+}
+
 template <typename T>
 int project_from_products(const RayenPack* p, const T* Tm, int64_t ldt, const T* v, int64_t B, int64_t ldv, T* y,
                                  int64_t ldy, T* kappa, int32_t* active, int32_t* nan_flag, void* stream) {
@@ -302,6 +311,14 @@ int project_from_products(const RayenPack* p, const T* Tm, int64_t ldt, const T*
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess) return RAYEN_E_NO_DEVICE;
   if (dev != p->device) return RAYEN_E_DEVICE_MISMATCH;
+  if (p->wide == nullptr && lmi_products_pack(p)) {      // [linear rows] + one LMI: the workgroup-per-sample kernel reads S(v) from T
+    if (y == nullptr) return RAYEN_E_UNSUPPORTED;
+    g_last_forward = RAYEN_KERNEL_LMI_BLOCK;
+    if constexpr (sizeof(T) == 4)
+      return lmi_block_forward_products_f32(p, p->w32, Tm, ldt, v, B, ldv, y, ldy, kappa, active, nan_flag, static_cast<hipStream_t>(stream));
+    else
+      return lmi_block_forward_products_f64(p, p->w64, Tm, ldt, v, B, ldv, y, ldy, kappa, active, nan_flag, static_cast<hipStream_t>(stream));
+  }
   return wide_epilogue<T>(p, p->wide, Tm, ldt, v, B, ldv, y, ldy, kappa, active, nan_flag,
                           static_cast<hipStream_t>(stream));
 }
@@ -760,6 +777,16 @@ int rayen_ray_project_from_products_f64(const RayenPack* p, const double* T, int
     int dev = -1;                                                                                                        \
     if (hipGetDevice(&dev) != hipSuccess) return RAYEN_E_NO_DEVICE;                                                      \
     if (dev != p->device) return RAYEN_E_DEVICE_MISMATCH;                                                                \
+    if (p->wide == nullptr && lmi_products_pack(p)) {                                                                    \
+      if constexpr (sizeof(T) == 4)                                                                                      \
+        return lmi_block_bwd_coefficients_f32(p, p->w32, (const float*)Tm, ldt, (const float*)v, B, ldv,                 \
+                                              (const float*)kappa, active, (const float*)grad_y, ldg, (float*)C, ldc,    \
+                                              (float*)gs, static_cast<hipStream_t>(stream));                             \
+      else                                                                                                               \
+        return lmi_block_bwd_coefficients_f64(p, p->w64, (const double*)Tm, ldt, (const double*)v, B, ldv,               \
+                                              (const double*)kappa, active, (const double*)grad_y, ldg, (double*)C, ldc, \
+                                              (double*)gs, static_cast<hipStream_t>(stream));                            \
+    }                                                                                                                    \
     return wide_bwd_coefficients<T>(p, p->wide, Tm, ldt, v, B, ldv, kappa, active, grad_y, ldg, C, ldc, gs,              \
                                     static_cast<hipStream_t>(stream));                                                   \
   }
@@ -768,7 +795,7 @@ RAYEN_BWD_COEFF(rayen_ray_project_bwd_coefficients_f64, double)
 #undef RAYEN_BWD_COEFF
 
 int64_t rayen_products_rows(const RayenPack* p) {
-  if (p == nullptr || p->wide == nullptr) return 0;
+  if (p == nullptr || (p->wide == nullptr && !lmi_products_pack(p))) return 0;
   return (int64_t)p->n_rows + (p->out_identity ? 0 : p->k);
 }
 

@@ -296,6 +296,21 @@ int lmi_block_backward_f32(const RayenPack* p, const LmiWaveImage* img, const fl
 int lmi_block_backward_f64(const RayenPack* p, const LmiWaveImage* img, const double* v, int64_t B, int64_t ldv,
                            const double* kappa, const int32_t* active, const double* grad_y, int64_t ldg, double* grad_v,
                            int64_t ldgv, hipStream_t stream, int only_lmi = 0);
+// ... from the products T = v W_ext' of a library GEMM (sets with many generators): forward, and the backward's coefficients
+bool lmi_block_products_serves_f32(const LmiWaveImage* img);
+bool lmi_block_products_serves_f64(const LmiWaveImage* img);
+int lmi_block_forward_products_f32(const RayenPack* p, const LmiWaveImage* img, const float* prods, int64_t ldt, const float* v,
+                                   int64_t B, int64_t ldv, float* y, int64_t ldy, float* kappa, int32_t* active,
+                                   int32_t* nan_flag, hipStream_t stream);
+int lmi_block_forward_products_f64(const RayenPack* p, const LmiWaveImage* img, const double* prods, int64_t ldt, const double* v,
+                                   int64_t B, int64_t ldv, double* y, int64_t ldy, double* kappa, int32_t* active,
+                                   int32_t* nan_flag, hipStream_t stream);
+int lmi_block_bwd_coefficients_f32(const RayenPack* p, const LmiWaveImage* img, const float* prods, int64_t ldt, const float* v,
+                                   int64_t B, int64_t ldv, const float* kappa, const int32_t* active, const float* grad_y,
+                                   int64_t ldg, float* C, int64_t ldc, float* gs, hipStream_t stream);
+int lmi_block_bwd_coefficients_f64(const RayenPack* p, const LmiWaveImage* img, const double* prods, int64_t ldt, const double* v,
+                                   int64_t B, int64_t ldv, const double* kappa, const int32_t* active, const double* grad_y,
+                                   int64_t ldg, double* C, int64_t ldc, double* gs, hipStream_t stream);
 bool lmi_wave_serves_f32(const LmiWaveImage* img);      // (the image may exist for the block kernel alone)
 bool lmi_wave_serves_f64(const LmiWaveImage* img);
 

@@ -495,13 +495,41 @@ __device__ __forceinline__ void head_phase(T* A, int r, T (&head)[HC / 2], T* dd
 }
 
 
+// S(v) out of a row of products (packed lower triangle, the order of the LMI's rows of W): into the LDS triangle and, with
+// register columns, into the slots (the same split as form_S_head)
+template <typename T, int NTH, int HC>
+__device__ __forceinline__ void copy_S(T* A, T (&head)[HC > 0 ? HC / 2 : 1], const T* __restrict__ srow, int r, int P, const int tid) {
+  if constexpr (HC == 0) {
+    for (int idx = tid; idx < P; idx += NTH) A[idx] = srow[idx];
+  } else {
+    constexpr int HS = HC / 2, NW = NTH / 64;
+    const int lane = tid & 63, wave = tid >> 6, rw = lane & 31, part = lane >> 5;
+    const int i = wave == NW - 1 ? rw : HC + 32 * wave + rw;
+    const bool has = wave == NW - 1 ? rw < HC : i < r;
+#pragma unroll
+    for (int s = 0; s < HS; ++s) head[s] = has && 2 * s + part <= i ? srow[(size_t)i * (i + 1) / 2 + 2 * s + part] : T(0);
+    const int rp = r - HC, Pl = rp * (rp + 1) / 2;
+    for (int idx = tid; idx < Pl; idx += NTH) {
+      int ip = (int)((sqrtf(8.f * (float)idx + 1.f) - 1.f) * 0.5f);
+      while ((ip + 1) * (ip + 2) / 2 <= idx) ++ip;
+      while (ip * (ip + 1) / 2 > idx) --ip;
+      const int jp = idx - ip * (ip + 1) / 2;
+      A[idx] = srow[(size_t)(ip + HC) * (ip + HC + 1) / 2 + jp + HC];
+    }
+  }
+}
+
 // (four waves per SIMD = two 512-thread workgroups per compute unit: one register more and it is one)
 template <typename T, int NTH, int HC>
 __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(NTH <= 256 ? kSmallWavesPerEu : 4))) void lmi_block_kernel(
     const T* __restrict__ gt, const T* __restrict__ dt, const T* __restrict__ nat, const T* __restrict__ y0,
     const int32_t* __restrict__ lin_id, int r, int n, int k, int m, int P, int Pp, int Mp, int Kp, int identity,
     int lmi_seg, const T* __restrict__ v, int64_t B, int64_t ldv, T* y, int64_t ldy,
-    T* kappa_out, int32_t* active_out, int32_t* __restrict__ nan_flag, const T* kappa_in, int64_t ldk_in) {
+    T* kappa_out, int32_t* active_out, int32_t* __restrict__ nan_flag, const T* kappa_in, int64_t ldk_in,
+    const T* __restrict__ prods, int64_t ldt, int lmi_row0, int n_rows) {
+  // prods != nullptr (sets with many generators, rayen_abi.hip::project_from_products): row b of T = v W_ext' from a library
+  // GEMM holds what this kernel otherwise forms per sample -- D v at the linear rows' W rows, S(v) packed at the LMI's rows,
+  // NA_E v behind the rows of W -- and v is read only for the output of sets without equalities (no copy of it in LDS)
   extern __shared__ __attribute__((aligned(16))) unsigned char lb_smem[];
   T* A = reinterpret_cast<T*>(lb_smem);
   T* dd = A + (HC > 0 ? (r - HC) * (r - HC + 1) / 2 : P);
@@ -517,7 +545,9 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(NTH <= 256 
 
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
     __syncthreads();          // (the previous sample's last readers of vs / dd / ee)
-    for (int a = tid; a < n; a += kThreads) vs[a] = v[b * ldv + a];
+    const T* prow = prods != nullptr ? prods + b * ldt : nullptr;
+    if (prow == nullptr)
+      for (int a = tid; a < n; a += kThreads) vs[a] = v[b * ldv + a];
     __syncthreads();
 
     // ---- linear rows: (value, index among the linear rows) of the largest D_i . v; the lowest index wins a tie
@@ -525,8 +555,12 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(NTH <= 256 
     int who = -1;
     for (int i = tid; i < m; i += kThreads) {
       T acc = T(0);
-      const T* col = dt + i;
-      for (int a = 0; a < n; ++a) acc = fma(vs[a], col[(size_t)a * Mp], acc);
+      if (prow != nullptr) {
+        acc = prow[lin_id[2 * i + 1]];
+      } else {
+        const T* col = dt + i;
+        for (int a = 0; a < n; ++a) acc = fma(vs[a], col[(size_t)a * Mp], acc);
+      }
       if (acc > kap) { kap = acc; who = i; }
     }
 #pragma unroll
@@ -542,7 +576,8 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(NTH <= 256 
     unsigned long long lb_t_ = clock64();
     const unsigned long long lb_start = lb_t_;
 #endif
-    if constexpr (HC > 0) form_S_head<T, NTH, HC>(A, head, gt, vs, n, r, Pp, tid);
+    if (prow != nullptr) copy_S<T, NTH, HC>(A, head, prow + lmi_row0, r, P, tid);
+    else if constexpr (HC > 0) form_S_head<T, NTH, HC>(A, head, gt, vs, n, r, Pp, tid);
     else form_S<T, NTH>(A, gt, vs, n, P, Pp, tid);
     __syncthreads();
     LB_TICK(4);
@@ -658,7 +693,9 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(NTH <= 256 
     T* yrow = y + b * ldy;
     for (int i = tid; i < k; i += kThreads) {
       T val;
-      if (identity) {
+      if (prow != nullptr) {
+        val = fma(identity ? v[b * ldv + i] : prow[n_rows + i], scl, y0[i]);
+      } else if (identity) {
         val = fma(vs[i], scl, y0[i]);
       } else {
         T acc = T(0);
@@ -685,12 +722,116 @@ __host__ __device__ inline size_t lds_bwd_elems(int r, int n) {
 // matrix (inverse iteration at the forward's kappa, the same factorisation with the same guards as rayen_lmi_wave.h:323-354);
 // then x x' (off-diagonal entries twice) replaces the matrix in packed order and every generator is ONE dot product with it,
 // a wave each -- the same n P words of G the forward reads.
+// The unit eigenvector of lambda_max in zz = dd (visible to the whole workgroup on return), after tridiagonalise<KEEP> (and
+// head_phase): inverse iteration on the tridiagonal matrix at the forward's kappa (the factorisation and guards of
+// rayen_lmi_wave.h:323-354), then x = H_0 ... H_{r-3} z -- the reflectors whose columns are in the LDS by ONE wave with the
+// vector in its registers (row lane + 64 q: no barrier per reflector), those of the slot columns by the whole workgroup.
+template <typename T, int NTH, int HC>
+__device__ __forceinline__ void top_eigenvector(T* A, int r, T kap, T (&head)[HC > 0 ? HC / 2 : 1], T* dd, T* ee, T* tt, T* vv,
+                                                T* ww, T* red, const int tid) {
+  constexpr int NW = NTH / 64, kMaxChunks = 5;
+  const int lane = tid & 63, wave = tid >> 6;
+  T* zz = dd;
+  // ---- z: inverse iteration on M = (kappa + shift) I - T = L D L'.  ww: D, vv: the sub-diagonal of L.
+  if (wave == 0) {
+    T scale = fabs(kap);
+    for (int i = lane; i < r; i += 64) scale = fmax(scale, fabs(dd[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) scale = fmax(scale, __shfl_xor(scale, o));
+    const T shift = lw::Eps<T>::shift * fmax(scale, lw::Eps<T>::tiny);
+    if (lane == 0) {
+      T dprev = fmax(kap + shift - dd[0], shift * T(1e-3));
+      ww[0] = dprev;
+      vv[0] = T(0);
+      for (int i = 1; i < r; ++i) {
+        const T li = ee[i - 1] / dprev;              // M's off-diagonal is -ee: l = -ee / D, kept with the sign folded
+        const T di = fmax(kap + shift - dd[i] - li * ee[i - 1], shift * T(1e-3));
+        vv[i] = -li;
+        ww[i] = T(1) / di;                           // (the solves multiply)
+        dprev = di;
+      }
+      ww[0] = T(1) / ww[0];
+      for (int i = 0; i < r; ++i) zz[i] = T(1) + T(0.01) * (T)i;   // not orthogonal to anything special
+      for (int it = 0; it < 3; ++it) {
+        T prev = zz[0];
+        for (int i = 1; i < r; ++i) { prev = fma(-vv[i], prev, zz[i]); zz[i] = prev; }     // L y = b
+        prev = prev * ww[r - 1];
+        zz[r - 1] = prev;
+        T nrm2 = prev * prev;
+        for (int i = r - 2; i >= 0; --i) {                                                   // D L' z = y
+          prev = fma(-vv[i + 1], prev, zz[i] * ww[i]);
+          zz[i] = prev;
+          nrm2 = fma(prev, prev, nrm2);
+        }
+        const T inv = T(1) / sqrt(fmax(nrm2, lw::Eps<T>::tiny));
+        for (int i = 0; i < r; ++i) zz[i] *= inv;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // ---- x = H_0 H_1 ... H_{r-3} z, the vector in this wave's registers (row lane + 64 q)
+    T xq[kMaxChunks];
+#pragma unroll
+    for (int q = 0; q < kMaxChunks; ++q) xq[q] = lane + 64 * q < r ? zz[lane + 64 * q] : T(0);
+    for (int c = r - 3; c >= HC; --c) {                // (the reflectors whose columns are in the LDS)
+      const T tc = tt[c];
+      if (tc == T(0)) continue;                      // (wave-uniform)
+      const T alpha = ee[c];
+      T hv[kMaxChunks];
+      T dot = T(0);
+#pragma unroll
+      for (int q = 0; q < kMaxChunks; ++q) {
+        const int i = lane + 64 * q;
+        T h = T(0);
+        if (i > c && i < r) {
+          h = A[(i - HC) * (i - HC + 1) / 2 + (c - HC)];
+          if (i == c + 1) h -= alpha;
+        }
+        hv[q] = h;
+        dot = fma(h, xq[q], dot);
+      }
+      dot = lw::wsum(dot) * tc;
+#pragma unroll
+      for (int q = 0; q < kMaxChunks; ++q) xq[q] = fma(-dot, hv[q], xq[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < kMaxChunks; ++q)
+      if (lane + 64 * q < r) zz[lane + 64 * q] = xq[q];
+  }
+  __syncthreads();
+  if constexpr (HC > 0) {
+    // ---- the reflectors of the columns in the slots, HC - 1 .. 0: their entries sit with the rows' lanes (head_phase)
+    const int rw = lane & 31, part = lane >> 5;
+    const bool head_wave = wave == NW - 1;
+    const int i = head_wave ? rw : HC + 32 * wave + rw;
+    const bool has = head_wave ? rw < HC : i < r;
+    for (int c = HC - 1; c >= 0; --c) {
+      const T tc = tt[c];
+      if (tc == T(0)) continue;                      // (the same for every thread)
+      T h = T(0);
+      if (has && i > c && part == (c & 1)) {
+        h = slot_of<T, HC / 2>(head, c >> 1);
+        if (i == c + 1) h -= ee[c];
+      }
+      const T dot = bsum<T, NW>(h != T(0) ? h * zz[i] : T(0), red + (c & 1) * 2 * kWaves, tid) * tc;
+      if (h != T(0)) zz[i] = fma(-dot, h, zz[i]);
+      __syncthreads();
+    }
+  }
+}
+
 template <typename T, int NTH, int HC>
 __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(NTH <= 256 ? kSmallWavesPerEu : 4))) void lmi_block_bwd_kernel(
     const T* __restrict__ gt, const T* __restrict__ dt, const T* __restrict__ nrm, const int32_t* __restrict__ rho_of, int r,
     int n, int k, int P, int Pp, int Mp, int identity, int lmi_seg, const T* __restrict__ v, int64_t B, int64_t ldv,
     const T* __restrict__ kappa, const int32_t* __restrict__ active, const T* __restrict__ gy, int64_t ldg,
-    T* __restrict__ gv, int64_t ldgv, int only_lmi) {
+    T* __restrict__ gv, int64_t ldgv, int only_lmi, const T* __restrict__ prods, int64_t ldt, T* __restrict__ coeff,
+    int64_t ldc, T* __restrict__ gs_out, int lmi_row0, int n_rows) {
+  // prods != nullptr (rayen_abi.hip: rayen_ray_project_bwd_coefficients_*): S(v) and NA_E v come out of row b of T = v W_ext',
+  // and instead of grad_v this kernel leaves the row of coefficients C with grad_v = s g [sets without equalities: gs_out]
+  // + C W_ext -- s g at the rows of NA_E, -s^2 (g'N v) at the active linear row or times (2 - [i = j]) x_i x_j at the LMI's
+  // rows -- for the library GEMM that follows (the k generators are contracted there, not one wave each here)
   extern __shared__ __attribute__((aligned(16))) unsigned char lb_smem[];
   T* A = reinterpret_cast<T*>(lb_smem);
   T* dd = A + (HC > 0 ? (r - HC) * (r - HC + 1) / 2 : P);
@@ -711,8 +852,44 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(NTH <= 256 
     // (sets with quadratics / cones: the lane kernel has written every sample's gradient but for the LMI's term)
     if (only_lmi && !(kappa[b] > T(1) && active[2 * b] == lmi_seg)) continue;
     __syncthreads();          // (the previous sample's last readers)
-    for (int a = tid; a < n; a += NTH) vs[a] = v[b * ldv + a];
     const T* grow = gy + b * ldg;
+    if (prods != nullptr) {
+      const T* prow = prods + b * ldt;
+      T* crow = coeff + b * ldc;
+      T part_tv = T(0);
+      if (identity) for (int a = tid; a < n; a += NTH) part_tv = fma(grow[a], v[b * ldv + a], part_tv);
+      else for (int i = tid; i < k; i += NTH) part_tv = fma(grow[i], prow[n_rows + i], part_tv);
+      const T tvp = bsum<T, NW>(part_tv, red + 2 * 2 * kWaves, tid);
+      const T kapp = kappa[b];
+      const int asegp = active[2 * b], arowp = active[2 * b + 1];
+      const bool clippedp = kapp > T(1) && asegp >= 0;
+      const T scp = T(1) / fmax(T(1), kapp);
+      const T coefp = clippedp ? scp * scp * tvp : T(0);
+      const bool lmi_active = clippedp && asegp == lmi_seg;
+      // everything but the LMI's rows (those below, once)
+      for (int j = tid; j < n_rows; j += NTH)
+        if (j < lmi_row0 || j >= lmi_row0 + P) crow[j] = clippedp && !lmi_active && j == arowp ? -coefp : T(0);
+      if (identity) for (int i = tid; i < k; i += NTH) gs_out[b * (int64_t)k + i] = scp * grow[i];
+      else for (int i = tid; i < k; i += NTH) crow[n_rows + i] = scp * grow[i];
+      if (!lmi_active) {
+        for (int idx = tid; idx < P; idx += NTH) crow[lmi_row0 + idx] = T(0);
+        continue;
+      }
+      copy_S<T, NTH, HC>(A, head, prow + lmi_row0, r, P, tid);
+      __syncthreads();
+      if constexpr (HC > 0) head_phase<T, NTH, HC, true>(A, r, head, dd, ee, tt, vv, ww, red, tid);
+      tridiagonalise<T, NTH, true>(A, r - HC, dd + HC, ee + HC, tt + HC, vv + HC, ww + HC, red, tid);
+      top_eigenvector<T, NTH, HC>(A, r, kapp, head, dd, ee, tt, vv, ww, red, tid);
+      for (int idx = tid; idx < P; idx += NTH) {
+        int i = (int)((sqrtf(8.f * (float)idx + 1.f) - 1.f) * 0.5f);
+        while ((i + 1) * (i + 2) / 2 <= idx) ++i;
+        while (i * (i + 1) / 2 > idx) --i;
+        const int j = idx - i * (i + 1) / 2;
+        crow[lmi_row0 + idx] = -coefp * (i == j ? T(1) : T(2)) * zz[i] * zz[j];
+      }
+      continue;
+    }
+    for (int a = tid; a < n; a += NTH) vs[a] = v[b * ldv + a];
     T tv = T(0);
     for (int a = tid; a < n; a += NTH) {
       T acc;
@@ -756,92 +933,8 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(NTH <= 256 
     if constexpr (HC > 0) head_phase<T, NTH, HC, true>(A, r, head, dd, ee, tt, vv, ww, red, tid);
     tridiagonalise<T, NTH, true>(A, r - HC, dd + HC, ee + HC, tt + HC, vv + HC, ww + HC, red, tid);
 
-    // ---- z: inverse iteration on M = (kappa + shift) I - T = L D L'.  ww: D, vv: the sub-diagonal of L.
-    if (wave == 0) {
-      T scale = fabs(kap);
-      for (int i = lane; i < r; i += 64) scale = fmax(scale, fabs(dd[i]));
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) scale = fmax(scale, __shfl_xor(scale, o));
-      const T shift = lw::Eps<T>::shift * fmax(scale, lw::Eps<T>::tiny);
-      if (lane == 0) {
-        T dprev = fmax(kap + shift - dd[0], shift * T(1e-3));
-        ww[0] = dprev;
-        vv[0] = T(0);
-        for (int i = 1; i < r; ++i) {
-          const T li = ee[i - 1] / dprev;              // M's off-diagonal is -ee: l = -ee / D, kept with the sign folded
-          const T di = fmax(kap + shift - dd[i] - li * ee[i - 1], shift * T(1e-3));
-          vv[i] = -li;
-          ww[i] = T(1) / di;                           // (the solves multiply)
-          dprev = di;
-        }
-        ww[0] = T(1) / ww[0];
-        for (int i = 0; i < r; ++i) zz[i] = T(1) + T(0.01) * (T)i;   // not orthogonal to anything special
-        for (int it = 0; it < 3; ++it) {
-          T prev = zz[0];
-          for (int i = 1; i < r; ++i) { prev = fma(-vv[i], prev, zz[i]); zz[i] = prev; }     // L y = b
-          prev = prev * ww[r - 1];
-          zz[r - 1] = prev;
-          T nrm2 = prev * prev;
-          for (int i = r - 2; i >= 0; --i) {                                                   // D L' z = y
-            prev = fma(-vv[i + 1], prev, zz[i] * ww[i]);
-            zz[i] = prev;
-            nrm2 = fma(prev, prev, nrm2);
-          }
-          const T inv = T(1) / sqrt(fmax(nrm2, lw::Eps<T>::tiny));
-          for (int i = 0; i < r; ++i) zz[i] *= inv;
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      // ---- x = H_0 H_1 ... H_{r-3} z, the vector in this wave's registers (row lane + 64 q)
-      T xq[kMaxChunks];
-#pragma unroll
-      for (int q = 0; q < kMaxChunks; ++q) xq[q] = lane + 64 * q < r ? zz[lane + 64 * q] : T(0);
-      for (int c = r - 3; c >= HC; --c) {                // (the reflectors whose columns are in the LDS)
-        const T tc = tt[c];
-        if (tc == T(0)) continue;                      // (wave-uniform)
-        const T alpha = ee[c];
-        T hv[kMaxChunks];
-        T dot = T(0);
-#pragma unroll
-        for (int q = 0; q < kMaxChunks; ++q) {
-          const int i = lane + 64 * q;
-          T h = T(0);
-          if (i > c && i < r) {
-            h = A[(i - HC) * (i - HC + 1) / 2 + (c - HC)];
-            if (i == c + 1) h -= alpha;
-          }
-          hv[q] = h;
-          dot = fma(h, xq[q], dot);
-        }
-        dot = lw::wsum(dot) * tc;
-#pragma unroll
-        for (int q = 0; q < kMaxChunks; ++q) xq[q] = fma(-dot, hv[q], xq[q]);
-      }
-#pragma unroll
-      for (int q = 0; q < kMaxChunks; ++q)
-        if (lane + 64 * q < r) zz[lane + 64 * q] = xq[q];
-    }
-    __syncthreads();
+    top_eigenvector<T, NTH, HC>(A, r, kap, head, dd, ee, tt, vv, ww, red, tid);
     if constexpr (HC > 0) {
-      // ---- the reflectors of the columns in the slots, HC - 1 .. 0: their entries sit with the rows' lanes (head_phase)
-      const int rw = lane & 31, part = lane >> 5;
-      const bool head_wave = wave == NW - 1;
-      const int i = head_wave ? rw : HC + 32 * wave + rw;
-      const bool has = head_wave ? rw < HC : i < r;
-      for (int c = HC - 1; c >= 0; --c) {
-        const T tc = tt[c];
-        if (tc == T(0)) continue;                      // (the same for every thread)
-        T h = T(0);
-        if (has && i > c && part == (c & 1)) {
-          h = slot_of<T, HC / 2>(head, c >> 1);
-          if (i == c + 1) h -= ee[c];
-        }
-        const T dot = bsum<T, NW>(h != T(0) ? h * zz[i] : T(0), red + (c & 1) * 2 * kWaves, tid) * tc;
-        if (h != T(0)) zz[i] = fma(-dot, h, zz[i]);
-        __syncthreads();
-      }
       // ---- d kappa / d v_a = x' G_a x, a wave per generator: lane l takes the columns l, l + 64, ... and walks down the rows
       // (the packed outer product of the plain kernel would not fit the LDS either)
       for (int a = wave; a < n; a += NW) {
@@ -996,13 +1089,16 @@ void with_instance(const Plan& p, F f) {
 // called by rayen_pack_create (the only place that may touch function attributes)
 template <typename T>
 int lmi_block_prepare_t(const LmiWaveImage* img) {
-  if (!lmi_block_serves_t<T>(img)) return RAYEN_OK;
+  if (img == nullptr) return RAYEN_OK;
   bool ok = true;
   auto raise = [&](auto kern) {
     ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax) == hipSuccess;
   };
-  with_instance<T>(plan_for<T>(img->r, img->n, false), raise);
+  if (lmi_block_serves_t<T>(img)) with_instance<T>(plan_for<T>(img->r, img->n, false), raise);
   if (lmi_block_bwd_serves_t<T>(img)) with_bwd_instance<T>(plan_for<T>(img->r, img->n, true), raise);
+  // (the shapes of the products route: no copy of v in LDS)
+  if (plan_for<T>(img->r, 0, false).nth != 0) with_instance<T>(plan_for<T>(img->r, 0, false), raise);
+  if (plan_for<T>(img->r, 0, true).nth != 0) with_bwd_instance<T>(plan_for<T>(img->r, 0, true), raise);
   if (!ok) { (void)hipGetLastError(); return RAYEN_E_LAUNCH; }
   return RAYEN_OK;
 }
@@ -1010,10 +1106,11 @@ int lmi_block_prepare_t(const LmiWaveImage* img) {
 template <typename T>
 int lmi_block_forward_t(const RayenPack* p, const LmiWaveImage* img, const T* v, int64_t B, int64_t ldv, T* y, int64_t ldy,
                         T* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream, const T* kappa_in = nullptr,
-                        int64_t ldk_in = 1) {
-  if (!lmi_block_serves_t<T>(img)) return RAYEN_E_UNSUPPORTED;
+                        int64_t ldk_in = 1, const T* prods = nullptr, int64_t ldt = 0) {
+  // (with products the kernel keeps no copy of v in LDS: the shape is planned for n = 0)
+  const Plan plan = img != nullptr ? plan_for<T>(img->r, prods != nullptr ? 0 : img->n, false) : Plan();
+  if (plan.nth == 0) return RAYEN_E_UNSUPPORTED;
   if (B == 0) return RAYEN_OK;
-  const Plan plan = plan_for<T>(img->r, img->n, false);
   const size_t lds = plan.lds;
   const int nth = plan.nth;
   int cus = 256;
@@ -1033,7 +1130,8 @@ int lmi_block_forward_t(const RayenPack* p, const LmiWaveImage* img, const T* v,
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(nth), lds, stream, static_cast<const T*>(img->gt),
                        static_cast<const T*>(img->dt), static_cast<const T*>(img->nat), static_cast<const T*>(img->y0),
                        img->lin_id, img->r, img->n, img->k, img->m, img->P, img->Pp, img->Mp, img->Kp, img->identity,
-                       img->lmi_seg, v, B, ldv, y, ldy, kappa, active, nan_flag, kappa_in, ldk_in);
+                       img->lmi_seg, v, B, ldv, y, ldy, kappa, active, nan_flag, kappa_in, ldk_in, prods, ldt, img->lmi_row0,
+                       img->n_rows);
   });
   return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
 }
@@ -1041,10 +1139,11 @@ int lmi_block_forward_t(const RayenPack* p, const LmiWaveImage* img, const T* v,
 template <typename T>
 int lmi_block_backward_t(const RayenPack* p, const LmiWaveImage* img, const T* v, int64_t B, int64_t ldv, const T* kappa,
                          const int32_t* active, const T* gy, int64_t ldg, T* gv, int64_t ldgv, hipStream_t stream,
-                         int only_lmi = 0) {
-  if (!lmi_block_bwd_serves_t<T>(img)) return RAYEN_E_UNSUPPORTED;
+                         int only_lmi = 0, const T* prods = nullptr, int64_t ldt = 0, T* coeff = nullptr, int64_t ldc = 0,
+                         T* gs_out = nullptr) {
+  const Plan plan = img != nullptr ? plan_for<T>(img->r, prods != nullptr ? 0 : img->n, true) : Plan();
+  if (plan.nth == 0) return RAYEN_E_UNSUPPORTED;
   if (B == 0) return RAYEN_OK;
-  const Plan plan = plan_for<T>(img->r, img->n, true);
   const size_t lds = plan.lds;
   const int nth = plan.nth;
   int cus = 256;
@@ -1062,7 +1161,8 @@ int lmi_block_backward_t(const RayenPack* p, const LmiWaveImage* img, const T* v
     const int64_t grid = B < (int64_t)cus * per_cu ? B : (int64_t)cus * per_cu;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(nth), lds, stream, static_cast<const T*>(img->gt),
                        static_cast<const T*>(img->dt), static_cast<const T*>(img->nrm), img->rho_of, img->r, img->n, img->k,
-                       img->P, img->Pp, img->Mp, img->identity, img->lmi_seg, v, B, ldv, kappa, active, gy, ldg, gv, ldgv, only_lmi);
+                       img->P, img->Pp, img->Mp, img->identity, img->lmi_seg, v, B, ldv, kappa, active, gy, ldg, gv, ldgv, only_lmi,
+                       prods, ldt, coeff, ldc, gs_out, img->lmi_row0, img->n_rows);
   });
   return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
 }

@@ -33,6 +33,7 @@ struct LmiWaveImage {
   int32_t* lin_id = nullptr;   // [m][2]  (segment, W row) of every linear row
   int32_t* rho_of = nullptr;   // [n_rows] index among the linear rows of a W row (-1: not a linear row)
   int r = 0, n = 0, k = 0, m = 0, P = 0, Pp = 0, Mp = 0, Kp = 0, identity = 0, lmi_seg = 0;
+  int lmi_row0 = 0, n_rows = 0;   // the LMI's first row of W, the rows of W (the products route of rayen_lmi_block.h)
   int64_t bytes = 0;
 };
 
@@ -431,6 +432,7 @@ int lmi_wave_build_t(const RayenPack* p, LmiWaveImage** out, int64_t* bytes) {
   }
   const int r = lmi->dim, m = (int)lin_rows.size(), P = r * (r + 1) / 2;
   img->r = r; img->n = n; img->k = k; img->m = m; img->P = P; img->identity = p->out_identity;
+  img->lmi_row0 = lmi->row0; img->n_rows = p->n_rows;
   img->Pp = (P + 63) / 64 * 64;
   img->Mp = m > 0 ? (m + 63) / 64 * 64 : 64;
   img->Kp = (k + 63) / 64 * 64;

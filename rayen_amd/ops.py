@@ -115,12 +115,28 @@ _BWD = {(torch.float32, False): "rayen_ray_project_bwd_f32", (torch.float64, Fal
 # goes GEMM + epilogue: T = v W_ext' on the vendor library (torch.mm -> hipBLASLt / rocBLAS on the caller's stream),
 # then ONE hand-written kernel over T (rayen_wide.hip).  ``RAYEN_WIDE_ROUTE=0`` pins the lane-per-sample kernel.
 _WIDE_MIN_N = {torch.float32: 129, torch.float64: 65}
+# Sets = [linear rows] + one LMI on the workgroup-per-sample kernels (round 5) take the same route much earlier: S(v) for the
+# whole batch is then ONE GEMM instead of every workgroup streaming all k generators for its sample.  Measured, B = 2 000, fp32,
+# forward / backward ms, products against fused (profiles/bench/r05_lmi_products_ab.txt): r = 100 k = 50 0.84 / 0.99 against
+# 0.89 / 1.14, k = 100 0.85 / 1.05 against 0.95 / 1.32, k = 1 000 1.01 / 1.31 against 2.34 / 7.72; r = 300 k = 100 14.9 / 17.3
+# against 19.2 / 25.9, k = 500 15.6 / 18.5 against 37.8 / 63.2; a tie at k = 10.  T and the backward's C are [B, rows of W_ext]
+# each: beyond _LMI_PRODUCTS_BYTES per matrix the fused kernels keep the batch (they need no scratch).
+_LMI_WIDE_MIN_N = 32
+_LMI_PRODUCTS_BYTES = 4 << 30
 
 
 def _wide_route(v, pack, force_generic, old_head):
-    if force_generic or old_head or pack.consts.n < _WIDE_MIN_N[v.dtype] or os.environ.get("RAYEN_WIDE_ROUTE", "1") == "0":
+    if force_generic or old_head or os.environ.get("RAYEN_WIDE_ROUTE", "1") == "0":
         return None
-    return pack.products_matrix(v.dtype)
+    env = os.environ.get("RAYEN_WIDE_MIN_N")          # (developer A/B)
+    has_lmi = any(seg.type == _lib.SEG_LMI for seg in pack.consts.segments)
+    min_n = int(env) if env else (_LMI_WIDE_MIN_N if has_lmi else _WIDE_MIN_N[v.dtype])
+    if pack.consts.n < min_n:
+        return None
+    Wt = pack.products_matrix(v.dtype)
+    if Wt is not None and has_lmi and v.shape[0] * Wt.shape[1] * v.element_size() > _LMI_PRODUCTS_BYTES:
+        return None
+    return Wt
 
 
 def project_raw(v, pack, want_y=True, force_generic=False, want_active=True, old_head=False, out=None,

@@ -215,3 +215,63 @@ def test_wave_kernel_small_and_ragged_batches_and_nan_rows(kernel, monkeypatch):
     keep = torch.ones(67, dtype=torch.bool, device="cuda")
     keep[7] = False
     assert torch.equal(yb[keep], y_all[keep])
+
+
+MANY = {
+    "r50_k160_lin_eq": dict(k=160, r=50, m=10, n_eq=2, seed=31),      # NA_E != I: its products ride behind the rows of W
+    "r120_k200": dict(k=200, r=120, m=0, n_eq=0, seed=32),
+    "r290_k140_lin": dict(k=140, r=290, m=5, n_eq=0, seed=33),        # register columns (fp32 only)
+}
+
+
+@pytest.mark.parametrize("name", list(MANY))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_many_generators_take_the_products_route(name, dtype, monkeypatch):
+    """n >= 129 (fp64: 65): S(v) for the whole batch is ONE library GEMM, T = v W_ext' (ops._wide_route), and the
+    workgroup-per-sample kernels read S(v), D v and NA_E v from its rows (rayen_ray_project_from_products_*); the backward
+    leaves the row of coefficients for the second GEMM (rayen_ray_project_bwd_coefficients_*).  Same answers as the fused
+    kernels (RAYEN_WIDE_ROUTE=0), which form S(v) sample by sample."""
+    r = MANY[name]["r"]
+    if dtype == torch.float64 and r > 212:
+        pytest.skip("fp64: the workgroup kernel holds r <= 212")
+    raw = _case(**MANY[name])
+    cs, layer = _layer(raw, dtype)
+    dp, _ = layer.device_pack(torch.device("cuda", 0))
+    assert dp.products_matrix(dtype) is not None
+    gen = torch.Generator().manual_seed(4)
+    B = 24
+    x = torch.empty(B, cs.n).uniform_(-2.0, 2.0, generator=gen)
+    x[:2] *= 1e-4
+    x[2] = 0.0
+    xd = x.to(dtype).cuda()
+    y, kappa, active = ops.project_raw(xd, dp, want_active=True)
+    assert _lib.load().rayen_last_forward_kernel() == _lib.KERNEL_LMI_BLOCK
+    buf64 = oracle.precompute(csd_from_cs(cs), torch.float64)
+    xr = x.double().unsqueeze(2).requires_grad_(True)
+    y_true_t = oracle.forward(buf64, xr)
+    y_true = y_true_t.detach().numpy()[:, :, 0]
+    err = rel_err_rows(y.cpu().double().numpy(), y_true)
+    if dtype == torch.float64:
+        assert err.max() <= 1e-9, (name, err.max())
+    else:
+        y32 = oracle.forward(oracle.precompute(csd_from_cs(cs), torch.float32), x.unsqueeze(2)).numpy()[:, :, 0]
+        theirs = rel_err_rows(y32.astype(np.float64), y_true).max()
+        assert err.max() <= max(1e-5, 2.0 * theirs), (name, err.max(), theirs)
+    assert cs.getMaxViolation(y.cpu().double().numpy()) <= (1e-9 if dtype == torch.float64 else 2e-4)
+    got = _check_backward(cs, buf64, x, xd, xr, y_true_t, kappa, active, dp, dtype, r, gen, name)
+    # the fused kernels on the same inputs
+    monkeypatch.setenv("RAYEN_WIDE_ROUTE", "0")
+    y_f, kappa_f, active_f = ops.project_raw(xd, dp, want_active=True)
+    assert torch.equal(active_f, active)
+    tol = 1e-12 if dtype == torch.float64 else 2e-5
+    assert float((y_f - y).abs().max()) <= tol * max(1.0, float(y.abs().max()))
+    g = torch.ones(B, cs.k, dtype=dtype, device="cuda")
+    gv_f = ops.backward_raw(xd, kappa_f, active_f, g, dp)
+    monkeypatch.delenv("RAYEN_WIDE_ROUTE")
+    gv_p = ops.backward_raw(xd, kappa, active, g, dp)
+    scale = float(gv_f.abs().max())
+    assert float((gv_f - gv_p).abs().max()) <= (1e-9 if dtype == torch.float64 else 5e-3) * scale and got.shape == (B, cs.n)
+    # the module: forward + autograd, no detour
+    xg = xd.unsqueeze(2).clone().requires_grad_(True)
+    layer(xg).sum().backward()
+    assert not layer._hip_unsupported and torch.isfinite(xg.grad).all()
