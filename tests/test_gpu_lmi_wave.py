@@ -275,3 +275,16 @@ def test_many_generators_take_the_products_route(name, dtype, monkeypatch):
     xg = xd.unsqueeze(2).clone().requires_grad_(True)
     layer(xg).sum().backward()
     assert not layer._hip_unsupported and torch.isfinite(xg.grad).all()
+    # a NaN row raises the flag and touches no other row; smaller batches give the same rows
+    dp.nan_flag.zero_()
+    xb = xd.clone()
+    xb[5, 1] = float("nan")
+    yb, _, _ = ops.project_raw(xb, dp)
+    assert int(dp.nan_flag.item()) == 1
+    dp.nan_flag.zero_()
+    keep = torch.ones(B, dtype=torch.bool, device="cuda")
+    keep[5] = False
+    assert torch.equal(yb[keep], y[keep])
+    for b in (1, 7):       # (not bit for bit: the library picks its GEMM by the batch)
+        part = ops.project_raw(xd[:b].contiguous(), dp)[0]
+        assert float((part - y[:b]).abs().max()) <= tol * max(1.0, float(y.abs().max()))
