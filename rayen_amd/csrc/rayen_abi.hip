@@ -192,7 +192,9 @@ template <typename T> bool is_mixed(const RayenPack* p) { return sizeof(T) == 4 
 template <typename T>
 int mixed_forward(const RayenPack* p, const T* v, int64_t B, int64_t ldv, T* y, int64_t ldy, T* kappa, int32_t* active,
                   int32_t* nan_flag, int old_mode, hipStream_t stream) {
-  if (old_mode || y == nullptr) return RAYEN_E_UNSUPPORTED;
+  if (y == nullptr) return RAYEN_E_UNSUPPORTED;
+  // (RAYEN_old: kappa is the same, so the lane kernel runs WITHOUT the head -- it writes no y here -- and the workgroup
+  // kernel takes the step 1 / (||v|| e^beta + kappa))
   T* between = kappa != nullptr ? kappa : y;
   const int64_t ldk = kappa != nullptr ? 1 : ldy;
   const int rc = generic_forward<T>(p, image_of<T>(p), v, B, ldv, static_cast<T*>(nullptr), 0, between, active, nullptr, 0,
@@ -200,9 +202,9 @@ int mixed_forward(const RayenPack* p, const T* v, int64_t B, int64_t ldv, T* y, 
   if (rc) return rc;
   g_last_forward = RAYEN_KERNEL_LMI_BLOCK;
   if constexpr (sizeof(T) == 4)
-    return lmi_block_forward_f32(p, p->w32, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, between, ldk);
+    return lmi_block_forward_f32(p, p->w32, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, between, ldk, old_mode);
   else
-    return lmi_block_forward_f64(p, p->w64, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, between, ldk);
+    return lmi_block_forward_f64(p, p->w64, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, between, ldk, old_mode);
 }
 
 template <typename T>
@@ -260,16 +262,26 @@ int project_bwd(const RayenPack* p, const T* v, int64_t B, int64_t ldv, const T*
                                     static_cast<hipStream_t>(stream));
     }
   }
-  if (is_mixed<T>(p) && old_mode) return RAYEN_E_UNSUPPORTED;
   const int rcg = generic_backward<T>(p, image_of<T>(p), v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv,
                                       old_mode, static_cast<hipStream_t>(stream));
   if (rcg == RAYEN_OK && is_mixed<T>(p)) {        // (the lane kernel has left out the LMI's term: see mixed_forward)
     if constexpr (sizeof(T) == 4)
       return lmi_block_backward_f32(p, p->w32, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv,
-                                    static_cast<hipStream_t>(stream), 1);
+                                    static_cast<hipStream_t>(stream), 1, old_mode);
     else
       return lmi_block_backward_f64(p, p->w64, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv,
-                                    static_cast<hipStream_t>(stream), 1);
+                                    static_cast<hipStream_t>(stream), 1, old_mode);
+  }
+  if (rcg == RAYEN_E_UNSUPPORTED && old_mode) {    // (the RAYEN_old head: the workgroup-per-sample kernels have it, the wave kernels do not)
+    if constexpr (sizeof(T) == 4) {
+      if (p->w32 != nullptr && lmi_block_bwd_serves_f32(p->w32))
+        return lmi_block_backward_f32(p, p->w32, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv,
+                                      static_cast<hipStream_t>(stream), 0, 1);
+    } else {
+      if (p->w64 != nullptr && lmi_block_bwd_serves_f64(p->w64))
+        return lmi_block_backward_f64(p, p->w64, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv,
+                                      static_cast<hipStream_t>(stream), 0, 1);
+    }
   }
   if (rcg == RAYEN_E_UNSUPPORTED && !old_mode) {   // (nothing was launched)
     if constexpr (sizeof(T) == 4) {
@@ -845,6 +857,10 @@ static int project_f32(const RayenPack* p, const float* v, int64_t B, int64_t ld
   }
   g_last_forward = RAYEN_KERNEL_LANE;
   const int rcg = project_generic<float>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, old_mode);
+  if (rcg == RAYEN_E_UNSUPPORTED && p->w32 != nullptr && y != nullptr && old_mode && !p->mixed32 && lmi_block_serves_f32(p->w32)) {
+    g_last_forward = RAYEN_KERNEL_LMI_BLOCK;       // (the RAYEN_old head: only the workgroup-per-sample kernel has it)
+    return lmi_block_forward_f32(p, p->w32, v, B, ldv, y, ldy, kappa, active, nan_flag, static_cast<hipStream_t>(stream), nullptr, 1, 1);
+  }
   if (rcg == RAYEN_E_UNSUPPORTED && p->w32 != nullptr && y != nullptr && !old_mode) {   // (nothing was launched)
     if (lmi_block_preferred(lmi_block_serves_f32(p->w32), lmi_wave_serves_f32(p->w32), lmi_dim(p), false)) {
       g_last_forward = RAYEN_KERNEL_LMI_BLOCK;
@@ -949,6 +965,10 @@ static int project_f64(const RayenPack* p, const double* v, int64_t B, int64_t l
   }
   g_last_forward = RAYEN_KERNEL_LANE;
   const int rcg = project_generic<double>(p, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, old_mode);
+  if (rcg == RAYEN_E_UNSUPPORTED && p->w64 != nullptr && y != nullptr && old_mode && !p->mixed64 && lmi_block_serves_f64(p->w64)) {
+    g_last_forward = RAYEN_KERNEL_LMI_BLOCK;
+    return lmi_block_forward_f64(p, p->w64, v, B, ldv, y, ldy, kappa, active, nan_flag, static_cast<hipStream_t>(stream), nullptr, 1, 1);
+  }
   if (rcg == RAYEN_E_UNSUPPORTED && p->w64 != nullptr && y != nullptr && !old_mode &&
       lmi_block_preferred(lmi_block_serves_f64(p->w64), lmi_wave_serves_f64(p->w64), lmi_dim(p), true)) {
     g_last_forward = RAYEN_KERNEL_LMI_BLOCK;

@@ -284,18 +284,18 @@ bool lmi_block_eligible_mixed_f32(const RayenPack* p);     // ... with quadratic
 bool lmi_block_eligible_mixed_f64(const RayenPack* p);
 int lmi_block_forward_f32(const RayenPack* p, const LmiWaveImage* img, const float* v, int64_t B, int64_t ldv, float* y,
                           int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream,
-                          const float* kappa_in = nullptr, int64_t ldk_in = 1);
+                          const float* kappa_in = nullptr, int64_t ldk_in = 1, int old_mode = 0);
 int lmi_block_forward_f64(const RayenPack* p, const LmiWaveImage* img, const double* v, int64_t B, int64_t ldv, double* y,
                           int64_t ldy, double* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream,
-                          const double* kappa_in = nullptr, int64_t ldk_in = 1);
+                          const double* kappa_in = nullptr, int64_t ldk_in = 1, int old_mode = 0);
 bool lmi_block_bwd_serves_f32(const LmiWaveImage* img);
 bool lmi_block_bwd_serves_f64(const LmiWaveImage* img);
 int lmi_block_backward_f32(const RayenPack* p, const LmiWaveImage* img, const float* v, int64_t B, int64_t ldv,
                            const float* kappa, const int32_t* active, const float* grad_y, int64_t ldg, float* grad_v,
-                           int64_t ldgv, hipStream_t stream, int only_lmi = 0);
+                           int64_t ldgv, hipStream_t stream, int only_lmi = 0, int old_mode = 0);
 int lmi_block_backward_f64(const RayenPack* p, const LmiWaveImage* img, const double* v, int64_t B, int64_t ldv,
                            const double* kappa, const int32_t* active, const double* grad_y, int64_t ldg, double* grad_v,
-                           int64_t ldgv, hipStream_t stream, int only_lmi = 0);
+                           int64_t ldgv, hipStream_t stream, int only_lmi = 0, int old_mode = 0);
 // ... from the products T = v W_ext' of a library GEMM (sets with many generators): forward, and the backward's coefficients
 bool lmi_block_products_serves_f32(const LmiWaveImage* img);
 bool lmi_block_products_serves_f64(const LmiWaveImage* img);

@@ -526,7 +526,9 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(NTH <= 256 
     const int32_t* __restrict__ lin_id, int r, int n, int k, int m, int P, int Pp, int Mp, int Kp, int identity,
     int lmi_seg, const T* __restrict__ v, int64_t B, int64_t ldv, T* y, int64_t ldy,
     T* kappa_out, int32_t* active_out, int32_t* __restrict__ nan_flag, const T* kappa_in, int64_t ldk_in,
-    const T* __restrict__ prods, int64_t ldt, int lmi_row0, int n_rows) {
+    const T* __restrict__ prods, int64_t ldt, int lmi_row0, int n_rows, int old_mode) {
+  // old_mode: the RAYEN_old head (rayen/constraint_module.py:460-466) -- the same kappa, the step 1 / (||v|| e^beta + kappa)
+  // with beta in column n of the input (not with prods).
   // prods != nullptr (sets with many generators, rayen_abi.hip::project_from_products): row b of T = v W_ext' from a library
   // GEMM holds what this kernel otherwise forms per sample -- D v at the linear rows' W rows, S(v) packed at the LMI's rows,
   // NA_E v behind the rows of W -- and v is read only for the output of sets without equalities (no copy of it in LDS)
@@ -685,7 +687,13 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(NTH <= 256 
       }
     }
 
-    const T scl = T(1) / fmax(T(1), kap);
+    T scl = T(1) / fmax(T(1), kap);
+    if (old_mode) {
+      T part = T(0);
+      for (int a = tid; a < n; a += kThreads) part = fma(vs[a], vs[a], part);
+      const T nrm = sqrt(bsum<T, NW>(part, red, tid));           // (slot set 0: its last readers are barriers behind)
+      scl = nrm > T(0) ? T(1) / (nrm * exp(v[b * ldv + n]) + kap) : T(0);
+    }
     if (tid == 0) {
       if (kappa_out) kappa_out[b] = kap;
       if (active_out) { active_out[2 * b] = aseg; active_out[2 * b + 1] = arow; }
@@ -827,7 +835,9 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(NTH <= 256 
     int n, int k, int P, int Pp, int Mp, int identity, int lmi_seg, const T* __restrict__ v, int64_t B, int64_t ldv,
     const T* __restrict__ kappa, const int32_t* __restrict__ active, const T* __restrict__ gy, int64_t ldg,
     T* __restrict__ gv, int64_t ldgv, int only_lmi, const T* __restrict__ prods, int64_t ldt, T* __restrict__ coeff,
-    int64_t ldc, T* __restrict__ gs_out, int lmi_row0, int n_rows) {
+    int64_t ldc, T* __restrict__ gs_out, int lmi_row0, int n_rows, int old_mode) {
+  // old_mode (RAYEN_old, not with prods): s = 1 / (||v|| e^beta + kappa), so kappa always matters and ||v||, beta get gradients:
+  // grad_v = s t - s^2 (t.v) (e^beta v / ||v|| + grad kappa), grad_beta = -s^2 (t.v) ||v|| e^beta in column n (rayen_generic.hip)
   // prods != nullptr (rayen_abi.hip: rayen_ray_project_bwd_coefficients_*): S(v) and NA_E v come out of row b of T = v W_ext',
   // and instead of grad_v this kernel leaves the row of coefficients C with grad_v = s g [sets without equalities: gs_out]
   // + C W_ext -- s g at the rows of NA_E, -s^2 (g'N v) at the active linear row or times (2 - [i = j]) x_i x_j at the LMI's
@@ -850,7 +860,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(NTH <= 256 
 
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
     // (sets with quadratics / cones: the lane kernel has written every sample's gradient but for the LMI's term)
-    if (only_lmi && !(kappa[b] > T(1) && active[2 * b] == lmi_seg)) continue;
+    if (only_lmi && !((old_mode || kappa[b] > T(1)) && active[2 * b] == lmi_seg)) continue;   // (RAYEN_old: kappa always matters)
     __syncthreads();          // (the previous sample's last readers)
     const T* grow = gy + b * ldg;
     if (prods != nullptr) {
@@ -914,15 +924,25 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(NTH <= 256 
     tv = bsum<T, NW>(tv, red + 2 * 2 * kWaves, tid);         // (vs and ts are visible after this barrier)
     const T kap = kappa[b];
     const int aseg = active[2 * b], arow = active[2 * b + 1];
-    const bool clipped = kap > T(1) && aseg >= 0;
-    const T sc = T(1) / fmax(T(1), kap);
-    const T coef = clipped ? sc * sc * tv : T(0);
+    T r_nrm = T(0), e_beta = T(0);
+    if (old_mode) {
+      T part = T(0);
+      for (int a = tid; a < n; a += NTH) part = fma(vs[a], vs[a], part);
+      r_nrm = sqrt(bsum<T, NW>(part, red + 5 * kWaves, tid));
+      e_beta = exp(v[b * ldv + n]);
+    }
+    const bool clipped = old_mode ? (aseg >= 0 && r_nrm > T(0)) : (kap > T(1) && aseg >= 0);
+    const T sc = old_mode ? (r_nrm > T(0) ? T(1) / (r_nrm * e_beta + kap) : T(0)) : T(1) / fmax(T(1), kap);
+    const T coef = (clipped || old_mode) ? sc * sc * tv : T(0);        // (times grad kappa only where clipped: cu below)
+    const T cu = clipped ? coef : T(0);
+    const T cdir = old_mode && r_nrm > T(0) ? coef * e_beta / r_nrm : T(0);   // (times v: the old head's own term)
+    if (old_mode && tid == 0) gv[b * ldgv + n] = -coef * r_nrm * e_beta;
 
     if (!(clipped && aseg == lmi_seg)) {                     // (the same for the whole workgroup)
       const int rho = clipped ? rho_of[arow] : -1;
       for (int a = tid; a < n; a += NTH) {
         const T u = rho >= 0 ? dt[(size_t)a * Mp + rho] : T(0);
-        gv[b * ldgv + a] = fma(sc, ts[a], -coef * u);
+        gv[b * ldgv + a] = fma(sc, ts[a], -(cu * u + cdir * vs[a]));
       }
       continue;
     }
@@ -966,7 +986,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(NTH <= 256 
           acc = fma((s0 + s1) + (s2 + s3), xj, acc);
         }
         const T part_a = lw::wsum(acc);
-        if (lane == 0) gv[b * ldgv + a] = fma(sc, ts[a], -coef * part_a);
+        if (lane == 0) gv[b * ldgv + a] = fma(sc, ts[a], -(cu * part_a + cdir * vs[a]));
       }
       continue;
     }
@@ -992,7 +1012,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(NTH <= 256 
       }
       for (; idx < P; idx += 64) p0 = fma(col[idx], A[idx], p0);
       const T part = lw::wsum((p0 + p1) + (p2 + p3));
-      if (lane == 0) gv[b * ldgv + a] = fma(sc, ts[a], -coef * part);
+      if (lane == 0) gv[b * ldgv + a] = fma(sc, ts[a], -(cu * part + cdir * vs[a]));
     }
   }
 }
@@ -1106,7 +1126,8 @@ int lmi_block_prepare_t(const LmiWaveImage* img) {
 template <typename T>
 int lmi_block_forward_t(const RayenPack* p, const LmiWaveImage* img, const T* v, int64_t B, int64_t ldv, T* y, int64_t ldy,
                         T* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream, const T* kappa_in = nullptr,
-                        int64_t ldk_in = 1, const T* prods = nullptr, int64_t ldt = 0) {
+                        int64_t ldk_in = 1, const T* prods = nullptr, int64_t ldt = 0, int old_mode = 0) {
+  if (old_mode && prods != nullptr) return RAYEN_E_UNSUPPORTED;
   // (with products the kernel keeps no copy of v in LDS: the shape is planned for n = 0)
   const Plan plan = img != nullptr ? plan_for<T>(img->r, prods != nullptr ? 0 : img->n, false) : Plan();
   if (plan.nth == 0) return RAYEN_E_UNSUPPORTED;
@@ -1131,7 +1152,7 @@ int lmi_block_forward_t(const RayenPack* p, const LmiWaveImage* img, const T* v,
                        static_cast<const T*>(img->dt), static_cast<const T*>(img->nat), static_cast<const T*>(img->y0),
                        img->lin_id, img->r, img->n, img->k, img->m, img->P, img->Pp, img->Mp, img->Kp, img->identity,
                        img->lmi_seg, v, B, ldv, y, ldy, kappa, active, nan_flag, kappa_in, ldk_in, prods, ldt, img->lmi_row0,
-                       img->n_rows);
+                       img->n_rows, old_mode);
   });
   return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
 }
@@ -1140,7 +1161,8 @@ template <typename T>
 int lmi_block_backward_t(const RayenPack* p, const LmiWaveImage* img, const T* v, int64_t B, int64_t ldv, const T* kappa,
                          const int32_t* active, const T* gy, int64_t ldg, T* gv, int64_t ldgv, hipStream_t stream,
                          int only_lmi = 0, const T* prods = nullptr, int64_t ldt = 0, T* coeff = nullptr, int64_t ldc = 0,
-                         T* gs_out = nullptr) {
+                         T* gs_out = nullptr, int old_mode = 0) {
+  if (old_mode && prods != nullptr) return RAYEN_E_UNSUPPORTED;
   const Plan plan = img != nullptr ? plan_for<T>(img->r, prods != nullptr ? 0 : img->n, true) : Plan();
   if (plan.nth == 0) return RAYEN_E_UNSUPPORTED;
   if (B == 0) return RAYEN_OK;
@@ -1162,7 +1184,7 @@ int lmi_block_backward_t(const RayenPack* p, const LmiWaveImage* img, const T* v
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(nth), lds, stream, static_cast<const T*>(img->gt),
                        static_cast<const T*>(img->dt), static_cast<const T*>(img->nrm), img->rho_of, img->r, img->n, img->k,
                        img->P, img->Pp, img->Mp, img->identity, img->lmi_seg, v, B, ldv, kappa, active, gy, ldg, gv, ldgv, only_lmi,
-                       prods, ldt, coeff, ldc, gs_out, img->lmi_row0, img->n_rows);
+                       prods, ldt, coeff, ldc, gs_out, img->lmi_row0, img->n_rows, old_mode);
   });
   return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
 }

@@ -33,26 +33,28 @@ int lmi_block_prepare_f32(const LmiWaveImage* img) { return lb::lmi_block_prepar
 int lmi_block_prepare_f64(const LmiWaveImage* img) { return lb::lmi_block_prepare_t<double>(img); }
 int lmi_block_forward_f32(const RayenPack* p, const LmiWaveImage* img, const float* v, int64_t B, int64_t ldv, float* y,
                           int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream,
-                          const float* kappa_in, int64_t ldk_in) {
-  return lb::lmi_block_forward_t<float>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, kappa_in, ldk_in);
+                          const float* kappa_in, int64_t ldk_in, int old_mode) {
+  return lb::lmi_block_forward_t<float>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, kappa_in, ldk_in, nullptr, 0, old_mode);
 }
 int lmi_block_forward_f64(const RayenPack* p, const LmiWaveImage* img, const double* v, int64_t B, int64_t ldv, double* y,
                           int64_t ldy, double* kappa, int32_t* active, int32_t* nan_flag, hipStream_t stream,
-                          const double* kappa_in, int64_t ldk_in) {
-  return lb::lmi_block_forward_t<double>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, kappa_in, ldk_in);
+                          const double* kappa_in, int64_t ldk_in, int old_mode) {
+  return lb::lmi_block_forward_t<double>(p, img, v, B, ldv, y, ldy, kappa, active, nan_flag, stream, kappa_in, ldk_in, nullptr, 0, old_mode);
 }
 
 bool lmi_block_bwd_serves_f32(const LmiWaveImage* img) { return lb::lmi_block_bwd_serves_t<float>(img); }
 bool lmi_block_bwd_serves_f64(const LmiWaveImage* img) { return lb::lmi_block_bwd_serves_t<double>(img); }
 int lmi_block_backward_f32(const RayenPack* p, const LmiWaveImage* img, const float* v, int64_t B, int64_t ldv,
                            const float* kappa, const int32_t* active, const float* grad_y, int64_t ldg, float* grad_v,
-                           int64_t ldgv, hipStream_t stream, int only_lmi) {
-  return lb::lmi_block_backward_t<float>(p, img, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, stream, only_lmi);
+                           int64_t ldgv, hipStream_t stream, int only_lmi, int old_mode) {
+  return lb::lmi_block_backward_t<float>(p, img, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, stream, only_lmi, nullptr, 0, nullptr, 0,
+                                         nullptr, old_mode);
 }
 int lmi_block_backward_f64(const RayenPack* p, const LmiWaveImage* img, const double* v, int64_t B, int64_t ldv,
                            const double* kappa, const int32_t* active, const double* grad_y, int64_t ldg, double* grad_v,
-                           int64_t ldgv, hipStream_t stream, int only_lmi) {
-  return lb::lmi_block_backward_t<double>(p, img, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, stream, only_lmi);
+                           int64_t ldgv, hipStream_t stream, int only_lmi, int old_mode) {
+  return lb::lmi_block_backward_t<double>(p, img, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, stream, only_lmi, nullptr, 0, nullptr, 0,
+                                         nullptr, old_mode);
 }
 // the products route (sets with many generators): T = v W_ext' comes from a library GEMM, see rayen_abi.hip
 bool lmi_block_products_serves_f32(const LmiWaveImage* img) {

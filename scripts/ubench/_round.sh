@@ -1,2 +1,5 @@
 #!/bin/bash
-timeout 1500 python -m pytest tests/test_gpu_lmi_wave.py -m gpu -x -q -k "many_generators" 2>&1 | tail -25 | cut -c1-250
+mkdir -p gpurun_out/r05zt
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > gpurun_out/r05zt/pytest_full.log
+cat gpurun_out/r05zt/pytest_full.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2

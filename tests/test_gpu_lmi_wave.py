@@ -288,3 +288,51 @@ def test_many_generators_take_the_products_route(name, dtype, monkeypatch):
     for b in (1, 7):       # (not bit for bit: the library picks its GEMM by the batch)
         part = ops.project_raw(xd[:b].contiguous(), dp)[0]
         assert float((part - y[:b]).abs().max()) <= tol * max(1.0, float(y.abs().max()))
+
+
+OLD_HEAD = {
+    "r64_lin": dict(k=9, r=64, m=12, n_eq=0, seed=41),
+    "r100_eq": dict(k=10, r=100, m=0, n_eq=2, seed=42),
+    "r290": dict(k=5, r=290, m=0, n_eq=0, seed=43),            # register columns (fp32 only)
+}
+
+
+@pytest.mark.parametrize("name", list(OLD_HEAD))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_the_old_head_on_the_workgroup_kernels(name, dtype):
+    """method='RAYEN_old' (CM:460-466: y = y0 + N v_bar / (e^beta + kappa(v_bar)), beta = column n of the input) for LMIs
+    beyond the four-lane kernel's: the same kappa, another step, and gradients for ||v|| and beta -- forward against the
+    oracle's RAYEN_old, backward against autograd through it (strict mode: the device libraries would raise)."""
+    r = OLD_HEAD[name]["r"]
+    if dtype == torch.float64 and r > 212:
+        pytest.skip("fp64: the workgroup kernel holds r <= 212")
+    raw = _case(**OLD_HEAD[name])
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        cs = workloads.build_constraints(raw)
+        layer = ConstraintModule(cs, method="RAYEN_old", create_map=False).cuda()
+    finally:
+        torch.set_default_dtype(prev)
+    gen = torch.Generator().manual_seed(12)
+    B = 40
+    x = torch.empty(B, cs.n + 1, 1).uniform_(-1.5, 1.5, generator=gen)
+    xg = x.to(dtype).cuda().requires_grad_(True)
+    y = layer(xg)
+    assert _lib.load().rayen_last_forward_kernel() == _lib.KERNEL_LMI_BLOCK and not layer._hip_unsupported
+    buf64 = oracle.precompute(csd_from_cs(cs), torch.float64)
+    xr = x.double().requires_grad_(True)
+    y_true_t = oracle.forward(buf64, xr, method="RAYEN_old")
+    err = rel_err_rows(y.detach().cpu().double().numpy()[:, :, 0], y_true_t.detach().numpy()[:, :, 0])
+    assert err.max() <= (1e-9 if dtype == torch.float64 else 2e-5), (name, err.max())
+    assert cs.getMaxViolation(y.detach().cpu().double().numpy()[:, :, 0]) <= (1e-9 if dtype == torch.float64 else 2e-4)
+    w = torch.empty(B, cs.k, 1).uniform_(-1, 1, generator=gen)
+    (y * w.to(dtype).cuda()).sum().backward()
+    (y_true_t * w.double()).sum().backward()
+    got, want = xg.grad.cpu().double().numpy()[:, :, 0], xr.grad.numpy()[:, :, 0]
+    assert np.all(np.isfinite(got))
+    gerr = np.abs(got - want).max(axis=1) / np.maximum(np.abs(want).max(axis=1), 1e-30)
+    tol = 1e-7 if dtype == torch.float64 else 3e-3
+    # (kinks -- the two largest eigenvalues nearly tied, a linear row level with the LMI -- are a few rows at most)
+    assert (gerr > tol).sum() <= max(2, 0.05 * B), (name, np.sort(gerr)[-5:])
+    assert np.median(gerr) <= tol * 0.1
