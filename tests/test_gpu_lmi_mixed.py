@@ -50,7 +50,7 @@ def test_lmi_next_to_quadratics_and_cones(name, dtype):
     cs, layer = _layer(raw, dtype)
     dp, _ = layer.device_pack(torch.device("cuda", 0))
     gen = torch.Generator().manual_seed(8)
-    B = 96 if r <= 100 else 40
+    B = 64 if r <= 100 else 28
     x = torch.empty(B, cs.n).uniform_(-2.0, 2.0, generator=gen)
     x[:2] *= 1e-4                                             # interior
     x[2] = 0.0

@@ -100,7 +100,7 @@ def test_large_lmi_forward_and_backward(name, dtype, kernel, monkeypatch):
     cs, layer = _layer(raw, dtype)
     dp, _ = layer.device_pack(torch.device("cuda", 0))
     gen = torch.Generator().manual_seed(6)
-    B = 300 if r <= 48 else (128 if r <= 64 else 48)          # (the fp64 oracle's eigvalsh + autograd on the CPU sets the pace)
+    B = 160 if r <= 48 else (96 if r <= 64 else 40)           # (the fp64 oracle's eigvalsh + autograd on the CPU sets the pace)
     x = torch.empty(B, cs.n).uniform_(-2.0, 2.0, generator=gen)
     x[:2] *= 1e-4                                             # interior
     x[2] = 0.0
@@ -315,7 +315,7 @@ def test_the_old_head_on_the_workgroup_kernels(name, dtype):
     finally:
         torch.set_default_dtype(prev)
     gen = torch.Generator().manual_seed(12)
-    B = 40
+    B = 28
     x = torch.empty(B, cs.n + 1, 1).uniform_(-1.5, 1.5, generator=gen)
     xg = x.to(dtype).cuda().requires_grad_(True)
     y = layer(xg)
