@@ -248,7 +248,19 @@ class ConstraintModule(torch.nn.Module):
         if not v.is_cuda or self._refused(v) or v.dtype not in (torch.float32, torch.float64):
             return eager.evaluator_for(self, v).kappa(v[:, :self.n]).reshape(-1, 1, 1)
         dp, _ = self.device_pack(v.device)
-        _, kappa, _ = ops.project_raw(v, dp, want_y=False)
+        try:
+            _, kappa, _ = ops.project_raw(v, dp, want_y=False, want_active=False)
+        except _lib.RayenError as err:
+            if err.code != _lib.E_UNSUPPORTED:
+                raise
+            # the kernels that always write y (an LMI on the workgroup-per-sample kernels, alone, next to quadratics / cones
+            # or behind the products GEMM; rayen_abi.hip::mixed_forward) decline y == NULL: same kernels, a scratch y
+            try:
+                _, kappa, _ = ops.project_raw(v, dp, want_y=True, want_active=False)
+            except _lib.RayenError as err2:
+                if err2.code != _lib.E_UNSUPPORTED or os.environ.get("RAYEN_STRICT_HIP", "0") == "1":
+                    raise
+                return eager.evaluator_for(self, v).kappa(v[:, :self.n]).reshape(-1, 1, 1)
         return kappa.reshape(-1, 1, 1)
 
     def forwardForRAYEN(self, q):

@@ -550,6 +550,16 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(NTH <= 256 
     const T* prow = prods != nullptr ? prods + b * ldt : nullptr;
     if (prow == nullptr)
       for (int a = tid; a < n; a += kThreads) vs[a] = v[b * ldv + a];
+    // sets with quadratics / cones next to the LMI: the lane kernel has left the maximum over everything else (and its row, in
+    // active_out) where this sample's outputs go -- kappa_in may be kappa_out or COLUMN 0 OF y.  Every thread takes its copy
+    // HERE, barriers ahead of the first store to this sample's y / kappa_out / active_out (a read next to those stores, with
+    // no barrier in between, let a late wave see thread 0's y[b][0] as the other constraints' kappa).
+    T other = T(0);
+    int other_seg = -1, other_row = 0;
+    if (kappa_in != nullptr) {
+      other = kappa_in[b * ldk_in];
+      if (active_out) { other_seg = active_out[2 * b]; other_row = active_out[2 * b + 1]; }
+    }
     __syncthreads();
 
     // ---- linear rows: (value, index among the linear rows) of the largest D_i . v; the lowest index wins a tie
@@ -677,14 +687,9 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(NTH <= 256 
     if (threadIdx.x == 0 && blockIdx.x == 0) { g_lb_prof[6] += clock64() - lb_start; g_lb_prof[7] += 1; }
 #endif
     if (lam > kap) { kap = lam; aseg = lmi_seg; arow = 0; }
-    if (kappa_in != nullptr) {
-      // sets with quadratics / cones next to the LMI: the lane kernel has left the maximum over everything else (and its
-      // row, in active_out) where this sample's outputs go -- kappa_in may be kappa_out or column 0 of y
-      const T other = kappa_in[b * ldk_in];
-      if (other >= kap) {
-        kap = other;
-        if (active_out) { aseg = active_out[2 * b]; arow = active_out[2 * b + 1]; }
-      }
+    if (kappa_in != nullptr && other >= kap) {        // (the copies taken at the top of this sample)
+      kap = other;
+      if (active_out) { aseg = other_seg; arow = other_row; }
     }
 
     T scl = T(1) / fmax(T(1), kap);
@@ -1059,9 +1064,11 @@ Plan plan_for(int r, int n, bool bwd) {
     return env != nullptr ? std::atoi(env) : 0;
   }();
   if ((forced == 128 || forced == 256) && r - 1 <= forced && plain <= kLdsMax) { p.nth = forced; p.hc = 0; p.lds = plain; return p; }
-  if (forced == 0 && r <= 80) { p.nth = 128; p.hc = 0; p.lds = plain; }
-  else if (forced == 0 && r <= 140) { p.nth = 256; p.hc = 0; p.lds = plain; }
-  else if (r <= upto && (r <= 128 || 2 * plain <= kLdsMax)) { p.nth = 512; p.hc = 0; p.lds = plain; }
+  // (every branch checks its LDS: vs[n] (+ ts[n] backward) of the fused route grows with n -- fp64 backward at r = 140 runs out
+  // near n = 4 900 -- and such a shape must fall through to UNSUPPORTED, not fail at the launch)
+  if (forced == 0 && r <= 80 && plain <= kLdsMax) { p.nth = 128; p.hc = 0; p.lds = plain; }
+  else if (forced == 0 && r <= 140 && plain <= kLdsMax) { p.nth = 256; p.hc = 0; p.lds = plain; }
+  else if (r <= upto && plain <= kLdsMax && (r <= 128 || 2 * plain <= kLdsMax)) { p.nth = 512; p.hc = 0; p.lds = plain; }
   else if (r <= upto && r - HC <= 224 && 2 * head <= kLdsMax) { p.nth = 512; p.hc = HC; p.lds = head; }   // (7 waves of rows + 1)
   else if (plain <= kLdsMax) { p.nth = 1024; p.hc = 0; p.lds = plain; }
   else if (head <= kLdsMax) { p.nth = 1024; p.hc = HC; p.lds = head; }

@@ -123,3 +123,44 @@ def test_the_old_head_on_such_a_set(dtype):
     tol = 1e-7 if dtype == torch.float64 else 3e-3
     assert np.all(np.isfinite(got)) and (gerr > tol).sum() <= max(2, 0.05 * B), np.sort(gerr)[-5:]
     assert np.median(gerr) <= tol * 0.1
+
+
+@pytest.mark.parametrize("name", ["r60_all", "r40_lin_quad_eq"])
+def test_compute_kappa_and_a_full_grid_of_workgroups_on_such_a_set(name):
+    """(round 6, the advisor's two findings on round 5's kernels.)  (i) ``computeKappa`` -- the reference's public helper
+    CM:351 -- on a set the workgroup kernels serve: they always write y, so the module hands them a scratch y instead of
+    raising.  (ii) The module's default inference call (no kappa wanted) parks the other families' kappa in column 0 of y:
+    with MANY MORE samples than workgroups every wave must have taken its copy before thread 0 stores y[b][0] -- the rows must
+    equal, bit for bit, those of the call with a separate kappa buffer, in every repetition."""
+    raw = _mixed(**CASES[name])
+    cs, layer = _layer(raw, torch.float32)
+    dp, _ = layer.device_pack(torch.device("cuda", 0))
+    gen = torch.Generator().manual_seed(21)
+    B = 6000
+    xd = torch.empty(B, cs.n).uniform_(-2.0, 2.0, generator=gen).cuda()
+    y, kappa, _ = ops.project_raw(xd, dp, want_active=True)
+    assert _lib.load().rayen_last_forward_kernel() == _lib.KERNEL_LMI_BLOCK
+    for _ in range(5):
+        y_nok, _, _ = ops.project_raw(xd, dp, want_active=False, want_kappa=False)
+        assert torch.equal(y_nok, y)
+    got = layer.computeKappa(xd[:512].unsqueeze(2))
+    assert not layer._hip_unsupported and got.shape == (512, 1, 1)
+    assert torch.equal(got[:, 0, 0], kappa[:512])
+    buf64 = oracle.precompute(csd_from_cs(cs), torch.float64)
+    want = oracle.compute_kappa(buf64, xd[:128].cpu().double().unsqueeze(2))[:, 0, 0].numpy()
+    assert np.max(np.abs(got[:128, 0, 0].cpu().double().numpy() - want) / np.maximum(np.abs(want), 1e-3)) <= 2e-5
+
+
+def test_compute_kappa_on_a_large_lmi_alone():
+    """``computeKappa`` on [linear rows] + one LMI of the workgroup kernels, fused route and products route (32 generators on)."""
+    for k, r in ((10, 64), (40, 48)):
+        raw = workloads.random_lmi(k, r, seed=5)
+        cs, layer = _layer(raw, torch.float32)
+        gen = torch.Generator().manual_seed(2)
+        x = torch.empty(300, cs.n, 1).uniform_(-2.0, 2.0, generator=gen)
+        got = layer.computeKappa(x.cuda())
+        assert not layer._hip_unsupported
+        want = oracle.compute_kappa(oracle.precompute(csd_from_cs(cs), torch.float64), x.double())[:, 0, 0].numpy()
+        err = np.abs(got[:, 0, 0].cpu().double().numpy() - want) / np.maximum(np.abs(want), 1e-3)
+        assert err.max() <= 2e-5, (k, r, err.max())
+
