@@ -433,6 +433,31 @@ def main(argv=None):
     max_violation = float(row_violation.max()) if B else 0.0
     violation_detail = workloads.violation_report(cs, sl[:8192]) if B else None
 
+    # the same rows with the inward bias on (RAYEN_PREPARE_INWARD_BIAS, include/rayen_hip.h: the fp32 images evaluate
+    # (1 + eps) kappa, clipped samples stop eps short of the boundary) -- feasibility before / after and what it costs in parity
+    bias_report = None
+    if on_gpu and world == 1 and rank == 0 and not args.mapper and dtype == torch.float32 and B and not args.no_families:
+        bias_report = {"what": "fp64 residuals of the fp32 outputs on the same rows, pack built with RAYEN_INWARD_BIAS=eps; "
+                               "shift = per-row inf-norm distance from the unbiased outputs, relative to the row",
+                       "rows": int(sl.shape[0]),
+                       "0": {"max_violation": max_violation, "violations_gt_0": int((row_violation > 0).sum()),
+                             "violations_gt_1e-6": int((row_violation > 1e-6).sum())}}
+        import numpy as _np
+        for log2 in (-22, -20, -19):
+            os.environ["RAYEN_INWARD_BIAS"] = repr(2.0 ** log2)
+            try:
+                biased = ConstraintModule(cs, method="RAYEN", create_map=False).to(device)
+                biased.check_nan = False
+                with torch.no_grad():
+                    yb = biased(x[: sl.shape[0]])[:, :, 0].double().cpu().numpy()
+            finally:
+                del os.environ["RAYEN_INWARD_BIAS"]
+            rows_b = cs.getViolationRows(yb)
+            shift = _np.abs(yb - sl).max(axis=1) / _np.maximum(_np.abs(sl).max(axis=1), 1e-30)
+            bias_report[f"2^{log2}"] = {"max_violation": float(rows_b.max()), "violations_gt_0": int((rows_b > 0).sum()),
+                                        "violations_gt_1e-6": int((rows_b > 1e-6).sum()), "max_rel_shift": float(shift.max())}
+            del biased
+
     if rank == 0:
         bytes_pp, flops_pp = workloads.algorithmic_work(cs)
         if args.mapper:
@@ -532,6 +557,7 @@ def main(argv=None):
             # (per family: the residual next to what rounding a feasible y to fp32 alone can leave -- sets with large
             # coefficients, configs 5 / 5r, sit above 1e-6 in absolute terms at a ratio of a few units)
             "violation_detail": violation_detail,
+            "inward_bias": bias_report,
             "roofline": roof,
         }
         if use_dist:

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define RAYEN_ABI_VERSION 7
+#define RAYEN_ABI_VERSION 8
 
 enum {
   RAYEN_OK = 0,
@@ -66,7 +66,13 @@ enum {
   RAYEN_PREPARE_ALL = 0,
   RAYEN_PREPARE_F32 = 1,
   RAYEN_PREPARE_F64 = 2,
-  RAYEN_PREPARE_FWD_ONLY = 4
+  RAYEN_PREPARE_FWD_ONLY = 4,
+  /* (ABI v8) not a family: the fp32 images evaluate (1 + 2^-20) kappa, so clipped samples stop 9.5e-7 (relative to the
+   * step) short of the boundary instead of ON it, where half of the fp32 roundings fall outside -- SURVEY.md section 7
+   * "fp32 feasibility", CM:374.  Measured on 65 536 rows (profiles/bench/r06_inward_bias.txt): config 3 rows with a residual
+   * > 0: 31 594 -> 1; outputs move by at most 1.3e-6 of a row (the parity bar is 1e-5).  fp64 is untouched.
+   * RAYEN_INWARD_BIAS=<eps> in the environment of rayen_pack_create overrides (0 = off, at most 1e-3). */
+  RAYEN_PREPARE_INWARD_BIAS = 8
 };
 
 enum {
@@ -215,6 +221,9 @@ int rayen_ray_project_generic_f64(const RayenPack* pack, const double* v, int64_
  * read from the LMI's rows of T, and the backward leaves (2 - [i = j]) x_i x_j there for the caller's second GEMM); any other
  * pack with an LMI is not (RAYEN_E_UNSUPPORTED; rayen_products_rows() == 0). */
 int64_t rayen_products_rows(const RayenPack* pack);
+/* (ABI v8) 1 when the products route serves this pack at the given precision (f64 = 0: fp32, 1: fp64), forward and backward:
+ * a pack with an LMI of 213 ... 304 rows has the route in fp32 only -- ask before running the GEMM. */
+int rayen_products_served(const RayenPack* pack, int f64);
 int rayen_ray_project_from_products_f32(const RayenPack* pack, const float* T, int64_t ldt, const float* v, int64_t B,
                                         int64_t ldv, float* y, int64_t ldy, float* kappa, int32_t* active,
                                         int32_t* nan_flag, void* stream);

@@ -10,11 +10,11 @@ import os
 
 from ._build import LIBRARY
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 SEG_LIN, SEG_QUAD_SYM, SEG_QUAD_FAC, SEG_SOC, SEG_LMI = range(5)
 E_UNSUPPORTED = -6      # RAYEN_E_UNSUPPORTED (include/rayen_hip.h)
-PREPARE_ALL, PREPARE_F32, PREPARE_F64, PREPARE_FWD_ONLY = 0, 1, 2, 4
+PREPARE_ALL, PREPARE_F32, PREPARE_F64, PREPARE_FWD_ONLY, PREPARE_INWARD_BIAS = 0, 1, 2, 4, 8
 
 # every symbol include/rayen_hip.h declares
 EXPORTS = (
@@ -28,7 +28,7 @@ EXPORTS = (
     "rayen_ray_project_mapped_image_f32", "rayen_bwd_workspace_bytes_f32", "rayen_ray_project_bwd_ws_f32",
     "rayen_bwd_workspace_bytes_f64", "rayen_ray_project_bwd_ws_f64", "rayen_last_forward_kernel",
     "rayen_pair_schedule", "rayen_reserve_cus",
-    "rayen_products_rows", "rayen_ray_project_from_products_f32", "rayen_ray_project_from_products_f64",
+    "rayen_products_rows", "rayen_products_served", "rayen_ray_project_from_products_f32", "rayen_ray_project_from_products_f64",
     "rayen_ray_project_bwd_coefficients_f32", "rayen_ray_project_bwd_coefficients_f64",
 )
 KERNEL_NONE, KERNEL_LANE, KERNEL_MFMA, KERNEL_TRIPLE, KERNEL_PAIR, KERNEL_PAIR_IO, KERNEL_LMI_QUAD, KERNEL_LMI_WAVE, KERNEL_PAIR_WS, KERNEL_PRODUCTS, KERNEL_LMI_BLOCK = range(11)
@@ -115,6 +115,8 @@ def load():
         getattr(lib, name).argtypes = [p, p, i64, p, i64, i64, p, i32p, p, i64, p, i64, p, p]
     lib.rayen_products_rows.restype = ctypes.c_int64
     lib.rayen_products_rows.argtypes = [p]
+    lib.rayen_products_served.restype = ctypes.c_int
+    lib.rayen_products_served.argtypes = [p, ctypes.c_int]
     bwd = [p, p, i64, i64, p, i32p, p, i64, p, i64, p]
     for name in ("rayen_ray_project_bwd_f32", "rayen_ray_project_bwd_f64", "rayen_ray_project_bwd_generic_f32",
                  "rayen_ray_project_bwd_generic_f64",

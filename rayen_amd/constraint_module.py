@@ -150,6 +150,9 @@ class ConstraintModule(torch.nn.Module):
         # evaluate the mapper inside the projection kernel when the shapes allow it (one launch, v
         # never written to memory in inference); False = always run nn.Linear as its own GEMM
         self.fuse_mapper = True
+        # True: clipped samples stop 2^-20 (relative to the step) short of the boundary in fp32 instead of on it (the fp32
+        # kernels evaluate (1 + 2^-20) kappa; fp64 untouched).  Read when a device's constants are packed (first forward).
+        self.inward_bias = False
         self._device_packs = {}
         self._consts = None
         self._fast = {}
@@ -187,7 +190,9 @@ class ConstraintModule(torch.nn.Module):
         index = device.index if device.index is not None else torch.cuda.current_device()
         entry = self._device_packs.get(index)
         if entry is None:
-            dp = _pack.DevicePack(self.packed_constants(), index)
+            # (inward_bias: RAYEN_PREPARE_INWARD_BIAS, include/rayen_hip.h -- set the attribute before the first forward)
+            dp = _pack.DevicePack(self.packed_constants(), index,
+                                  prepare=_lib.PREPARE_INWARD_BIAS if getattr(self, "inward_bias", False) else 0)
             entry = (dp, ops.register_pack(dp))
             self._device_packs[index] = entry
         return entry

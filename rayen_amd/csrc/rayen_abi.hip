@@ -133,6 +133,24 @@ int build_images(RayenPack* p, int prepare) {
   const bool bwd = !(prepare & RAYEN_PREPARE_FWD_ONLY);
   int rc = RAYEN_OK;
   if ((rc = build_one(p, true, &p->wide, wide_build))) return rc;
+  // The inward bias (RAYEN_PREPARE_INWARD_BIAS / RAYEN_INWARD_BIAS, SURVEY.md section 7 "fp32 feasibility"): every term of
+  // kappa is positively homogeneous of degree 1 in the rows of W, so the fp32 images built from (1 + eps) W evaluate
+  // (1 + eps) kappa -- a step 1 / max(1, (1 + eps) kappa) that stops eps short of the boundary the fp32 arithmetic would
+  // otherwise land ON (half of its roundings outside).  No kernel changes, the backward differentiates the same biased
+  // function, interior samples (kappa <= 1 / (1 + eps)) are untouched, and the fp64 images keep the exact W.
+  struct Restore {
+    RayenPack* p; std::vector<double> keep;
+    ~Restore() { if (!keep.empty()) p->W.swap(keep); }
+  } restore{p, {}};
+  if (f32 && p->inward_bias > 0.0) {
+    restore.keep = p->W;
+    for (double& w : p->W) w *= 1.0 + p->inward_bias;
+    // (a symmetric form enters as sqrt(v'G v): ITS rows take the factor twice, or phi . v + sqrt(..) with phi . v < 0 --
+    // most directions -- would move the other way; factors U, cone rows, LMI generators and linear rows enter linearly)
+    for (const RayenSegment& g : p->segs)
+      if (g.type == RAYEN_SEG_QUAD_SYM)
+        for (size_t i = (size_t)g.row0 * p->n; i < (size_t)(g.row0 + g.nrows) * p->n; ++i) p->W[i] *= 1.0 + p->inward_bias;
+  }
   if (f32) {
     p->prepared |= RAYEN_PREPARE_F32;
     p->mixed32 = lmi_block_eligible_mixed_f32(p) && !generic_holds_lmis<float>(p);
@@ -162,6 +180,7 @@ int build_images(RayenPack* p, int prepare) {
         return rc;
     }
   }
+  if (!restore.keep.empty()) { p->W.swap(restore.keep); restore.keep.clear(); }     // (the exact rows again)
   if (f64) {
     p->prepared |= RAYEN_PREPARE_F64;
     p->mixed64 = lmi_block_eligible_mixed_f64(p) && !generic_holds_lmis<double>(p);
@@ -659,7 +678,7 @@ int rayen_pack_create(const RayenPackDesc* desc, RayenPack** out) {
   if (desc->abi_version != RAYEN_ABI_VERSION) return RAYEN_E_ABI;
   int rc = check_table(desc);
   if (rc) return rc;
-  if (desc->prepare < 0 || desc->prepare > 7 || desc->fp32_mode < 0 || desc->fp32_mode > 4) return RAYEN_E_BAD_ARG;
+  if (desc->prepare < 0 || desc->prepare > 15 || desc->fp32_mode < 0 || desc->fp32_mode > 4) return RAYEN_E_BAD_ARG;
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess) return RAYEN_E_NO_DEVICE;
   if (!device_is_gfx950(dev)) return RAYEN_E_NO_DEVICE;
@@ -680,6 +699,16 @@ int rayen_pack_create(const RayenPackDesc* desc, RayenPack** out) {
     const char* env = std::getenv("RAYEN_FP32_MODE");
     if (env != nullptr && env[0] >= '0' && env[0] <= '4') p->fp32_mode = env[0] - '0';
   }
+  {
+    // RAYEN_PREPARE_INWARD_BIAS: eps = 2^-20; RAYEN_INWARD_BIAS=<eps> (0 ... 1e-3; 0 = off) overrides the descriptor
+    p->inward_bias = (desc->prepare & RAYEN_PREPARE_INWARD_BIAS) ? 0x1p-20 : 0.0;
+    const char* env = std::getenv("RAYEN_INWARD_BIAS");
+    if (env != nullptr && env[0] != '\0') {
+      char* end = nullptr;
+      const double eps = std::strtod(env, &end);
+      if (end != env && eps >= 0.0 && eps <= 1e-3) p->inward_bias = eps;
+    }
+  }
   p->W.assign(desc->W, desc->W + (size_t)desc->n_rows * desc->n);
   p->y0.assign(desc->y0, desc->y0 + desc->k);
   p->NA_E.assign((size_t)desc->k * desc->n, 0.0);
@@ -689,7 +718,7 @@ int rayen_pack_create(const RayenPackDesc* desc, RayenPack** out) {
     p->NA_E.assign(desc->NA_E, desc->NA_E + (size_t)desc->k * desc->n);
   }
   p->segs.assign(desc->segments, desc->segments + desc->n_segments);
-  rc = build_images(p, desc->prepare);
+  rc = build_images(p, desc->prepare & 7);
   if (rc == RAYEN_OK) rc = fp32_selfcheck(p);
   if (rc == RAYEN_OK) rc = bwd32_selfcheck(p);
   if (rc != RAYEN_OK) { rayen_pack_destroy(p); return rc; }
@@ -809,6 +838,14 @@ RAYEN_BWD_COEFF(rayen_ray_project_bwd_coefficients_f64, double)
 int64_t rayen_products_rows(const RayenPack* p) {
   if (p == nullptr || (p->wide == nullptr && !lmi_products_pack(p))) return 0;
   return (int64_t)p->n_rows + (p->out_identity ? 0 : p->k);
+}
+
+// per precision (ABI v8): an LMI pack may serve the products route in fp32 only (r in (212, 304]); forward AND backward
+int rayen_products_served(const RayenPack* p, int f64) {
+  if (p == nullptr) return 0;
+  if (p->wide != nullptr) return 1;
+  if (!lmi_products_pack(p)) return 0;
+  return f64 ? (p->w64 != nullptr && lmi_block_products_serves_f64(p->w64)) : (p->w32 != nullptr && lmi_block_products_serves_f32(p->w32));
 }
 
 static int project_f32(const RayenPack* p, const float* v, int64_t B, int64_t ldv, float* y, int64_t ldy,

@@ -71,6 +71,7 @@ struct RayenPack {
   int out_identity = 0;
   int fp32_mode = 0;             // RayenPackDesc.fp32_mode (after the environment override)
   int prepared = 0;              // RAYEN_PREPARE_F32 | RAYEN_PREPARE_F64 | 4 (backward images)
+  double inward_bias = 0.0;      // eps of RAYEN_PREPARE_INWARD_BIAS: the fp32 images are built from (1 + eps) W
   std::vector<double> W;         // host copy [n_rows, n]
   std::vector<double> NA_E;      // host copy [k, n] (identity materialised)
   std::vector<double> y0;        // host copy [k]

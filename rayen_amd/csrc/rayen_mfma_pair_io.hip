@@ -119,6 +119,23 @@ __device__ __forceinline__ void store16_nt(char* gbase, const unsigned voff, con
 
 }  // namespace
 
+// developer build (scripts/ubench/tu_variant.sh rayen_mfma_pair_io iostamps -DRAYEN_IO_STAMPS; scripts/ubench/io_stamps.py):
+// s_memtime per tile of BOTH groups of waves 0 / 3 / 4 of every 64th workgroup -- [tile top | burst + row operations issued |
+// epilogue done] -- and the group's top, end of walk, end of drain, end of the boundary code.  Nothing in the library build.
+#ifdef RAYEN_IO_STAMPS
+__device__ unsigned long long io_stamp_buf[16 * 3 * 2 * 32 * 4];
+extern "C" int rayen_debug_io_stamps(void* dst, size_t bytes) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(io_stamp_buf), bytes < sizeof(io_stamp_buf) ? bytes : sizeof(io_stamp_buf)) == hipSuccess ? 0 : -1;
+}
+#define RAYEN_IO_STAMP(tile, slot)                                                                                   \
+  do {                                                                                                               \
+    if (stamp_on && lane == 0 && (tile) < 32)                                                                        \
+      io_stamp_buf[(((stamp_row * 2 + stamp_round) * 32) + (tile)) * 4 + (slot)] = __builtin_amdgcn_s_memtime();     \
+  } while (0)
+#else
+#define RAYEN_IO_STAMP(tile, slot) do { } while (0)
+#endif
+
 template <int NKK, bool TRACK>
 __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_io_kernel(
     const f16x8* __restrict__ Wh, const MItem* __restrict__ items, int n_items,
@@ -143,6 +160,13 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_io_
   const int64_t wave_id = (int64_t)blockIdx.x * kMfmaWaves + wave;
   const int64_t wave_stride = (int64_t)gridDim.x * kMfmaWaves;
   bool bad = false;
+#ifdef RAYEN_IO_STAMPS
+  const int stamp_wsel = wave == 0 ? 0 : wave == 3 ? 1 : wave == 4 ? 2 : -1;
+  const int stamp_row = (int)(blockIdx.x >> 6) * 3 + stamp_wsel;           // 16 workgroups x 3 waves at most
+  const bool stamp_on = (blockIdx.x & 63) == 0 && (blockIdx.x >> 6) < 16 && stamp_wsel >= 0;
+  int stamp_round = -1;
+  if (stamp_on && lane == 0) io_stamp_buf[(((stamp_row * 2 + 0) * 32) + 31) * 4 + 3] = __builtin_amdgcn_s_memtime();   // kernel entry
+#endif
   for (int i = threadIdx.x; i < NKK * 32; i += kMfmaWaves * 64) y0_lds[i] = y0[i];
   __syncthreads();  // the only workgroup barrier
   (void)k; (void)n;
@@ -215,6 +239,8 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_io_
     }
   };
   // ... -> scaled f16 pairs.  sv = 2^(13 - floor(log2 max|v|)): exponent arithmetic only (rayen_mfma_pair.hip)
+  // (two instructions per value, rayen_split_image.h::pair_split_lo/_hi; nan_row[t]: a NaN or Inf among the row's components)
+  bool nan_row[NT];
   auto split_rows = [&](const float (&vr)[KK], const int t) {
     float m = 0.f;
 #pragma unroll
@@ -224,17 +250,24 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_io_
     int sv_exp;
     pow2_scale(m, sv, v_inv[t], sv_exp);
     v_scl[t] = sv;
+    f16x2 z = {(_Float16)0.f, (_Float16)0.f};
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
+    for (int sp = 0; sp < NS; ++sp) {
+      u32x4 w1, w2;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int i = (q & 1) * 4 + c;
-        const float x = vr[4 * q + c] * sv;
-        const _Float16 p1 = (_Float16)x;
-        const float r1 = x - (float)p1;
-        vb[t][0][q >> 1][i] = p1;
-        vb[t][1][q >> 1][i] = (_Float16)r1;
+      for (int j = 0; j < 4; ++j) {           // register j of the K-step: elements i = 2 j, 2 j + 1 = columns q = 2 sp + (j >> 1), c = 2 (j & 1) + {0, 1}
+        const int q = 2 * sp + (j >> 1), c = 2 * (j & 1);
+        unsigned a, b;
+        pair_split_lo(a, b, vr[4 * q + c], sv);
+        pair_split_hi(a, b, vr[4 * q + c + 1], sv);
+        w1[j] = a;
+        w2[j] = b;
+        pair_nan_fold(z, a);
       }
+      vb[t][0][sp] = __builtin_bit_cast(f16x8, w1);
+      vb[t][1][sp] = __builtin_bit_cast(f16x8, w2);
+    }
+    nan_row[t] = pair_nan_seen(z);
   };
   auto fetch_tile = [&](const int t) {
     float vr[KK];
@@ -279,6 +312,10 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_io_
     const bool trickle_ld = has_next && (next + 1) * (NT * 32) <= B;   // whole groups only: every lane takes part
     const char* vnext = uniform_ptr(v + (has_next ? next : grp) * (NT * 32) * ldv);
     char* yprev = const_cast<char*>(uniform_ptr(y + prev_base * ldy));
+#ifdef RAYEN_IO_STAMPS
+    stamp_round = stamp_round < 1 ? stamp_round + 1 : 1;
+#endif
+    RAYEN_IO_STAMP(31, 0);
     if (need_fetch) {   // a wave's first group, or a ragged one (requested in one burst at the last boundary)
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -307,6 +344,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_io_
         const char* next_tile = reinterpret_cast<const char*>(Wh) + (size_t)(((ts >> 30) & 1) ? 0 : (ts & 0xFFFFFF) + 1) * (NCH * 1024);
         const bool slot = it < NBLK;
         f32x4 ytmp = {0.f, 0.f, 0.f, 0.f};
+        RAYEN_IO_STAMP(it, 0);
         if (slot && has_prev) ytmp = *reinterpret_cast<const f32x4*>(io + it * 1024 + lane * 16);
         {
           const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -383,6 +421,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_io_
           }
           __builtin_amdgcn_sched_barrier(0);
           prio_epilogue();
+          RAYEN_IO_STAMP(it, 1);
         }
         if (item.type == MI_LIN) {
           const int lin_code = (item.seg << 20) + item.row0 + 4 * hi;
@@ -452,10 +491,13 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_io_
             }
           }
         }
+        RAYEN_IO_STAMP(it, 2);
       }
     }
+    RAYEN_IO_STAMP(31, 1);
     // every row of v(next) has landed, y(prev) is out, the next group's first tile is in the A buffer
     drain();
+    RAYEN_IO_STAMP(31, 2);
 
     // ---- kappa is final
 #pragma unroll
@@ -484,6 +526,8 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_io_
     auto stage_tile = [&](const int t) {
       unsigned base, xh;
       row_addr(t, base, xh);
+      float one = 1.0f;
+      asm volatile("" : "+v"(one));
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const f32x4 o4 = *reinterpret_cast<const f32x4*>(&y0_lds[8 * q + 4 * hi]);
@@ -491,12 +535,13 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_io_
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const int i = (q & 1) * 4 + c;
-          const float val = (float)vb[t][0][q >> 1][i] + (float)vb[t][1][q >> 1][i];
+          const unsigned w1 = __builtin_bit_cast(u32x4, vb[t][0][q >> 1])[i >> 1], w2 = __builtin_bit_cast(u32x4, vb[t][1][q >> 1])[i >> 1];
+          const float val = (i & 1) ? pair_rebuild_hi(w1, w2, one) : pair_rebuild_lo(w1, w2, one);     // fl32(p1 + p2)
           o[c] = fmaf(val, scale[t], o4[c]);
-          bad |= live[t] && (o[c] != o[c]);
         }
         *reinterpret_cast<f32x4*>(io + base + ((unsigned)(32 * q) ^ xh)) = o;
       }
+      bad |= live[t] && nan_row[t];      // (the row's own components: y is NaN exactly when one of them is NaN or Inf)
     };
 
     // The buffer holds v(next) when its rows were trickled in: per sample tile, read the next rows, write this
@@ -519,8 +564,10 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_io_
     has_prev = trickle_ld;
     prev_base = s_base;
     need_fetch = false;
+    RAYEN_IO_STAMP(30, 0);
     if (!trickle_ld) {
       burst_store(s_base);
+      RAYEN_IO_STAMP(30, 1);
       if (has_next) {   // a ragged last group: requested only now, in one burst
         burst_load(next * (NT * 32));
         drain();
@@ -663,6 +710,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_iof
 #pragma unroll
       for (int c = 0; c < 4; ++c) vr[4 * q + c] = (8 * q + 4 * (l >> 5) + c < n) ? row[8 * q + c] : 0.f;
   };
+  bool nan_row[NT];
   auto split_rows = [&](const float (&vr)[KK], const int t) {
     float m = 0.f;
 #pragma unroll
@@ -672,17 +720,24 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_iof
     int sv_exp;
     pow2_scale(m, sv, v_inv[t], sv_exp);
     v_scl[t] = sv;
+    f16x2 z = {(_Float16)0.f, (_Float16)0.f};
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
+    for (int sp = 0; sp < NS; ++sp) {          // (two instructions per value: rayen_split_image.h::pair_split_lo/_hi)
+      u32x4 w1, w2;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int i = (q & 1) * 4 + c;
-        const float x = vr[4 * q + c] * sv;
-        const _Float16 p1 = (_Float16)x;
-        const float r1 = x - (float)p1;
-        vb[t][0][q >> 1][i] = p1;
-        vb[t][1][q >> 1][i] = (_Float16)r1;
+      for (int j = 0; j < 4; ++j) {
+        const int q = 2 * sp + (j >> 1), c = 2 * (j & 1);
+        unsigned a, b;
+        pair_split_lo(a, b, vr[4 * q + c], sv);
+        pair_split_hi(a, b, vr[4 * q + c + 1], sv);
+        w1[j] = a;
+        w2[j] = b;
+        pair_nan_fold(z, a);
       }
+      vb[t][0][sp] = __builtin_bit_cast(f16x8, w1);
+      vb[t][1][sp] = __builtin_bit_cast(f16x8, w2);
+    }
+    nan_row[t] = pair_nan_seen(z);
   };
 
   int64_t grp = wave_id;
@@ -976,18 +1031,19 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_iof
           int l = lane;
           asm volatile("" : "+v"(l));
           float* row = io_f + (32 * t + (l & 31)) * k + 4 * (l >> 5);
+          float one = 1.0f;
+          asm volatile("" : "+v"(one));
 #pragma unroll
           for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
               const int i = (q & 1) * 4 + c;
-              const float val = (float)vb[t][0][q >> 1][i] + (float)vb[t][1][q >> 1][i];
+              const unsigned w1 = __builtin_bit_cast(u32x4, vb[t][0][q >> 1])[i >> 1], w2 = __builtin_bit_cast(u32x4, vb[t][1][q >> 1])[i >> 1];
+              const float val = (i & 1) ? pair_rebuild_hi(w1, w2, one) : pair_rebuild_lo(w1, w2, one);     // fl32(p1 + p2)
               const float o = fmaf(val, scale[t], y0_lds[8 * q + 4 * (l >> 5) + c]);
-              if (8 * q + 4 * (l >> 5) + c < k) {
-                bad |= live[t] && (o != o);
-                row[8 * q + c] = o;
-              }
+              if (8 * q + 4 * (l >> 5) + c < k) row[8 * q + c] = o;
             }
+          bad |= live[t] && nan_row[t];    // (columns beyond n are zero: the row's pieces are NaN / Inf exactly when y is NaN)
         }
         __builtin_amdgcn_sched_barrier(0);
         if (trickle_ld) {

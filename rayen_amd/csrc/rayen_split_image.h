@@ -160,6 +160,41 @@ __device__ __forceinline__ void pow2_scale(const float m, float& scale, float& i
   exp_scale = 140 - (int)e;
 }
 
+// ---- the group boundary of the f16-pair walks in the instructions it needs (round 6).  By the cycle accounting of DESIGN.md
+// 4.0 a SIMD's vector work and its MFMAs are serial, and 1 300 of the 2 000 vector instructions a wave spends per 64-sample
+// group were boundary code: hipcc turned `x = v sv; p1 = (f16) x; p2 = (f16)(x - p1)` into 3.5 instructions per value
+// (v_mul, half a v_cvt_pk_f16_f32, two v_fma_mix*) and `(float) p1 + (float) p2` into three (two conversions and an add).
+// The mixed-precision FMA does each in ONE: f16(v sv + 0), f16(v sv - p1) (the product by a power of two is exact, so the
+// fused forms round the same values: same bits), and fl32(p1 * 1 + p2).
+// pair_split_lo / _hi: p1, p2 of v * sv into the LOW / HIGH half of the registers w1, w2 (low first: it defines the register).
+__device__ __forceinline__ void pair_split_lo(unsigned& w1, unsigned& w2, const float v, const float sv) {
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(w1) : "v"(v), "v"(sv));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(w2) : "v"(v), "v"(sv), "v"(w1));
+}
+__device__ __forceinline__ void pair_split_hi(unsigned& w1, unsigned& w2, const float v, const float sv) {
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(w1) : "v"(v), "v"(sv));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(w2) : "v"(v), "v"(sv), "v"(w1));
+}
+// fl32(p1 + p2) of the LOW / HIGH halves of w1, w2 (`one` = 1.0f in a register)
+__device__ __forceinline__ float pair_rebuild_lo(const unsigned w1, const unsigned w2, const float one) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(w1), "v"(one), "v"(w2));
+  return r;
+}
+__device__ __forceinline__ float pair_rebuild_hi(const unsigned w1, const unsigned w2, const float one) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(w1), "v"(one), "v"(w2));
+  return r;
+}
+// NaN / Inf anywhere in a row, from its p1 pieces (eight f16 per u32x4): z <- p1 * 0 + z per register pair -- a finite piece
+// leaves z alone, an infinite or NaN piece makes it NaN and it stays NaN.  y = y0 + v / max(1, kappa) is NaN exactly when a
+// component of v is (an infinite one: inf * 0 from the step), so ONE test of z per row replaces a compare per output value.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void pair_nan_fold(f16x2& z, const unsigned w1) {
+  asm("v_pk_fma_f16 %0, %1, 0, %0" : "+v"(z) : "v"(w1));
+}
+__device__ __forceinline__ bool pair_nan_seen(const f16x2 z) { return (z[0] != z[0]) || (z[1] != z[1]); }
+
 // kappa candidate of a second-order cone from the walk's scaled quantities (f16-pair kernels): a' x^2 + b' x + c' = 0
 // (rayen/constraint_module.py:392-396, 339-348), a' < 0.  The coefficients mix in the set's constants f0 = tau,
 // f1 = a', so they are formed in natural units (wi = 1 / (gW f_s), vi = 1 / sv) and the root goes back to the scaled

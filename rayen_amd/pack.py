@@ -273,7 +273,7 @@ class DevicePack:
         cache = self.__dict__.setdefault("_products", {})
         if dtype not in cache:
             rows = int(_lib.load().rayen_products_rows(self.handle))
-            if rows <= 0:
+            if rows <= 0 or not _lib.load().rayen_products_served(self.handle, int(dtype == torch.float64)):
                 cache[dtype] = None
             else:
                 c = self.consts
