@@ -150,8 +150,13 @@ class ConstraintModule(torch.nn.Module):
         # evaluate the mapper inside the projection kernel when the shapes allow it (one launch, v
         # never written to memory in inference); False = always run nn.Linear as its own GEMM
         self.fuse_mapper = True
-        # True: clipped samples stop 2^-20 (relative to the step) short of the boundary in fp32 instead of on it (the fp32
-        # kernels evaluate (1 + 2^-20) kappa; fp64 untouched).  Read when a device's constants are packed (first forward).
+        # True: clipped samples stop 2^-20 of their step short of the boundary in fp32 instead of ON it, where half of the fp32
+        # roundings fall outside (the fp32 kernels evaluate (1 + 2^-20) kappa, RAYEN_PREPARE_INWARD_BIAS in include/rayen_hip.h;
+        # fp64 and interior samples untouched).  Measured on 65 536 rows of config 3 (profiles/bench/r06_inward_bias.txt): rows
+        # with a positive fp64 residual 31 594 -> 1, outputs moved by at most 1.3e-6 of a row.  OFF by default: the shift is
+        # 2^-20 of the STEP y - y0, and on a row whose y is small against its step (the reference's example sets: a point near the
+        # origin reached from y0 = (0.5, 0.5)) that is more than the 1e-5 of the row the parity bar allows -- the golden vectors
+        # fail with it on (round 6, gpurun_out/r06d).  Read when a device's constants are packed (first forward on that device).
         self.inward_bias = False
         self._device_packs = {}
         self._consts = None
