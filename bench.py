@@ -393,6 +393,9 @@ def main(argv=None):
         dist.barrier()
     # ---- the projection alone (the whole step at N = 1)
     elapsed_p, dev_ms = timed_loop(module_step, x, args.steps, args.warmup, use_dist, graph=graph, on_gpu=on_gpu)
+    if on_gpu:
+        from rayen_amd import _lib as _klib
+        timed_kernel = _klib.load().rayen_last_forward_kernel()      # which instruction stream served the TIMED launches
     # ---- the same launches on ONE (x, y) pair (128 MiB at config 3: resident in the Infinity Cache) -- reported beside
     l3_ms = None
     if pairs > 1:
@@ -480,9 +483,11 @@ def main(argv=None):
             pieces = {2: 6.0, 3: 3.0}.get(info.mfma_f32, 1.0)    # piece products per fp32 product
             kernel_tag = (({3: "mfma_pair_f16x2 (fp32-grade)", 2: "mfma_split_bf16x3 (fp32-grade)", 1: "mfma_f32"}.get(info.mfma_f32, "lmi_lanes" if lmi else "generic"))
                           if dtype == torch.float32 else ("mfma_f64" if info.mfma_f64 else ("lmi_lanes" if lmi else "generic")))
-            served_by = _lib.load().rayen_last_forward_kernel()      # which instruction stream the last call ran
+            served_by = timed_kernel      # (read right behind the timed loop: the checks since then launched smaller batches)
             if served_by == _lib.KERNEL_PAIR_IO:
                 kernel_tag = "mfma_pair_io_f16x2 (fp32-grade; rows of v and y trickled through LDS under the tile walk)"
+            elif served_by == getattr(_lib, "KERNEL_PAIR_WL", -1):
+                kernel_tag = "mfma_pair_wl_f16x2 (fp32-grade; the image of W resident in LDS, rows straight from / to memory, four waves per SIMD)"
             elif served_by == getattr(_lib, "KERNEL_PAIR_WS", -1):
                 kernel_tag = "mfma_pair_ws_f16x2 (fp32-grade; W resident in the registers of a workgroup's waves, batch streamed through LDS)"
         else:
@@ -627,6 +632,22 @@ def main(argv=None):
         if split and world == 1 and not args.mapper and not args.no_families:
             # the same workload on the other fp32 families (RayenPackDesc.fp32_mode / RAYEN_FP32_MODE at pack
             # creation), timed the same way, so that one line carries all of them
+            if served_by == getattr(_lib, "KERNEL_PAIR_WL", -1):
+                # the same pack on the default schedule of rounds 3-5 (rows trickled through LDS, W streamed from L2): same values
+                prev = _lib.load().rayen_pair_schedule(1)
+                try:
+                    with torch.no_grad():
+                        for _ in range(SETTLE_LAUNCHES // 3):
+                            module_step(x)
+                    torch.cuda.synchronize()
+                    _, ms = timed_loop(module_step, x, args.steps, args.warmup, False, graph=graph)
+                finally:
+                    _lib.load().rayen_pair_schedule(prev)
+                tf = flops_pp * B / (ms * 1e-3) / 1e12
+                out["pair_kernel_with_trickled_rows"] = {
+                    "value": B / (ms * 1e-3), "unit": "projections/s", "ms_per_step": ms,
+                    "roofline": {"bound": "mfma", "achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": tf / peak_tf},
+                    "how": "rayen_pair_schedule(1): rayen_mfma_pair_io.hip (the default of rounds 3-5), same pack, same inputs, same step count"}
             if served_by == _lib.KERNEL_PAIR_IO:
                 # the same pack on the plain f16-pair kernel (rows loaded / stored at the group boundaries): same values
                 prev = _lib.load().rayen_pair_schedule(0)

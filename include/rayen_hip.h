@@ -155,16 +155,18 @@ enum {
   RAYEN_KERNEL_PAIR_WS = 8,   /* f16 pairs, W-stationary (ABI v6): the tiles of W resident in the registers of a workgroup's eight
                                  waves, the batch streamed through a shared B-operand image in LDS */
   RAYEN_KERNEL_PRODUCTS = 9,  /* wide sets (ABI v7): the epilogue over products T = v W_ext' of a library GEMM */
+  RAYEN_KERNEL_PAIR_WL = 11,  /* f16 pairs, the image of W resident in LDS, three waves per SIMD on groups of 32 samples (round 6) */
   RAYEN_KERNEL_LMI_BLOCK = 10 /* one workgroup per sample, the packed lower triangle in LDS (one LMI to ~280 x 280 + linear rows; round 5) */
 };
 int rayen_last_forward_kernel(void);
 
 /* Tuning / A-B switch (ABI v4, process-wide): which SCHEDULE of the f16-pair forward serves the calls whose shape
- * allows it -- 1 (default): rows of v and y trickled through LDS under the tile walk for batches that give every
- * resident wave a group (B >= 131 072 on MI355X), the W-stationary kernel for 32 768 <= B < 131 072 where it serves the
- * pack (ABI v7), else the plain kernel | 0: always the plain kernel | 2 (ABI v6): the W-stationary kernel wherever it
- * serves, else as 1.  All compute the same values bit for bit.  Initial value from the
- * environment variable RAYEN_PAIR_IO.  mode outside 0..2 only queries.  Returns the previous setting. */
+ * allows it -- 3 (default since ABI v8 / round 6): the image of W resident in LDS (NA_E = I, n = k = 32 or 64, the image
+ * within 160 KiB, B >= 98 304 on MI355X), else as 1 | 1 (the default of ABI v4-v7): rows of v and y trickled through LDS
+ * under the tile walk for batches that give every resident wave a group (B >= 131 072 on MI355X), the W-stationary kernel
+ * for 32 768 <= B < 131 072 where it serves the pack (ABI v7), else the plain kernel | 0: always the plain kernel |
+ * 2 (ABI v6): the W-stationary kernel wherever it serves, else as 1.  All compute the same values bit for bit.  Initial
+ * value from the environment variable RAYEN_PAIR_IO.  mode outside 0..3 only queries.  Returns the previous setting. */
 int rayen_pair_schedule(int mode);
 
 /* Multi-GPU step (ABI v4, process-wide): leave `cus` compute units out of the persistent grids of the projection

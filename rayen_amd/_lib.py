@@ -31,7 +31,7 @@ EXPORTS = (
     "rayen_products_rows", "rayen_products_served", "rayen_ray_project_from_products_f32", "rayen_ray_project_from_products_f64",
     "rayen_ray_project_bwd_coefficients_f32", "rayen_ray_project_bwd_coefficients_f64",
 )
-KERNEL_NONE, KERNEL_LANE, KERNEL_MFMA, KERNEL_TRIPLE, KERNEL_PAIR, KERNEL_PAIR_IO, KERNEL_LMI_QUAD, KERNEL_LMI_WAVE, KERNEL_PAIR_WS, KERNEL_PRODUCTS, KERNEL_LMI_BLOCK = range(11)
+KERNEL_NONE, KERNEL_LANE, KERNEL_MFMA, KERNEL_TRIPLE, KERNEL_PAIR, KERNEL_PAIR_IO, KERNEL_LMI_QUAD, KERNEL_LMI_WAVE, KERNEL_PAIR_WS, KERNEL_PRODUCTS, KERNEL_LMI_BLOCK, KERNEL_PAIR_WL = range(12)
 
 
 class RayenSegment(ctypes.Structure):

@@ -46,14 +46,15 @@ template <> GenericImage<double>& image_of<double>(const RayenPack* p) { return 
 // which kernel family served this thread's most recent forward call (rayen_last_forward_kernel)
 thread_local int g_last_forward = RAYEN_KERNEL_NONE;
 
-// Schedules of the f16-pair forward (same arithmetic): 1 (default) = rows of v and y trickled through LDS under the tile
-// walk (rayen_mfma_pair_io.hip) where the call's shape allows it | 0 = rayen_mfma_pair.hip always | 2 = W-stationary
-// (rayen_mfma_pair_ws8.hip) where the pack and the call allow it, else as 1: bit-exact and measured ~12 % slower than 1 on
-// config 3, kept selectable.  RAYEN_PAIR_IO / rayen_pair_schedule select (A/B runs).
+// Schedules of the f16-pair forward (same arithmetic): 3 (default, round 6) = the image of W resident in LDS
+// (rayen_mfma_pair_wl.hip) where the pack and the call allow it, else as 1 | 1 (the default of rounds 3-5) = rows of v and y
+// trickled through LDS under the tile walk (rayen_mfma_pair_io.hip) where the call's shape allows it, the W-stationary
+// kernel for mid-size batches | 0 = rayen_mfma_pair.hip always | 2 = W-stationary (rayen_mfma_pair_ws8.hip) where the pack
+// and the call allow it, else as 1.  All bit-identical.  RAYEN_PAIR_IO / rayen_pair_schedule select (A/B runs).
 std::atomic<int>& pair_schedule_cell() {
   static std::atomic<int> mode([] {
     const char* e = std::getenv("RAYEN_PAIR_IO");
-    return (e != nullptr && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;   // (2 once it is the faster one)
+    return (e != nullptr && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 3;
   }());
   return mode;
 }
@@ -163,6 +164,7 @@ int build_images(RayenPack* p, int prepare) {
       if ((rc = build_one(p, split_ok && mode != 3, &p->sp32, mfma_split_build))) return rc;
       if ((rc = build_one(p, split_ok && (mode == 0 || mode == 3), &p->pr32, mfma_pair_build))) return rc;
       if (p->pr32 != nullptr && (rc = mfma_pair_io_prepare(p, p->pr32))) return rc;
+      if (p->pr32 != nullptr && (rc = mfma_pair_wl_prepare(p, p->pr32))) return rc;
       if (p->pr32 != nullptr && (rc = mfma_pair_ws8_build(p, p->pr32, &p->ws8_32))) return rc;
       // (the instances behind the fused mapper walk an image without shared tiles, rayen_mfma_pair.hip)
       if (p->pr32 != nullptr && mfma_pair_has_halves(p->pr32) && (rc = build_one(p, true, &p->pr32m, mfma_pair_build_dense))) return rc;
@@ -375,7 +377,7 @@ int rayen_reserve_cus(int cus) {
 }
 
 int rayen_pair_schedule(int mode) {
-  if (mode >= 0 && mode <= 2) return pair_schedule_cell().exchange(mode, std::memory_order_relaxed);
+  if (mode >= 0 && mode <= 3) return pair_schedule_cell().exchange(mode, std::memory_order_relaxed);
   return pair_schedule();
 }
 
@@ -856,6 +858,10 @@ static int project_f32(const RayenPack* p, const float* v, int64_t B, int64_t ld
   const int rc = check_ready<float>(p, false);
   if (rc) return rc;
   if (p->pr32 != nullptr && p->pr32_state == 1 && y != nullptr && !old_mode) {
+    if (pair_schedule() == 3 && mfma_pair_wl_serves(p, p->pr32, v, B, ldv, y, ldy)) {
+      g_last_forward = RAYEN_KERNEL_PAIR_WL;
+      return mfma_pair_wl_forward(p, p->pr32, v, B, ldv, y, ldy, kappa, active, nan_flag, static_cast<hipStream_t>(stream));
+    }
     if (pair_schedule() == 2 && mfma_pair_ws8_serves(p, p->pr32, p->ws8_32, v, B, ldv, y, ldy)) {
       g_last_forward = RAYEN_KERNEL_PAIR_WS;
       return mfma_pair_ws8_forward(p, p->pr32, p->ws8_32, v, B, ldv, y, ldy, kappa, active, nan_flag, static_cast<hipStream_t>(stream));

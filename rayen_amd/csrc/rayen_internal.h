@@ -177,6 +177,15 @@ int mfma_pair_io_forward(const RayenPack* p, const PairImage* img, const float* 
                          float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
                          hipStream_t stream);
 
+// the same arithmetic with the image of W resident in LDS, rows straight from / to memory one group ahead, three waves per
+// SIMD on groups of 32 samples (rayen_mfma_pair_wl.hip, round 6)
+bool mfma_pair_wl_serves(const RayenPack* p, const PairImage* img, const float* v, int64_t B, int64_t ldv,
+                         const float* y, int64_t ldy);
+int mfma_pair_wl_prepare(const RayenPack* p, PairImage* img);   // function attributes (pack creation only)
+int mfma_pair_wl_forward(const RayenPack* p, const PairImage* img, const float* v, int64_t B, int64_t ldv,
+                         float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
+                         hipStream_t stream);
+
 // the same arithmetic, W-stationary: the tiles of W in the registers of a workgroup's eight waves, the batch through an
 // LDS image (rayen_mfma_pair_ws8.hip)
 int mfma_pair_ws8_build(const RayenPack* p, const PairImage* img, Ws8Image** out);   // *out = null: not served

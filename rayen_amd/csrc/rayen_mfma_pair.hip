@@ -737,6 +737,7 @@ static int pair_build(const RayenPack* p, PairImage** out, int64_t* bytes, const
   // chunk (tile, k-step s, piece) = 64 lanes x 8 elements, element i of lane l = column
   // 16 s + 8 (i >> 2) + 4 (l >> 5) + (i & 3) of row l & 31 = entry [2 s + (i >> 2)][l][i & 3] of the fp32 image
   const int n_tiles = b.n_tiles(), ns = b.nq() / 2;
+  img->n_tiles = n_tiles;
   std::vector<_Float16> wh((size_t)n_tiles * ns * 2 * 64 * 8);
   for (int t = 0; t < n_tiles; ++t)
     for (int sp = 0; sp < ns; ++sp)

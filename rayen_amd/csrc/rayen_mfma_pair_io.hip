@@ -136,6 +136,15 @@ extern "C" int rayen_debug_io_stamps(void* dst, size_t bytes) {
 #define RAYEN_IO_STAMP(tile, slot) do { } while (0)
 #endif
 
+// developer build (-DRAYEN_IO_CLOCK; scripts/ubench/wl_clock.py): s_memtime and s_memrealtime (100 MHz) at entry and exit of wave
+// 0 of every 16th workgroup -- the shader clock the kernel actually ran at.  Nothing in the library build.
+#ifdef RAYEN_IO_CLOCK
+__device__ unsigned long long io_clock_buf[16 * 4];
+extern "C" int rayen_debug_io_clock(void* dst, size_t bytes) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(io_clock_buf), bytes < sizeof(io_clock_buf) ? bytes : sizeof(io_clock_buf)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 template <int NKK, bool TRACK>
 __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_io_kernel(
     const f16x8* __restrict__ Wh, const MItem* __restrict__ items, int n_items,
@@ -166,6 +175,13 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_io_
   const bool stamp_on = (blockIdx.x & 63) == 0 && (blockIdx.x >> 6) < 16 && stamp_wsel >= 0;
   int stamp_round = -1;
   if (stamp_on && lane == 0) io_stamp_buf[(((stamp_row * 2 + 0) * 32) + 31) * 4 + 3] = __builtin_amdgcn_s_memtime();   // kernel entry
+#endif
+#ifdef RAYEN_IO_CLOCK
+  const bool clk_probe = (blockIdx.x & 15) == 0 && threadIdx.x == 0;
+  if (clk_probe) {
+    io_clock_buf[(blockIdx.x >> 4) * 4 + 0] = __builtin_amdgcn_s_memtime();
+    io_clock_buf[(blockIdx.x >> 4) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+  }
 #endif
   for (int i = threadIdx.x; i < NKK * 32; i += kMfmaWaves * 64) y0_lds[i] = y0[i];
   __syncthreads();  // the only workgroup barrier
@@ -577,6 +593,12 @@ __global__ __launch_bounds__(kMfmaWaves * 64, kMfmaWaves / 4) void mfma_pair_io_
     grp = next;
   }  // persistent loop over sample groups
   if (nan_flag && bad) atomicOr(nan_flag, 1);
+#ifdef RAYEN_IO_CLOCK
+  if (clk_probe) {
+    io_clock_buf[(blockIdx.x >> 4) * 4 + 2] = __builtin_amdgcn_s_memtime();
+    io_clock_buf[(blockIdx.x >> 4) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 // =============================================================================================

@@ -1,0 +1,588 @@
+// Paired-half forward with the IMAGE OF W RESIDENT IN LDS (round 6; rayen/constraint_module.py:468-474, 351-458 in one
+// launch; the arithmetic is rayen_mfma_pair.hip's, bit for bit).
+//
+// Why: in rayen_mfma_pair.hip / rayen_mfma_pair_io.hip every wave pulls the whole image through the CU's vector-memory
+// path once per 64 samples -- eight 1-KiB global_load_dwordx4 per tile and wave, sixteen cycles of that path each
+// (scripts/ubench/mfma_coissue.hip: 64 B per clock and CU), ten with the two row operations: eight waves keep it busy
+// 1 280 of the ~2 400 cycles a tile takes, and a wave that cannot hand over its re-load cannot issue its next MFMA either
+// (HISTORY.md, "the same ablations on config 3's walk": no A re-loads -18 %, neither re-loads nor row operations -29 %).
+// Here the image is copied into LDS ONCE per workgroup (one workgroup per CU; config 3: 14 tiles = 112 KiB) and an A
+// operand is a ds_read_b128: 4 LDS cycles instead of 16 vector-memory cycles, on a path nothing else uses.  What that
+// buys besides:
+//   * no row buffers in LDS (there is no room for them and no need): a lane reads ITS sample's row straight from memory as
+//     eight 16-byte pieces (fragment shape: lanes (col, hi) of a row cover 32 contiguous bytes, four consecutive
+//     instructions complete a 128-byte line) one group AHEAD, into registers, right behind the split of the current
+//     group -- a whole walk (~10 k cycles) for the HBM round trip -- and writes its row of y the same way;
+//   * vmcnt counts nothing but those rows: no counted waits, no stand-in operations, no M0;
+//   * groups of 32 samples (one sample tile per wave): 96 instead of 160 live registers in the walk, so THREE waves per
+//     SIMD (twelve per workgroup) take turns on the matrix pipe -- by the same microbenchmark a partner's plain VALU /
+//     SALU / LDS instructions issue while a wave's MFMAs execute -- and the first rows a wave waits for are 8 KiB, not 16.
+// The item list, the image, the epilogues and the order of the products inside a tile are the other schedules': same bits.
+//
+// Served: NA_E = I, n = k = 32 NKK, rows 16-byte aligned, the image + the aux patches within 160 KiB of LDS, at most
+// AUXR aux rows at NKK = 2.  Everything else stays on the other schedules.
+#include "rayen_split_image.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <mutex>
+#include <type_traits>
+
+namespace rayen {
+
+namespace {
+#ifndef RAYEN_WL_WAVES
+#define RAYEN_WL_WAVES 16
+#endif
+#ifndef RAYEN_WL_NT
+#define RAYEN_WL_NT 1
+#endif
+// 1: a group's rows are requested one group ahead (64 registers at two sample tiles) | 0: at the top of the group, the wait
+// left to the other waves of the SIMD
+#ifndef RAYEN_WL_AHEAD
+#define RAYEN_WL_AHEAD 0
+#endif
+constexpr int kWlWaves = RAYEN_WL_WAVES;      // waves per workgroup = per CU
+constexpr int kWlNT = RAYEN_WL_NT;            // sample tiles (of 32) per wave and group
+// developer ablation builds (scripts/ubench/tu_variant.sh rayen_mfma_pair_wl <name> -DRAYEN_WL_ABL=<bits>; WRONG RESULTS):
+// 1 rows requested once per wave | 2 no rows of y stored | 4 non-temporal loads | 8 plain stores | 16 no epilogues | 32 no MFMAs
+#ifndef RAYEN_WL_ABL
+#define RAYEN_WL_ABL 0
+#endif
+#ifndef RAYEN_WL_PRIO
+#define RAYEN_WL_PRIO 0
+#endif
+template <int NKK> struct WlGeom { static constexpr int AUXR = NKK == 2 ? 8 : 32; };
+// a wave's own LDS: the aux patch during the walk ([sample tile][aux row][sample]), then the 4 KiB through which its rows of
+// y leave as whole 128-byte lines (32 rows x one line)
+// (one sample tile per wave: 16 rows at a time through 2 KiB, so that three or four waves per SIMD fit next to the image)
+#ifndef RAYEN_WL_SR
+#define RAYEN_WL_SR 0
+#endif
+constexpr int wl_stage_rows(int nt) { return RAYEN_WL_SR ? RAYEN_WL_SR : (nt == 1 ? 16 : 32); }
+constexpr int wl_region_bytes(int nkk, int nt) {
+  return nt * WlGeom<2>::AUXR * 128 * (nkk == 2 ? 1 : 4) > wl_stage_rows(nt) * 128 ? nt * WlGeom<2>::AUXR * 128 * (nkk == 2 ? 1 : 4) : wl_stage_rows(nt) * 128;
+}
+}  // namespace
+
+// developer build (scripts/ubench/tu_variant.sh rayen_mfma_pair_wl clock -DRAYEN_WL_CLOCK; scripts/ubench/wl_clock.py): s_memtime
+// (shader clocks) and s_memrealtime (100 MHz) at entry and exit of wave 0 of every 16th workgroup -- the shader clock the
+// kernel actually ran at (the chip lowers it under matrix load).  Nothing in the library build.
+// developer build (-DRAYEN_WL_STAMPS; scripts/ubench/wl_stamps.py): s_memtime per item of the SECOND group of waves 0 and 4 of
+// workgroup 0 -- [item top | burst and the next item's reads issued | epilogue done].  Nothing in the library build.
+#ifdef RAYEN_WL_STAMPS
+#ifndef RAYEN_WL_STAMP_ROUND
+#define RAYEN_WL_STAMP_ROUND 1
+#endif
+__device__ unsigned long long wl_stamp_buf[2 * 40 * 4];
+extern "C" int rayen_debug_wl_stamps(void* dst, size_t bytes) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(wl_stamp_buf), bytes < sizeof(wl_stamp_buf) ? bytes : sizeof(wl_stamp_buf)) == hipSuccess ? 0 : -1;
+}
+#define RAYEN_WL_STAMP(item, slot)                                                                              \
+  do {                                                                                                          \
+    if (stamp_on && lane == 0 && (item) < 40) wl_stamp_buf[((wave >> 2) * 40 + (item)) * 4 + (slot)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define RAYEN_WL_STAMP(item, slot) do { } while (0)
+#endif
+#ifdef RAYEN_WL_CLOCK
+__device__ unsigned long long wl_clock_buf[16 * 4];
+extern "C" int rayen_debug_wl_clock(void* dst, size_t bytes) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(wl_clock_buf), bytes < sizeof(wl_clock_buf) ? bytes : sizeof(wl_clock_buf)) == hipSuccess ? 0 : -1;
+}
+#endif
+
+template <int NKK, bool TRACK, int NT, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void mfma_pair_wl_kernel(
+    const f16x8* __restrict__ Wh, const MItem* __restrict__ items, int n_items,
+    const MPack* __restrict__ packs, const float* __restrict__ y0, int n_tiles,
+    const float* __restrict__ v, int64_t B, int64_t ldv, float* __restrict__ y, int64_t ldy,
+    float* __restrict__ kappa_out, int32_t* __restrict__ active_out,
+    int32_t* __restrict__ nan_flag, const float w_scale, const float w_inv) {
+  constexpr int NS = NKK * 2, NCH = NS * 2, NQ = NKK * 4, AUXR = WlGeom<NKK>::AUXR;
+  extern __shared__ __attribute__((aligned(1024))) char wl_smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col = lane & 31;
+  const int hi = lane >> 5;
+  char* const wimg = wl_smem;                                                   // [n_tiles][NS][2][64] x 16 bytes
+  constexpr int REGION = wl_region_bytes(NKK, NT), SR = wl_stage_rows(NT);
+  char* const stage = wl_smem + (size_t)n_tiles * (NCH * 1024) + wave * REGION;
+  float (*const aux_lds)[AUXR][32] = reinterpret_cast<float (*)[AUXR][32]>(stage);   // [sample tile][row][sample]
+  float* const y0_lds = reinterpret_cast<float*>(wl_smem + (size_t)n_tiles * (NCH * 1024) + NW * REGION);
+  unsigned* const take_lds = reinterpret_cast<unsigned*>(y0_lds + NKK * 32);     // the workgroup's next unclaimed group
+  // Groups are dealt to WORKGROUPS statically (group b + j gridDim.x is the j-th of workgroup b) and to the waves of a
+  // workgroup on demand, j from a counter in LDS: the issue arbiter prefers the older wave of a SIMD, so with equal shares
+  // the first waves of a workgroup finish early and their partners walk alone at the end (s_memtime / s_memrealtime probes,
+  // B = 1 048 576: wave 0 lives 156 us of a 191 us launch)
+  const int64_t n_groups = (B + NT * 32 - 1) / (NT * 32);
+  const int64_t grp_stride = (int64_t)gridDim.x;
+  int64_t grp = (int64_t)blockIdx.x + (int64_t)wave * grp_stride;
+  bool bad = false;
+  bool first_walk = true;
+  // developer A/B (-DRAYEN_WL_PRIO=n): 1 = a STATIC issue priority per wave of a SIMD (waves w, w + 4, w + 8, w + 12 share one):
+  // a burst of the higher wave is never interleaved with a lower one's, so the waves of a SIMD cannot fall into step (all
+  // in their bursts, then all in their epilogues); the shares they end up with are evened out by the group counter
+#if RAYEN_WL_PRIO == 1
+  if ((wave >> 2) == 0) __builtin_amdgcn_s_setprio(0);
+  else if ((wave >> 2) == 1) __builtin_amdgcn_s_setprio(1);
+  else if ((wave >> 2) == 2) __builtin_amdgcn_s_setprio(2);
+  else __builtin_amdgcn_s_setprio(3);
+#elif RAYEN_WL_PRIO == 2
+  if ((wave >> 2) == 0) __builtin_amdgcn_s_setprio(3);
+  else if ((wave >> 2) == 1) __builtin_amdgcn_s_setprio(2);
+  else if ((wave >> 2) == 2) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef RAYEN_WL_STAMPS
+  int stamp_round = 0;
+  bool stamp_on = false;
+#endif
+#ifdef RAYEN_WL_CLOCK
+  const bool probe = (blockIdx.x & 15) == 0 && threadIdx.x == 0;
+  if (probe) {
+    wl_clock_buf[(blockIdx.x >> 4) * 4 + 0] = __builtin_amdgcn_s_memtime();
+    wl_clock_buf[(blockIdx.x >> 4) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
+
+  // ---- the image, once: chunk c (1 KiB) by wave c mod NW, requested in front of the wave's first rows (loads retire in
+  // order: the copy must not wait behind an HBM round trip)
+  {
+    const int n_chunks = n_tiles * NCH;
+    const char* src = reinterpret_cast<const char*>(Wh) + lane * 16;
+#pragma unroll 4
+    for (int c = wave; c < n_chunks; c += NW)
+      *reinterpret_cast<u32x4*>(wimg + c * 1024 + lane * 16) = *reinterpret_cast<const u32x4*>(src + (size_t)c * 1024);
+    for (int i = threadIdx.x; i < NKK * 32; i += NW * 64) y0_lds[i] = y0[i];
+    if (threadIdx.x == 0) *take_lds = NW;     // (the first NW are the waves' first groups)
+  }
+
+  // this lane's rows of group g (one per sample tile): pieces 2 q + hi (columns 8 q + 4 hi .. + 3), zero beyond the batch
+  f32x4 vraw[NT][NQ];
+  auto request = [&](const int64_t g) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int64_t row = g * (NT * 32) + t * 32 + col;
+      const bool in = row < B;
+      const float* src = v + (in ? row : 0) * ldv + 4 * hi;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        vraw[t][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (in) {
+          // (plain loads: the four instructions that complete a 128-byte line find it in L1 after the first; non-temporal
+          // ones go to L2 four times -- 55.0 against 62.5 us at B = 262 144, gpurun_out/r06j)
+          if constexpr (RAYEN_WL_ABL & 4) vraw[t][q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + 8 * q));
+          else vraw[t][q] = *reinterpret_cast<const f32x4*>(src + 8 * q);
+        }
+      }
+    }
+  };
+  // largest |component| of the requested rows (this lane's half of each): the FIRST use of the rows' registers.  It sits in
+  // front of the previous group's stores of y -- vmcnt retires in order and counts stores, so a wait for these loads that
+  // came behind the stores would wait for the stores' HBM round trip as well
+  float m_half[NT];
+  auto half_max = [&]() {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float m = 0.f;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) m = fmaxf(m, __builtin_fabsf(vraw[t][q][c]));
+      m_half[t] = m;
+      asm volatile("" : "+v"(m_half[t]));   // (pinned here: hipcc otherwise sinks the maxima -- and their wait -- behind the stores)
+    }
+  };
+#pragma unroll
+  for (int t = 0; t < NT; ++t) m_half[t] = 0.f;
+  if (RAYEN_WL_AHEAD && grp < n_groups) {
+    request(grp);
+    half_max();
+  }
+  __syncthreads();  // the only workgroup barrier: the image is in LDS
+
+  while (grp < n_groups) {
+    const int64_t s_base = grp * (NT * 32);
+    int taken = 0;
+    if (lane == 0) taken = (int)atomicAdd(take_lds, 1u);
+    const int64_t next = (int64_t)blockIdx.x + (int64_t)__builtin_amdgcn_readfirstlane(taken) * grp_stride;
+    bool live[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) live[t] = (s_base + t * 32 + col) < B;
+    if constexpr (!RAYEN_WL_AHEAD) {
+      request(grp);
+      half_max();
+    }
+
+#ifdef RAYEN_WL_STAMPS
+    stamp_on = blockIdx.x == 0 && (wave == 0 || wave == 4) && stamp_round == RAYEN_WL_STAMP_ROUND;
+    ++stamp_round;
+    RAYEN_WL_STAMP(38, 0);
+#endif
+    // ---- rows -> scaled f16 pairs.  sv = 2^(13 - floor(log2 max|v|)): exponent arithmetic only (rayen_mfma_pair.hip);
+    // vb[t][piece][k-step] = 8 f16 = the B operand of one MFMA; element i = column 16 sp + 8 (i >> 2) + 4 hi + (i & 3)
+    f16x8 vb[NT][2][NS];
+    float v_scl[NT], v_inv[NT];
+    bool nan_row[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float m = fmaxf(m_half[t], xhalf(m_half[t]));
+      float sv;
+      int sv_exp;
+      pow2_scale(m, sv, v_inv[t], sv_exp);
+      v_scl[t] = sv;
+      f16x2 z = {(_Float16)0.f, (_Float16)0.f};
+#pragma unroll
+      for (int sp = 0; sp < NS; ++sp) {
+        u32x4 w1, w2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {           // register j of the K-step: columns q = 2 sp + (j >> 1), c = 2 (j & 1) + {0, 1}
+          const int q = 2 * sp + (j >> 1), c = 2 * (j & 1);
+          unsigned a, b;
+          pair_split_lo(a, b, vraw[t][q][c], sv);
+          pair_split_hi(a, b, vraw[t][q][c + 1], sv);
+          w1[j] = a;
+          w2[j] = b;
+          pair_nan_fold(z, a);
+        }
+        vb[t][0][sp] = __builtin_bit_cast(f16x8, w1);
+        vb[t][1][sp] = __builtin_bit_cast(f16x8, w2);
+      }
+      nan_row[t] = pair_nan_seen(z);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- the next group's rows: in flight for the whole walk
+    if (RAYEN_WL_AHEAD && next < n_groups && !(RAYEN_WL_ABL & 1)) request(next);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // kap, part, the aux patch and the accumulators live in the SCALED domain (gW sv times the natural value)
+    float kap[NT], part[NT];
+    int acode[NT];   // arg-max bookkeeping in one register: (segment << 20) | row, -1 = none
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { kap[t] = 0.f; part[t] = 0.f; acode[t] = -1; }
+    {
+      f32x16 acc[NT];
+      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      // The A operands of an item are read from LDS one item AHEAD, right behind the previous item's MFMAs: their latency
+      // runs under that item's epilogue (the chunk registers are dead once its MFMAs have read them).  The last item of a
+      // group fetches the first item's chunks for the next group.
+      const int ts_first = items[0].tile_shape;
+      int ts_next = ts_first;
+      u32x4 abuf[NCH];   // [2 sp + 0] leading piece, [2 sp + 1] second piece of K-step sp
+      auto fetch = [&](const int ts_of) {
+        const char* tb = wimg + (size_t)(ts_of & 0xFFFFFF) * (NCH * 1024) + lane * 16;
+        if constexpr (NS == 4) {
+          const int shape = __builtin_amdgcn_readfirstlane((ts_of >> 24) & 3);
+          if (shape != MS_HALF_B) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) abuf[c] = *reinterpret_cast<const u32x4*>(tb + c * 1024);
+          }
+          if (shape != MS_HALF_A) {
+#pragma unroll
+            for (int c = 4; c < 8; ++c) abuf[c] = *reinterpret_cast<const u32x4*>(tb + c * 1024);
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) abuf[c] = *reinterpret_cast<const u32x4*>(tb + c * 1024);
+        }
+      };
+      if (first_walk) {
+        fetch(ts_first);
+        first_walk = false;
+      }
+      for (int it = 0; it < n_items; ++it) {
+        RAYEN_WL_STAMP(it, 0);
+        const int ts = ts_next;      // (known since the previous item: nothing in front of the burst waits for a scalar load)
+        // Two passes over the item's K-steps, by product size: the 2^-11 cross products first, the leading products last
+        // (rayen_mfma_pair.hip).  A full tile multiplies all K-steps; the halves of a shared tile (rayen_tiles.h) K-steps
+        // 0,1 or 2,3, the accumulator starting afresh at the first of them.
+        auto burst = [&](auto S0, auto S1) {
+          constexpr int s0 = decltype(S0)::value, s1 = decltype(S1)::value;
+#pragma unroll
+          for (int sp = s0; sp < s1; ++sp) {
+            const f16x8 a1 = __builtin_bit_cast(f16x8, abuf[2 * sp + 0]), a2 = __builtin_bit_cast(f16x8, abuf[2 * sp + 1]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, vb[t][0][sp], sp == s0 ? zero : acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, vb[t][1][sp], acc[t], 0, 0, 0);
+          }
+#pragma unroll
+          for (int sp = s0; sp < s1; ++sp) {
+            const f16x8 a1 = __builtin_bit_cast(f16x8, abuf[2 * sp + 0]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, vb[t][0][sp], acc[t], 0, 0, 0);
+          }
+        };
+        __builtin_amdgcn_sched_barrier(0);
+#if RAYEN_WL_PRIO == 3
+        __builtin_amdgcn_s_setprio(3);
+#elif RAYEN_WL_PRIO == 4
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        if constexpr (RAYEN_WL_ABL & 32) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[t][g] = __builtin_bit_cast(float, __builtin_bit_cast(u32x4, vb[t][0][g & 3])[g >> 2]);
+        } else if constexpr (NS == 4) {
+          const int shape = __builtin_amdgcn_readfirstlane((ts >> 24) & 3);
+          if (shape == MS_FULL) burst(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+          else if (shape == MS_HALF_A) burst(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+          else burst(std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
+        } else {
+          burst(std::integral_constant<int, 0>{}, std::integral_constant<int, NS>{});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // (the item's record is requested BEHIND its MFMAs: LDS and scalar loads share a counter that hipcc can only wait
+        // out in full, so a request in front of the burst would hold the MFMAs back for the scalar cache's latency)
+#if RAYEN_WL_PRIO == 3
+        __builtin_amdgcn_s_setprio(0);
+#elif RAYEN_WL_PRIO == 4
+        __builtin_amdgcn_s_setprio(3);
+#endif
+        const MItem item = items[it];
+        ts_next = (it + 1 < n_items) ? item.qbegin : ts_first;      // (qbegin: the NEXT item's tile and shape, mfma_pair_build)
+        if constexpr (!(RAYEN_WL_ABL & 32)) fetch(ts_next);
+        RAYEN_WL_STAMP(it, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (RAYEN_WL_ABL & 16) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) kap[t] = fmaxf(kap[t], acc[t][0]);
+          continue;
+        }
+
+        if (item.type == MI_LIN) {
+          const int lin_code = (item.seg << 20) + item.row0 + 4 * hi;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            if (TRACK) {
+#pragma unroll
+              for (int g = 0; g < 16; ++g)
+                if (acc[t][g] > kap[t]) {
+                  kap[t] = acc[t][g];
+                  acode[t] = lin_code + ((g & 3) + 8 * (g >> 2));
+                }
+            } else {
+#pragma unroll
+              for (int g = 0; g < 16; ++g) kap[t] = fmaxf(kap[t], acc[t][g]);
+            }
+          }
+        } else if (item.type == MI_QFAC || item.type == MI_SOC) {
+          // a running sum of squares over the segment's tiles, closed on its last tile (two chains of plain FMAs: the values
+          // of the other schedules' packed FMA, in instructions that issue under a partner's MFMAs)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            float s0 = (item.flags & MF_FIRST) ? 0.f : part[t], s1 = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; g += 2) {
+              s0 = fmaf(acc[t][g], acc[t][g], s0);
+              s1 = fmaf(acc[t][g + 1], acc[t][g + 1], s1);
+            }
+            part[t] = s0 + s1;
+          }
+          if (item.flags & MF_LAST) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              const float total = part[t] + xhalf(part[t]);
+              const float a0 = aux_lds[t][item.aux][col];
+              float kc;
+              if (item.type != MI_SOC) {
+                kc = (a0 + __builtin_amdgcn_sqrtf(fmaxf(total, 0.f))) * item.seg_inv;   // (the segment's own power of two undone)
+              } else {
+                kc = pair_soc_candidate(a0, aux_lds[t][item.aux + 1][col], total, w_inv * item.seg_inv, v_inv[t], item.f0,
+                                        item.f1, v_scl[t], w_scale);
+              }
+              if (kc > kap[t]) { kap[t] = kc; acode[t] = item.seg << 20; }
+            }
+          }
+        } else if (item.type == MI_AUX) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < (AUXR == 8 ? 4 : 16); ++g) aux_lds[t][(g & 3) + 8 * (g >> 2) + 4 * hi][col] = acc[t][g];
+          __builtin_amdgcn_wave_barrier();
+        } else if (item.type == MI_PACK) {
+          const MPack pk = packs[item.aux];
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            const int slot = hi ? pk.aux[a][1] : pk.aux[a][0];
+            const int sid = hi ? pk.seg[a][1] : pk.seg[a][0];
+            const bool pair = (item.row0 >> a) & 1;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              float qs = acc[t][4 * a] * acc[t][4 * a];
+#pragma unroll
+              for (int c = 1; c < 4; ++c) qs = fmaf(acc[t][4 * a + c], acc[t][4 * a + c], qs);
+              if (pair) qs += xhalf(qs);
+              const float kc = (aux_lds[t][slot & (AUXR - 1)][col] + __builtin_amdgcn_sqrtf(qs)) * (hi ? pk.inv[a][1] : pk.inv[a][0]);
+              if (sid >= 0 && kc > kap[t]) { kap[t] = kc; acode[t] = sid << 20; }
+            }
+          }
+        }
+        RAYEN_WL_STAMP(it, 2);
+      }
+    }
+    RAYEN_WL_STAMP(38, 1);
+
+    // ---- kappa is final
+    float knat[NT], scale[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float other = xhalf(kap[t]);
+      if (TRACK) {
+        const int ocode = __shfl_xor(acode[t], 32);
+        if (other > kap[t] || (other == kap[t] && hi == 1)) acode[t] = ocode;
+      }
+      kap[t] = fmaxf(kap[t], other);
+      knat[t] = (kap[t] * w_inv) * v_inv[t];
+      scale[t] = v_inv[t] * (1.0f / fmaxf(1.0f, knat[t]));   // (the rebuilt direction carries sv only)
+    }
+    if (hi == 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (!live[t]) continue;
+        const int64_t s = s_base + t * 32 + col;
+        if (kappa_out) kappa_out[s] = knat[t];
+        if (TRACK) { active_out[2 * s] = acode[t] >> 20; active_out[2 * s + 1] = acode[t] < 0 ? 0 : (acode[t] & 0xFFFFF); }
+      }
+    }
+
+    // the next rows have had the walk to arrive: first use (see half_max; unconditional -- on every path into the next group
+    // the loads have been waited for)
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (RAYEN_WL_AHEAD) half_max();
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- y = y0 + v / max(1, kappa): v rebuilt from its pieces (22 bits of it; scaled by sv, undone by `scale`).  A lane
+    // holds pieces 2 q + hi of ITS row: written to memory as they are, every store instruction would touch 32 lines with 32
+    // bytes each (measured: non-temporal 331 us, plain 197 us at B = 1 048 576 against 157 without the stores, and the plain
+    // ones leave the L2 dirty for the end of the kernel).  So one 128-byte line of each of the tile's 32 rows at a time goes
+    // through the wave's 4 KiB of LDS (slot = piece ^ (row & 7): the eight lanes of a write or read group hit eight different
+    // 16-byte bank groups) and leaves as whole lines: lane L stores slot L & 7 of row 8 i + (L >> 3).
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float one = 1.0f;
+      asm volatile("" : "+v"(one));
+#pragma unroll
+      for (int h = 0; h < NKK; ++h) {          // line h of the tile's rows
+        f32x4 o[4];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          const int q = 4 * h + qq;
+          const f32x4 o4 = *reinterpret_cast<const f32x4*>(&y0_lds[8 * q + 4 * hi]);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int i = (q & 1) * 4 + c;
+            const unsigned w1 = __builtin_bit_cast(u32x4, vb[t][0][q >> 1])[i >> 1], w2 = __builtin_bit_cast(u32x4, vb[t][1][q >> 1])[i >> 1];
+            const float val = (i & 1) ? pair_rebuild_hi(w1, w2, one) : pair_rebuild_lo(w1, w2, one);     // fl32(p1 + p2)
+            o[qq][c] = fmaf(val, scale[t], o4[c]);
+          }
+        }
+#pragma unroll
+        for (int part = 0; part < 32 / SR; ++part) {      // rows [SR part, SR part + SR) of the tile
+          if (SR == 32 || (col / SR) == part) {
+            char* slot = stage + (col % SR) * 128;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) *reinterpret_cast<f32x4*>(slot + (((2 * qq + hi) ^ (col & 7)) * 16)) = o[qq];
+          }
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int i = 0; i < SR / 8; ++i) {
+            const int r = 8 * i + (lane >> 3);
+            const f32x4 x = *reinterpret_cast<const f32x4*>(stage + r * 128 + (lane & 7) * 16);
+            const int64_t srow = s_base + t * 32 + part * SR + r;
+            float* dst = y + srow * ldy + 32 * h + 4 * ((lane & 7) ^ (r & 7));
+            if constexpr (RAYEN_WL_ABL & 2) { if (x[0] == 123.456f) dst[0] = x[1]; }
+            else if (srow < B) {
+              if constexpr (RAYEN_WL_ABL & 8) *reinterpret_cast<f32x4*>(dst) = x;
+              else __builtin_nontemporal_store(x, reinterpret_cast<f32x4*>(dst));
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+      bad |= live[t] && nan_row[t];      // (the row's own components: y is NaN exactly when one of them is NaN or Inf)
+    }
+    RAYEN_WL_STAMP(38, 2);
+    grp = next;
+  }  // persistent loop over sample groups
+  if (nan_flag && bad) atomicOr(nan_flag, 1);
+#ifdef RAYEN_WL_CLOCK
+  if (probe) {
+    wl_clock_buf[(blockIdx.x >> 4) * 4 + 2] = __builtin_amdgcn_s_memtime();
+    wl_clock_buf[(blockIdx.x >> 4) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------
+static int pair_wl_lds_bytes(const PairImage* img) {
+  return img->n_tiles * (img->nkk * 4 * 1024) + kWlWaves * wl_region_bytes(img->nkk, kWlNT) + img->nkk * 128 + 16;
+}
+
+bool mfma_pair_wl_serves(const RayenPack* p, const PairImage* img, const float* v, int64_t B, int64_t ldv,
+                         const float* y, int64_t ldy) {
+  if (img == nullptr || img->nkk < 1 || img->nkk > 2 || img->n_tiles <= 0 || !img->wl_ready) return false;
+  if (!img->identity || p->n != img->nkk * 32 || p->k != p->n) return false;
+  if ((ldv % 4) != 0 || (ldy % 4) != 0) return false;
+  if ((reinterpret_cast<uintptr_t>(v) & 15) != 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0) return false;
+  if (img->nkk == 2 && img->aux_rows > WlGeom<2>::AUXR) return false;
+  if (pair_wl_lds_bytes(img) > 160 * 1024) return false;
+  // one workgroup per CU copies the image first (3 us): measured against the other schedules on config 3 (gpurun_out/r06za) it
+  // wins from three quarters of a group per resident wave on -- B = 98 304: 21.8 against 28.4 us, 196 608: 40.7 / 48.4,
+  // 262 144: 49.3 / 53.1, 524 288: 92.7 / 100 -- ties at half a group (65 536: 20.2 / 20.7) and loses below (32 768: 20.1 / 12.9)
+  const int64_t n_groups = (B + kWlNT * 32 - 1) / (kWlNT * 32);
+  return 4 * n_groups >= 3 * (int64_t)(img->n_simd / 4) * kWlWaves;
+}
+
+// called by rayen_pack_create (the only place that may touch function attributes)
+int mfma_pair_wl_prepare(const RayenPack* p, PairImage* img) {
+  (void)p;
+  if (img == nullptr || img->nkk < 1 || img->nkk > 2 || img->n_tiles <= 0 || !img->identity) return RAYEN_OK;
+  const int lds = pair_wl_lds_bytes(img);
+  if (lds > 160 * 1024) return RAYEN_OK;
+  static std::mutex mu;
+  static int promised = 0;      // (the attribute belongs to the kernel instance: every pack asks for the running maximum)
+  std::lock_guard<std::mutex> hold(mu);
+  promised = std::max(promised, lds);
+  const int ask = promised;
+  bool ok = true;
+  auto want = [&](auto kern) {
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ask) == hipSuccess;
+  };
+  want(mfma_pair_wl_kernel<1, false, kWlNT, kWlWaves>); want(mfma_pair_wl_kernel<1, true, kWlNT, kWlWaves>);
+  want(mfma_pair_wl_kernel<2, false, kWlNT, kWlWaves>); want(mfma_pair_wl_kernel<2, true, kWlNT, kWlWaves>);
+  if (!ok) return RAYEN_E_LAUNCH;
+  img->wl_ready = true;
+  return RAYEN_OK;
+}
+
+int mfma_pair_wl_forward(const RayenPack* p, const PairImage* img, const float* v, int64_t B, int64_t ldv,
+                         float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
+                         hipStream_t stream) {
+  if (B == 0) return RAYEN_OK;
+  if (!mfma_pair_wl_serves(p, img, v, B, ldv, y, ldy)) return RAYEN_E_UNSUPPORTED;
+  const int64_t n_groups = (B + kWlNT * 32 - 1) / (kWlNT * 32);
+  const int64_t cus = launch_simds(img->n_simd) / 4;
+  const unsigned grid = (unsigned)std::min<int64_t>(cus, (n_groups + kWlWaves - 1) / kWlWaves);   // one workgroup per CU
+  const int lds = pair_wl_lds_bytes(img);
+  auto go = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWlWaves * 64), lds, stream, static_cast<const f16x8*>(img->Wh), img->items,
+                       img->n_items, img->packs, img->y0, img->n_tiles, v, B, ldv, y, ldy, kappa, active, nan_flag,
+                       img->w_scale, img->w_inv);
+  };
+  if (img->nkk == 1) {
+    if (active != nullptr) go(mfma_pair_wl_kernel<1, true, kWlNT, kWlWaves>);
+    else go(mfma_pair_wl_kernel<1, false, kWlNT, kWlWaves>);
+  } else {
+    if (active != nullptr) go(mfma_pair_wl_kernel<2, true, kWlNT, kWlWaves>);
+    else go(mfma_pair_wl_kernel<2, false, kWlNT, kWlWaves>);
+  }
+  return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
+}
+
+}  // namespace rayen

@@ -1,0 +1,8 @@
+out=gpurun_out/r06v; mkdir -p $out
+V=$PWD/scripts/ubench/variants
+export RAYEN_HIP_LIBRARY=$V/librayen_mfma_pair_wl_clock.so
+timeout 200 python scripts/ubench/wl_clock.py --schedule 3 --batches 1048576 2>&1 | grep -v amdgpu.ids >> $out/clock.txt
+timeout 200 python scripts/ubench/wl_clock.py --schedule 3 --batches 524288 --reserve 128 2>&1 | grep -v amdgpu.ids >> $out/clock.txt
+timeout 200 python scripts/ubench/wl_clock.py --schedule 3 --batches 262144 --reserve 192 2>&1 | grep -v amdgpu.ids >> $out/clock.txt
+timeout 200 python scripts/ubench/wl_clock.py --schedule 3 --batches 131072 --reserve 224 2>&1 | grep -v amdgpu.ids >> $out/clock.txt
+cat $out/clock.txt

@@ -1,0 +1,7 @@
+set -x
+out=gpurun_out/r06i; mkdir -p $out
+timeout 300 python scripts/ubench/wl_check.py --batches 262144,1048576 > $out/wl_check.txt 2>&1; cat $out/wl_check.txt
+for abl in 1 2 3 16 32 48; do
+  RAYEN_HIP_LIBRARY=$PWD/scripts/ubench/variants/librayen_mfma_pair_wl_abl$abl.so timeout 200 python scripts/ubench/io_bench.py --schedule 3 --batches 262144,1048576 2>&1 | grep -v amdgpu.ids | sed "s/^/abl$abl: /" >> $out/abl.txt
+done
+cat $out/abl.txt

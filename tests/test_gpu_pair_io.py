@@ -45,6 +45,15 @@ def _run(dp, v, want_active):
     return y, kappa, active, _lib.load().rayen_last_forward_kernel()
 
 
+@pytest.fixture(autouse=True)
+def _schedule_of_rounds_3_to_5():
+    """This file is about schedule 1 (the default until round 6: trickled rows / W-stationary for mid-size batches); since
+    round 6 the process default is 3 (W in LDS, tests/test_gpu_pair_wl.py), which would take the larger batches here."""
+    prev = _lib.load().rayen_pair_schedule(1)
+    yield
+    _lib.load().rayen_pair_schedule(prev)
+
+
 SCHEDULES = {"rows": (1, _lib.KERNEL_PAIR_IO)}
 
 

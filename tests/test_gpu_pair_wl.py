@@ -1,0 +1,159 @@
+"""The W-in-LDS schedule of the f16-pair forward (rayen_mfma_pair_wl.hip, round 6: the image of W copied into LDS once per
+workgroup, a lane's rows straight from / to memory, groups dealt to the waves of a workgroup on demand).  Wherever it serves
+a call its outputs must equal the plain pair kernel's BIT FOR BIT (y, kappa, arg-max record) -- whatever the batch (ragged
+last groups, fewer groups than waves, many groups per wave), the leading dimensions, NaN rows -- and meet the reference's
+bar against the oracle (rayen/constraint_module.py:351-474).  The order in which the waves of a workgroup claim groups
+varies from launch to launch: the results must not.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_err_rows, csd_from_cs
+from oracle import rayen_oracle as oracle
+from rayen_amd import _lib, ops, workloads
+from rayen_amd.constraint_module import ConstraintModule
+
+pytestmark = pytest.mark.gpu
+
+
+def _pack(raw):
+    cs = workloads.build_constraints(raw)
+    layer = ConstraintModule(cs, method="RAYEN", create_map=False).to("cuda")
+    dp, _ = layer.device_pack(torch.device("cuda", torch.cuda.current_device()))
+    return cs, layer, dp
+
+
+def _sets():
+    return {
+        "c3": workloads.make_raw("c3", seed=7),                                                   # n = 64: shared tiles, 8 aux rows
+        "n32": workloads.random_lin_quad_soc(k=32, m=300, n_quad=3, n_soc=2, seed=17),            # n = 32
+        "n32_many_aux": workloads.random_lin_quad_soc(k=32, m=200, n_quad=12, n_soc=3, seed=18),  # 18 aux rows
+    }
+
+
+def _misaligned_copy(v):
+    B, n = v.shape
+    buf = torch.empty(B * n + 4, dtype=v.dtype, device=v.device)
+    w = buf[1:1 + B * n].view(B, n)
+    w.copy_(v)
+    assert w.data_ptr() % 16 != 0
+    return w
+
+
+def _run(dp, v, want_active):
+    y, kappa, active = ops.project_raw(v, dp, want_active=want_active)
+    return y, kappa, active, _lib.load().rayen_last_forward_kernel()
+
+
+@pytest.fixture
+def lds_schedule():
+    prev = _lib.load().rayen_pair_schedule(3)
+    yield _lib.KERNEL_PAIR_WL
+    _lib.load().rayen_pair_schedule(prev)
+
+
+def test_the_w_in_lds_schedule_is_the_default():
+    assert _lib.load().rayen_pair_schedule(-1) == 3
+
+
+# a group = 32 rows; 256 CUs x 16 waves: B = 131072 is one group per wave; the schedule serves from 98304 on
+@pytest.mark.parametrize("B", [98304, 98304 + 17, 131072, 131072 + 32 * 5 + 11, 262144, 262144 - 1, 393216 + 29, 1048576 + 3])
+@pytest.mark.parametrize("name", ["c3", "n32", "n32_many_aux"])
+@pytest.mark.parametrize("want_active", [False, True])
+def test_w_in_lds_equals_the_plain_pair_kernel_bit_for_bit(name, B, want_active, lds_schedule):
+    if name != "c3" and B > 300000:
+        pytest.skip("the round structures are covered on c3")
+    cs, layer, dp = _pack(_sets()[name])
+    if dp.info().mfma_f32 != 3:
+        pytest.skip("the f16-pair family does not serve this pack")
+    gen = torch.Generator(device="cuda").manual_seed(B)
+    v = torch.empty(B, cs.n, device="cuda").uniform_(-1.5, 1.5, generator=gen)
+    v[B // 3] = 0.0
+    v[B // 2] *= 1e-3
+    v[B - 1] *= 1e4
+    y1, k1, a1, fam1 = _run(dp, v, want_active)
+    assert fam1 == lds_schedule, "which kernel served the aligned call"
+    y2, k2, a2, fam2 = _run(dp, _misaligned_copy(v), want_active)
+    assert fam2 == _lib.KERNEL_PAIR
+    assert torch.equal(y1, y2)
+    assert torch.equal(k1, k2)
+    if want_active:
+        assert torch.equal(a1, a2)
+    take = torch.cat([torch.arange(0, min(B, 700)), torch.arange(max(B - 700, 0), B)]).unique()
+    x = v[take.cuda()].cpu().unsqueeze(2)
+    y_ref = oracle.forward(oracle.precompute(csd_from_cs(cs), torch.float32), x).numpy()[:, :, 0]
+    assert np.max(rel_err_rows(y1[take.cuda()].cpu().numpy(), y_ref)) <= 1e-5
+
+
+def test_below_its_threshold_the_other_schedules_serve(lds_schedule):
+    cs, layer, dp = _pack(_sets()["c3"])
+    if dp.info().mfma_f32 != 3:
+        pytest.skip("the f16-pair family does not serve this pack")
+    for B, fams in ((4096, (_lib.KERNEL_PAIR,)), (65536, (_lib.KERNEL_PAIR_WS, _lib.KERNEL_PAIR))):
+        v = torch.empty(B, cs.n, device="cuda").uniform_(-1.5, 1.5)
+        assert _run(dp, v, False)[3] in fams, B
+
+
+@pytest.mark.parametrize("name", ["c3", "n32"])
+def test_w_in_lds_with_padded_leading_dimensions_and_nan_rows(name, lds_schedule):
+    """Rows at a stride (ldv, ldy > n, multiples of 4 floats); a NaN / Inf row raises the flag and touches no other row; rows
+    beyond the batch are never written."""
+    cs, layer, dp = _pack(_sets()[name])
+    if dp.info().mfma_f32 != 3:
+        pytest.skip("the f16-pair family does not serve this pack")
+    B, n = 262144 + 77, cs.n
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    wide = torch.empty(B, n + 8, device="cuda").uniform_(-1.5, 1.5, generator=gen)
+    v = wide[:, :n]
+    out = torch.full((B + 40, n + 12), -7.0, device="cuda")
+    y_ref, k_ref, _ = ops.project_raw(_misaligned_copy(v.contiguous()), dp, want_active=False)
+    assert _lib.load().rayen_last_forward_kernel() == _lib.KERNEL_PAIR
+    y, kappa, _ = ops.project_raw(v, dp, want_active=False, out=out[:B])
+    assert _lib.load().rayen_last_forward_kernel() == lds_schedule
+    assert torch.equal(out[:B, :n], y_ref) and torch.equal(kappa, k_ref)
+    assert bool((out[:, n:] == -7.0).all())            # nothing written beyond the k columns ...
+    assert bool((out[B:] == -7.0).all())               # ... nor beyond the batch (the last group is ragged)
+    dp.nan_flag.zero_()
+    v2 = v.contiguous().clone()
+    v2[B - 5, 3] = float("nan")
+    v2[70000, 0] = float("inf")
+    y2, _, _ = ops.project_raw(v2, dp, want_active=False)
+    assert _lib.load().rayen_last_forward_kernel() == lds_schedule
+    assert int(dp.nan_flag.item()) == 1
+    dp.nan_flag.zero_()
+    keep = torch.ones(B, dtype=torch.bool, device="cuda")
+    keep[B - 5] = False
+    keep[70000] = False
+    assert torch.equal(y2[keep], y_ref[keep])
+    assert bool(torch.isnan(y2[B - 5]).any()) and bool(torch.isnan(y2[70000]).any())
+
+
+def test_w_in_lds_is_the_same_on_every_launch(lds_schedule):
+    """Which wave of a workgroup claims which group differs from launch to launch (a counter in LDS); a group's results do
+    not depend on it.  200 launches into fresh buffers, every byte compared."""
+    cs, layer, dp = _pack(_sets()["c3"])
+    if dp.info().mfma_f32 != 3:
+        pytest.skip("the f16-pair family does not serve this pack")
+    B = 262144 + 4096 + 13
+    v = torch.empty(B, cs.n, device="cuda").uniform_(-2.0, 2.0, generator=torch.Generator(device="cuda").manual_seed(11))
+    y0, k0, a0, fam = _run(dp, v, True)
+    assert fam == lds_schedule
+    for _ in range(200):
+        out = torch.full((B, cs.k), float("nan"), device="cuda")
+        y, k, a = ops.project_raw(v, dp, want_active=True, out=out)
+        assert torch.equal(y, y0) and torch.equal(k, k0) and torch.equal(a, a0)
+
+
+def test_module_forward_takes_the_w_in_lds_schedule_on_the_headline_shape():
+    """BASELINE.json's headline call (config 3, B = 262 144, fp32, the module's own forward) runs on this kernel by default and
+    meets the fp32 bar against the fp64 oracle on a slice."""
+    raw = workloads.make_raw("c3", seed=0)
+    cs = workloads.build_constraints(raw)
+    layer = ConstraintModule(cs, method="RAYEN", create_map=False).to("cuda")
+    x = torch.empty(262144, cs.n, 1, device="cuda").uniform_(-1, 1, generator=torch.Generator(device="cuda").manual_seed(5))
+    with torch.no_grad():
+        y = layer(x)
+    assert _lib.load().rayen_last_forward_kernel() == _lib.KERNEL_PAIR_WL
+    take = torch.arange(0, 262144, 257)
+    y_ref = oracle.forward(oracle.precompute(csd_from_cs(cs), torch.float64), x[take.cuda()].double().cpu()).numpy()[:, :, 0]
+    assert np.max(rel_err_rows(y[take.cuda(), :, 0].cpu().numpy(), y_ref)) <= 1e-5

@@ -16,6 +16,15 @@ from rayen_amd.constraint_module import ConstraintModule
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _schedule_of_rounds_3_to_5():
+    """This file is about schedule 1 (the default until round 6: trickled rows / W-stationary for mid-size batches); since
+    round 6 the process default is 3 (W in LDS, tests/test_gpu_pair_wl.py), which would take the larger batches here."""
+    prev = _lib.load().rayen_pair_schedule(1)
+    yield
+    _lib.load().rayen_pair_schedule(prev)
+
+
 def _pack(raw):
     cs = workloads.build_constraints(raw)
     layer = ConstraintModule(cs, method="RAYEN", create_map=False).to("cuda")
