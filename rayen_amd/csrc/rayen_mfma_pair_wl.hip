@@ -49,9 +49,6 @@ constexpr int kWlNT = RAYEN_WL_NT;            // sample tiles (of 32) per wave a
 #ifndef RAYEN_WL_ABL
 #define RAYEN_WL_ABL 0
 #endif
-#ifndef RAYEN_WL_PRIO
-#define RAYEN_WL_PRIO 0
-#endif
 template <int NKK> struct WlGeom { static constexpr int AUXR = NKK == 2 ? 8 : 32; };
 // a wave's own LDS: the aux patch during the walk ([sample tile][aux row][sample]), then the 4 KiB through which its rows of
 // y leave as whole 128-byte lines (32 rows x one line)
@@ -120,20 +117,6 @@ __global__ __launch_bounds__(NW * 64, 1) void mfma_pair_wl_kernel(
   int64_t grp = (int64_t)blockIdx.x + (int64_t)wave * grp_stride;
   bool bad = false;
   bool first_walk = true;
-  // developer A/B (-DRAYEN_WL_PRIO=n): 1 = a STATIC issue priority per wave of a SIMD (waves w, w + 4, w + 8, w + 12 share one):
-  // a burst of the higher wave is never interleaved with a lower one's, so the waves of a SIMD cannot fall into step (all
-  // in their bursts, then all in their epilogues); the shares they end up with are evened out by the group counter
-#if RAYEN_WL_PRIO == 1
-  if ((wave >> 2) == 0) __builtin_amdgcn_s_setprio(0);
-  else if ((wave >> 2) == 1) __builtin_amdgcn_s_setprio(1);
-  else if ((wave >> 2) == 2) __builtin_amdgcn_s_setprio(2);
-  else __builtin_amdgcn_s_setprio(3);
-#elif RAYEN_WL_PRIO == 2
-  if ((wave >> 2) == 0) __builtin_amdgcn_s_setprio(3);
-  else if ((wave >> 2) == 1) __builtin_amdgcn_s_setprio(2);
-  else if ((wave >> 2) == 2) __builtin_amdgcn_s_setprio(1);
-  else __builtin_amdgcn_s_setprio(0);
-#endif
 #ifdef RAYEN_WL_STAMPS
   int stamp_round = 0;
   bool stamp_on = false;
@@ -316,11 +299,6 @@ __global__ __launch_bounds__(NW * 64, 1) void mfma_pair_wl_kernel(
           }
         };
         __builtin_amdgcn_sched_barrier(0);
-#if RAYEN_WL_PRIO == 3
-        __builtin_amdgcn_s_setprio(3);
-#elif RAYEN_WL_PRIO == 4
-        __builtin_amdgcn_s_setprio(0);
-#endif
         if constexpr (RAYEN_WL_ABL & 32) {
 #pragma unroll
           for (int t = 0; t < NT; ++t)
@@ -337,11 +315,6 @@ __global__ __launch_bounds__(NW * 64, 1) void mfma_pair_wl_kernel(
         __builtin_amdgcn_sched_barrier(0);
         // (the item's record is requested BEHIND its MFMAs: LDS and scalar loads share a counter that hipcc can only wait
         // out in full, so a request in front of the burst would hold the MFMAs back for the scalar cache's latency)
-#if RAYEN_WL_PRIO == 3
-        __builtin_amdgcn_s_setprio(0);
-#elif RAYEN_WL_PRIO == 4
-        __builtin_amdgcn_s_setprio(3);
-#endif
         const MItem item = items[it];
         ts_next = (it + 1 < n_items) ? item.qbegin : ts_first;      // (qbegin: the NEXT item's tile and shape, mfma_pair_build)
         if constexpr (!(RAYEN_WL_ABL & 32)) fetch(ts_next);
