@@ -70,6 +70,9 @@ def parse(argv=None):
     ap.add_argument("--no-gather", action="store_true", help="N>1: time the projection alone (no all-gather of y)")
     ap.add_argument("--gather", action="store_true",
                     help="with --force-dist on one GPU: run the all-gather step anyway (one-rank RCCL group)")
+    ap.add_argument("--gather-impl", choices=["rccl", "peer"], default="rccl",
+                    help="the all-gather of y: RCCL's collective, or direct copies into the peers' buffers (hipMemcpyPeerAsync / SDMA, "
+                         "no compute units; rayen_amd/dist.py) -- an A/B for multi-GPU runs")
     ap.add_argument("--chunks", type=int, default=2, help="row blocks per rank whose all-gathers overlap the next block's projection")
     ap.add_argument("--reserve-cus", type=int, default=0,
                     help="compute units the projection's persistent grid leaves to RCCL's kernels during the gather step")
@@ -146,13 +149,14 @@ def cpu_baseline(raw, cs, B, dtype, budget_s, rng=1.0):
 
 
 def make_step(project_into, sizes, k, dtype, device, gather, chunks, group=None, gather_alone=False,
-              reserve_cus=0, set_reserve=None):
+              reserve_cus=0, set_reserve=None, gather_impl="rccl", peer_buffers=None):
     """The multi-rank step ``bench.py`` times: ``rayen_amd.dist.ShardedStep`` around ``project_into(x_rows,
     out_rows)`` -- on the GPU the C-ABI projection writing straight into the gather's send buffer; in
     ``tests/test_dist_gloo.py`` a CPU stand-in, so the code the 8-GPU driver run executes is the code tested."""
     from rayen_amd.dist import ShardedStep
     return ShardedStep(project_into, sizes, k, dtype, device, chunks=chunks, gather=gather, group=group,
-                       gather_alone=gather_alone, reserve_cus=reserve_cus, set_reserve=set_reserve)
+                       gather_alone=gather_alone, reserve_cus=reserve_cus, set_reserve=set_reserve,
+                       gather_impl=gather_impl, peer_buffers=peer_buffers)
 
 
 def local_sizes(config_batch, per_gpu_batch, world, scaling):
@@ -369,7 +373,8 @@ def main(argv=None):
 
     def gather_step(project):
         return make_step(project, sizes, cs.k, dtype, device, gather=True, chunks=args.chunks, gather_alone=True,
-                         reserve_cus=args.reserve_cus, set_reserve=set_reserve)
+                         reserve_cus=args.reserve_cus, set_reserve=set_reserve,
+                         gather_impl=args.gather_impl if on_gpu else "rccl")
 
     sharded = gather_step(project_into) if gather else None
 
@@ -620,7 +625,8 @@ def main(argv=None):
                 ms_b = min(timed_loop(lambda t_: ops.backward_raw(t_, k_rec, a_rec, g_in, dp), xv, args.steps, args.warmup, False)[1]
                            for _ in range(3))
             bwd_names = {0: "lane-per-sample", 1: "exact-fp32 MFMA (dense forms)", 2: "exact-fp32 MFMA (general shapes)",
-                         3: "f16 pairs (packed low-rank forms)", 4: "four lanes per sample (LMI)", 5: "one wave per sample (LMI)"}
+                         3: "f16 pairs (packed low-rank forms)", 4: "four lanes per sample (LMI)", 5: "one wave per sample (LMI)",
+                         7: "f16 pairs, dense forms resident in LDS, one launch (round 6)"}
             out["training_step"] = {
                 "forward_with_record_ms": ms_ft, "backward_ms": ms_b, "unit": "ms per call, eager, HIP events",
                 "backward_kernel": bwd_names.get(int(info.bwd_f32), str(info.bwd_f32)) if dtype == torch.float32 else "fp64 kernels",

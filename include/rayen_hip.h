@@ -126,7 +126,9 @@ typedef struct RayenPackInfo {
   int32_t bwd_f32;              /* fp32 backward: 0 lane-per-sample kernel | 1 fp32 MFMA kernel (NA_E = I, dense forms) | 2 fp32
                                    MFMA kernel, general shapes | 3 f16-pair kernel (packed low-rank quadratics, n <= 32; accepted
                                    by a creation-time measurement like the forward's) | 4 the four-lanes-per-sample LMI kernel | 5 the
-                                   wave-per-sample LMI kernel (matrices the lane kernels cannot hold) */
+                                   wave-per-sample LMI kernel (matrices the lane kernels cannot hold) | 7 (round 6) f16-pair kernel for
+                                   dense forms at n = k = 64, forms resident in LDS, one launch, no workspace (accepted by the same
+                                   measurement; batches below a group per resident wave and RAYEN_old stay on 1) */
   double fp32_check_split;      /* worst row error (relative to the row's size) against fp64 on the creation-time probe */
   double fp32_check_exact;      /* directions: bf16-triple kernel, exact-fp32 kernel, */
   double fp32_check_pair;       /* f16-pair kernel; -1 = not measured */

@@ -12,7 +12,7 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 INCLUDE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
-SOURCES = ["rayen_abi.hip", "rayen_generic.hip", "rayen_mfma.hip", "rayen_mfma_split.hip", "rayen_mfma_pair.hip", "rayen_mfma_pair_io.hip", "rayen_mfma_pair_wl.hip", "rayen_mfma_pair_ws8.hip", "rayen_wide.hip", "rayen_mfma_mapped.hip", "rayen_mfma_bwd.hip", "rayen_mfma_bwdg.hip", "rayen_mfma_bwdp.hip", "rayen_lmi_wave32.hip", "rayen_lmi_wave64.hip", "rayen_lmi_block.hip", "rayen_mfma_bwdg64.hip", "rayen_mfma_bwd64.hip", "rayen_mfma_f64.hip",
+SOURCES = ["rayen_abi.hip", "rayen_generic.hip", "rayen_mfma.hip", "rayen_mfma_split.hip", "rayen_mfma_pair.hip", "rayen_mfma_pair_io.hip", "rayen_mfma_pair_wl.hip", "rayen_mfma_pair_ws8.hip", "rayen_wide.hip", "rayen_mfma_mapped.hip", "rayen_mfma_bwd.hip", "rayen_mfma_bwdg.hip", "rayen_mfma_bwdp.hip", "rayen_mfma_bwdd.hip", "rayen_lmi_wave32.hip", "rayen_lmi_wave64.hip", "rayen_lmi_block.hip", "rayen_mfma_bwdg64.hip", "rayen_mfma_bwd64.hip", "rayen_mfma_f64.hip",
            "rayen_lmi_quad32.hip", "rayen_lmi_quad64.hip"]
 # On gfx950 a packed-fp32 instruction whose low result reads the HIGH half of its second source (op_sel:[0,1,..]: how hipcc's
 # SLP vectoriser broadcasts the second element of a register pair) reads that operand as 0 in lanes 48-63 now and then while
@@ -26,7 +26,8 @@ COMMON_FLAGS = []     # extra compiler flags of every translation unit
 EXTRA_FLAGS = {"rayen_generic.hip": ["-fno-slp-vectorize"],          # per-source compiler flags
                "rayen_mfma_pair_io.hip": ["-fno-slp-vectorize"],
                # (packed fp32 instructions do not issue while another wave's MFMAs execute: scripts/ubench/mfma_coissue.hip)
-               "rayen_mfma_pair_wl.hip": ["-fno-slp-vectorize"]}
+               "rayen_mfma_pair_wl.hip": ["-fno-slp-vectorize"],
+               "rayen_mfma_bwdd.hip": ["-fno-slp-vectorize"]}
 LIBRARY = os.environ.get("RAYEN_HIP_LIBRARY") or os.path.join(CSRC, "librayen_hip.so")
 
 

@@ -175,6 +175,10 @@ int build_images(RayenPack* p, int prepare) {
     if (p->w32 != nullptr && (rc = lmi_block_prepare_f32(p->w32))) return rc;
     if (bwd) {
       if ((rc = build_one(p, mfma_bwd_eligible(p), &p->mb32, mfma_bwd_build))) return rc;
+      // (f16 pairs in the backward follow the forward's switch: fp32_mode 0 measured, 3 unmeasured, 1 / 2 / 4 never)
+      if (p->mb32 != nullptr && (p->fp32_mode == 0 || p->fp32_mode == 3) &&
+          (rc = build_one(p, mfma_bwdd_eligible(p), &p->mbd32, mfma_bwdd_build)))
+        return rc;
       if (p->mb32 == nullptr && (rc = build_one(p, mfma_bwdg_eligible(p), &p->mbg32, mfma_bwdg_build))) return rc;
       // (f16 pairs in the backward follow the forward's switch: fp32_mode 0 measured, 3 unmeasured, 1 / 2 / 4 never)
       if (p->mbg32 != nullptr && (p->fp32_mode == 0 || p->fp32_mode == 3) &&
@@ -241,6 +245,12 @@ int project_generic(const RayenPack* p, const T* v, int64_t B, int64_t ldv, T* y
                             static_cast<hipStream_t>(stream));
 }
 
+// developer A/B: RAYEN_BWD_DENSE_PAIRS=0 keeps config-3-like packs on the bucketed exact-fp32 backward (rayen_mfma_bwd.hip)
+static bool dense_pairs_backward_enabled() {
+  static const bool on = [] { const char* e = std::getenv("RAYEN_BWD_DENSE_PAIRS"); return !(e != nullptr && e[0] == '0'); }();
+  return on;
+}
+
 template <typename T>
 int project_bwd(const RayenPack* p, const T* v, int64_t B, int64_t ldv, const T* kappa,
                 const int32_t* active, const T* grad_y, int64_t ldg, T* grad_v, int64_t ldgv, void* stream,
@@ -257,6 +267,10 @@ int project_bwd(const RayenPack* p, const T* v, int64_t B, int64_t ldv, const T*
                                      static_cast<hipStream_t>(stream));
     }
     if (!force_generic) {
+      if (p->mbd32 != nullptr && p->mbd32_state == 1 && !old_mode && dense_pairs_backward_enabled() &&
+          mfma_bwdd_serves(p, p->mbd32, v, B, ldv, grad_y, ldg, grad_v, ldgv))
+        return mfma_bwdd_backward(p, p->mbd32, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv,
+                                  static_cast<hipStream_t>(stream));
       if (p->mb32 != nullptr)
         return mfma_backward(p, p->mb32, v, B, ldv, kappa, active, grad_y, ldg, grad_v, ldgv, old_mode, workspace,
                              workspace_bytes, static_cast<hipStream_t>(stream));
@@ -580,8 +594,12 @@ static int fp32_selfcheck(RayenPack* p) {
 // (the fp64 forward's), so they differentiate the same branch -- and it may serve the pack if its worst gradient row is
 // within 4e-6 of the row's size or within 1.5 x the exact-fp32 kernel's own error.
 static int bwd32_selfcheck(RayenPack* p) {
-  if (p->mbp32 == nullptr) return RAYEN_OK;
-  if (p->fp32_mode == 3 || p->mbg32 == nullptr) { p->mbp32_state = 1; return RAYEN_OK; }
+  // (two f16-pair backwards exist, never for the same pack: packed low-rank quadratics at n <= 32 -- mbp32, measured next to
+  // mbg32 -- and dense forms at n = k = 64 -- mbd32, measured next to mb32)
+  const bool dense = p->mbd32 != nullptr;
+  if (p->mbp32 == nullptr && !dense) return RAYEN_OK;
+  if (dense && p->fp32_mode == 3) { p->mbd32_state = 1; return RAYEN_OK; }
+  if (!dense && (p->fp32_mode == 3 || p->mbg32 == nullptr)) { p->mbp32_state = 1; return RAYEN_OK; }
   const int n = p->n, k = p->k;
   uint32_t state = 0x2545F491u;
   auto uniform = [&state]() {
@@ -634,9 +652,11 @@ static int bwd32_selfcheck(RayenPack* p) {
       ok = hipMemcpyAsync(dk, kap32.data(), (size_t)B0 * sizeof(float), hipMemcpyHostToDevice, st) == hipSuccess;
     }
     if (ok) {
-      rc = mfma_bwdp_backward(p, p->mbp32, dv, B0, n, dk, dact, dg, k, dgf, n, st);
+      rc = dense ? mfma_bwdd_backward(p, p->mbd32, dv, B0, n, dk, dact, dg, k, dgf, n, st)
+                 : mfma_bwdp_backward(p, p->mbp32, dv, B0, n, dk, dact, dg, k, dgf, n, st);
       if (rc == RAYEN_OK)
-        rc = mfma_bwdg_backward(p, p->mbg32, dv, B0, n, dk, dact, dg, k, dgf + nv, n, 0, nullptr, 0, st);
+        rc = dense ? mfma_backward(p, p->mb32, dv, B0, n, dk, dact, dg, k, dgf + nv, n, 0, nullptr, 0, st)
+                   : mfma_bwdg_backward(p, p->mbg32, dv, B0, n, dk, dact, dg, k, dgf + nv, n, 0, nullptr, 0, st);
       ok = rc == RAYEN_OK &&
            hipMemcpyAsync(gf.data(), dgf, 2 * nv * sizeof(float), hipMemcpyDeviceToHost, st) == hipSuccess &&
            hipMemcpyAsync(gt.data(), dgt, nv * sizeof(double), hipMemcpyDeviceToHost, st) == hipSuccess &&
@@ -670,7 +690,7 @@ static int bwd32_selfcheck(RayenPack* p) {
     if (broken[f]) worst[f] = std::numeric_limits<double>::infinity();
   p->check_bwd_pair = worst[0];
   p->check_bwd_exact = worst[1];
-  p->mbp32_state = (worst[0] <= 4e-6 || (std::isfinite(worst[1]) && worst[0] <= 1.5 * worst[1])) ? 1 : 2;
+  (dense ? p->mbd32_state : p->mbp32_state) = (worst[0] <= 4e-6 || (std::isfinite(worst[1]) && worst[0] <= 1.5 * worst[1])) ? 1 : 2;
   return RAYEN_OK;
 }
 
@@ -741,6 +761,7 @@ void rayen_pack_destroy(RayenPack* p) {
   if (p->mb64) mfma64_bwd_free(p->mb64);
   if (p->mbg32) mfma_bwdg_free(p->mbg32);
   if (p->mbp32) mfma_bwdp_free(p->mbp32);
+  if (p->mbd32) mfma_bwdd_free(p->mbd32);
   if (p->mbg64) mfma64_bwdg_free(p->mbg64);
   if (p->sp32) mfma_split_free(p->sp32);
   if (p->pr32) mfma_pair_free(p->pr32);
@@ -772,6 +793,7 @@ int rayen_pack_info(const RayenPack* p, RayenPackInfo* info) {
   info->fp32_check_pair = p->check_pair;
   info->bwd_f32 = !(p->prepared & 4) ? 0
                   : (p->q32 != nullptr && lmi_quad_bwd_serves_f32(p, p->q32)) ? 4
+                  : (p->mbd32 != nullptr && p->mbd32_state == 1) ? 7
                   : p->mb32 != nullptr ? 1
                   : (p->mbp32 != nullptr && p->mbp32_state == 1) ? 3
                   : p->mbg32 != nullptr ? 2
@@ -1043,8 +1065,13 @@ int rayen_ray_project_bwd_f32(const RayenPack* p, const float* v, int64_t B, int
 int64_t rayen_bwd_workspace_bytes_f32(const RayenPack* p, int64_t B) {
   if (p == nullptr || B <= 0 || check_ready<float>(p, true) != RAYEN_OK) return 0;
   if (p->q32 != nullptr && lmi_quad_bwd_serves_f32(p, p->q32)) return 0;
+  // (the f16-pair backwards stream the batch in order: nothing to sort.  The dense-form one declines rows that are not 16-byte
+  // aligned -- the bucketed walk then runs unsorted, same results)
+  if (p->mbd32 != nullptr && p->mbd32_state == 1 && dense_pairs_backward_enabled() &&
+      mfma_bwdd_serves(p, p->mbd32, nullptr, B, 4, nullptr, 4, nullptr, 4))
+    return 0;
   if (p->mb32 != nullptr) return mfma_bwd_workspace_bytes(p, p->mb32, B);
-  if (p->mbp32 != nullptr && p->mbp32_state == 1) return 0;   // (streams the batch in order: nothing to sort)
+  if (p->mbp32 != nullptr && p->mbp32_state == 1) return 0;
   return p->mbg32 != nullptr ? mfma_bwdg_workspace_bytes(p, p->mbg32, B) : 0;
 }
 

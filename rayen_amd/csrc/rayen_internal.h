@@ -53,6 +53,7 @@ struct MfmaBwdImage; // rayen_mfma_bwd.hip
 struct Mfma64BwdImage;  // rayen_mfma_bwd64.hip
 struct MfmaBwdgImage;   // rayen_mfma_bwdg.hip
 struct MfmaBwdpImage;   // rayen_mfma_bwdp.hip
+struct MfmaBwddImage;   // rayen_mfma_bwdd.hip
 struct Mfma64BwdgImage; // rayen_mfma_bwdg64.hip
 struct LmiQuadImage;    // rayen_lmi_quad.h
 struct LmiWaveImage;    // rayen_lmi_wave.h
@@ -85,6 +86,8 @@ struct RayenPack {
   rayen::MfmaBwdgImage* mbg32 = nullptr;
   rayen::MfmaBwdpImage* mbp32 = nullptr;   // f16-pair backward (packed low-rank quadratics, n <= 32)
   int mbp32_state = 0;           // 1: may serve the pack | 2: rejected by bwd32_selfcheck
+  rayen::MfmaBwddImage* mbd32 = nullptr;   // f16-pair backward of dense forms at n = k = 64 (next to mb32, which it is measured against)
+  int mbd32_state = 0;           // the same
   double check_bwd_pair = -1.0, check_bwd_exact = -1.0;  // worst gradient-row errors against the fp64 lane backward
   rayen::Mfma64BwdgImage* mbg64 = nullptr;
   rayen::LmiQuadImage* q32 = nullptr;
@@ -242,6 +245,15 @@ int lmi_quad_forward_f64(const RayenPack* p, const LmiQuadImage* img, const doub
 
 // fp32 MFMA backward for sets with equalities / packed low-rank quadratics (rayen_mfma_bwdg.hip)
 // the same shapes with every quadratic in packed tiles, n <= 32: backward on f16 pairs (rayen_mfma_bwdp.hip)
+// fp32 backward of dense-form sets at n = k = 64 on f16 pairs, forms resident in LDS, unbucketed (rayen_mfma_bwdd.hip, round 6)
+bool mfma_bwdd_eligible(const RayenPack* p);
+int mfma_bwdd_build(const RayenPack* p, MfmaBwddImage** out, int64_t* bytes);
+void mfma_bwdd_free(MfmaBwddImage* img);
+bool mfma_bwdd_serves(const RayenPack* p, const MfmaBwddImage* img, const float* v, int64_t B, int64_t ldv,
+                      const float* gy, int64_t ldg, const float* gv, int64_t ldgv);
+int mfma_bwdd_backward(const RayenPack* p, const MfmaBwddImage* img, const float* v, int64_t B, int64_t ldv,
+                       const float* kappa, const int32_t* active, const float* grad_y, int64_t ldg, float* grad_v,
+                       int64_t ldgv, hipStream_t stream);
 bool mfma_bwdp_eligible(const RayenPack* p);
 int mfma_bwdp_build(const RayenPack* p, MfmaBwdpImage** out, int64_t* bytes);
 void mfma_bwdp_free(MfmaBwdpImage* img);

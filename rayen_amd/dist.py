@@ -27,11 +27,56 @@ chunking exists to start it early (after 1/chunks of the compute), not to hide i
 
 ``project_into`` is a parameter so that exactly this code runs on CPU with the
 ``gloo`` backend in ``tests/test_dist_gloo.py`` (the HIP kernels cannot run there).
+
+``gather_impl="peer"`` (round 6; ``bench.py --gather-impl peer``) replaces the collective by what an all-gather IS on a
+direct xGMI mesh: every rank copies block ``c`` of its send buffer straight into slot ``[c, rank]`` of every peer's gather
+buffer (``hipMemcpyPeerAsync``: SDMA engines, no compute units taken from the projection's persistent grid, one copy per
+link) on a side stream behind the projection of that block, and one barrier at the end of the step tells every rank that
+its own buffer is complete.  The peers' buffers are opened once, at construction, through :class:`CudaIpcBuffers` (the
+``torch.multiprocessing`` CUDA-IPC reduction, dmabuf handles); ``tests/test_dist_gloo.py`` drives the same indexing on
+the host with :class:`ShmBuffers` (every rank's buffer a file under ``/dev/shm`` that all ranks map).  Never run on more
+than one GPU (no node was available): an A/B for the first multi-GPU run, RCCL stays the default.
 """
 from __future__ import annotations
 
 import torch
 import torch.distributed as dist
+
+
+class CudaIpcBuffers:
+    """The gather buffers of all ranks, each opened in every process: ``allocate`` returns ``(own, views)`` with
+    ``views[r]`` = rank ``r``'s buffer as a tensor of THIS process (``views[rank] is own``)."""
+
+    def allocate(self, shape, dtype, device, rank, world, group):
+        from torch.multiprocessing.reductions import reduce_tensor
+        own = torch.empty(shape, dtype=dtype, device=device)
+        rebuild, args = reduce_tensor(own)                     # (the CUDA-IPC handle of the allocation + the view's geometry)
+        handles = [None] * world
+        dist.all_gather_object(handles, (rebuild, args), group=group)
+        views = [own if r == rank else handles[r][0](*handles[r][1]) for r in range(world)]
+        self._keep = handles                                   # (the senders' reference counters live as long as the step)
+        return own, views
+
+
+class ShmBuffers:
+    """Host stand-in for :class:`CudaIpcBuffers` (tests): rank ``r``'s buffer is the file ``<prefix>.<r>`` under ``/dev/shm``,
+    mapped by every rank -- a write into ``views[r]`` lands in rank ``r``'s own tensor, as a peer copy does."""
+
+    def __init__(self, prefix):
+        self.prefix = prefix
+
+    def allocate(self, shape, dtype, device, rank, world, group):
+        import numpy as np
+        np_dtype = {torch.float32: np.float32, torch.float64: np.float64}[dtype]
+        count = 1
+        for d in shape:
+            count *= int(d)
+        path = f"{self.prefix}.{rank}"
+        np.memmap(path, dtype=np_dtype, mode="w+", shape=(max(count, 1),)).flush()
+        dist.barrier(group=group)                              # every file exists
+        self._maps = [np.memmap(f"{self.prefix}.{r}", dtype=np_dtype, mode="r+", shape=(max(count, 1),)) for r in range(world)]
+        views = [torch.from_numpy(m)[:count].view(shape) for m in self._maps]
+        return views[rank], views
 
 
 def shard_bounds(total: int, world: int, rank: int):
@@ -53,7 +98,7 @@ class ShardedStep:
     """
 
     def __init__(self, project_into, sizes, k, dtype, device, chunks=4, gather=True, group=None, gather_alone=False,
-                 reserve_cus=0, set_reserve=None):
+                 reserve_cus=0, set_reserve=None, gather_impl="rccl", peer_buffers=None):
         """``reserve_cus`` / ``set_reserve``: compute units the projection's persistent grid leaves free while a
         gather step runs (``set_reserve(n) -> previous`` = ``rayen_reserve_cus`` of the C ABI; ``None`` on CPU).
         RCCL's all-gather kernels need CUs: behind a grid that fills every SIMD they would simply queue.
@@ -61,7 +106,11 @@ class ShardedStep:
         atomic): another thread or pack that launches a projection inside that window gets the smaller grid too (same
         results, fewer workgroups).  One stepping thread per process is the supported arrangement; the default is 0
         (no reservation) until a multi-GPU run shows that leaving CUs free pays."""
+        if gather_impl not in ("rccl", "peer"):
+            raise ValueError(f"gather_impl must be 'rccl' or 'peer', got {gather_impl!r}")
         self.project_into = project_into
+        self.gather_impl = gather_impl
+        self.peer_views = None
         self.reserve_cus = int(reserve_cus)
         self.set_reserve = set_reserve
         self.last_trace = None
@@ -80,7 +129,15 @@ class ShardedStep:
         self.rows = -(-max_rows // self.chunks) if max_rows else 0          # rows per chunk (last one ragged)
         if self.gather:
             # [chunk][rank][row][k]: chunk c of every rank is one contiguous all-gather output
-            self.out = torch.empty((self.chunks, self.world, self.rows, self.k), dtype=dtype, device=device)
+            shape = (self.chunks, self.world, self.rows, self.k)
+            if gather_impl == "peer":
+                # (gather_impl "peer": every rank's buffer opened in every process, once; the step only copies)
+                buffers = peer_buffers if peer_buffers is not None else CudaIpcBuffers()
+                self.out, self.peer_views = buffers.allocate(shape, dtype, device, self.rank, self.world, group)
+                self._buffers = buffers
+                self._copy_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
+            else:
+                self.out = torch.empty(shape, dtype=dtype, device=device)
             self.send = torch.empty((self.chunks, self.rows, self.k), dtype=dtype, device=device)
         else:
             self.out = None
@@ -121,12 +178,19 @@ class ShardedStep:
                 if hi > lo:
                     self.project_into(x_local[lo:hi], send[: hi - lo])      # rows beyond hi - lo: padding, never read
                 projected = stamp()
-                works.append(dist.all_gather_into_tensor(self.out[c].view(self.world * self.rows, self.k), send,
-                                                         group=self.group, async_op=True))
+                if self.gather_impl == "peer":
+                    works.append(self._peer_copies(c, send))
+                else:
+                    works.append(dist.all_gather_into_tensor(self.out[c].view(self.world * self.rows, self.k), send,
+                                                             group=self.group, async_op=True))
                 stamps.append([projected, None])
             for c, work in enumerate(works):
-                work.wait()
+                if work is not None:
+                    work.wait()
                 stamps[c][1] = stamp()
+            if self.gather_impl == "peer":
+                # every rank has issued (and waited for) ITS copies; the barrier says the others' have landed here too
+                dist.barrier(group=self.group)
         finally:
             if prev is not None:
                 self.set_reserve(prev)
@@ -139,6 +203,26 @@ class ShardedStep:
             self.last_trace = [{"chunk": c, "rows": int(min((c + 1) * self.rows, self.n_local) - min(c * self.rows, self.n_local)),
                                 "projection_end_ms": ms(a), "gather_end_ms": ms(b)} for c, (a, b) in enumerate(stamps)]
         return self.out
+
+    def _peer_copies(self, c, send):
+        """Block ``c`` of this rank into slot ``[c, rank]`` of every rank's buffer (its own included).  On a device: on the
+        copy stream, behind the projection that produced the block; returns an object whose ``wait()`` makes the main stream
+        wait for the copies."""
+        if self._copy_stream is None:
+            for view in self.peer_views:
+                view[c, self.rank].copy_(send)
+            return None
+        main = torch.cuda.current_stream()
+        self._copy_stream.wait_stream(main)
+        with torch.cuda.stream(self._copy_stream):
+            for view in self.peer_views:
+                view[c, self.rank].copy_(send, non_blocking=True)
+        stream = self._copy_stream
+
+        class _Wait:
+            def wait(self_inner):
+                main.wait_stream(stream)
+        return _Wait()
 
     def rows_of(self, rank):
         """Strided view ``[sizes[rank], k]``-equivalent of rank ``rank``'s rows inside the gather buffer, in their

@@ -130,6 +130,69 @@ def _bench_worker(rank, world, port, scaling, chunks, config_batch, per_gpu, res
         dist.destroy_process_group()
 
 
+def _peer_worker(rank, world, port, chunks, sizes, result_dir):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        from helpers import csd_from_cs
+        from oracle import rayen_oracle as oracle
+        from rayen_amd import workloads
+        from rayen_amd.dist import ShmBuffers
+
+        torch.set_num_threads(1)
+        cs = workloads.build_constraints(workloads.make_raw("c2", seed=3))
+        buf = oracle.precompute(csd_from_cs(cs), torch.float32)
+
+        def project_into(x_rows, out_rows):
+            out_rows.copy_(oracle.forward(buf, x_rows)[:, :, 0])
+
+        xs = [torch.empty(sizes[r], cs.n, 1).uniform_(-1, 1, generator=torch.Generator().manual_seed(1000 + r))
+              for r in range(world)]
+        rccl = bench.make_step(project_into, sizes, cs.k, torch.float32, torch.device("cpu"), gather=True, chunks=chunks)
+        # the peers' buffers: files under /dev/shm that every rank maps (the host stand-in for CUDA IPC: a write into
+        # views[r] lands in rank r's own tensor, as hipMemcpyPeerAsync does)
+        prefix = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else result_dir, f"rayen_peer_{port}")
+        peer = bench.make_step(project_into, sizes, cs.k, torch.float32, torch.device("cpu"), gather=True, chunks=chunks,
+                               gather_impl="peer", peer_buffers=ShmBuffers(prefix))
+        assert peer.gather_impl == "peer" and len(peer.peer_views) == world and peer.peer_views[rank] is peer.out
+        for _ in range(2):                                  # repeatable: slots are overwritten, nothing accumulates
+            a = rccl(xs[rank])
+            b = peer(xs[rank])
+        dist.barrier()
+        assert a.shape == b.shape
+        for r in range(world):                              # same rows in the same slots, whichever way they travelled
+            assert torch.equal(peer.rows_of(r).reshape(-1, cs.k)[: sizes[r]], rccl.rows_of(r).reshape(-1, cs.k)[: sizes[r]]), (rank, r)
+            # (and they are the projection of rank r's rows: the whole batch at once may sum in another order than a block)
+            assert torch.allclose(peer.rows_of(r).reshape(-1, cs.k)[: sizes[r]], oracle.forward(buf, xs[r])[:, :, 0], rtol=1e-5, atol=1e-6)
+        assert torch.equal(peer.gathered(), rccl.gathered())
+        dist.barrier()
+        if rank == 0:
+            for r in range(world):
+                try:
+                    os.remove(f"{prefix}.{r}")
+                except OSError:
+                    pass
+        np.save(os.path.join(result_dir, f"ok_{rank}.npy"), np.array([1]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,chunks,sizes", [(2, 1, [96, 96]), (2, 3, [101, 77]), (4, 2, [33, 64, 1, 50])])
+def test_peer_copy_gather_fills_the_same_slots_as_the_collective(tmp_path, world, chunks, sizes):
+    """`--gather-impl peer` (direct copies into the peers' gather buffers; on the GPU hipMemcpyPeerAsync through CUDA-IPC views)
+    against the collective: the same rows in the same `[chunk, rank, row]` slots on every rank, equal and unequal shards,
+    ragged chunks, world 2 and 4.  The copy itself is a host write into a shared mapping here; the indexing is the code the
+    multi-GPU run executes."""
+    port = _free_port()
+    mp.spawn(_peer_worker, args=(world, port, chunks, sizes, str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        assert os.path.exists(tmp_path / f"ok_{rank}.npy")
+
+
 @pytest.mark.parametrize("scaling,chunks,config_batch,per_gpu", [("weak", 1, 0, 96), ("weak", 4, 0, 101),
                                                                  ("strong", 2, 203, 0), ("strong", 3, 64, 0)])
 def test_bench_step_function_world2(tmp_path, scaling, chunks, config_batch, per_gpu):

@@ -438,7 +438,7 @@ def test_bucketed_backward_equals_the_plain_walk(name, B, dtype):
         torch.set_default_dtype(prev)
     dp, _ = layer.device_pack(torch.device("cuda", 0))
     dp_layer = dp
-    if dtype == torch.float32 and dp.info().bwd_f32 == 3:
+    if dtype == torch.float32 and dp.info().bwd_f32 in (3, 7):
         # (the f16-pair backward streams the batch in order and asks for no workspace: the bucketed walk of the exact-fp32
         # kernel behind it is what this test is about)
         from rayen_amd import pack as _pack

@@ -144,8 +144,11 @@ def test_modes_pin_the_backward_family():
     assert forced.bwd_f32 == 3 and forced.bwd32_check_pair == -1.0
     measured = _pack.DevicePack(consts, 0).info()
     assert measured.bwd_f32 == 3 and 0.0 <= measured.bwd32_check_pair <= max(4e-6, 1.5 * measured.bwd32_check_exact)
-    # other shapes keep their kernels: config 3 (dense forms, NA_E = I) 1, config 4 (LMI) 4, config 1 (linear rows only) 1
-    for name, want in (("c3", (1,)), ("c4", (4,)), ("c2", (1,))):
+    # other shapes keep their kernels: config 4 (LMI) 4, config 2 (n = 16) 1; config 3 (dense forms at n = k = 64) has its own
+    # f16-pair backward since round 6 (7, tests/test_gpu_backward_dense_pairs.py), the exact kernel 1 under fp32_mode 1
+    cs3 = workloads.build_constraints(workloads.make_raw("c3", seed=1))
+    assert _pack.DevicePack(ConstraintModule(cs3, create_map=False).cuda().packed_constants(), 0, fp32_mode=1).info().bwd_f32 == 1
+    for name, want in (("c3", (7,)), ("c4", (4,)), ("c2", (1,))):
         cs2 = workloads.build_constraints(workloads.make_raw(name, seed=1))
         info = ConstraintModule(cs2, create_map=False).cuda().device_pack(torch.device("cuda", 0))[0].info()
         assert info.bwd_f32 in want, (name, info.bwd_f32)

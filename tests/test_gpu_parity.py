@@ -89,7 +89,25 @@ SUBSTITUTED_CAP = 0.05      # at most this fraction of a batch may take the pack
 BISECTED_ROWS = 1024        # rows of every replaced batch held to bisection on the raw constraints
 
 
+_ORACLE_CACHE = {}
+
+
 def _oracle_forward(cs, x_cpu, dtype):
+    """Memoised per (constraint data, inputs, dtype): several tests of this file hold different kernels to the SAME oracle
+    outputs, and on config 5 one evaluation (with its bisection of the replaced rows) takes half a minute of host time."""
+    import hashlib
+    key = (str(dtype), tuple(x_cpu.shape), hashlib.sha1(x_cpu.contiguous().numpy().tobytes()).hexdigest(),
+           hashlib.sha1(np.ascontiguousarray(np.asarray(cs.A_p, dtype=np.float64)).tobytes()
+                        + np.ascontiguousarray(np.asarray(cs.y0, dtype=np.float64)).tobytes()).hexdigest(),
+           len(cs.qcs), len(cs.socs), bool(cs.has_lmi_constraints))
+    if key not in _ORACLE_CACHE:
+        if len(_ORACLE_CACHE) > 64:
+            _ORACLE_CACHE.clear()
+        _ORACLE_CACHE[key] = _oracle_forward_uncached(cs, x_cpu, dtype)
+    return _ORACLE_CACHE[key].copy()
+
+
+def _oracle_forward_uncached(cs, x_cpu, dtype):
     """The reference's op sequence at ``dtype`` -- and where THAT is NaN, the reference's op sequence at fp64, rounded.
 
     On the corridor set (config 5) the reference takes ``sqrt`` of slightly negative radicands (CM:374): NaN on EVERY row at
@@ -147,7 +165,8 @@ def _ray_bisection_truth(cs, v64):
 
     inside = worst(y0[None] + d) <= 0.0
     lo, hi = np.zeros(len(d)), np.ones(len(d))
-    for _ in range(110):                      # (halving until a feasible step is known, then relative: t may be 1e-12)
+    for _ in range(72):                       # (halving until a feasible step is known -- t may be 1e-12 --, then the gap
+                                              # between lo and hi halves in the LOGARITHM every step: 1e-15 long before 72)
         mid = np.where(lo > 0.0, np.sqrt(lo * hi), 0.5 * hi)
         ok = worst(y0[None] + mid[:, None] * d) <= 0.0
         lo, hi = np.where(ok, mid, lo), np.where(ok, hi, mid)
@@ -662,7 +681,13 @@ def test_batches_beyond_2_31_elements(name, dtype):
     grad = ops.backward_raw(v, kappa, active, g, dp)
     for lo, hi in windows:
         grad_w = ops.backward_raw(v[lo:hi].clone(), kappa[lo:hi].clone(), active[lo:hi].clone(), g[lo:hi].clone(), dp)
-        assert torch.equal(grad[lo:hi], grad_w), (name, lo, hi)
+        if dtype == torch.float32 and dp.info().bwd_f32 == 7:
+            # (round 6: the big batch runs on the f16-pair dense-form backward, a window of a few hundred rows on the
+            # exact-fp32 kernel it replaces -- two fp32-grade evaluations of the same gradient, not the same bits)
+            size = grad_w.abs().amax(dim=1).clamp_min(1e-30)
+            assert float(((grad[lo:hi] - grad_w).abs().amax(dim=1) / size).max()) <= 2e-5, (name, lo, hi)
+        else:
+            assert torch.equal(grad[lo:hi], grad_w), (name, lo, hi)
     tail = y[B - 1037:].cpu().numpy().astype(np.float64)
     assert oracle.max_violation(raw, tail) <= _violation_bound(raw, cs, v[B - 1037:], dtype)
 
