@@ -54,6 +54,18 @@ constexpr int kBdWaves = RAYEN_BWDD_WAVES;
 constexpr int kBdStage = 2048;     // a wave's staging bytes: 16 rows x one 128-byte line
 }  // namespace
 
+// developer build (-DRAYEN_BWDD_STAMPS; scripts/ubench/bwdd_stamps.py): s_memtime at the phases of the SECOND group of waves 0 and 4
+// of workgroup 0.  Nothing in the library build.
+#ifdef RAYEN_BWDD_STAMPS
+__device__ unsigned long long bwdd_stamp_buf[2 * 32];
+extern "C" int rayen_debug_bwdd_stamps(void* dst, size_t bytes) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(bwdd_stamp_buf), bytes < sizeof(bwdd_stamp_buf) ? bytes : sizeof(bwdd_stamp_buf)) == hipSuccess ? 0 : -1;
+}
+#define RAYEN_BD_STAMP(slot) do { if (stamp_on && lane == 0) bwdd_stamp_buf[(wave >> 2) * 32 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RAYEN_BD_STAMP(slot) do { } while (0)
+#endif
+
 template <bool DUMMY>
 __global__ __launch_bounds__(kBdWaves * 64, 1) void mfma_bwdd_kernel(
     const f16x8* __restrict__ Sh, const BItem* __restrict__ items, int n_tiles, int n_dense,
@@ -71,10 +83,17 @@ __global__ __launch_bounds__(kBdWaves * 64, 1) void mfma_bwdd_kernel(
   float* const auxr = reinterpret_cast<float*>(lin + (size_t)lin_n * 256);         // [n_dense][2][64]: phi | c, M'beta of form d
   char* const stage = reinterpret_cast<char*>(auxr + (size_t)n_dense * 128) + wave * kBdStage;
   unsigned* const take_lds = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(auxr + (size_t)n_dense * 128) + kBdWaves * kBdStage);
+  float* const ftab = reinterpret_cast<float*>(take_lds + 4);                      // [n_dense][4]: type | tau | a' | - of form d
   const int64_t n_groups = (B + 31) / 32;
   const int64_t grp_stride = (int64_t)gridDim.x;
   int64_t grp = (int64_t)blockIdx.x + (int64_t)wave * grp_stride;
 
+#ifdef RAYEN_BWDD_STAMPS
+  if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0) {
+    bwdd_stamp_buf[(wave >> 2) * 32 + 8] = __builtin_amdgcn_s_memtime();
+    bwdd_stamp_buf[(wave >> 2) * 32 + 9] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
   // ---- once per workgroup: forms, linear rows, aux rows -> LDS
   {
     const int n_chunks = n_tiles * NCH;
@@ -90,8 +109,18 @@ __global__ __launch_bounds__(kBdWaves * 64, 1) void mfma_bwdd_kernel(
     for (int i = threadIdx.x; i < n_dense * 128; i += kBdWaves * 64)
       auxr[i] = Wrow[(size_t)items[(i >> 7) * 2].aux_row * NP + (i & 127)];     // (rows aux_row, aux_row + 1 are contiguous)
     if (threadIdx.x == 0) *take_lds = kBdWaves;
+    if (threadIdx.x < n_dense) {
+      const BItem it0 = items[threadIdx.x * 2];
+      ftab[threadIdx.x * 4 + 0] = __builtin_bit_cast(float, it0.type);
+      ftab[threadIdx.x * 4 + 1] = it0.f0;
+      ftab[threadIdx.x * 4 + 2] = it0.f1;
+      ftab[threadIdx.x * 4 + 3] = 0.f;
+    }
   }
   __syncthreads();  // the only workgroup barrier
+#ifdef RAYEN_BWDD_STAMPS
+  if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0) bwdd_stamp_buf[(wave >> 2) * 32 + 10] = __builtin_amdgcn_s_memtime();
+#endif
 
   // this lane's pieces 2 q + hi of its sample's rows of v and g (zero beyond the batch), kappa and the arg-max record.  A
   // group's rows are requested at the END of the previous group, in front of its staged stores: by then nothing but the
@@ -119,7 +148,16 @@ __global__ __launch_bounds__(kBdWaves * 64, 1) void mfma_bwdd_kernel(
   };
   if (grp < n_groups) request(grp);
 
+#ifdef RAYEN_BWDD_STAMPS
+  int stamp_round = 0;
+  bool stamp_on = false;
+#endif
   while (grp < n_groups) {
+#ifdef RAYEN_BWDD_STAMPS
+    stamp_on = blockIdx.x == 0 && (wave == 0 || wave == 4) && stamp_round == 1;
+    ++stamp_round;
+#endif
+    RAYEN_BD_STAMP(0);
     const int64_t row = grp * 32 + col;
     const bool live = row < B;
     int taken = 0;
@@ -137,10 +175,10 @@ __global__ __launch_bounds__(kBdWaves * 64, 1) void mfma_bwdd_kernel(
       const float dot = (d4[0] + d4[1]) + (d4[2] + d4[3]);
       tv = dot + xhalf(dot);
     }
+    RAYEN_BD_STAMP(1);     // rows have landed, g . v
     float ur[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) ur[i] = 0.f;
-    bool matched = false;
 
     if (__ballot(clipped) != 0) {  // wave-uniform: a wave of interior samples skips the walk
       // ---- v -> scaled f16 pairs (the forward's split: per-row power of two)
@@ -170,7 +208,9 @@ __global__ __launch_bounds__(kBdWaves * 64, 1) void mfma_bwdd_kernel(
           vb[1][sp] = __builtin_bit_cast(f16x8, w2);
         }
       }
-      float part = 0.f;
+      RAYEN_BD_STAMP(2);   // split
+      float part = 0.f, tot = 0.f;
+      int form = -1;       // the dense form this lane's active constraint is (-1: a linear row, or not clipped)
       f32x16 acc;
       const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       u32x4 abuf[NCH];
@@ -218,80 +258,77 @@ __global__ __launch_bounds__(kBdWaves * 64, 1) void mfma_bwdd_kernel(
           part = (s4[0] + s4[1]) + (s4[2] + s4[3]);
         }
         if (item.flags & MF_LAST) {
-          const float* ax = auxr + (size_t)(it >> 1) * 128 + 4 * hi;      // rows phi | c, then M'beta of this form
-          float cw, c0, c1;
-          if (item.type == BI_QUAD) {
-            const float total = ((part + xhalf(part)) * s_inv) * v_inv;   // v'S v
-            cw = total > 0.f ? 1.f / sqrtf(total) : 0.f;
-            c0 = 1.f;
-            c1 = 0.f;
-          } else {
-            float c4[4] = {0.f, 0.f, 0.f, 0.f}, b4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-              const f32x4 x0 = *reinterpret_cast<const f32x4*>(ax + 8 * q);
-              const f32x4 x1 = *reinterpret_cast<const f32x4*>(ax + NP + 8 * q);
-#pragma unroll
-              for (int c = 0; c < 4; ++c) {
-                c4[c] = fmaf(x0[c], vr[4 * q + c], c4[c]);
-                b4[c] = fmaf(x1[c], vr[4 * q + c], b4[c]);
-              }
-              __builtin_amdgcn_sched_barrier(0);     // (one piece at a time: hoisted, the sixteen LDS reads hold 64 registers)
-            }
-            const float cr = (c4[0] + c4[1]) + (c4[2] + c4[3]), br = (b4[0] + b4[1]) + (b4[2] + b4[3]);
-            const float crs = cr + xhalf(cr), brs = br + xhalf(br);
-            const float tau = item.f0, ap = item.f1;
-            const float bp = 2.f * brs - 2.f * crs * tau;
-            const float den = 2.f * ap * kap + bp;  // dF/dkappa at the root
-            const float inv = den != 0.f ? -1.f / den : 0.f;
-            cw = 2.f * inv;                            // d c'/dv = 2 M'Mv - 2 (c.v) c
-            c0 = inv * (-2.f * crs - 2.f * tau * kap);
-            c1 = inv * 2.f * kap;                      // kappa * d b'/dv = kappa (2 M'beta - 2 tau c)
-          }
-#pragma unroll
-          for (int q = 0; q < NQ; ++q) {
-            const f32x4 x0 = *reinterpret_cast<const f32x4*>(ax + 8 * q);
-            f32x4 x1 = {0.f, 0.f, 0.f, 0.f};
-            if (item.type == BI_SOC) x1 = *reinterpret_cast<const f32x4*>(ax + NP + 8 * q);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              const float un = (ur[4 * q + c] * s_inv) * v_inv;      // (S v) in natural units
-              const float u = fmaf(cw, un, fmaf(c0, x0[c], c1 * x1[c]));
-              ur[4 * q + c] = sel ? u : ur[4 * q + c];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          matched |= sel;
+          // the form's lanes only RECORD what their closer needs (v'S v and which form): the closers themselves run once per
+          // group, below, every lane on its own form -- six forms closing one after the other on all 32 lanes were 1 200 of
+          // the ~2 000 vector instructions of a group
+          const float total = part + xhalf(part);
+          tot = sel ? total : tot;
+          form = sel ? (it >> 1) : form;
         }
       }
-      // every quadratic / cone is in the item list: what is left is a linear row
-      if (clipped && !matched) {
+      RAYEN_BD_STAMP(3);   // walk
+      // ---- grad kappa of every lane's own constraint, in one pass: u = cw (S v) + c0 x0 + c1 x1 with
+      //   quadratic   x0 = phi,  cw = 1 / sqrt(v'S v), c0 = 1, c1 = 0                                    (:374)
+      //   cone        x0 = c, x1 = M'beta: the implicit derivative of the root (rayen_mfma_bwd.hip)      (:383-399)
+      //   linear row  x0 = D_i, cw = 0, c0 = 1, c1 = 0                                                   (:353)
+      // x0 | x1 are rows in LDS at a per-lane address (the form's aux rows, or the arg-max row of the linear block, whose
+      // pieces sit in slots p ^ (r & 15)); lanes whose linear row is outside the LDS block gather it from memory.
+      {
+        const bool dense = form >= 0;
         const int r = arow - lin_lo;
-        if (r >= 0 && r < lin_n) {
-          const char* rp = lin + r * 256;
+        const bool lin_lds = !dense && r >= 0 && r < lin_n;
+        const f32x4 ft = *reinterpret_cast<const f32x4*>(ftab + (dense ? form : 0) * 4);     // type | tau | a' | -
+        const bool soc = dense && __builtin_bit_cast(int, ft[0]) == BI_SOC;
+        const char* base = dense ? reinterpret_cast<const char*>(auxr + (size_t)form * 128) : lin + (lin_lds ? r : 0) * 256;
+        const int sw = dense ? 0 : (r & 15);
+        float c4[4] = {0.f, 0.f, 0.f, 0.f}, b4[4] = {0.f, 0.f, 0.f, 0.f};
+        f32x4 x0[NQ];
 #pragma unroll
-          for (int q = 0; q < NQ; ++q) {
-            const f32x4 x = *reinterpret_cast<const f32x4*>(rp + (((2 * q + hi) ^ (r & 15)) * 16));
-            ur[4 * q + 0] = x[0]; ur[4 * q + 1] = x[1]; ur[4 * q + 2] = x[2]; ur[4 * q + 3] = x[3];
-            __builtin_amdgcn_sched_barrier(0);
+        for (int q = 0; q < NQ; ++q) {
+          x0[q] = *reinterpret_cast<const f32x4*>(base + (((2 * q + hi) ^ sw) * 16));
+          const f32x4 x1 = *reinterpret_cast<const f32x4*>(base + 256 + (2 * q + hi) * 16);      // (read by every lane, used by cones)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            c4[c] = fmaf(x0[q][c], vr[4 * q + c], c4[c]);
+            b4[c] = fmaf(x1[c], vr[4 * q + c], b4[c]);
           }
-        } else {
+        }
+        if (clipped && !dense && !lin_lds) {      // (a linear row beyond the block in LDS)
           const float* rw = Wrow + (int64_t)arow * NP + 4 * hi;
 #pragma unroll
-          for (int q = 0; q < NQ; ++q) {
-            const f32x4 x = *reinterpret_cast<const f32x4*>(rw + 8 * q);
-            ur[4 * q + 0] = x[0]; ur[4 * q + 1] = x[1]; ur[4 * q + 2] = x[2]; ur[4 * q + 3] = x[3];
-          }
+          for (int q = 0; q < NQ; ++q) x0[q] = *reinterpret_cast<const f32x4*>(rw + 8 * q);
+        }
+        const float cr = (c4[0] + c4[1]) + (c4[2] + c4[3]), br = (b4[0] + b4[1]) + (b4[2] + b4[3]);
+        const float crs = cr + xhalf(cr), brs = br + xhalf(br);
+        // quadratic
+        const float total = (tot * s_inv) * v_inv;                    // v'S v in natural units
+        const float cw_q = total > 0.f ? 1.f / sqrtf(total) : 0.f;
+        // cone
+        const float tau = ft[1], ap = ft[2];
+        const float bp = 2.f * brs - 2.f * crs * tau;
+        const float den = 2.f * ap * kap + bp;                        // dF/dkappa at the root
+        const float inv = den != 0.f ? -1.f / den : 0.f;
+        const float cw_n = dense ? (soc ? 2.f * inv : cw_q) : 0.f;    // d c'/dv = 2 M'Mv - 2 (c.v) c
+        const float c0 = soc ? inv * (-2.f * crs - 2.f * tau * kap) : 1.f;
+        const float c1 = soc ? inv * 2.f * kap : 0.f;                 // kappa * d b'/dv = kappa (2 M'beta - 2 tau c)
+        const float cw = (cw_n * s_inv) * v_inv;                      // (S v sits in ur with the scales gS sv on it)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const f32x4 x1 = *reinterpret_cast<const f32x4*>(base + 256 + (2 * q + hi) * 16);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) ur[4 * q + c] = fmaf(cw, ur[4 * q + c], fmaf(c0, x0[q][c], c1 * x1[c]));
         }
       }
     }
 
+    RAYEN_BD_STAMP(4);     // closers
     // ---- grad_v = s g - coef grad kappa, out as whole 128-byte lines through the wave's 2 KiB of LDS (rayen_mfma_pair_wl.hip)
     {
       const float coef = clipped ? sc * sc * tv : 0.f;
 #pragma unroll
       for (int i = 0; i < 32; ++i) ur[i] = fmaf(sc, gr[i], -coef * ur[i]);
       __builtin_amdgcn_sched_barrier(0);
+      RAYEN_BD_STAMP(5);   // combined
       if (next < n_groups) request(next);      // (v, g, kappa and the record of this group are dead)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -319,8 +356,18 @@ __global__ __launch_bounds__(kBdWaves * 64, 1) void mfma_bwdd_kernel(
         }
       }
     }
+    RAYEN_BD_STAMP(6);     // next rows requested, this group's lines staged and stored
     grp = next;
+#ifdef RAYEN_BWDD_STAMPS
+    if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0) bwdd_stamp_buf[(wave >> 2) * 32 + 13] = stamp_round;
+#endif
   }
+#ifdef RAYEN_BWDD_STAMPS
+  if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0) {
+    bwdd_stamp_buf[(wave >> 2) * 32 + 11] = __builtin_amdgcn_s_memtime();
+    bwdd_stamp_buf[(wave >> 2) * 32 + 12] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -385,7 +432,7 @@ int mfma_bwdd_build(const RayenPack* p, MfmaBwddImage** out, int64_t* bytes) {
     if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0)
       img->n_simd = prop.multiProcessorCount * 4;
   }
-  auto lds_of = [&](int lin_n) { return n_tiles * 8192 + lin_n * 256 + img->n_dense * 512 + kBdWaves * kBdStage + 16; };
+  auto lds_of = [&](int lin_n) { return n_tiles * 8192 + lin_n * 256 + img->n_dense * 512 + kBdWaves * kBdStage + 16 + img->n_dense * 16; };
   if (lds_of(img->lin_n) > 160 * 1024) img->lin_n = 0;      // (the linear rows stay in L2: gathered from there)
   img->lds_bytes = lds_of(img->lin_n);
   if (img->lds_bytes > 160 * 1024) { delete img; return RAYEN_OK; }
