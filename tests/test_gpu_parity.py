@@ -165,8 +165,8 @@ def _ray_bisection_truth(cs, v64):
 
     inside = worst(y0[None] + d) <= 0.0
     lo, hi = np.zeros(len(d)), np.ones(len(d))
-    for _ in range(72):                       # (halving until a feasible step is known -- t may be 1e-12 --, then the gap
-                                              # between lo and hi halves in the LOGARITHM every step: 1e-15 long before 72)
+    for _ in range(60):                       # (halving until a feasible step is known -- t may be 1e-12 --, then the gap
+                                              # between lo and hi halves in the LOGARITHM every step: 1e-15 long before 60)
         mid = np.where(lo > 0.0, np.sqrt(lo * hi), 0.5 * hi)
         ok = worst(y0[None] + mid[:, None] * d) <= 0.0
         lo, hi = np.where(ok, mid, lo), np.where(ok, hi, mid)
