@@ -12,6 +12,6 @@ db = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)[0]
 rows = [{"name": r[0][:110], "calls": r[1], "avg_us": r[3], "pct": r[4]}
         for r in sqlite3.connect(db).execute("select name,total_calls,total_duration,average,percentage from top_kernels limit 6")]
 json.dump({"command": f"rocprofv3 --kernel-trace --stats -- python scripts/ubench/bwd_profile.py {cfg}",
-           "note": "200 backward calls at B = 262144 (fp32) after one tracked forward; the kernels of one backward call (bucketed walks: count + scatter + walk)",
+           "note": "200 backward calls at B = 262144 (fp32) after one tracked forward; the kernels of one backward call",
            "kernel_stats": rows}, open(out, "w"), indent=1)
 print(json.dumps(rows[:4]))
