@@ -309,6 +309,11 @@ def main(argv=None):
     if world != args.gpus:
         _note(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size is what runs")
     on_gpu = BACKEND != "gloo"
+    # stdout carries ONE line, the JSON: whatever libraries write to file descriptor 1 on the way (RCCL's version banner comes
+    # through C stdio at the first collective) goes to stderr instead
+    json_fd = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
     if on_gpu:
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
@@ -708,7 +713,9 @@ def main(argv=None):
             ctypes.CDLL(None).fflush(None)
         except OSError:
             pass
-        print(line, flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (line + "\n").encode())
+    os.close(json_fd)
 
 
 if __name__ == "__main__":
