@@ -45,7 +45,7 @@ namespace {
 constexpr int kWlWaves = RAYEN_WL_WAVES;      // waves per workgroup = per CU
 constexpr int kWlNT = RAYEN_WL_NT;            // sample tiles (of 32) per wave and group
 // developer ablation builds (scripts/ubench/tu_variant.sh rayen_mfma_pair_wl <name> -DRAYEN_WL_ABL=<bits>; WRONG RESULTS):
-// 1 rows requested once per wave | 2 no rows of y stored | 4 non-temporal loads | 8 plain stores | 16 no epilogues | 32 no MFMAs
+// 1 rows requested once per wave | 2 no rows of y stored | 8 plain stores | 16 no epilogues | 32 no MFMAs
 #ifndef RAYEN_WL_ABL
 #define RAYEN_WL_ABL 0
 #endif
@@ -141,25 +141,25 @@ __global__ __launch_bounds__(NW * 64, 1) void mfma_pair_wl_kernel(
     if (threadIdx.x == 0) *take_lds = NW;     // (the first NW are the waves' first groups)
   }
 
-  // this lane's rows of group g (one per sample tile): pieces 2 q + hi (columns 8 q + 4 hi .. + 3), zero beyond the batch
+  // this lane's rows of group g (one per sample tile): pieces 2 q + hi (columns 8 q + 4 hi .. + 3), zero beyond the batch.
+  // Buffer addressing (round 6, from the ISA: the 64-bit `row * ldv` products, the predicates and the zeroing of the flat form
+  // were ~70 vector instructions per group, the multiplies at a quarter rate; the stores of y ~80): the descriptor's extent is
+  // B rows, the lane's byte offset inside a group is a constant, a group adds one uniform term -- and rows beyond the batch are
+  // out of range: their loads return 0, their stores are dropped by the hardware.  (Offsets are 32-bit: mfma_pair_wl_serves.)
+  const __amdgpu_buffer_rsrc_t v_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(v), 0, (int)(unsigned)((uint64_t)B * (uint64_t)ldv * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t y_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(y, 0, (int)(unsigned)((uint64_t)B * (uint64_t)ldy * 4u), 0x00020000);
+  const unsigned v_lane_off = (unsigned)col * (unsigned)ldv * 4u + 16u * (unsigned)hi;
+  const unsigned y_lane_off = (unsigned)(lane >> 3) * (unsigned)ldy * 4u + 16u * (unsigned)((lane & 7) ^ ((lane >> 3) & 7));
   f32x4 vraw[NT][NQ];
   auto request = [&](const int64_t g) {
+    const unsigned goff = v_lane_off + (unsigned)g * (unsigned)(NT * 32) * (unsigned)ldv * 4u;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int64_t row = g * (NT * 32) + t * 32 + col;
-      const bool in = row < B;
-      const float* src = v + (in ? row : 0) * ldv + 4 * hi;
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        vraw[t][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (in) {
-          // (plain loads: the four instructions that complete a 128-byte line find it in L1 after the first; non-temporal
-          // ones go to L2 four times -- 55.0 against 62.5 us at B = 262 144, gpurun_out/r06j)
-          if constexpr (RAYEN_WL_ABL & 4) vraw[t][q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + 8 * q));
-          else vraw[t][q] = *reinterpret_cast<const f32x4*>(src + 8 * q);
-        }
-      }
-    }
+      for (int q = 0; q < NQ; ++q)
+        vraw[t][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, goff + (unsigned)t * 32u * (unsigned)ldv * 4u + 32u * q, 0, 0));
   };
   // largest |component| of the requested rows (this lane's half of each): the FIRST use of the rows' registers.  It sits in
   // front of the previous group's stores of y -- vmcnt retires in order and counts stores, so a wait for these loads that
@@ -434,6 +434,7 @@ __global__ __launch_bounds__(NW * 64, 1) void mfma_pair_wl_kernel(
     // ones leave the L2 dirty for the end of the kernel).  So one 128-byte line of each of the tile's 32 rows at a time goes
     // through the wave's 4 KiB of LDS (slot = piece ^ (row & 7): the eight lanes of a write or read group hit eight different
     // 16-byte bank groups) and leaves as whole lines: lane L stores slot L & 7 of row 8 i + (L >> 3).
+    const unsigned y_goff = y_lane_off + (unsigned)s_base * (unsigned)ldy * 4u;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       float one = 1.0f;
@@ -465,13 +466,11 @@ __global__ __launch_bounds__(NW * 64, 1) void mfma_pair_wl_kernel(
           for (int i = 0; i < SR / 8; ++i) {
             const int r = 8 * i + (lane >> 3);
             const f32x4 x = *reinterpret_cast<const f32x4*>(stage + r * 128 + (lane & 7) * 16);
-            const int64_t srow = s_base + t * 32 + part * SR + r;
-            float* dst = y + srow * ldy + 32 * h + 4 * ((lane & 7) ^ (r & 7));
-            if constexpr (RAYEN_WL_ABL & 2) { if (x[0] == 123.456f) dst[0] = x[1]; }
-            else if (srow < B) {
-              if constexpr (RAYEN_WL_ABL & 8) *reinterpret_cast<f32x4*>(dst) = x;
-              else __builtin_nontemporal_store(x, reinterpret_cast<f32x4*>(dst));
-            }
+            // row (lane >> 3) of the eight, slot (lane & 7) ^ (row & 7): the lane's constant; rows beyond the batch are dropped
+            const unsigned off = y_goff + (unsigned)(t * 32 + part * SR + 8 * i) * (unsigned)ldy * 4u + 128u * h;
+            if constexpr (RAYEN_WL_ABL & 2) { if (x[0] == 123.456f) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), y_rsrc, off, 0, 0); }
+            else if constexpr (RAYEN_WL_ABL & 8) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), y_rsrc, off, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), y_rsrc, off, 0, 2);   // (2: non-temporal)
           }
           __builtin_amdgcn_wave_barrier();
         }
@@ -502,6 +501,8 @@ bool mfma_pair_wl_serves(const RayenPack* p, const PairImage* img, const float* 
   if (img == nullptr || img->nkk < 1 || img->nkk > 2 || img->n_tiles <= 0 || !img->wl_ready) return false;
   if (!img->identity || p->n != img->nkk * 32 || p->k != p->n) return false;
   if ((ldv % 4) != 0 || (ldy % 4) != 0) return false;
+  // (buffer addressing with 32-bit byte offsets; the rows of the ragged last group beyond the batch must not wrap)
+  if ((uint64_t)(B + 64) * (uint64_t)ldv * 4u >= (1ull << 32) || (uint64_t)(B + 64) * (uint64_t)ldy * 4u >= (1ull << 32)) return false;
   if ((reinterpret_cast<uintptr_t>(v) & 15) != 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0) return false;
   if (img->nkk == 2 && img->aux_rows > WlGeom<2>::AUXR) return false;
   if (pair_wl_lds_bytes(img) > 160 * 1024) return false;

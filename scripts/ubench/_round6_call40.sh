@@ -1,8 +1,7 @@
 out=gpurun_out/r06zv; mkdir -p $out
-timeout 1500 python -m pytest tests/test_gpu_backward_dense_pairs.py -m gpu -q --timeout 900 -p no:cacheprovider > $out/pytest_bwd.log 2>&1; tail -3 $out/pytest_bwd.log
-for i in 1 2; do
-echo "== new" >> $out/bwd_bench.txt; timeout 300 python scripts/ubench/bwd_bench.py c3 2>&1 | grep -v amdgpu >> $out/bwd_bench.txt
-echo "== old" >> $out/bwd_bench.txt; RAYEN_BWD_DENSE_PAIRS=0 timeout 300 python scripts/ubench/bwd_bench.py c3 2>&1 | grep -v amdgpu >> $out/bwd_bench.txt
-done
-cat $out/bwd_bench.txt
-RAYEN_HIP_LIBRARY=$PWD/scripts/ubench/variants/librayen_mfma_bwdd_stamps.so timeout 200 python scripts/ubench/bwdd_stamps.py 2>&1 | grep -v amdgpu | head -2
+rocm-smi --showclocks --showpower --showtemp 2>&1 | grep -v "^$" | head -30 > $out/smi_before.txt
+for i in 1 2 3; do timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-families > $out/bench_c3_$i.json 2>/dev/null; python -c "
+import json;d=json.loads(open('$out/bench_c3_$i.json').read().strip().splitlines()[-1]);print(d['ms_per_step'], d['roofline']['kernel_ms'], d['training_step']['backward_ms'], d['training_step']['forward_with_record_ms'])"; done
+for i in 1 2; do timeout 200 python scripts/ubench/wl_check.py 2>&1 | grep -v amdgpu | tail -3; done
+rocm-smi --showclocks --showpower --showtemp 2>&1 | grep -v "^$" | head -30 > $out/smi_after.txt
+cat $out/smi_after.txt

@@ -1,6 +1,3 @@
-mkdir -p gpurun_out/r06prof
-for cfg in c4 c5 c2 c1; do
-  bash scripts/ubench/_round6_prof.sh r06_$cfg r06_${cfg}_fp32_rocprofv3.json "config $cfg, fp32, default kernels" --config $cfg
-done
-for cfg in c3 c5; do timeout 600 python scripts/ubench/bwd_profile_summary.py $cfg gpurun_out/r06prof/r06_${cfg}_backward_rocprofv3.json; done
-ls gpurun_out/r06prof
+out=gpurun_out/r06zx2; mkdir -p $out
+timeout 900 python -m pytest tests/test_gpu_pair_wl.py -m gpu -q -x --timeout 600 -p no:cacheprovider > $out/pytest_wl.log 2>&1; tail -4 $out/pytest_wl.log
+for i in 1 2; do timeout 200 python scripts/ubench/wl_check.py 2>&1 | grep -v amdgpu | grep "time us" ; done

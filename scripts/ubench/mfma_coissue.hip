@@ -145,6 +145,48 @@ __device__ __forceinline__ float run_role(const float* in, const int iters, floa
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     for (int i = 0; i < 8; ++i) r += t[i][0];
+  } else if constexpr (ROLE == 33) {
+    // LDS-DMA: global_load_lds_dwordx4 x 8 (cached lines) + wait; nothing returns through the vector registers
+    const unsigned off = lane * 16;
+    const unsigned ldsb = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds + (threadIdx.x >> 6) * 1024);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 offset:%3" : : "v"(off), "s"(ldsb), "s"(in), "n"(i * 512) : "memory");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    r = lds[lane];
+  } else if constexpr (ROLE == 34) {
+    // global_store_dwordx4 x 8 (the same 8 lines of this wave's own 4 KiB of `out`) + wait
+    f32x4 t = {in[lane], in[lane + 1], in[lane + 2], in[lane + 3]};
+    float* dst = in == nullptr ? nullptr : const_cast<float*>(in) + 16384 + (blockIdx.x * 8 + (threadIdx.x >> 6)) * 1024 + lane * 4;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("global_store_dwordx4 %0, %1, off offset:%2" : : "v"(dst), "v"(t), "n"(i * 512 - 2048 + 2048) : "memory");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    r = t[0];
+  } else if constexpr (ROLE == 35) {
+    // global_load_dword x 8 (256 B per instruction) + wait
+    const float* p = in + lane + 512;
+    float t[8];
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(t[i]) : "v"(p), "n"(i * 256 - 1024));
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    for (int i = 0; i < 8; ++i) r += t[i];
+  } else if constexpr (ROLE == 36) {
+    // LDS-DMA of single words: global_load_lds_dword x 8 + wait
+    const unsigned off = lane * 4;
+    const unsigned ldsb = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds + (threadIdx.x >> 6) * 1024);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, %2 offset:%3" : : "v"(off), "s"(ldsb), "s"(in), "n"(i * 256) : "memory");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    r = lds[lane];
   } else if constexpr (ROLE == 32) {
     // one dependent chain of MFMAs (the W-in-LDS kernel's burst: one accumulator)
     f16x8 a, b;
@@ -207,7 +249,7 @@ int main(int argc, char** argv) {
   printf("workgroups: %d\n", g_blocks);
   std::vector<float> h(1 << 16);
   for (auto& x : h) x = (float)rand() / RAND_MAX * 2.f - 1.f;
-  hipMalloc(&g_in, h.size() * 4); hipMalloc(&g_out, 256 * 512 * 4); hipMalloc(&g_clk, 64); hipMalloc(&g_hw, 32);
+  hipMalloc(&g_in, (h.size() + 16384 + 256 * 8 * 1024 + 4096) * 4); hipMalloc(&g_out, 256 * 512 * 4); hipMalloc(&g_clk, 64); hipMalloc(&g_hw, 32);
   hipMemcpy(g_in, h.data(), h.size() * 4, hipMemcpyHostToDevice);
   const int IA = 4000;            // x 24 MFMAs x 32 cycles = 3.07 M cycles
   run<1, 0>("A: MFMA stream alone (waves 0-3; 24 x 4000 MFMAs each)", IA, 0);
@@ -219,6 +261,8 @@ int main(int argc, char** argv) {
   printf(")\n");
   run<1, 1>("A+A: MFMA stream on both waves of a SIMD", IA, IA);
   if (quick) return 0;
+  const bool vmem_only = getenv("COISSUE_VMEM_ONLY") != nullptr;
+  if (!vmem_only) {
   run<0, 2>("B: v_fma_f32 alone (waves 4-7; 64 x 12000)", 0, 12000);
   run<1, 2>("A+B: MFMA stream | v_fma_f32 on the partner wave", IA, 12000);
   run<0, 6>("B': v_pk_fma_f32 alone (64 x 8000)", 0, 8000);
@@ -238,7 +282,9 @@ int main(int argc, char** argv) {
   run<5, 5, 8>("F8+F8: both waves, 8 v_fma_f32 behind every MFMA", IA, IA);
   run<32, 0>("G: ONE dependent MFMA chain alone (24 x 4000)", IA, 0);
   run<32, 32>("G+G: one dependent chain on both waves", IA, IA);
+  }
 #define CLASS(R, NAME, N) run<0, R>(NAME " alone", 0, N); run<1, R>("   A | " NAME, IA, N);
+  if (!vmem_only) {
   CLASS(10, "v_max3_f32", 12000)
   CLASS(11, "v_max_f32", 12000)
   CLASS(12, "v_mul_f32", 12000)
@@ -253,7 +299,12 @@ int main(int argc, char** argv) {
   CLASS(21, "v_pk_mul_f32", 8000)
   CLASS(22, "v_accvgpr_write_b32", 12000)
   CLASS(23, "v_readfirstlane_b32", 12000)
+  }
   CLASS(30, "ds_read_b128 x 8 + wait (no arithmetic)", 20000)
   CLASS(31, "global_load_dwordx4 x 8 cached + wait (no arithmetic)", 6000)
+  CLASS(33, "global_load_lds_dwordx4 x 8 cached + wait (LDS-DMA)", 6000)
+  CLASS(34, "global_store_dwordx4 x 8 + wait", 6000)
+  CLASS(35, "global_load_dword x 8 cached + wait", 6000)
+  CLASS(36, "global_load_lds_dword x 8 cached + wait (LDS-DMA)", 6000)
   return 0;
 }

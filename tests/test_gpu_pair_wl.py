@@ -157,3 +157,27 @@ def test_module_forward_takes_the_w_in_lds_schedule_on_the_headline_shape():
     take = torch.arange(0, 262144, 257)
     y_ref = oracle.forward(oracle.precompute(csd_from_cs(cs), torch.float64), x[take.cuda()].double().cpu()).numpy()[:, :, 0]
     assert np.max(rel_err_rows(y[take.cuda(), :, 0].cpu().numpy(), y_ref)) <= 1e-5
+
+
+@pytest.mark.parametrize("B", [98304 + 1, 131072 + 31, 262144 - 13])
+def test_nothing_is_written_or_used_beyond_a_ragged_batch(B, lds_schedule):
+    """The rows of the last group beyond the batch are out of range of the buffer descriptors (round 6): their loads return
+    zero and their stores are dropped by the hardware.  y and v are views of larger allocations whose tails hold a canary /
+    NaN: the canary must survive, the NaN must not be seen (nan_flag stays clear, the outputs equal the plain kernel's)."""
+    cs, layer, dp = _pack(_sets()["c3"])
+    if dp.info().mfma_f32 != 3:
+        pytest.skip("the f16-pair family does not serve this pack")
+    gen = torch.Generator(device="cuda").manual_seed(B + 5)
+    v_all = torch.full((B + 64, cs.n), float("nan"), device="cuda")
+    v_all[:B].uniform_(-1.5, 1.5, generator=gen)
+    y_all = torch.full((B + 64, cs.k), 777.0, device="cuda")
+    v = v_all[:B]
+    out = y_all[:B]
+    y, kappa, _ = ops.project_raw(v, dp, out=out)
+    assert _lib.load().rayen_last_forward_kernel() == lds_schedule
+    assert y.data_ptr() == out.data_ptr()
+    assert bool((y_all[B:] == 777.0).all()), "rows beyond the batch were written"
+    assert bool(torch.isfinite(y).all()) and bool(torch.isfinite(kappa).all())
+    y2, k2, _ = ops.project_raw(_misaligned_copy(v), dp)
+    assert _lib.load().rayen_last_forward_kernel() == _lib.KERNEL_PAIR
+    assert torch.equal(y, y2) and torch.equal(kappa, k2)
