@@ -127,24 +127,38 @@ __global__ __launch_bounds__(kBdWaves * 64, 1) void mfma_bwdd_kernel(
   // finished gradient is live, and the round trip runs under the stores and the next group's first instructions
   float vr[32], gr[32], kap_in = 0.f;
   int aseg_in = -1, arow_in = 0;
+  // Buffer addressing (rayen_mfma_pair_wl.hip, round 6): descriptors whose extent is the batch, the lane's byte offset inside
+  // a group a constant, one uniform term per group; rows beyond the batch are out of range -- loads return 0, stores are dropped
+  const __amdgpu_buffer_rsrc_t v_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(v), 0, (int)(unsigned)((uint64_t)B * (uint64_t)ldv * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t g_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gy), 0, (int)(unsigned)((uint64_t)B * (uint64_t)ldg * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t o_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(gv, 0, (int)(unsigned)((uint64_t)B * (uint64_t)ldgv * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t k_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(kappa), 0, (int)(unsigned)((uint64_t)B * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t a_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(active), 0, (int)(unsigned)((uint64_t)B * 8u), 0x00020000);
+  const unsigned v_lane_off = (unsigned)col * (unsigned)ldv * 4u + 16u * (unsigned)hi;
+  const unsigned g_lane_off = (unsigned)col * (unsigned)ldg * 4u + 16u * (unsigned)hi;
+  const unsigned o_lane_off = (unsigned)(lane >> 3) * (unsigned)ldgv * 4u + 16u * (unsigned)((lane & 7) ^ ((lane >> 3) & 7));
   auto request = [&](const int64_t g_) {
-    const int64_t row = g_ * 32 + col;
-    const bool live = row < B;
-    const float* vs = v + (live ? row : 0) * ldv + 4 * hi;
-    const float* gs = gy + (live ? row : 0) * ldg + 4 * hi;
+    const unsigned g32 = (unsigned)g_ * 32u;
+    const unsigned voff = v_lane_off + g32 * (unsigned)ldv * 4u, goff = g_lane_off + g32 * (unsigned)ldg * 4u;
+    const bool live = g_ * 32 + col < B;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      f32x4 x = {0.f, 0.f, 0.f, 0.f}, g = {0.f, 0.f, 0.f, 0.f};
-      if (live) {
-        x = *reinterpret_cast<const f32x4*>(vs + 8 * q);
-        g = *reinterpret_cast<const f32x4*>(gs + 8 * q);
-      }
+      const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, voff + 32u * q, 0, 0));
+      const f32x4 g = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, goff + 32u * q, 0, 0));
 #pragma unroll
       for (int c = 0; c < 4; ++c) { vr[4 * q + c] = x[c]; gr[4 * q + c] = g[c]; }
     }
-    kap_in = live ? kappa[row] : 0.f;
-    aseg_in = live ? active[2 * row] : -1;
-    arow_in = live ? active[2 * row + 1] : 0;
+    const unsigned roff = (g32 + (unsigned)col) * 4u;
+    kap_in = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(k_rsrc, roff, 0, 0));
+    const int a0 = (int)__builtin_amdgcn_raw_buffer_load_b32(a_rsrc, 2u * roff, 0, 0);
+    const int a1 = (int)__builtin_amdgcn_raw_buffer_load_b32(a_rsrc, 2u * roff + 4u, 0, 0);
+    aseg_in = live ? a0 : -1;
+    arow_in = a1;
   };
   if (grp < n_groups) request(grp);
 
@@ -331,6 +345,7 @@ __global__ __launch_bounds__(kBdWaves * 64, 1) void mfma_bwdd_kernel(
       RAYEN_BD_STAMP(5);   // combined
       if (next < n_groups) request(next);      // (v, g, kappa and the record of this group are dead)
       __builtin_amdgcn_sched_barrier(0);
+      const unsigned o_goff = o_lane_off + (unsigned)grp * 32u * (unsigned)ldgv * 4u;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -348,9 +363,9 @@ __global__ __launch_bounds__(kBdWaves * 64, 1) void mfma_bwdd_kernel(
           for (int i = 0; i < SR / 8; ++i) {
             const int r = 8 * i + (lane >> 3);
             const f32x4 x = *reinterpret_cast<const f32x4*>(stage + r * 128 + (lane & 7) * 16);
-            const int64_t srow = grp * 32 + part16 * SR + r;
-            if (srow < B)
-              __builtin_nontemporal_store(x, reinterpret_cast<f32x4*>(gv + srow * ldgv + 32 * h + 4 * ((lane & 7) ^ (r & 7))));
+            (void)r;   // (row (lane >> 3) of the eight, slot (lane & 7) ^ (row & 7): o_lane_off)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), o_rsrc,
+                                                   o_goff + (unsigned)(part16 * SR + 8 * i) * (unsigned)ldgv * 4u + 128u * h, 0, 2);
           }
           __builtin_amdgcn_wave_barrier();
         }
@@ -473,6 +488,9 @@ bool mfma_bwdd_serves(const RayenPack* p, const MfmaBwddImage* img, const float*
   if (img == nullptr || !img->ready) return false;
   auto aligned = [](const void* ptr, int64_t ld) { return (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(ptr) & 15) == 0); };
   if (!aligned(v, ldv) || !aligned(gy, ldg) || !aligned(gv, ldgv)) return false;
+  // (buffer addressing with 32-bit byte offsets; the rows of the ragged last group beyond the batch must not wrap)
+  auto fits = [&](int64_t ld) { return (uint64_t)(B + 64) * (uint64_t)ld * 4u < (1ull << 32); };
+  if (!fits(ldv) || !fits(ldg) || !fits(ldgv)) return false;
   // one workgroup per CU copies ~130 KiB first: from a group per resident wave on
   return (B + 31) / 32 >= (int64_t)(img->n_simd / 4) * kBdWaves;
 }
