@@ -49,6 +49,12 @@ constexpr int kWlNT = RAYEN_WL_NT;            // sample tiles (of 32) per wave a
 #ifndef RAYEN_WL_ABL
 #define RAYEN_WL_ABL 0
 #endif
+// bit 0: the image is copied by LDS-DMA (0: through registers) | bit 1: a wave's first rows are pulled towards L2 meanwhile
+// (config 3, B = 262 144, gpurun_out/r06zza: 0 -> 46.1-46.6 us, 1 -> 45.3-45.9, 2 -> 47.4-49.4: the extra requests cost more than the
+// round trip they hide)
+#ifndef RAYEN_WL_HEAD
+#define RAYEN_WL_HEAD 1
+#endif
 template <int NKK> struct WlGeom { static constexpr int AUXR = NKK == 2 ? 8 : 32; };
 // a wave's own LDS: the aux patch during the walk ([sample tile][aux row][sample]), then the 4 KiB through which its rows of
 // y leave as whole 128-byte lines (32 rows x one line)
@@ -59,6 +65,17 @@ template <int NKK> struct WlGeom { static constexpr int AUXR = NKK == 2 ? 8 : 32
 constexpr int wl_stage_rows(int nt) { return RAYEN_WL_SR ? RAYEN_WL_SR : (nt == 1 ? 16 : 32); }
 constexpr int wl_region_bytes(int nkk, int nt) {
   return nt * WlGeom<2>::AUXR * 128 * (nkk == 2 ? 1 : 4) > wl_stage_rows(nt) * 128 ? nt * WlGeom<2>::AUXR * 128 * (nkk == 2 ? 1 : 4) : wl_stage_rows(nt) * 128;
+}
+// one LDS-DMA: every lane fetches 16 bytes from gbase + voff; lane L lands at LDS byte lds + 16 L.  Nothing returns through the
+// vector registers -- by scripts/ubench/mfma_coissue.hip such loads run beside a partner wave's MFMAs, register loads do not.
+// (M0 = the LDS base; written in the statement that reads it, restored behind it)
+__device__ __forceinline__ void wl_dma16(const char* gbase, const unsigned voff, const unsigned lds) {
+  unsigned keep;
+  uint64_t asm_base;
+  asm volatile(RAYEN_ASM_BASE_COPY "s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[off], " RAYEN_ASM_BASE "\n\ts_mov_b32 m0, %[k]"
+               : [k] "=&s"(keep), [b] "=&s"(asm_base)
+               : [off] "v"(voff), [base] "s"(gbase), [lds] "s"(lds)
+               : "memory");
 }
 }  // namespace
 
@@ -129,17 +146,19 @@ __global__ __launch_bounds__(NW * 64, 1) void mfma_pair_wl_kernel(
   }
 #endif
 
-  // ---- the image, once: chunk c (1 KiB) by wave c mod NW, requested in front of the wave's first rows (loads retire in
-  // order: the copy must not wait behind an HBM round trip)
+  // ---- the image, once: chunk c (1 KiB) by wave c mod NW, by LDS-DMA (RAYEN_WL_HEAD; nothing passes through the registers, nothing
+  // is waited for before the barrier).  See below the request lambda for the rest of the head.
+  for (int i = threadIdx.x; i < NKK * 32; i += NW * 64) y0_lds[i] = y0[i];
+  if (threadIdx.x == 0) *take_lds = NW;     // (the first NW are the waves' first groups)
+#if !(RAYEN_WL_HEAD & 1)
   {
     const int n_chunks = n_tiles * NCH;
     const char* src = reinterpret_cast<const char*>(Wh) + lane * 16;
 #pragma unroll 4
     for (int c = wave; c < n_chunks; c += NW)
       *reinterpret_cast<u32x4*>(wimg + c * 1024 + lane * 16) = *reinterpret_cast<const u32x4*>(src + (size_t)c * 1024);
-    for (int i = threadIdx.x; i < NKK * 32; i += NW * 64) y0_lds[i] = y0[i];
-    if (threadIdx.x == 0) *take_lds = NW;     // (the first NW are the waves' first groups)
   }
+#endif
 
   // this lane's rows of group g (one per sample tile): pieces 2 q + hi (columns 8 q + 4 hi .. + 3), zero beyond the batch.
   // Buffer addressing (round 6, from the ISA: the 64-bit `row * ldv` products, the predicates and the zeroing of the flat form
@@ -179,6 +198,30 @@ __global__ __launch_bounds__(NW * 64, 1) void mfma_pair_wl_kernel(
   };
 #pragma unroll
   for (int t = 0; t < NT; ++t) m_half[t] = 0.f;
+#if RAYEN_WL_HEAD
+  {
+    // the image's chunks, then -- behind them, loads retire in order -- the wave's first rows, pulled towards L2 into the wave's own
+    // (still unused) kilobyte and thrown away: the group's real request at the top of the walk finds the lines in L2 instead of
+    // paying an HBM round trip behind the barrier.  Whole groups only (this path has no bounds).  Only the image is waited for.
+    const int n_chunks = n_tiles * NCH;
+    const unsigned img_at = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(wimg));
+    const unsigned lane16 = lane * 16;
+    if (RAYEN_WL_HEAD & 1)
+      for (int c = wave; c < n_chunks; c += NW)
+        wl_dma16(reinterpret_cast<const char*>(Wh) + (size_t)c * 1024, lane16, img_at + c * 1024);
+    if ((RAYEN_WL_HEAD & 2) && (grp + 1) * (NT * 32) <= B) {
+      const char* gb = reinterpret_cast<const char*>(v + grp * (NT * 32) * ldv);
+      const unsigned lds_at = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(stage));
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) wl_dma16(gb, v_lane_off + (unsigned)t * 32u * (unsigned)ldv * 4u + 32u * q, lds_at);
+      asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NT * NQ) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+#endif
   if (RAYEN_WL_AHEAD && grp < n_groups) {
     request(grp);
     half_max();
