@@ -143,7 +143,9 @@ def _oracle_forward_uncached(cs, x_cpu, dtype):
         pick = np.unique(np.concatenate((np.flatnonzero(bad64)[:None if over_cap else BISECTED_ROWS], pick)))
         indep = _ray_bisection_truth(cs, x64[pick][:, :cs.n, 0].numpy())
         gap = rel_err_rows(truth[pick], indep)
-        assert gap.max() <= 1e-8, ("replacement rows against bisection on the raw constraints", gap.max())
+        # (the fp64 op sequence takes the square root of a radicand that cancels to ~1e-16 of its terms: where such a form is the
+        # active one its kappa carries ~1e-8, seen up to 4.5e-8 on one GPU box's host -- two orders inside the 1e-5 bar this truth backs)
+        assert gap.max() <= 5e-7, ("replacement rows against bisection on the raw constraints", gap.max())
         print(f"\n  [oracle NaN rows] {len(rows)} / {len(bad)} at {str(dtype)[6:]} take the fp64 ORACLE rounded; of those "
               f"{int(bad64.sum())} ({bad64.sum() / len(bad):.2%} of the batch, cap {SUBSTITUTED_CAP:.0%}"
               f"{': EXCEEDED on this host, every such row bisected' if over_cap else ''}) are NaN at fp64 too and "
