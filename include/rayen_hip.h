@@ -157,14 +157,14 @@ enum {
   RAYEN_KERNEL_PAIR_WS = 8,   /* f16 pairs, W-stationary (ABI v6): the tiles of W resident in the registers of a workgroup's eight
                                  waves, the batch streamed through a shared B-operand image in LDS */
   RAYEN_KERNEL_PRODUCTS = 9,  /* wide sets (ABI v7): the epilogue over products T = v W_ext' of a library GEMM */
-  RAYEN_KERNEL_PAIR_WL = 11,  /* f16 pairs, the image of W resident in LDS, three waves per SIMD on groups of 32 samples (round 6) */
+  RAYEN_KERNEL_PAIR_WL = 11,  /* f16 pairs, the image of W resident in LDS, four waves per SIMD on groups of 32 samples (round 6) */
   RAYEN_KERNEL_LMI_BLOCK = 10 /* one workgroup per sample, the packed lower triangle in LDS (one LMI to ~280 x 280 + linear rows; round 5) */
 };
 int rayen_last_forward_kernel(void);
 
 /* Tuning / A-B switch (ABI v4, process-wide): which SCHEDULE of the f16-pair forward serves the calls whose shape
  * allows it -- 3 (default since ABI v8 / round 6): the image of W resident in LDS (NA_E = I, n = k = 32 or 64, the image
- * within 160 KiB, B >= 98 304 on MI355X), else as 1 | 1 (the default of ABI v4-v7): rows of v and y trickled through LDS
+ * within 160 KiB, rows 16-byte aligned and within 4 GiB; every batch size), else as 1 | 1 (the default of ABI v4-v7): rows of v and y trickled through LDS
  * under the tile walk for batches that give every resident wave a group (B >= 131 072 on MI355X), the W-stationary kernel
  * for 32 768 <= B < 131 072 where it serves the pack (ABI v7), else the plain kernel | 0: always the plain kernel |
  * 2 (ABI v6): the W-stationary kernel wherever it serves, else as 1.  All compute the same values bit for bit.  Initial

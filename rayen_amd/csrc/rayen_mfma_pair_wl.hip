@@ -549,11 +549,14 @@ bool mfma_pair_wl_serves(const RayenPack* p, const PairImage* img, const float* 
   if ((reinterpret_cast<uintptr_t>(v) & 15) != 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0) return false;
   if (img->nkk == 2 && img->aux_rows > WlGeom<2>::AUXR) return false;
   if (pair_wl_lds_bytes(img) > 160 * 1024) return false;
-  // one workgroup per CU copies the image first (3 us): measured against the other schedules on config 3 (gpurun_out/r06za) it
-  // wins from three quarters of a group per resident wave on -- B = 98 304: 21.8 against 28.4 us, 196 608: 40.7 / 48.4,
-  // 262 144: 49.3 / 53.1, 524 288: 92.7 / 100 -- ties at half a group (65 536: 20.2 / 20.7) and loses below (32 768: 20.1 / 12.9)
+  // Every batch size (round 6, gpurun_out/r06zzd, r06zze; config 3, us per call): the grid is one workgroup per CU as soon as there is
+  // a group for it, so a small batch leaves most waves of a workgroup idle and its busy waves alone on their SIMDs --
+  //   B = 32: 10.7 (plain 15.6) | 4 096: 11.3 (18.6) | 32 768: 13.6 (19.3) | 65 536: 15.9 (20.9, W-stationary) | 98 304: 20.5 (24.9) | 131 072: 25.5 (29.7)
+  // (the other schedules pull the 112 KiB image through every wave's vector-memory path from L2; here one copy per CU, then LDS).
+  // Until the grid covered every CU (it was n_groups / 16 workgroups) this schedule lost below 98 304 rows.
   const int64_t n_groups = (B + kWlNT * 32 - 1) / (kWlNT * 32);
-  return 4 * n_groups >= 3 * (int64_t)(img->n_simd / 4) * kWlWaves;
+  static const int64_t min_groups_env = [] { const char* e = getenv("RAYEN_WL_MIN_GROUPS"); return e ? atoll(e) : 1ll; }();   // developer sweeps
+  return n_groups >= min_groups_env;
 }
 
 // called by rayen_pack_create (the only place that may touch function attributes)
@@ -585,7 +588,9 @@ int mfma_pair_wl_forward(const RayenPack* p, const PairImage* img, const float* 
   if (!mfma_pair_wl_serves(p, img, v, B, ldv, y, ldy)) return RAYEN_E_UNSUPPORTED;
   const int64_t n_groups = (B + kWlNT * 32 - 1) / (kWlNT * 32);
   const int64_t cus = launch_simds(img->n_simd) / 4;
-  const unsigned grid = (unsigned)std::min<int64_t>(cus, (n_groups + kWlWaves - 1) / kWlWaves);   // one workgroup per CU
+  // one workgroup per CU; every CU takes part as soon as there is a group for it (a workgroup whose waves have no group of their own
+  // to start with just leaves them idle: two busy waves on a SIMD run twice as fast as four)
+  const unsigned grid = (unsigned)std::min<int64_t>(cus, n_groups);
   const int lds = pair_wl_lds_bytes(img);
   auto go = [&](auto kern) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kWlWaves * 64), lds, stream, static_cast<const f16x8*>(img->Wh), img->items,

@@ -56,8 +56,10 @@ def test_the_w_in_lds_schedule_is_the_default():
     assert _lib.load().rayen_pair_schedule(-1) == 3
 
 
-# a group = 32 rows; 256 CUs x 16 waves: B = 131072 is one group per wave; the schedule serves from 98304 on
-@pytest.mark.parametrize("B", [98304, 98304 + 17, 131072, 131072 + 32 * 5 + 11, 262144, 262144 - 1, 393216 + 29, 1048576 + 3])
+# a group = 32 rows; 256 CUs x 16 waves: B = 131072 is one group per wave; the schedule serves every batch size (one workgroup
+# per CU as soon as there is a group for it: below 4 096 groups some waves, below 256 some CUs have nothing to do)
+@pytest.mark.parametrize("B", [1, 31, 33, 1000, 4096 + 7, 8192, 32768 + 5, 65536, 98304, 98304 + 17, 131072, 131072 + 32 * 5 + 11,
+                               262144, 262144 - 1, 393216 + 29, 1048576 + 3])
 @pytest.mark.parametrize("name", ["c3", "n32", "n32_many_aux"])
 @pytest.mark.parametrize("want_active", [False, True])
 def test_w_in_lds_equals_the_plain_pair_kernel_bit_for_bit(name, B, want_active, lds_schedule):
@@ -85,13 +87,17 @@ def test_w_in_lds_equals_the_plain_pair_kernel_bit_for_bit(name, B, want_active,
     assert np.max(rel_err_rows(y1[take.cuda()].cpu().numpy(), y_ref)) <= 1e-5
 
 
-def test_below_its_threshold_the_other_schedules_serve(lds_schedule):
+def test_small_batches_are_served_too_and_what_it_cannot_address_is_not(lds_schedule):
+    """Round 6: no batch threshold any more (a small batch leaves waves idle, it does not lose: DESIGN.md 4.0).  What the
+    buffer descriptors cannot address (4 GiB of rows) and rows that are not 16-byte aligned go to the other schedules."""
     cs, layer, dp = _pack(_sets()["c3"])
     if dp.info().mfma_f32 != 3:
         pytest.skip("the f16-pair family does not serve this pack")
-    for B, fams in ((4096, (_lib.KERNEL_PAIR,)), (65536, (_lib.KERNEL_PAIR_WS, _lib.KERNEL_PAIR))):
+    for B in (1, 64, 4096, 65536):
         v = torch.empty(B, cs.n, device="cuda").uniform_(-1.5, 1.5)
-        assert _run(dp, v, False)[3] in fams, B
+        assert _run(dp, v, False)[3] == lds_schedule, B
+    v = torch.empty(4096, cs.n, device="cuda").uniform_(-1.5, 1.5)
+    assert _run(dp, _misaligned_copy(v), False)[3] == _lib.KERNEL_PAIR
 
 
 @pytest.mark.parametrize("name", ["c3", "n32"])
