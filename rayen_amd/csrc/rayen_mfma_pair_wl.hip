@@ -544,8 +544,8 @@ bool mfma_pair_wl_serves(const RayenPack* p, const PairImage* img, const float* 
   if (img == nullptr || img->nkk < 1 || img->nkk > 2 || img->n_tiles <= 0 || !img->wl_ready) return false;
   if (!img->identity || p->n != img->nkk * 32 || p->k != p->n) return false;
   if ((ldv % 4) != 0 || (ldy % 4) != 0) return false;
-  // (buffer addressing with 32-bit byte offsets; the rows of the ragged last group beyond the batch must not wrap)
-  if ((uint64_t)(B + 64) * (uint64_t)ldv * 4u >= (1ull << 32) || (uint64_t)(B + 64) * (uint64_t)ldy * 4u >= (1ull << 32)) return false;
+  // (buffer addressing with 32-bit byte offsets: mfma_pair_wl_forward cuts a batch beyond 4 GiB of rows into several launches)
+  if (ldv > (1 << 22) || ldy > (1 << 22)) return false;
   if ((reinterpret_cast<uintptr_t>(v) & 15) != 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0) return false;
   if (img->nkk == 2 && img->aux_rows > WlGeom<2>::AUXR) return false;
   if (pair_wl_lds_bytes(img) > 160 * 1024) return false;
@@ -586,23 +586,34 @@ int mfma_pair_wl_forward(const RayenPack* p, const PairImage* img, const float* 
                          hipStream_t stream) {
   if (B == 0) return RAYEN_OK;
   if (!mfma_pair_wl_serves(p, img, v, B, ldv, y, ldy)) return RAYEN_E_UNSUPPORTED;
-  const int64_t n_groups = (B + kWlNT * 32 - 1) / (kWlNT * 32);
   const int64_t cus = launch_simds(img->n_simd) / 4;
-  // one workgroup per CU; every CU takes part as soon as there is a group for it (a workgroup whose waves have no group of their own
-  // to start with just leaves them idle: two busy waves on a SIMD run twice as fast as four)
-  const unsigned grid = (unsigned)std::min<int64_t>(cus, n_groups);
   const int lds = pair_wl_lds_bytes(img);
-  auto go = [&](auto kern) {
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWlWaves * 64), lds, stream, static_cast<const f16x8*>(img->Wh), img->items,
-                       img->n_items, img->packs, img->y0, img->n_tiles, v, B, ldv, y, ldy, kappa, active, nan_flag,
-                       img->w_scale, img->w_inv);
-  };
-  if (img->nkk == 1) {
-    if (active != nullptr) go(mfma_pair_wl_kernel<1, true, kWlNT, kWlWaves>);
-    else go(mfma_pair_wl_kernel<1, false, kWlNT, kWlWaves>);
-  } else {
-    if (active != nullptr) go(mfma_pair_wl_kernel<2, true, kWlNT, kWlWaves>);
-    else go(mfma_pair_wl_kernel<2, false, kWlNT, kWlWaves>);
+  // The descriptors address 32-bit byte offsets, and the rows of a ragged last group beyond the batch must not wrap: a
+  // batch whose rows span more than that goes out as several launches over whole groups (same groups, same bits).
+  const int64_t ld_max = std::max<int64_t>(std::max(ldv, ldy), 1);
+  const int64_t rows_max = (((int64_t)0xFFFFFFFFll / (ld_max * 4)) - 64) / (kWlNT * 32) * (kWlNT * 32);
+  for (int64_t r0 = 0; r0 < B; r0 += rows_max) {
+    const int64_t Bc = std::min(B - r0, rows_max);
+    const int64_t n_groups = (Bc + kWlNT * 32 - 1) / (kWlNT * 32);
+    // one workgroup per CU; every CU takes part as soon as there is a group for it (a workgroup whose waves have no group of their own
+    // to start with just leaves them idle: two busy waves on a SIMD run twice as fast as four)
+    const unsigned grid = (unsigned)std::min<int64_t>(cus, n_groups);
+    const float* vc = v + r0 * ldv;
+    float* yc = y + r0 * ldy;
+    float* kc = kappa ? kappa + r0 : nullptr;
+    int32_t* ac = active ? active + 2 * r0 : nullptr;
+    auto go = [&](auto kern) {
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(kWlWaves * 64), lds, stream, static_cast<const f16x8*>(img->Wh), img->items,
+                         img->n_items, img->packs, img->y0, img->n_tiles, vc, Bc, ldv, yc, ldy, kc, ac, nan_flag,
+                         img->w_scale, img->w_inv);
+    };
+    if (img->nkk == 1) {
+      if (active != nullptr) go(mfma_pair_wl_kernel<1, true, kWlNT, kWlWaves>);
+      else go(mfma_pair_wl_kernel<1, false, kWlNT, kWlWaves>);
+    } else {
+      if (active != nullptr) go(mfma_pair_wl_kernel<2, true, kWlNT, kWlWaves>);
+      else go(mfma_pair_wl_kernel<2, false, kWlNT, kWlWaves>);
+    }
   }
   return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
 }

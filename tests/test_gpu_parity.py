@@ -658,6 +658,11 @@ def test_batches_beyond_2_31_elements(name, dtype):
     windows = [(0, 700), (mark - 650, mark + 650), (B - 1037, B)]
     y, kappa, active = ops.project_raw(v, dp, want_active=True)
     assert y.shape == (B, cs.k) and min(y.numel(), v.numel()) > (1 << 31)
+    if name == "c3" and dtype == torch.float32 and dp.info().mfma_f32 == 3:
+        # (round 6: the W-in-LDS schedule addresses rows through 32-bit buffer offsets and cuts a batch beyond 4 GiB into
+        # launches over whole groups; the window around the 2^31-element mark straddles such a cut)
+        from rayen_amd import _lib
+        assert _lib.load().rayen_last_forward_kernel() == _lib.KERNEL_PAIR_WL
     # config 4: the big batch runs lane-per-sample, a window of 700 rows four lanes per sample -- two
     # algorithms for lambda_max, equal to fp32 accuracy but not bit for bit
     exact = name != "c4"
