@@ -23,6 +23,8 @@
 #include "rayen_bwd_tiles.h"
 #include "rayen_split_image.h"
 
+#include <cstdlib>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -491,8 +493,11 @@ bool mfma_bwdd_serves(const RayenPack* p, const MfmaBwddImage* img, const float*
   // (buffer addressing with 32-bit byte offsets; the rows of the ragged last group beyond the batch must not wrap)
   auto fits = [&](int64_t ld) { return (uint64_t)(B + 64) * (uint64_t)ld * 4u < (1ull << 32); };
   if (!fits(ldv) || !fits(ldg) || !fits(ldgv)) return false;
-  // one workgroup per CU copies ~130 KiB first: from a group per resident wave on
-  return (B + 31) / 32 >= (int64_t)(img->n_simd / 4) * kBdWaves;
+  // Every batch size (round 6, gpurun_out/r06zzh; config 3, ms per call): one workgroup per CU as soon as there is a group for it --
+  //   B = 1 024: 0.012 (bucketed exact-fp32 walk: 0.072) | 16 384: 0.014 (0.076) | 32 768: 0.015 (0.039) | 65 536: 0.021 (0.043) | 131 072: 0.035 (0.068)
+  // (the bucketed walk pays three launches and a pass over the batch per bucket whatever the batch).
+  static const int64_t min_groups_env = [] { const char* e = getenv("RAYEN_BWDD_MIN_GROUPS"); return e ? atoll(e) : 1ll; }();   // developer sweeps
+  return (B + 31) / 32 >= min_groups_env;
 }
 
 int mfma_bwdd_backward(const RayenPack* p, const MfmaBwddImage* img, const float* v, int64_t B, int64_t ldv,
@@ -503,7 +508,7 @@ int mfma_bwdd_backward(const RayenPack* p, const MfmaBwddImage* img, const float
   if (img == nullptr || !img->ready) return RAYEN_E_UNSUPPORTED;
   const int64_t n_groups = (B + 31) / 32;
   const int64_t cus = launch_simds(img->n_simd) / 4;
-  const unsigned grid = (unsigned)std::min<int64_t>(cus, (n_groups + kBdWaves - 1) / kBdWaves);
+  const unsigned grid = (unsigned)std::min<int64_t>(cus, n_groups);   // (every CU as soon as there is a group for it: rayen_mfma_pair_wl.hip)
   hipLaunchKernelGGL((mfma_bwdd_kernel<false>), dim3(grid), dim3(kBdWaves * 64), img->lds_bytes, stream, img->Sh, img->items,
                      img->n_tiles, img->n_dense, img->Wrow, img->lin_lo, img->lin_n, v, B, ldv, kappa, active, grad_y, ldg,
                      grad_v, ldgv, img->s_inv);

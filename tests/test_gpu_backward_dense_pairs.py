@@ -52,7 +52,7 @@ def test_dense_pair_backward_is_fp32_grade(name):
     exact = _pack.DevicePack(layer.packed_constants(), 0, fp32_mode=1)            # the exact-fp32 kernels, forward and backward
     assert exact.info().bwd_f32 == 1
     dp64, _ = layer64.device_pack(dev)
-    B = 65536 + 4096 + 37                                                        # (served from a group per resident wave on)
+    B = 65536 + 4096 + 37
     gen = torch.Generator().manual_seed(17)
     v = torch.empty(B, cs.n).uniform_(-1.5, 1.5, generator=gen)
     v[:64] *= 1e-4                                                               # interior: the gradient is g itself
@@ -107,9 +107,10 @@ def test_dense_pair_backward_equals_itself_in_every_addressing_mode(B):
     assert float(((flat - lane).abs().amax(dim=1) / size).max()) <= 2e-5
 
 
-def test_small_batches_and_misaligned_rows_stay_on_the_exact_kernel():
-    """Below a group per resident wave the workgroup's copy of the forms is not worth it, and rows that are not 16-byte
-    aligned cannot be read as pieces: the bucketed exact-fp32 kernel serves, same gradients to fp32 rounding."""
+def test_small_batches_are_served_too_and_misaligned_rows_stay_on_the_exact_kernel():
+    """Round 6: no batch threshold (one workgroup per CU as soon as there is a group for it: 0.012 ms at B = 1 024 against 0.072
+    for the bucketed walk) -- a slice of a batch gives the slice of its gradient bit for bit (rows are independent); rows that
+    are not 16-byte aligned cannot be read as pieces: the bucketed exact-fp32 kernel serves them, same gradients to fp32 rounding."""
     cs, layer, _ = _layers(_sets()["c3"])
     dp, _ = layer.device_pack(torch.device("cuda", 0))
     gen = torch.Generator().manual_seed(5)
@@ -118,9 +119,13 @@ def test_small_batches_and_misaligned_rows_stay_on_the_exact_kernel():
     g = torch.empty(B, cs.k).uniform_(-1, 1, generator=gen).cuda()
     _, kappa, active = ops.project_raw(v, dp, want_active=True)
     big = ops.backward_raw(v, kappa, active, g, dp)
-    small = ops.backward_raw(v[:4096], kappa[:4096], active[:4096], g[:4096], dp)
-    size = big[:4096].abs().amax(dim=1).clamp_min(1e-30)
-    assert float(((small - big[:4096]).abs().amax(dim=1) / size).max()) <= 2e-5
+    for lo, hi in ((0, 4096), (0, 1), (33, 64), (5000, 5000 + 1037)):
+        small = ops.backward_raw(v[lo:hi].clone(), kappa[lo:hi].clone(), active[lo:hi].clone(), g[lo:hi].clone(), dp)
+        assert torch.equal(small, big[lo:hi]), (lo, hi)
+    exact = _pack.DevicePack(layer.packed_constants(), 0, fp32_mode=1)
+    ref = ops.backward_raw(v[:4096], kappa[:4096], active[:4096], g[:4096], exact)
+    size = ref.abs().amax(dim=1).clamp_min(1e-30)
+    assert float(((big[:4096] - ref).abs().amax(dim=1) / size).max()) <= 2e-5
     buf = torch.empty(B * cs.n + 4, device="cuda")
     w = buf[1:1 + B * cs.n].view(B, cs.n)
     w.copy_(v)
