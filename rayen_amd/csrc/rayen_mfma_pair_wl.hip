@@ -19,7 +19,7 @@
 //     SALU / LDS instructions issue while a wave's MFMAs execute -- and the first rows a wave waits for are 8 KiB, not 16.
 // The item list, the image, the epilogues and the order of the products inside a tile are the other schedules': same bits.
 //
-// Served: NA_E = I, n = k = 32 NKK, rows 16-byte aligned, the image + the aux patches within 160 KiB of LDS, at most
+// Served: NA_E = I, n = k in (32 (NKK - 1), 32 NKK] and a multiple of 4, rows 16-byte aligned, the image + the aux patches within 160 KiB of LDS, at most
 // AUXR aux rows at NKK = 2.  Everything else stays on the other schedules.
 #include "rayen_split_image.h"
 
@@ -109,7 +109,7 @@ extern "C" int rayen_debug_wl_clock(void* dst, size_t bytes) {
 template <int NKK, bool TRACK, int NT, int NW>
 __global__ __launch_bounds__(NW * 64, 1) void mfma_pair_wl_kernel(
     const f16x8* __restrict__ Wh, const MItem* __restrict__ items, int n_items,
-    const MPack* __restrict__ packs, const float* __restrict__ y0, int n_tiles,
+    const MPack* __restrict__ packs, const float* __restrict__ y0, int n_tiles, int n,
     const float* __restrict__ v, int64_t B, int64_t ldv, float* __restrict__ y, int64_t ldy,
     float* __restrict__ kappa_out, int32_t* __restrict__ active_out,
     int32_t* __restrict__ nan_flag, const float w_scale, const float w_inv) {
@@ -172,13 +172,20 @@ __global__ __launch_bounds__(NW * 64, 1) void mfma_pair_wl_kernel(
   const unsigned v_lane_off = (unsigned)col * (unsigned)ldv * 4u + 16u * (unsigned)hi;
   const unsigned y_lane_off = (unsigned)(lane >> 3) * (unsigned)ldy * 4u + 16u * (unsigned)((lane & 7) ^ ((lane >> 3) & 7));
   f32x4 vraw[NT][NQ];
+  // n = k below the padded width (a multiple of 4: whole pieces): the pieces beyond a row's n columns would be the next row's --
+  // their offset is sent out of range instead (loads return 0, stores are dropped), one select per piece
+  const bool ragged_n = n < NKK * 32;
+  constexpr unsigned kNowhere = 0xFFFFFFF0u;
   auto request = [&](const int64_t g) {
     const unsigned goff = v_lane_off + (unsigned)g * (unsigned)(NT * 32) * (unsigned)ldv * 4u;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int q = 0; q < NQ; ++q)
-        vraw[t][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, goff + (unsigned)t * 32u * (unsigned)ldv * 4u + 32u * q, 0, 0));
+      for (int q = 0; q < NQ; ++q) {
+        unsigned off = goff + (unsigned)t * 32u * (unsigned)ldv * 4u + 32u * q;
+        if (ragged_n) off = (8 * q + 4 * hi < n) ? off : kNowhere;
+        vraw[t][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, off, 0, 0));
+      }
   };
   // largest |component| of the requested rows (this lane's half of each): the FIRST use of the rows' registers.  It sits in
   // front of the previous group's stores of y -- vmcnt retires in order and counts stores, so a wait for these loads that
@@ -510,7 +517,8 @@ __global__ __launch_bounds__(NW * 64, 1) void mfma_pair_wl_kernel(
             const int r = 8 * i + (lane >> 3);
             const f32x4 x = *reinterpret_cast<const f32x4*>(stage + r * 128 + (lane & 7) * 16);
             // row (lane >> 3) of the eight, slot (lane & 7) ^ (row & 7): the lane's constant; rows beyond the batch are dropped
-            const unsigned off = y_goff + (unsigned)(t * 32 + part * SR + 8 * i) * (unsigned)ldy * 4u + 128u * h;
+            unsigned off = y_goff + (unsigned)(t * 32 + part * SR + 8 * i) * (unsigned)ldy * 4u + 128u * h;
+            if (ragged_n) off = (32 * h + 4 * ((lane & 7) ^ ((lane >> 3) & 7)) < n) ? off : kNowhere;
             if constexpr (RAYEN_WL_ABL & 2) { if (x[0] == 123.456f) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), y_rsrc, off, 0, 0); }
             else if constexpr (RAYEN_WL_ABL & 8) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), y_rsrc, off, 0, 0);
             else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), y_rsrc, off, 0, 2);   // (2: non-temporal)
@@ -542,7 +550,9 @@ static int pair_wl_lds_bytes(const PairImage* img) {
 bool mfma_pair_wl_serves(const RayenPack* p, const PairImage* img, const float* v, int64_t B, int64_t ldv,
                          const float* y, int64_t ldy) {
   if (img == nullptr || img->nkk < 1 || img->nkk > 2 || img->n_tiles <= 0 || !img->wl_ready) return false;
-  if (!img->identity || p->n != img->nkk * 32 || p->k != p->n) return false;
+  // (n = k: the padded width or, round 6, anything down to the next narrower instance in whole 16-byte pieces -- config 2's 16)
+  if (!img->identity || p->k != p->n || p->n > img->nkk * 32 || p->n <= (img->nkk - 1) * 32 || (p->n % 4) != 0) return false;
+  if (ldv < p->n || ldy < p->n) return false;
   if ((ldv % 4) != 0 || (ldy % 4) != 0) return false;
   // (buffer addressing with 32-bit byte offsets: mfma_pair_wl_forward cuts a batch beyond 4 GiB of rows into several launches)
   if (ldv > (1 << 22) || ldy > (1 << 22)) return false;
@@ -604,7 +614,7 @@ int mfma_pair_wl_forward(const RayenPack* p, const PairImage* img, const float* 
     int32_t* ac = active ? active + 2 * r0 : nullptr;
     auto go = [&](auto kern) {
       hipLaunchKernelGGL(kern, dim3(grid), dim3(kWlWaves * 64), lds, stream, static_cast<const f16x8*>(img->Wh), img->items,
-                         img->n_items, img->packs, img->y0, img->n_tiles, vc, Bc, ldv, yc, ldy, kc, ac, nan_flag,
+                         img->n_items, img->packs, img->y0, img->n_tiles, p->n, vc, Bc, ldv, yc, ldy, kc, ac, nan_flag,
                          img->w_scale, img->w_inv);
     };
     if (img->nkk == 1) {

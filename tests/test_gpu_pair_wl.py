@@ -28,6 +28,12 @@ def _sets():
         "c3": workloads.make_raw("c3", seed=7),                                                   # n = 64: shared tiles, 8 aux rows
         "n32": workloads.random_lin_quad_soc(k=32, m=300, n_quad=3, n_soc=2, seed=17),            # n = 32
         "n32_many_aux": workloads.random_lin_quad_soc(k=32, m=200, n_quad=12, n_soc=3, seed=18),  # 18 aux rows
+        # n = k below the padded width, in whole 16-byte pieces (round 6): the pieces beyond a row's n columns are out of range
+        "c2": workloads.make_raw("c2", seed=1),                                                   # n = 16 (BASELINE configs[1])
+        "n20": workloads.random_lin_quad_soc(k=20, m=90, n_quad=2, n_soc=1, seed=21),
+        "n28": workloads.random_lin_quad_soc(k=28, m=64, n_quad=3, n_soc=0, seed=22),
+        "n36": workloads.random_lin_quad_soc(k=36, m=100, n_quad=2, n_soc=1, seed=23),            # NKK = 2, 36 of 64 columns
+        "n60": workloads.random_lin_quad_soc(k=60, m=128, n_quad=3, n_soc=2, seed=24),
     }
 
 
@@ -60,11 +66,13 @@ def test_the_w_in_lds_schedule_is_the_default():
 # per CU as soon as there is a group for it: below 4 096 groups some waves, below 256 some CUs have nothing to do)
 @pytest.mark.parametrize("B", [1, 31, 33, 1000, 4096 + 7, 8192, 32768 + 5, 65536, 98304, 98304 + 17, 131072, 131072 + 32 * 5 + 11,
                                262144, 262144 - 1, 393216 + 29, 1048576 + 3])
-@pytest.mark.parametrize("name", ["c3", "n32", "n32_many_aux"])
+@pytest.mark.parametrize("name", ["c3", "n32", "n32_many_aux", "c2", "n20", "n28", "n36", "n60"])
 @pytest.mark.parametrize("want_active", [False, True])
 def test_w_in_lds_equals_the_plain_pair_kernel_bit_for_bit(name, B, want_active, lds_schedule):
     if name != "c3" and B > 300000:
         pytest.skip("the round structures are covered on c3")
+    if name in ("n20", "n28", "n36", "n60", "c2") and B not in (1, 33, 4096 + 7, 65536, 131072 + 32 * 5 + 11):
+        pytest.skip("the ragged widths are covered on five batch shapes")
     cs, layer, dp = _pack(_sets()[name])
     if dp.info().mfma_f32 != 3:
         pytest.skip("the f16-pair family does not serve this pack")
@@ -100,7 +108,7 @@ def test_small_batches_are_served_too_and_what_it_cannot_address_is_not(lds_sche
     assert _run(dp, _misaligned_copy(v), False)[3] == _lib.KERNEL_PAIR
 
 
-@pytest.mark.parametrize("name", ["c3", "n32"])
+@pytest.mark.parametrize("name", ["c3", "n32", "c2", "n20", "n36"])
 def test_w_in_lds_with_padded_leading_dimensions_and_nan_rows(name, lds_schedule):
     """Rows at a stride (ldv, ldy > n, multiples of 4 floats); a NaN / Inf row raises the flag and touches no other row; rows
     beyond the batch are never written."""
