@@ -982,9 +982,16 @@ int rayen_ray_project_mapped_image_f32(const RayenPack* p, const float* x, int64
     return RAYEN_E_BAD_ARG;
   const int rc = check_ready<float>(p, false);
   if (rc) return rc;
-  if (p->pr32 != nullptr && p->pr32_state == 1)
+  if (p->pr32 != nullptr && p->pr32_state == 1) {
+    // (round 6: the W-in-LDS schedule with the mapper's image next to W's -- on the pack's own image, shared tiles included)
+    if (pair_schedule() == 3 && mfma_pair_wl_serves_mapped(p, p->pr32, x, B, ldx, in_dim, v_out, ldvo, y, ldy)) {
+      g_last_forward = RAYEN_KERNEL_PAIR_WL;
+      return mfma_pair_wl_forward_mapped(p, p->pr32, x, B, ldx, in_dim, image, v_out, ldvo, y, ldy, kappa, active, nan_flag,
+                                         static_cast<hipStream_t>(stream));
+    }
     return mfma_pair_forward_mapped(p, p->pr32m != nullptr ? p->pr32m : p->pr32, x, B, ldx, in_dim, image, v_out, ldvo, y, ldy,
                                     kappa, active, nan_flag, static_cast<hipStream_t>(stream));
+  }
   if (p->sp32 == nullptr || p->sp32_state != 1) return RAYEN_E_UNSUPPORTED;
   return mfma_split_forward_mapped(p, p->sp32, x, B, ldx, in_dim, image, v_out, ldvo, y, ldy, kappa, active, nan_flag,
                                    static_cast<hipStream_t>(stream));

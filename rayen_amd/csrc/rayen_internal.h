@@ -185,6 +185,11 @@ int mfma_pair_io_forward(const RayenPack* p, const PairImage* img, const float* 
 bool mfma_pair_wl_serves(const RayenPack* p, const PairImage* img, const float* v, int64_t B, int64_t ldv,
                          const float* y, int64_t ldy);
 int mfma_pair_wl_prepare(const RayenPack* p, PairImage* img);   // function attributes (pack creation only)
+bool mfma_pair_wl_serves_mapped(const RayenPack* p, const PairImage* img, const float* x, int64_t B, int64_t ldx, int in_dim,
+                                const float* v_out, int64_t ldvo, const float* y, int64_t ldy);
+int mfma_pair_wl_forward_mapped(const RayenPack* p, const PairImage* img, const float* x, int64_t B, int64_t ldx, int in_dim,
+                                const void* image, float* v_out, int64_t ldvo, float* y, int64_t ldy, float* kappa,
+                                int32_t* active, int32_t* nan_flag, hipStream_t stream);
 int mfma_pair_wl_forward(const RayenPack* p, const PairImage* img, const float* v, int64_t B, int64_t ldv,
                          float* y, int64_t ldy, float* kappa, int32_t* active, int32_t* nan_flag,
                          hipStream_t stream);

@@ -77,6 +77,12 @@ __device__ __forceinline__ void wl_dma16(const char* gbase, const unsigned voff,
                : [off] "v"(voff), [base] "s"(gbase), [lds] "s"(lds)
                : "memory");
 }
+// the mapped instances carry the mapper's image (up to 16 KiB) next to W's: eight rows at a time through 1 KiB
+constexpr int kWlStageRowsMapped = 8;
+constexpr int wl_region_bytes_mapped(int nkk, int nt) {
+  return nt * WlGeom<2>::AUXR * 128 * (nkk == 2 ? 1 : 4) > kWlStageRowsMapped * 128 ? nt * WlGeom<2>::AUXR * 128 * (nkk == 2 ? 1 : 4)
+                                                                                     : kWlStageRowsMapped * 128;
+}
 }  // namespace
 
 // developer build (scripts/ubench/tu_variant.sh rayen_mfma_pair_wl clock -DRAYEN_WL_CLOCK; scripts/ubench/wl_clock.py): s_memtime
@@ -106,25 +112,34 @@ extern "C" int rayen_debug_wl_clock(void* dst, size_t bytes) {
 }
 #endif
 
-template <int NKK, bool TRACK, int NT, int NW>
+// NKX > 0: the module's mapper v = Wm x + b in front of the walk (rayen/constraint_module.py:259-263, 525; the arithmetic of
+// rayen_mfma_pair.hip's mapped instances, bit for bit): `v` / `ldv` / `n_in` are then x, its leading dimension and its width, the
+// mapper's f16-pair image (NKK x 2 NKX K-steps x 2 pieces of 1 KiB, then bias, gM, 1 / gM: pair_mapper_image_kernel) is copied into
+// LDS behind the image of W, and v reaches memory only when v_out != null (training).
+template <int NKK, bool TRACK, int NT, int NW, int NKX = 0>
 __global__ __launch_bounds__(NW * 64, 1) void mfma_pair_wl_kernel(
     const f16x8* __restrict__ Wh, const MItem* __restrict__ items, int n_items,
     const MPack* __restrict__ packs, const float* __restrict__ y0, int n_tiles, int n,
     const float* __restrict__ v, int64_t B, int64_t ldv, float* __restrict__ y, int64_t ldy,
     float* __restrict__ kappa_out, int32_t* __restrict__ active_out,
-    int32_t* __restrict__ nan_flag, const float w_scale, const float w_inv) {
+    int32_t* __restrict__ nan_flag, const float w_scale, const float w_inv,
+    const f16x8* __restrict__ mimg, int n_in, float* __restrict__ v_out, int64_t ldvo) {
   constexpr int NS = NKK * 2, NCH = NS * 2, NQ = NKK * 4, AUXR = WlGeom<NKK>::AUXR;
+  constexpr int NSX = NKX * 2, NQX = NKX * 4, MCH = NKK * NSX * 2;   // the mapper's K-steps, row pieces, 1-KiB chunks
   extern __shared__ __attribute__((aligned(1024))) char wl_smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col = lane & 31;
   const int hi = lane >> 5;
   char* const wimg = wl_smem;                                                   // [n_tiles][NS][2][64] x 16 bytes
-  constexpr int REGION = wl_region_bytes(NKK, NT), SR = wl_stage_rows(NT);
-  char* const stage = wl_smem + (size_t)n_tiles * (NCH * 1024) + wave * REGION;
+  constexpr int REGION = NKX > 0 ? wl_region_bytes_mapped(NKK, NT) : wl_region_bytes(NKK, NT);
+  constexpr int SR = NKX > 0 ? kWlStageRowsMapped : wl_stage_rows(NT);
+  char* const mlds = wl_smem + (size_t)n_tiles * (NCH * 1024);                  // (mapped) [NKK][NSX][2][64] x 16 bytes
+  char* const stage = mlds + MCH * 1024 + wave * REGION;
   float (*const aux_lds)[AUXR][32] = reinterpret_cast<float (*)[AUXR][32]>(stage);   // [sample tile][row][sample]
-  float* const y0_lds = reinterpret_cast<float*>(wl_smem + (size_t)n_tiles * (NCH * 1024) + NW * REGION);
-  unsigned* const take_lds = reinterpret_cast<unsigned*>(y0_lds + NKK * 32);     // the workgroup's next unclaimed group
+  float* const y0_lds = reinterpret_cast<float*>(mlds + MCH * 1024 + NW * REGION);
+  float* const bias_lds = y0_lds + NKK * 32;                                    // (mapped) gM b, zero-padded
+  unsigned* const take_lds = reinterpret_cast<unsigned*>(bias_lds + (NKX > 0 ? NKK * 32 : 0));   // the workgroup's next unclaimed group
   // Groups are dealt to WORKGROUPS statically (group b + j gridDim.x is the j-th of workgroup b) and to the waves of a
   // workgroup on demand, j from a counter in LDS: the issue arbiter prefers the older wave of a SIMD, so with equal shares
   // the first waves of a workgroup finish early and their partners walk alone at the end (s_memtime / s_memrealtime probes,
@@ -150,6 +165,15 @@ __global__ __launch_bounds__(NW * 64, 1) void mfma_pair_wl_kernel(
   // is waited for before the barrier).  See below the request lambda for the rest of the head.
   for (int i = threadIdx.x; i < NKK * 32; i += NW * 64) y0_lds[i] = y0[i];
   if (threadIdx.x == 0) *take_lds = NW;     // (the first NW are the waves' first groups)
+  float gm_inv = 1.f;
+  int gm_exp = 0;
+  if constexpr (NKX > 0) {
+    const float* tail = reinterpret_cast<const float*>(mimg + (size_t)MCH * 64);
+    const float gm = tail[NKK * 32];
+    gm_inv = tail[NKK * 32 + 1];
+    gm_exp = (int)((__builtin_bit_cast(unsigned, gm) >> 23) & 255u) - 127;
+    for (int i = threadIdx.x; i < NKK * 32; i += NW * 64) bias_lds[i] = tail[i] * gm;
+  }
 #if !(RAYEN_WL_HEAD & 1)
   {
     const int n_chunks = n_tiles * NCH;
@@ -172,20 +196,32 @@ __global__ __launch_bounds__(NW * 64, 1) void mfma_pair_wl_kernel(
   const unsigned v_lane_off = (unsigned)col * (unsigned)ldv * 4u + 16u * (unsigned)hi;
   const unsigned y_lane_off = (unsigned)(lane >> 3) * (unsigned)ldy * 4u + 16u * (unsigned)((lane & 7) ^ ((lane >> 3) & 7));
   f32x4 vraw[NT][NQ];
+  f32x4 xraw[NT][NKX > 0 ? NQX : 1];     // (mapped) the rows of x; vraw then holds gM sx v out of the mapper's accumulators
   // n = k below the padded width (a multiple of 4: whole pieces): the pieces beyond a row's n columns would be the next row's --
   // their offset is sent out of range instead (loads return 0, stores are dropped), one select per piece
   const bool ragged_n = n < NKK * 32;
+  const bool ragged_in = NKX > 0 && n_in < NKX * 32;
   constexpr unsigned kNowhere = 0xFFFFFFF0u;
   auto request = [&](const int64_t g) {
     const unsigned goff = v_lane_off + (unsigned)g * (unsigned)(NT * 32) * (unsigned)ldv * 4u;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {
+      if constexpr (NKX > 0) {
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        unsigned off = goff + (unsigned)t * 32u * (unsigned)ldv * 4u + 32u * q;
-        if (ragged_n) off = (8 * q + 4 * hi < n) ? off : kNowhere;
-        vraw[t][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, off, 0, 0));
+        for (int q = 0; q < NQX; ++q) {
+          unsigned off = goff + (unsigned)t * 32u * (unsigned)ldv * 4u + 32u * q;
+          if (ragged_in) off = (8 * q + 4 * hi < n_in) ? off : kNowhere;
+          xraw[t][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, off, 0, 0));
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          unsigned off = goff + (unsigned)t * 32u * (unsigned)ldv * 4u + 32u * q;
+          if (ragged_n) off = (8 * q + 4 * hi < n) ? off : kNowhere;
+          vraw[t][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, off, 0, 0));
+        }
       }
+    }
   };
   // largest |component| of the requested rows (this lane's half of each): the FIRST use of the rows' registers.  It sits in
   // front of the previous group's stores of y -- vmcnt retires in order and counts stores, so a wait for these loads that
@@ -195,16 +231,52 @@ __global__ __launch_bounds__(NW * 64, 1) void mfma_pair_wl_kernel(
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       float m = 0.f;
+      if constexpr (NKX > 0) {
 #pragma unroll
-      for (int q = 0; q < NQ; ++q)
+        for (int q = 0; q < NQX; ++q)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) m = fmaxf(m, __builtin_fabsf(vraw[t][q][c]));
+          for (int c = 0; c < 4; ++c) m = fmaxf(m, __builtin_fabsf(xraw[t][q][c]));
+      } else {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) m = fmaxf(m, __builtin_fabsf(vraw[t][q][c]));
+      }
       m_half[t] = m;
       asm volatile("" : "+v"(m_half[t]));   // (pinned here: hipcc otherwise sinks the maxima -- and their wait -- behind the stores)
     }
   };
 #pragma unroll
   for (int t = 0; t < NT; ++t) m_half[t] = 0.f;
+  // One 128-byte line (h) of each of a sample tile's 32 rows out of the registers that hold pieces 2 qq + hi of the lane's OWN row:
+  // through the wave's LDS (slot = piece ^ (row & 7): the eight lanes of a write or read group hit eight different 16-byte bank
+  // groups), SR rows at a time, and out as whole lines -- lane L stores slot L & 7 of row 8 i + (L >> 3).  `goff` = the lane's
+  // constant offset + the group's rows, `ld4` = the leading dimension in bytes; pieces beyond `width` columns and rows beyond
+  // the batch are out of the descriptor's range.
+  auto put_lines = [&](const f32x4 (&o)[4], const int h, const int t, const __amdgpu_buffer_rsrc_t rsrc, const unsigned goff,
+                       const unsigned ld4, const int width, const bool ragged) {
+#pragma unroll
+    for (int part = 0; part < 32 / SR; ++part) {      // rows [SR part, SR part + SR) of the tile
+      if (SR == 32 || (col / SR) == part) {
+        char* slot = stage + (col % SR) * 128;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) *reinterpret_cast<f32x4*>(slot + (((2 * qq + hi) ^ (col & 7)) * 16)) = o[qq];
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < SR / 8; ++i) {
+        const int r = 8 * i + (lane >> 3);
+        const f32x4 x = *reinterpret_cast<const f32x4*>(stage + r * 128 + (lane & 7) * 16);
+        // row (lane >> 3) of the eight, slot (lane & 7) ^ (row & 7): the lane's constant; rows beyond the batch are dropped
+        unsigned off = goff + (unsigned)(t * 32 + part * SR + 8 * i) * ld4 + 128u * h;
+        if (ragged) off = (32 * h + 4 * ((lane & 7) ^ ((lane >> 3) & 7)) < width) ? off : kNowhere;
+        if constexpr (RAYEN_WL_ABL & 2) { if (x[0] == 123.456f) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), rsrc, off, 0, 0); }
+        else if constexpr (RAYEN_WL_ABL & 8) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), rsrc, off, 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), rsrc, off, 0, 2);   // (2: non-temporal)
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  };
 #if RAYEN_WL_HEAD
   {
     // the image's chunks, then -- behind them, loads retire in order -- the wave's first rows, pulled towards L2 into the wave's own
@@ -216,6 +288,9 @@ __global__ __launch_bounds__(NW * 64, 1) void mfma_pair_wl_kernel(
     if (RAYEN_WL_HEAD & 1)
       for (int c = wave; c < n_chunks; c += NW)
         wl_dma16(reinterpret_cast<const char*>(Wh) + (size_t)c * 1024, lane16, img_at + c * 1024);
+    if constexpr (NKX > 0)
+      for (int c = wave; c < MCH; c += NW)
+        wl_dma16(reinterpret_cast<const char*>(mimg) + (size_t)c * 1024, lane16, img_at + (n_chunks + c) * 1024);
     if ((RAYEN_WL_HEAD & 2) && (grp + 1) * (NT * 32) <= B) {
       const char* gb = reinterpret_cast<const char*>(v + grp * (NT * 32) * ldv);
       const unsigned lds_at = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(stage));
@@ -258,6 +333,77 @@ __global__ __launch_bounds__(NW * 64, 1) void mfma_pair_wl_kernel(
     f16x8 vb[NT][2][NS];
     float v_scl[NT], v_inv[NT];
     bool nan_row[NT];
+    int sx_exp[NT];
+    if constexpr (NKX > 0) {
+      // ---- the mapper: x scaled per sample (sx, a power of two) and split like v; the accumulators start at gM sx b; per K-step
+      // of x and row tile of v the three products in the order of rayen_mfma_pair.hip (a2 x1, a1 x2, a1 x1); A operands from LDS.
+      // The fp32 results ARE in B-operand order: register 4 a + c of row tile tp is direction element 32 tp + 8 a + 4 hi + c.
+      static_assert(NT == 1, "the mapped instances walk one sample tile per wave");
+      static_assert((RAYEN_WL_HEAD & 1) != 0, "the mapper's image is copied by the LDS-DMA head");
+      const unsigned vo_goff = (unsigned)(lane >> 3) * (unsigned)ldvo * 4u + 16u * (unsigned)((lane & 7) ^ ((lane >> 3) & 7)) +
+                               (unsigned)s_base * (unsigned)ldvo * 4u;
+      const __amdgpu_buffer_rsrc_t vo_rsrc =
+          __builtin_amdgcn_make_buffer_rsrc(v_out, 0, (int)(unsigned)((uint64_t)B * (uint64_t)ldvo * 4u), 0x00020000);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float mx = fmaxf(m_half[t], xhalf(m_half[t]));
+        float sx, sx_inv;
+        pow2_scale(mx, sx, sx_inv, sx_exp[t]);
+        f32x16 macc[NKK];
+#pragma unroll
+        for (int tp = 0; tp < NKK; ++tp)
+#pragma unroll
+          for (int a4 = 0; a4 < 4; ++a4) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(&bias_lds[32 * tp + 8 * a4 + 4 * hi]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) macc[tp][4 * a4 + c] = b4[c] * sx;
+          }
+#pragma unroll
+        for (int sxs = 0; sxs < NSX; ++sxs) {
+          u32x4 w1, w2;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int q = 2 * sxs + (j >> 1), c = 2 * (j & 1);
+            unsigned a, b;
+            pair_split_lo(a, b, xraw[t][q][c], sx);
+            pair_split_hi(a, b, xraw[t][q][c + 1], sx);
+            w1[j] = a;
+            w2[j] = b;
+          }
+          const f16x8 xb0 = __builtin_bit_cast(f16x8, w1), xb1 = __builtin_bit_cast(f16x8, w2);
+#pragma unroll
+          for (int tp = 0; tp < NKK; ++tp) {
+            const char* ch = mlds + (size_t)((tp * NSX + sxs) * 2) * 1024 + lane * 16;
+            const f16x8 a1 = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(ch));
+            const f16x8 a2 = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(ch + 1024));
+            macc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, xb0, macc[tp], 0, 0, 0);
+            macc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xb1, macc[tp], 0, 0, 0);
+            macc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xb0, macc[tp], 0, 0, 0);
+          }
+        }
+        // macc = gM sx v.  v itself leaves only for the backward (training): the same lines as y
+        if (v_out != nullptr) {
+#pragma unroll
+          for (int h = 0; h < NKK; ++h) {
+            f32x4 o[4];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+              for (int c = 0; c < 4; ++c) o[qq][c] = fmaf(macc[h][4 * qq + c] * gm_inv, sx_inv, 0.f);
+            put_lines(o, h, t, vo_rsrc, vo_goff, (unsigned)ldvo * 4u, n, ragged_n);
+          }
+        }
+        float m = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            vraw[t][q][c] = macc[q >> 2][4 * (q & 3) + c];
+            m = fmaxf(m, __builtin_fabsf(vraw[t][q][c]));
+          }
+        m_half[t] = m;
+      }
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const float m = fmaxf(m_half[t], xhalf(m_half[t]));
@@ -265,6 +411,14 @@ __global__ __launch_bounds__(NW * 64, 1) void mfma_pair_wl_kernel(
       int sv_exp;
       pow2_scale(m, sv, v_inv[t], sv_exp);
       v_scl[t] = sv;
+      if constexpr (NKX > 0) {
+        // the pieces are split from f x (gM sx v), f = the power of two above; sv = f gM sx as a power of two (the exponents are
+        // added: the product of the floats could overflow on the way)
+        int e = sv_exp + gm_exp + sx_exp[t];
+        e = e > 126 ? 126 : (e < -126 ? -126 : e);
+        v_scl[t] = __builtin_bit_cast(float, (unsigned)(127 + e) << 23);
+        v_inv[t] = __builtin_bit_cast(float, (unsigned)(127 - e) << 23);
+      }
       f16x2 z = {(_Float16)0.f, (_Float16)0.f};
 #pragma unroll
       for (int sp = 0; sp < NS; ++sp) {
@@ -504,27 +658,7 @@ __global__ __launch_bounds__(NW * 64, 1) void mfma_pair_wl_kernel(
             o[qq][c] = fmaf(val, scale[t], o4[c]);
           }
         }
-#pragma unroll
-        for (int part = 0; part < 32 / SR; ++part) {      // rows [SR part, SR part + SR) of the tile
-          if (SR == 32 || (col / SR) == part) {
-            char* slot = stage + (col % SR) * 128;
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) *reinterpret_cast<f32x4*>(slot + (((2 * qq + hi) ^ (col & 7)) * 16)) = o[qq];
-          }
-          __builtin_amdgcn_wave_barrier();
-#pragma unroll
-          for (int i = 0; i < SR / 8; ++i) {
-            const int r = 8 * i + (lane >> 3);
-            const f32x4 x = *reinterpret_cast<const f32x4*>(stage + r * 128 + (lane & 7) * 16);
-            // row (lane >> 3) of the eight, slot (lane & 7) ^ (row & 7): the lane's constant; rows beyond the batch are dropped
-            unsigned off = y_goff + (unsigned)(t * 32 + part * SR + 8 * i) * (unsigned)ldy * 4u + 128u * h;
-            if (ragged_n) off = (32 * h + 4 * ((lane & 7) ^ ((lane >> 3) & 7)) < n) ? off : kNowhere;
-            if constexpr (RAYEN_WL_ABL & 2) { if (x[0] == 123.456f) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), y_rsrc, off, 0, 0); }
-            else if constexpr (RAYEN_WL_ABL & 8) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), y_rsrc, off, 0, 0);
-            else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), y_rsrc, off, 0, 2);   // (2: non-temporal)
-          }
-          __builtin_amdgcn_wave_barrier();
-        }
+        put_lines(o, h, t, y_rsrc, y_goff, (unsigned)ldy * 4u, n, ragged_n);
       }
       bad |= live[t] && nan_row[t];      // (the row's own components: y is NaN exactly when one of them is NaN or Inf)
     }
@@ -543,6 +677,10 @@ __global__ __launch_bounds__(NW * 64, 1) void mfma_pair_wl_kernel(
 // ---------------------------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------------------------
+static int pair_wl_lds_bytes_mapped(const PairImage* img, int nkx) {
+  return img->n_tiles * (img->nkk * 4 * 1024) + img->nkk * (nkx * 2) * 2 * 1024 + kWlWaves * wl_region_bytes_mapped(img->nkk, 1) +
+         2 * img->nkk * 128 + 16;
+}
 static int pair_wl_lds_bytes(const PairImage* img) {
   return img->n_tiles * (img->nkk * 4 * 1024) + kWlWaves * wl_region_bytes(img->nkk, kWlNT) + img->nkk * 128 + 16;
 }
@@ -588,7 +726,76 @@ int mfma_pair_wl_prepare(const RayenPack* p, PairImage* img) {
   want(mfma_pair_wl_kernel<2, false, kWlNT, kWlWaves>); want(mfma_pair_wl_kernel<2, true, kWlNT, kWlWaves>);
   if (!ok) return RAYEN_E_LAUNCH;
   img->wl_ready = true;
+  // the mapped instances, for the widest mapper this pack can be given (in_dim = the padded width): attributes are set HERE, never
+  // on a launch path; a pack whose image leaves no room for it keeps its mapped calls on rayen_mfma_pair.hip
+  const int lds_m = pair_wl_lds_bytes_mapped(img, img->nkk);
+  if (kWlNT == 1 && lds_m <= 160 * 1024) {
+    static int promised_m = 0;
+    promised_m = std::max(promised_m, lds_m);
+    const int ask_m = promised_m;
+    auto want_m = [&](auto kern) {
+      ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ask_m) == hipSuccess;
+    };
+    want_m(mfma_pair_wl_kernel<1, false, 1, kWlWaves, 1>); want_m(mfma_pair_wl_kernel<1, true, 1, kWlWaves, 1>);
+    want_m(mfma_pair_wl_kernel<2, false, 1, kWlWaves, 1>); want_m(mfma_pair_wl_kernel<2, true, 1, kWlWaves, 1>);
+    want_m(mfma_pair_wl_kernel<2, false, 1, kWlWaves, 2>); want_m(mfma_pair_wl_kernel<2, true, 1, kWlWaves, 2>);
+    if (!ok) return RAYEN_E_LAUNCH;
+    img->wl_mapped_ready = true;
+  }
   return RAYEN_OK;
+}
+
+// ---- the module's mapper in front (rayen_ray_project_mapped_image_f32): x [B, in_dim] -> v = Wm x + b -> y, one launch
+bool mfma_pair_wl_serves_mapped(const RayenPack* p, const PairImage* img, const float* x, int64_t B, int64_t ldx, int in_dim,
+                                const float* v_out, int64_t ldvo, const float* y, int64_t ldy) {
+  if (kWlNT != 1 || img == nullptr || img->nkk < 1 || img->nkk > 2 || img->n_tiles <= 0 || !img->wl_mapped_ready) return false;
+  if (!img->identity || p->k != p->n || p->n > img->nkk * 32 || p->n <= (img->nkk - 1) * 32 || (p->n % 4) != 0) return false;
+  if (in_dim < 4 || in_dim > img->nkk * 32 || (in_dim % 4) != 0 || ldx < in_dim || ldy < p->n) return false;
+  if ((ldx % 4) != 0 || (ldy % 4) != 0 || ldx > (1 << 22) || ldy > (1 << 22)) return false;
+  if ((reinterpret_cast<uintptr_t>(x) & 15) != 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0) return false;
+  if (v_out != nullptr && ((ldvo % 4) != 0 || ldvo < p->n || ldvo > (1 << 22) || (reinterpret_cast<uintptr_t>(v_out) & 15) != 0)) return false;
+  if (img->nkk == 2 && img->aux_rows > WlGeom<2>::AUXR) return false;
+  if (pair_wl_lds_bytes_mapped(img, (in_dim + 31) / 32) > 160 * 1024) return false;
+  static const int64_t min_groups_env = [] { const char* e = getenv("RAYEN_WL_MIN_GROUPS"); return e ? atoll(e) : 1ll; }();   // developer sweeps
+  return B >= 1 && (B + 31) / 32 >= min_groups_env;
+}
+
+int mfma_pair_wl_forward_mapped(const RayenPack* p, const PairImage* img, const float* x, int64_t B, int64_t ldx, int in_dim,
+                                const void* image, float* v_out, int64_t ldvo, float* y, int64_t ldy, float* kappa,
+                                int32_t* active, int32_t* nan_flag, hipStream_t stream) {
+  if (B == 0) return RAYEN_OK;
+  if (image == nullptr || !mfma_pair_wl_serves_mapped(p, img, x, B, ldx, in_dim, v_out, ldvo, y, ldy)) return RAYEN_E_UNSUPPORTED;
+  const int nkx = (in_dim + 31) / 32;
+  const int64_t cus = launch_simds(img->n_simd) / 4;
+  const int lds = pair_wl_lds_bytes_mapped(img, nkx);
+  const int64_t ld_max = std::max<int64_t>(std::max(std::max(ldx, ldy), v_out ? ldvo : 1), 1);
+  const int64_t rows_max = (((int64_t)0xFFFFFFFFll / (ld_max * 4)) - 64) / 32 * 32;
+  for (int64_t r0 = 0; r0 < B; r0 += rows_max) {
+    const int64_t Bc = std::min(B - r0, rows_max);
+    const int64_t n_groups = (Bc + 31) / 32;
+    const unsigned grid = (unsigned)std::min<int64_t>(cus, n_groups);
+    const float* xc = x + r0 * ldx;
+    float* yc = y + r0 * ldy;
+    float* voc = v_out ? v_out + r0 * ldvo : nullptr;
+    float* kc = kappa ? kappa + r0 : nullptr;
+    int32_t* ac = active ? active + 2 * r0 : nullptr;
+    auto go = [&](auto kern) {
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(kWlWaves * 64), lds, stream, static_cast<const f16x8*>(img->Wh), img->items,
+                         img->n_items, img->packs, img->y0, img->n_tiles, p->n, xc, Bc, ldx, yc, ldy, kc, ac, nan_flag,
+                         img->w_scale, img->w_inv, static_cast<const f16x8*>(image), in_dim, voc, ldvo);
+    };
+    if (img->nkk == 1) {
+      if (active != nullptr) go(mfma_pair_wl_kernel<1, true, 1, kWlWaves, 1>);
+      else go(mfma_pair_wl_kernel<1, false, 1, kWlWaves, 1>);
+    } else if (nkx == 1) {
+      if (active != nullptr) go(mfma_pair_wl_kernel<2, true, 1, kWlWaves, 1>);
+      else go(mfma_pair_wl_kernel<2, false, 1, kWlWaves, 1>);
+    } else {
+      if (active != nullptr) go(mfma_pair_wl_kernel<2, true, 1, kWlWaves, 2>);
+      else go(mfma_pair_wl_kernel<2, false, 1, kWlWaves, 2>);
+    }
+  }
+  return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
 }
 
 int mfma_pair_wl_forward(const RayenPack* p, const PairImage* img, const float* v, int64_t B, int64_t ldv,
@@ -615,7 +822,7 @@ int mfma_pair_wl_forward(const RayenPack* p, const PairImage* img, const float* 
     auto go = [&](auto kern) {
       hipLaunchKernelGGL(kern, dim3(grid), dim3(kWlWaves * 64), lds, stream, static_cast<const f16x8*>(img->Wh), img->items,
                          img->n_items, img->packs, img->y0, img->n_tiles, p->n, vc, Bc, ldv, yc, ldy, kc, ac, nan_flag,
-                         img->w_scale, img->w_inv);
+                         img->w_scale, img->w_inv, static_cast<const f16x8*>(nullptr), 0, static_cast<float*>(nullptr), (int64_t)0);
     };
     if (img->nkk == 1) {
       if (active != nullptr) go(mfma_pair_wl_kernel<1, true, kWlNT, kWlWaves>);

@@ -247,7 +247,8 @@ struct PairImage {
   int first_out = 0;       // index of the first NA_E tile in the item list (n_items when NA_E = I)
   bool has_halves = false; // some items read half of a shared tile (rayen_tiles.h): not for the mapped instances
   int n_tiles = 0;         // tiles of the image (rayen_mfma_pair_wl.hip copies all of them into LDS)
-  bool wl_ready = false;   // the W-in-LDS kernels were promised their dynamic LDS at pack creation
+  bool wl_ready = false;          // the W-in-LDS kernels were promised their dynamic LDS at pack creation
+  bool wl_mapped_ready = false;   // ... and their mapped instances (room for the widest mapper next to the image)
   int64_t bytes = 0;
   std::vector<MItem> host_items;   // the item list as uploaded (rayen_mfma_pair_ws8.hip deals it out to eight waves)
 };

@@ -195,3 +195,45 @@ def test_nothing_is_written_or_used_beyond_a_ragged_batch(B, lds_schedule):
     y2, k2, _ = ops.project_raw(_misaligned_copy(v), dp)
     assert _lib.load().rayen_last_forward_kernel() == _lib.KERNEL_PAIR
     assert torch.equal(y, y2) and torch.equal(kappa, k2)
+
+
+@pytest.mark.parametrize("name,in_dim", [("c3", 64), ("c3", 36), ("c3", 20), ("c2", 8), ("n32", 32), ("n36", 12), ("n60", 64)])
+def test_mapped_w_in_lds_against_the_plain_mapped_kernel_and_against_itself(name, in_dim):
+    """The module's mapper in front of the walk (rayen/constraint_module.py:259-263, 525), round 6: the W-in-LDS schedule with
+    the mapper's image next to W's (rayen_mfma_pair_wl.hip, NKX > 0).
+      * v = Wm x + b equals the mapped instances of rayen_mfma_pair.hip (rayen_pair_schedule(0)) bit for bit: same image of the
+        mapper, same order of products;
+      * y, kappa and the arg-max record equal the UNMAPPED W-in-LDS kernel fed with that v bit for bit: v leaves as an exact
+        power-of-two multiple of the accumulators the pieces are split from;
+      * against the plain mapped kernel y agrees to fp32 rounding only -- that one walks the pack's image WITHOUT shared tiles
+        (other row order inside the sums of squares);
+      * the instance without the record returns the same y."""
+    lib = _lib.load()
+    cs = workloads.build_constraints(_sets()[name])
+    torch.manual_seed(in_dim)
+    layer = ConstraintModule(cs, input_dim=in_dim, create_map=True).cuda()
+    dp, _ = layer.device_pack(torch.device("cuda", 0))
+    if dp.info().mfma_f32 != 3 or dp.mapper_mode(in_dim) != 2:
+        pytest.skip("the f16-pair family does not fuse this mapper")
+    pid = ops.register_pack(dp)
+    w, b = layer.mapper.weight.detach(), layer.mapper.bias.detach()
+    prev = lib.rayen_pair_schedule(-1)
+    try:
+        for B in (1, 33, 1000, 65536 + 7, 262144):
+            x = torch.empty(B, in_dim, device="cuda").uniform_(-2.0, 2.0, generator=torch.Generator(device="cuda").manual_seed(B))
+            x[B // 2] *= 1e-3
+            lib.rayen_pair_schedule(3)
+            y, kappa, active, v = ops.ray_project_mapped(x, w, b, pid, True)
+            assert lib.rayen_last_forward_kernel() == _lib.KERNEL_PAIR_WL, (name, in_dim, B)
+            y_plain, _, _, _ = ops.ray_project_mapped(x, w, b, pid, False)
+            assert torch.equal(y_plain, y), (name, in_dim, B, "without the record")
+            y_u, kappa_u, active_u = ops.project_raw(v, dp, want_active=True)
+            assert lib.rayen_last_forward_kernel() == _lib.KERNEL_PAIR_WL
+            assert torch.equal(y, y_u) and torch.equal(kappa, kappa_u) and torch.equal(active, active_u), (name, in_dim, B, "unmapped on v")
+            lib.rayen_pair_schedule(0)
+            y0_, kappa0, active0, v0 = ops.ray_project_mapped(x, w, b, pid, True)      # the mapped instances of rayen_mfma_pair.hip
+            assert torch.equal(v, v0), (name, in_dim, B, "v")
+            size = y0_.abs().amax(dim=1).clamp_min(1e-30)
+            assert float(((y - y0_).abs().amax(dim=1) / size).max()) <= 2e-6, (name, in_dim, B, "y against the plain mapped kernel")
+    finally:
+        lib.rayen_pair_schedule(prev)
