@@ -637,6 +637,30 @@ def main(argv=None):
                 "backward_kernel": bwd_names.get(int(info.bwd_f32), str(info.bwd_f32)) if dtype == torch.float32 else "fp64 kernels",
                 "backward_check_pair_vs_fp64": info.bwd32_check_pair, "backward_check_exact_vs_fp64": info.bwd32_check_exact,
                 "clipped_fraction": float((k_rec > 1).double().mean())}
+        if on_gpu and world == 1 and not args.mapper and not args.no_families and B and dtype == torch.float32 \
+                and cs.n <= 64 and cs.n % 4 == 0 and dp.mapper_fusable(cs.n):
+            # the same workload behind the module's own mapper (create_map=True, the reference's default: rayen/constraint_module.py
+            # :259-263, 525): x -> v = Wm x + b -> y in ONE launch, timed the same way, outside `value`
+            try:
+                torch.manual_seed(0)
+                mapped = ConstraintModule(cs, input_dim=cs.n, method="RAYEN", create_map=True).to(device)
+                mapped.check_nan = False
+                xm = torch.empty(B, cs.n, device=device, dtype=dtype).uniform_(-1, 1)
+                with torch.no_grad():
+                    for _ in range(SETTLE_LAUNCHES // 3):
+                        mapped(xm)
+                torch.cuda.synchronize()
+                _, ms_m = timed_loop(lambda xx: mapped(xx), xm, args.steps, args.warmup, False, graph=graph)
+                out["module_with_mapper"] = {
+                    "value": B / (ms_m * 1e-3), "unit": "projections/s", "ms_per_step": ms_m,
+                    "mapper": f"nn.Linear({cs.n}, {cs.n}) fused into the projection kernel",
+                    "kernel": ("mfma_pair_wl_f16x2 with the mapper's image next to W's in LDS (round 6)"
+                               if _lib.load().rayen_last_forward_kernel() == getattr(_lib, "KERNEL_PAIR_WL", -1)
+                               else "mapped instances of the plain schedule"),
+                    "how": "ConstraintModule(cs, input_dim=n, create_map=True) in eval mode, same batch, same step count; "
+                           "`python bench.py --mapper D` times it as the main line"}
+            except Exception as e:   # (a leg beside the measurement: never the reason the line is missing)
+                out["module_with_mapper"] = {"error": repr(e)}
         if args.mapper:
             fused = on_gpu and (not args.no_fuse) and dtype == torch.float32 and dp.mapper_fusable(args.mapper)
             out["config"]["mapper"] = f"nn.Linear({args.mapper}, {cs.n}) " + ("fused into the projection kernel" if fused else "as its own GEMM")
