@@ -20,7 +20,7 @@
 // The item list, the image, the epilogues and the order of the products inside a tile are the other schedules': same bits.
 //
 // Served: NA_E = I, n = k in (32 (NKK - 1), 32 NKK] and a multiple of 4, rows 16-byte aligned, the image + the aux patches within 160 KiB of LDS, at most
-// AUXR aux rows at NKK = 2.  Everything else stays on the other schedules.
+// sixteen aux rows at NKK = 2 (eight behind a mapper).  Everything else stays on the other schedules.
 #include "rayen_split_image.h"
 
 #include <algorithm>
@@ -55,7 +55,9 @@ constexpr int kWlNT = RAYEN_WL_NT;            // sample tiles (of 32) per wave a
 #ifndef RAYEN_WL_HEAD
 #define RAYEN_WL_HEAD 1
 #endif
-template <int NKK> struct WlGeom { static constexpr int AUXR = NKK == 2 ? 8 : 32; };
+// aux rows a wave keeps per sample tile: 32 at NKK = 1; at NKK = 2 sixteen (2 KiB: what the staging of y needs anyway), eight in the
+// mapped instances (1 KiB: the mapper's image takes the room)
+template <int NKK, bool MAPPED = false> struct WlGeom { static constexpr int AUXR = NKK == 2 ? (MAPPED ? 8 : 16) : 32; };
 // a wave's own LDS: the aux patch during the walk ([sample tile][aux row][sample]), then the 4 KiB through which its rows of
 // y leave as whole 128-byte lines (32 rows x one line)
 // (one sample tile per wave: 16 rows at a time through 2 KiB, so that three or four waves per SIMD fit next to the image)
@@ -64,7 +66,8 @@ template <int NKK> struct WlGeom { static constexpr int AUXR = NKK == 2 ? 8 : 32
 #endif
 constexpr int wl_stage_rows(int nt) { return RAYEN_WL_SR ? RAYEN_WL_SR : (nt == 1 ? 16 : 32); }
 constexpr int wl_region_bytes(int nkk, int nt) {
-  return nt * WlGeom<2>::AUXR * 128 * (nkk == 2 ? 1 : 4) > wl_stage_rows(nt) * 128 ? nt * WlGeom<2>::AUXR * 128 * (nkk == 2 ? 1 : 4) : wl_stage_rows(nt) * 128;
+  return nt * (nkk == 2 ? WlGeom<2>::AUXR : WlGeom<1>::AUXR) * 128 > wl_stage_rows(nt) * 128 ? nt * (nkk == 2 ? WlGeom<2>::AUXR : WlGeom<1>::AUXR) * 128
+                                                                                             : wl_stage_rows(nt) * 128;
 }
 // one LDS-DMA: every lane fetches 16 bytes from gbase + voff; lane L lands at LDS byte lds + 16 L.  Nothing returns through the
 // vector registers -- by scripts/ubench/mfma_coissue.hip such loads run beside a partner wave's MFMAs, register loads do not.
@@ -80,8 +83,9 @@ __device__ __forceinline__ void wl_dma16(const char* gbase, const unsigned voff,
 // the mapped instances carry the mapper's image (up to 16 KiB) next to W's: eight rows at a time through 1 KiB
 constexpr int kWlStageRowsMapped = 8;
 constexpr int wl_region_bytes_mapped(int nkk, int nt) {
-  return nt * WlGeom<2>::AUXR * 128 * (nkk == 2 ? 1 : 4) > kWlStageRowsMapped * 128 ? nt * WlGeom<2>::AUXR * 128 * (nkk == 2 ? 1 : 4)
-                                                                                     : kWlStageRowsMapped * 128;
+  return nt * (nkk == 2 ? WlGeom<2, true>::AUXR : WlGeom<1, true>::AUXR) * 128 > kWlStageRowsMapped * 128
+             ? nt * (nkk == 2 ? WlGeom<2, true>::AUXR : WlGeom<1, true>::AUXR) * 128
+             : kWlStageRowsMapped * 128;
 }
 }  // namespace
 
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(NW * 64, 1) void mfma_pair_wl_kernel(
     float* __restrict__ kappa_out, int32_t* __restrict__ active_out,
     int32_t* __restrict__ nan_flag, const float w_scale, const float w_inv,
     const f16x8* __restrict__ mimg, int n_in, float* __restrict__ v_out, int64_t ldvo) {
-  constexpr int NS = NKK * 2, NCH = NS * 2, NQ = NKK * 4, AUXR = WlGeom<NKK>::AUXR;
+  constexpr int NS = NKK * 2, NCH = NS * 2, NQ = NKK * 4, AUXR = WlGeom<NKK, (NKX > 0)>::AUXR;
   constexpr int NSX = NKX * 2, NQX = NKX * 4, MCH = NKK * NSX * 2;   // the mapper's K-steps, row pieces, 1-KiB chunks
   extern __shared__ __attribute__((aligned(1024))) char wl_smem[];
   const int lane = threadIdx.x & 63;
@@ -578,7 +582,7 @@ __global__ __launch_bounds__(NW * 64, 1) void mfma_pair_wl_kernel(
 #pragma unroll
           for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int g = 0; g < (AUXR == 8 ? 4 : 16); ++g) aux_lds[t][(g & 3) + 8 * (g >> 2) + 4 * hi][col] = acc[t][g];
+            for (int g = 0; g < AUXR / 2; ++g) aux_lds[t][(g & 3) + 8 * (g >> 2) + 4 * hi][col] = acc[t][g];   // (rows 0 .. AUXR - 1 of the tile)
           __builtin_amdgcn_wave_barrier();
         } else if (item.type == MI_PACK) {
           const MPack pk = packs[item.aux];
@@ -754,7 +758,7 @@ bool mfma_pair_wl_serves_mapped(const RayenPack* p, const PairImage* img, const 
   if ((ldx % 4) != 0 || (ldy % 4) != 0 || ldx > (1 << 22) || ldy > (1 << 22)) return false;
   if ((reinterpret_cast<uintptr_t>(x) & 15) != 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0) return false;
   if (v_out != nullptr && ((ldvo % 4) != 0 || ldvo < p->n || ldvo > (1 << 22) || (reinterpret_cast<uintptr_t>(v_out) & 15) != 0)) return false;
-  if (img->nkk == 2 && img->aux_rows > WlGeom<2>::AUXR) return false;
+  if (img->nkk == 2 && img->aux_rows > WlGeom<2, true>::AUXR) return false;
   if (pair_wl_lds_bytes_mapped(img, (in_dim + 31) / 32) > 160 * 1024) return false;
   static const int64_t min_groups_env = [] { const char* e = getenv("RAYEN_WL_MIN_GROUPS"); return e ? atoll(e) : 1ll; }();   // developer sweeps
   return B >= 1 && (B + 31) / 32 >= min_groups_env;

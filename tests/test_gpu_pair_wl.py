@@ -34,6 +34,7 @@ def _sets():
         "n28": workloads.random_lin_quad_soc(k=28, m=64, n_quad=3, n_soc=0, seed=22),
         "n36": workloads.random_lin_quad_soc(k=36, m=100, n_quad=2, n_soc=1, seed=23),            # NKK = 2, 36 of 64 columns
         "n60": workloads.random_lin_quad_soc(k=60, m=128, n_quad=3, n_soc=2, seed=24),
+        "n64_many_aux": workloads.random_lin_quad_soc(k=64, m=32, n_quad=5, n_soc=3, seed=25),     # 11 aux rows at NKK = 2 (sixteen fit)
     }
 
 
@@ -66,12 +67,12 @@ def test_the_w_in_lds_schedule_is_the_default():
 # per CU as soon as there is a group for it: below 4 096 groups some waves, below 256 some CUs have nothing to do)
 @pytest.mark.parametrize("B", [1, 31, 33, 1000, 4096 + 7, 8192, 32768 + 5, 65536, 98304, 98304 + 17, 131072, 131072 + 32 * 5 + 11,
                                262144, 262144 - 1, 393216 + 29, 1048576 + 3])
-@pytest.mark.parametrize("name", ["c3", "n32", "n32_many_aux", "c2", "n20", "n28", "n36", "n60"])
+@pytest.mark.parametrize("name", ["c3", "n32", "n32_many_aux", "c2", "n20", "n28", "n36", "n60", "n64_many_aux"])
 @pytest.mark.parametrize("want_active", [False, True])
 def test_w_in_lds_equals_the_plain_pair_kernel_bit_for_bit(name, B, want_active, lds_schedule):
     if name != "c3" and B > 300000:
         pytest.skip("the round structures are covered on c3")
-    if name in ("n20", "n28", "n36", "n60", "c2") and B not in (1, 33, 4096 + 7, 65536, 131072 + 32 * 5 + 11):
+    if name in ("n20", "n28", "n36", "n60", "c2", "n64_many_aux") and B not in (1, 33, 4096 + 7, 65536, 131072 + 32 * 5 + 11):
         pytest.skip("the ragged widths are covered on five batch shapes")
     cs, layer, dp = _pack(_sets()[name])
     if dp.info().mfma_f32 != 3:
