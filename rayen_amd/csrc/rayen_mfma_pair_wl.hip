@@ -57,7 +57,10 @@ constexpr int kWlNT = RAYEN_WL_NT;            // sample tiles (of 32) per wave a
 #endif
 // aux rows a wave keeps per sample tile: 32 at NKK = 1; at NKK = 2 sixteen (2 KiB: what the staging of y needs anyway), eight in the
 // mapped instances (1 KiB: the mapper's image takes the room)
-template <int NKK, bool MAPPED = false> struct WlGeom { static constexpr int AUXR = NKK == 2 ? (MAPPED ? 8 : 16) : 32; };
+#ifndef RAYEN_WL_AUXR2
+#define RAYEN_WL_AUXR2 16
+#endif
+template <int NKK, bool MAPPED = false> struct WlGeom { static constexpr int AUXR = NKK == 2 ? (MAPPED ? 8 : RAYEN_WL_AUXR2) : 32; };
 // a wave's own LDS: the aux patch during the walk ([sample tile][aux row][sample]), then the 4 KiB through which its rows of
 // y leave as whole 128-byte lines (32 rows x one line)
 // (one sample tile per wave: 16 rows at a time through 2 KiB, so that three or four waves per SIMD fit next to the image)
