@@ -221,11 +221,21 @@ __global__ __launch_bounds__(NW * 64, 1) void mfma_pair_wl_kernel(
           xraw[t][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, off, 0, 0));
         }
       } else {
+        // (two copies behind a wave-uniform branch, the empty statement keeps hipcc from folding them back into one with a select
+        // per piece: at the padded width -- the headline -- the selects were 3 % of the kernel's vector instructions)
+        if (__builtin_expect(ragged_n, 0)) {
+          asm volatile("; ragged width" ::: "memory");
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          unsigned off = goff + (unsigned)t * 32u * (unsigned)ldv * 4u + 32u * q;
-          if (ragged_n) off = (8 * q + 4 * hi < n) ? off : kNowhere;
-          vraw[t][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, off, 0, 0));
+          for (int q = 0; q < NQ; ++q) {
+            unsigned off = goff + (unsigned)t * 32u * (unsigned)ldv * 4u + 32u * q;
+            off = (8 * q + 4 * hi < n) ? off : kNowhere;
+            vraw[t][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, off, 0, 0));
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            vraw[t][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                v_rsrc, goff + (unsigned)t * 32u * (unsigned)ldv * 4u + 32u * q, 0, 0));
         }
       }
     }
@@ -276,7 +286,10 @@ __global__ __launch_bounds__(NW * 64, 1) void mfma_pair_wl_kernel(
         const f32x4 x = *reinterpret_cast<const f32x4*>(stage + r * 128 + (lane & 7) * 16);
         // row (lane >> 3) of the eight, slot (lane & 7) ^ (row & 7): the lane's constant; rows beyond the batch are dropped
         unsigned off = goff + (unsigned)(t * 32 + part * SR + 8 * i) * ld4 + 128u * h;
-        if (ragged) off = (32 * h + 4 * ((lane & 7) ^ ((lane >> 3) & 7)) < width) ? off : kNowhere;
+        if (__builtin_expect(ragged, 0)) {
+          asm volatile("; ragged width" ::: "memory");     // (a branch, not a select per store: see request)
+          off = (32 * h + 4 * ((lane & 7) ^ ((lane >> 3) & 7)) < width) ? off : kNowhere;
+        }
         if constexpr (RAYEN_WL_ABL & 2) { if (x[0] == 123.456f) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), rsrc, off, 0, 0); }
         else if constexpr (RAYEN_WL_ABL & 8) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), rsrc, off, 0, 0);
         else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), rsrc, off, 0, 2);   // (2: non-temporal)
