@@ -214,11 +214,19 @@ __global__ __launch_bounds__(NW * 64, 1) void mfma_pair_wl_kernel(
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       if constexpr (NKX > 0) {
+        if (__builtin_expect(ragged_in, 0)) {
+          asm volatile("; ragged width" ::: "memory");
 #pragma unroll
-        for (int q = 0; q < NQX; ++q) {
-          unsigned off = goff + (unsigned)t * 32u * (unsigned)ldv * 4u + 32u * q;
-          if (ragged_in) off = (8 * q + 4 * hi < n_in) ? off : kNowhere;
-          xraw[t][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, off, 0, 0));
+          for (int q = 0; q < NQX; ++q) {
+            unsigned off = goff + (unsigned)t * 32u * (unsigned)ldv * 4u + 32u * q;
+            off = (8 * q + 4 * hi < n_in) ? off : kNowhere;
+            xraw[t][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, off, 0, 0));
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < NQX; ++q)
+            xraw[t][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                v_rsrc, goff + (unsigned)t * 32u * (unsigned)ldv * 4u + 32u * q, 0, 0));
         }
       } else {
         // (two copies behind a wave-uniform branch, the empty statement keeps hipcc from folding them back into one with a select
