@@ -11,12 +11,18 @@
 // buys besides:
 //   * no row buffers in LDS (there is no room for them and no need): a lane reads ITS sample's row straight from memory as
 //     eight 16-byte pieces (fragment shape: lanes (col, hi) of a row cover 32 contiguous bytes, four consecutive
-//     instructions complete a 128-byte line) one group AHEAD, into registers, right behind the split of the current
-//     group -- a whole walk (~10 k cycles) for the HBM round trip -- and writes its row of y the same way;
-//   * vmcnt counts nothing but those rows: no counted waits, no stand-in operations, no M0;
-//   * groups of 32 samples (one sample tile per wave): 96 instead of 160 live registers in the walk, so THREE waves per
-//     SIMD (twelve per workgroup) take turns on the matrix pipe -- by the same microbenchmark a partner's plain VALU /
-//     SALU / LDS instructions issue while a wave's MFMAs execute -- and the first rows a wave waits for are 8 KiB, not 16.
+//     instructions complete a 128-byte line) at the top of its group -- the wait is left to the other waves of the SIMD --
+//     through a buffer descriptor whose extent is the batch (one add per group; rows beyond the batch and pieces beyond
+//     a ragged width are out of range: loads return 0, stores are dropped), and writes its row of y through 2 KiB of LDS
+//     as whole lines;
+//   * vmcnt counts nothing but those rows: no counted waits, no stand-in operations;
+//   * groups of 32 samples (one sample tile per wave): ~120 instead of 160+ live registers, so FOUR waves per SIMD
+//     (sixteen per workgroup, dealt groups on demand from a counter in LDS) take turns on the matrix pipe -- by the same
+//     microbenchmark a partner's plain VALU / SALU / LDS instructions issue while a wave's MFMAs execute; measured
+//     monotone in the wave count (16: 46.4 us, 12: 49.5, 8: 54.7) -- and the first rows a wave waits for are 8 KiB, not 16;
+//   * the image itself arrives by LDS-DMA (global_load_lds_dwordx4: nothing through the registers);
+//   * every batch size (one workgroup per CU as soon as there is a group for it), n = k below the padded width, the
+//     module's mapper in front (NKX > 0: its image next to W's).
 // The item list, the image, the epilogues and the order of the products inside a tile are the other schedules': same bits.
 //
 // Served: NA_E = I, n = k in (32 (NKK - 1), 32 NKK] and a multiple of 4, rows 16-byte aligned, the image + the aux patches within 160 KiB of LDS, at most
