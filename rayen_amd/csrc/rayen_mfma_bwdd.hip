@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kBdWaves * 64, 1) void mfma_bwdd_kernel(
     const f16x8* __restrict__ Sh, const BItem* __restrict__ items, int n_tiles, int n_dense,
     const float* __restrict__ Wrow, int lin_lo, int lin_n, const float* __restrict__ v, int64_t B, int64_t ldv,
     const float* __restrict__ kappa, const int32_t* __restrict__ active, const float* __restrict__ gy, int64_t ldg,
-    float* __restrict__ gv, int64_t ldgv, const float s_inv) {
+    float* __restrict__ gv, int64_t ldgv, const float s_inv, const int n) {
   constexpr int NS = 4, NCH = 8, NQ = 8, NP = 64, SR = 16;
   extern __shared__ __attribute__((aligned(1024))) char bd_smem[];
   const int lane = threadIdx.x & 63;
@@ -148,12 +148,26 @@ __global__ __launch_bounds__(kBdWaves * 64, 1) void mfma_bwdd_kernel(
     const unsigned g32 = (unsigned)g_ * 32u;
     const unsigned voff = v_lane_off + g32 * (unsigned)ldv * 4u, goff = g_lane_off + g32 * (unsigned)ldg * 4u;
     const bool live = g_ * 32 + col < B;
+    // (n = k below 64, in whole 16-byte pieces: the pieces beyond a row's n columns are sent out of range -- loads return 0, stores are
+    // dropped; the forms and the linear rows are zero there.  Behind a wave-uniform branch, the empty statement keeps the copies apart.)
+    if (__builtin_expect(n < NP, 0)) {
+      asm volatile("; ragged width" ::: "memory");
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, voff + 32u * q, 0, 0));
-      const f32x4 g = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, goff + 32u * q, 0, 0));
+      for (int q = 0; q < NQ; ++q) {
+        const bool in = 8 * q + 4 * hi < n;
+        const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, in ? voff + 32u * q : 0xFFFFFFF0u, 0, 0));
+        const f32x4 g = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, in ? goff + 32u * q : 0xFFFFFFF0u, 0, 0));
 #pragma unroll
-      for (int c = 0; c < 4; ++c) { vr[4 * q + c] = x[c]; gr[4 * q + c] = g[c]; }
+        for (int c = 0; c < 4; ++c) { vr[4 * q + c] = x[c]; gr[4 * q + c] = g[c]; }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, voff + 32u * q, 0, 0));
+        const f32x4 g = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, goff + 32u * q, 0, 0));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { vr[4 * q + c] = x[c]; gr[4 * q + c] = g[c]; }
+      }
     }
     const unsigned roff = (g32 + (unsigned)col) * 4u;
     kap_in = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(k_rsrc, roff, 0, 0));
@@ -366,8 +380,12 @@ __global__ __launch_bounds__(kBdWaves * 64, 1) void mfma_bwdd_kernel(
             const int r = 8 * i + (lane >> 3);
             const f32x4 x = *reinterpret_cast<const f32x4*>(stage + r * 128 + (lane & 7) * 16);
             (void)r;   // (row (lane >> 3) of the eight, slot (lane & 7) ^ (row & 7): o_lane_off)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), o_rsrc,
-                                                   o_goff + (unsigned)(part16 * SR + 8 * i) * (unsigned)ldgv * 4u + 128u * h, 0, 2);
+            unsigned off = o_goff + (unsigned)(part16 * SR + 8 * i) * (unsigned)ldgv * 4u + 128u * h;
+            if (__builtin_expect(n < NP, 0)) {
+              asm volatile("; ragged width" ::: "memory");
+              off = (32 * h + 4 * ((lane & 7) ^ ((lane >> 3) & 7)) < n) ? off : 0xFFFFFFF0u;
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), o_rsrc, off, 0, 2);
           }
           __builtin_amdgcn_wave_barrier();
         }
@@ -391,7 +409,8 @@ __global__ __launch_bounds__(kBdWaves * 64, 1) void mfma_bwdd_kernel(
 // host
 // ---------------------------------------------------------------------------------------------
 bool mfma_bwdd_eligible(const RayenPack* p) {
-  return bwd_tiles_eligible(p) && p->n == 64 && p->k == 64 && p->out_identity;
+  // (n = k = 64, or -- round 6 -- anything above 32 in whole 16-byte pieces: the tiles are padded to 64 columns anyway)
+  return bwd_tiles_eligible(p) && p->n > 32 && p->n <= 64 && (p->n % 4) == 0 && p->k == p->n && p->out_identity;
 }
 
 void mfma_bwdd_free(MfmaBwddImage* img);
@@ -503,7 +522,6 @@ bool mfma_bwdd_serves(const RayenPack* p, const MfmaBwddImage* img, const float*
 int mfma_bwdd_backward(const RayenPack* p, const MfmaBwddImage* img, const float* v, int64_t B, int64_t ldv,
                        const float* kappa, const int32_t* active, const float* grad_y, int64_t ldg, float* grad_v,
                        int64_t ldgv, hipStream_t stream) {
-  (void)p;
   if (B == 0) return RAYEN_OK;
   if (img == nullptr || !img->ready) return RAYEN_E_UNSUPPORTED;
   const int64_t n_groups = (B + 31) / 32;
@@ -511,7 +529,7 @@ int mfma_bwdd_backward(const RayenPack* p, const MfmaBwddImage* img, const float
   const unsigned grid = (unsigned)std::min<int64_t>(cus, n_groups);   // (every CU as soon as there is a group for it: rayen_mfma_pair_wl.hip)
   hipLaunchKernelGGL((mfma_bwdd_kernel<false>), dim3(grid), dim3(kBdWaves * 64), img->lds_bytes, stream, img->Sh, img->items,
                      img->n_tiles, img->n_dense, img->Wrow, img->lin_lo, img->lin_n, v, B, ldv, kappa, active, grad_y, ldg,
-                     grad_v, ldgv, img->s_inv);
+                     grad_v, ldgv, img->s_inv, p->n);
   return hipGetLastError() == hipSuccess ? RAYEN_OK : RAYEN_E_LAUNCH;
 }
 

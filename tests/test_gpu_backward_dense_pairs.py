@@ -21,6 +21,9 @@ def _sets():
         "c3_other_seed": workloads.make_raw("c3", seed=3),
         "quads_only": workloads.random_lin_quad_soc(k=64, m=96, n_quad=6, n_soc=0, seed=41),
         "cones_only": workloads.random_lin_quad_soc(k=64, m=64, n_quad=0, n_soc=3, seed=42),
+        # n = k below 64 in whole 16-byte pieces (round 6): tiles padded to 64 columns, the pieces beyond n addressed out of range
+        "n60": workloads.random_lin_quad_soc(k=60, m=96, n_quad=3, n_soc=2, seed=43),
+        "n36": workloads.random_lin_quad_soc(k=36, m=64, n_quad=2, n_soc=1, seed=44),
     }
 
 
@@ -41,7 +44,7 @@ def _row_err(got, want):
     return np.abs(got - want).max(axis=1) / size
 
 
-@pytest.mark.parametrize("name", ["c3", "c3_other_seed", "quads_only", "cones_only"])
+@pytest.mark.parametrize("name", ["c3", "c3_other_seed", "quads_only", "cones_only", "n60", "n36"])
 def test_dense_pair_backward_is_fp32_grade(name):
     cs, layer, layer64 = _layers(_sets()[name])
     dev = torch.device("cuda", 0)
@@ -83,11 +86,12 @@ def test_dense_pair_backward_is_fp32_grade(name):
     assert np.all(got[170] == 0.0)
 
 
+@pytest.mark.parametrize("name", ["c3", "n36"])
 @pytest.mark.parametrize("B", [65536, 65536 + 31, 100001, 262144])
-def test_dense_pair_backward_equals_itself_in_every_addressing_mode(B):
+def test_dense_pair_backward_equals_itself_in_every_addressing_mode(B, name):
     """Padded leading dimensions of v, grad_y and grad_v: the same gradient bit for bit, nothing written beyond the n columns or
-    beyond the batch (the last group is ragged)."""
-    cs, layer, _ = _layers(_sets()["c3"])
+    beyond the batch (the last group is ragged; at n = 36 the pieces beyond a row's columns are out of range)."""
+    cs, layer, _ = _layers(_sets()[name])
     dp, _ = layer.device_pack(torch.device("cuda", 0))
     assert dp.info().bwd_f32 == 7
     gen = torch.Generator().manual_seed(B)
@@ -99,6 +103,8 @@ def test_dense_pair_backward_equals_itself_in_every_addressing_mode(B):
     wide_v[:, :cs.n] = v
     wide_g = torch.zeros(B, cs.k + 4, device="cuda")
     wide_g[:, :cs.k] = g
+    wide_v[:, cs.n:] = 123.0                       # (columns beyond n: never read as data ...)
+    wide_g[:, cs.k:] = -55.0
     got = ops.backward_raw(wide_v[:, :cs.n], kappa, active, wide_g[:, :cs.k], dp)
     assert torch.equal(got[:, :cs.n], flat)
     # against the lane-per-sample backward (another instruction stream, exact fp32): fp32-grade agreement
